@@ -1,0 +1,181 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.pt by running the REFERENCE's own
+code (imported from /root/reference through oracle/ref_harness.py) on CPU in fp32.
+
+Run in the build container:  python -m oracle.make_golden
+The fixtures are committed; the GPU box (no /root/reference) only reads them.
+
+Every fixture stores: the initial student/teacher state (reference key names), the RNG
+seeds the synthetic views are regenerated from (+ a checksum), the masks the reference
+sampled, and the reference's outputs: head logits captured by forward hooks, the four
+loss terms, total loss, grad-norm, and student/teacher parameters + loss centers after
+each optimizer step (Lightning hook order, see ReferenceRunner).
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import dinov2_oracle as O  # noqa: E402
+from oracle import ref_harness as H  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def synth_views(seed: int, b: int, g_size: int, l_size: int, n_local: int):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
+        torch.randn(b, 3, l_size, l_size, generator=g) for _ in range(n_local)
+    ]
+
+
+def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: dict, cfg: dict, b: int,
+                      g_size: int, l_size: int, n_local: int, n_steps: int, total_steps: int,
+                      keep_params_every_step: bool = True) -> None:
+    H.install()
+    from lightly_train._methods.dinov2 import utils as ref_utils
+
+    m = H.build_reference_method(arch=arch, patch_size=cfg["patch_size"], img_size=g_size,
+                                 model_kwargs=model_kwargs, method_kwargs=method_kwargs,
+                                 global_batch_size=b, total_steps=total_steps, seed=1234)
+    r = H.ReferenceRunner(m)
+    init = r.split_state()
+    # teacher backbone == deepcopy(student backbone) at init (dinov2.py:196-204): store once.
+    # The two heads are built independently (dinov2.py:215-241): store both.
+    for k, v in init["teacher_backbone"].items():
+        assert torch.equal(v, init["student_backbone"][k])
+    init_small = {"student_backbone": init["student_backbone"], "student_head": init["student_head"],
+                  "teacher_head": init["teacher_head"]}
+    fixture = {"name": name, "cfg": cfg, "method_kwargs": method_kwargs, "b": b, "g_size": g_size, "l_size": l_size,
+               "n_local": n_local, "total_steps": total_steps, "init": init_small, "steps": []}
+
+    # capture head outputs in call order: teacher(cls, patch), student(cls, patch, local)
+    cap: dict = {}
+    t_calls, s_calls = [], []
+    def spy_forward(mod, sink):
+        orig = mod.forward
+
+        def fwd(x):
+            out = orig(x)
+            sink.append(out.detach().clone())
+            return out
+
+        mod.forward = fwd
+
+    spy_forward(m.teacher_head.dino_head, t_calls)
+    spy_forward(m.student_head.dino_head, s_calls)
+    # capture masks the reference sampled
+    orig_ccm = ref_utils.create_collated_masks
+    import lightly_train._methods.dinov2.dinov2 as ref_dinov2
+
+    def spy_ccm(**kw):
+        out = orig_ccm(**kw)
+        cap["masks"] = {k: v.clone() for k, v in out.items()}
+        return out
+
+    ref_dinov2.create_collated_masks = spy_ccm
+
+    # oracle twin (must agree bit-for-bit on the first steps)
+    o = O.OracleDINOv2(init["student_backbone"], init["student_head"], cfg,
+                       args=dict(output_dim=method_kwargs.get("output_dim", 65536),
+                                 hidden_dim=method_kwargs.get("hidden_dim", 2048),
+                                 bottleneck_dim=method_kwargs.get("dino_bottleneck_dim", 256),
+                                 center_method=method_kwargs.get("center_method", "softmax")),
+                       global_batch_size=b, total_steps=total_steps,
+                       teacher_backbone=init["teacher_backbone"], teacher_head=init["teacher_head"])
+
+    for step in range(n_steps):
+        views = synth_views(1000 + step, b, g_size, l_size, n_local)
+        t_calls.clear(); s_calls.clear()
+        random.seed(77 + step)
+        logs = r.train_step(views)
+        random.seed(77 + step)
+        ologs = o.train_step(views)
+        for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
+            assert abs(logs[k] - ologs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (name, step, k, logs[k], ologs[k])
+        rec = {
+            "view_seed": 1000 + step,
+            "view_checksum": float(sum(v.double().sum() for v in views)),
+            "masks": cap["masks"],
+            "logs": logs,
+            "teacher_cls_logits": t_calls[0], "teacher_patch_logits": t_calls[1],
+            "student_cls_logits": s_calls[0], "student_patch_logits": s_calls[1],
+            "student_local_logits": s_calls[2] if n_local > 0 else None,
+            "dino_center": m.dino_loss.center.detach().clone(),
+            "ibot_center": m.ibot_loss.center.detach().clone(),
+        }
+        if keep_params_every_step or step == n_steps - 1:
+            rec["state"] = r.split_state()
+        fixture["steps"].append(rec)
+        print(name, step, {k: round(v, 6) for k, v in logs.items()})
+    ref_dinov2.create_collated_masks = orig_ccm
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(fixture, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_loss_kats() -> None:
+    """Literal tensors of the reference's own known-answer tests, evaluated by the reference
+    code (tests/_methods/dinov2/test_dinov2_loss.py:84-103,179-211; tests/test__torch_helpers.py:38-72)."""
+    H.install()
+    from lightly_train._methods.dinov2.dinov2_loss import DINOLoss, IBOTPatchLoss
+
+    dl = DINOLoss(out_dim=2, student_temp=0.1, center_momentum=0.9)
+    t = torch.tensor([[0.1, 0.2], [0.3, 0.4], [0.5, 0.6]])
+    s = torch.tensor([[0.7, 0.8], [0.9, 1.0], [1.1, 1.2]])
+    tp = dl.softmax_center_teacher(t, teacher_temp=0.04)
+    dino = float(dl.forward([s, s], [tp, tp]))
+    assert abs(dino - 1.5565) < 1.5565e-4, dino
+    il = IBOTPatchLoss(patch_out_dim=2, student_temp=0.2, center_momentum=0.9)
+    mask = torch.tensor([[True, False, True, False], [False, False, False, True], [False, False, False, False]])
+    tpc = il.softmax_center_teacher(t.unsqueeze(0), teacher_temp=0.1)
+    ibot = float(il.forward_masked(teacher_patch_tokens_masked=tpc, student_patch_tokens_masked=s,
+                                   student_masks_flat=mask))
+    assert abs(ibot - 0.4057) < 0.4057e-4, ibot
+    sp, tpp = s, t
+    # random medium-size cases for sinkhorn / softmax / CE
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(24, 384, generator=g)
+    dl2 = DINOLoss(out_dim=384)
+    sk = dl2.sinkhorn_knopp_teacher(logits.clone(), teacher_temp=0.05)
+    il2 = IBOTPatchLoss(patch_out_dim=384)
+    sk_ibot = il2.sinkhorn_knopp_teacher(logits.clone(), teacher_temp=0.05,
+                                         n_masked_patches_tensor=torch.tensor([24], dtype=torch.long))
+    dl2.center = torch.randn(1, 384, generator=g) * 0.1
+    sm = dl2.softmax_center_teacher(logits, teacher_temp=0.05)
+    s2 = torch.randn(24, 384, generator=g)
+    ce = float(dl2.forward(s2.chunk(2), list(sm.view(2, 12, 384))))
+    out = {"dino_kat": dino, "ibot_kat": ibot, "s": s, "t": t, "sp": sp, "tpp": tpp, "mask": mask,
+           "logits": logits, "sinkhorn": sk, "sinkhorn_ibot": sk_ibot, "center": dl2.center.clone(),
+           "softmax_center": sm, "student": s2, "dino_ce_2x2": ce}
+    torch.save(out, os.path.join(OUT, "loss_kats.pt"))
+    print("loss KATs", dino, ibot, ce)
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    make_loss_kats()
+    small_head = dict(output_dim=512, hidden_dim=64, dino_bottleneck_dim=32)
+    # (a) the reference tests' own toy model: D=8, depth 3, 2 heads (head_dim 4)
+    make_step_fixture("step_vittest_softmax", "_vit_test", {}, dict(small_head),
+                      dict(patch_size=16, num_heads=2, depth=3), b=8, g_size=64, l_size=32, n_local=4,
+                      n_steps=3, total_steps=20)
+    make_step_fixture("step_vittest_sinkhorn", "_vit_test", {}, dict(small_head, center_method="sinkhorn_knopp"),
+                      dict(patch_size=16, num_heads=2, depth=3), b=8, g_size=64, l_size=32, n_local=4,
+                      n_steps=2, total_steps=20)
+    # (b) head_dim 64 (the MFMA attention path): D=64, depth 2, 1 head; 96->6x6 global, 48->3x3 local
+    make_step_fixture("step_d64_softmax", "DinoVisionTransformer",
+                      dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0),
+                      dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64),
+                      dict(patch_size=16, num_heads=1, depth=2), b=8, g_size=96, l_size=48, n_local=2,
+                      n_steps=2, total_steps=50, keep_params_every_step=False)
+
+
+if __name__ == "__main__":
+    main()
