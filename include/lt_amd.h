@@ -1,0 +1,177 @@
+/* lt_amd.h -- C ABI of the MI355X-native DINOv2 training-step kernels (liblt_amd.so).
+ *
+ * The reference (lightly-ai/lightly-train v0.17.0) has no FFI for this path: every op below
+ * replaces a PyTorch ATen call sequence inside the reference's Python `Method.training_step_impl`
+ * / `ModelWrapper.forward_features`.  Each entry point cites the reference
+ * lines (relative to src/lightly_train/, "LT/") whose arithmetic it implements.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers borrowed from the caller (torch tensors); nothing is
+ *     allocated or freed inside the library; every launch goes to the caller's `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream);
+ *   - bf16 tensors are raw uint16 bfloat16 bits; "f32" = IEEE float; row-major, last dim contiguous;
+ *   - return 0 (LT_OK) or a negative code; lt_last_error() returns a thread-local message;
+ *   - re-entrant per stream, no global state.
+ */
+#ifndef LT_AMD_H
+#define LT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_OK 0
+#define LT_ERR_INVALID (-22)
+#define LT_ERR_HIP (-5)
+
+const char* lt_last_error(void);
+int lt_abi_version(void);
+/* device name / CU count of the current device (diagnostics for bench.py) */
+int lt_device_info(char* name, int name_len, int* compute_units, int* clock_khz);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  (LT/_models/dinov2_vit/dinov2_vit_src/layers/attention.py:44,51-55,64  qkv / proj Linear;
+ *        layers/mlp.py:36-42 fc1/GELU/fc2; layers/patch_embed.py:77-79,108-110 Conv2d as GEMM;
+ *        layers/layer_scale.py:27-28 + layers/block.py:90-115 gamma*branch + residual;
+ *        LT/_methods/dinov2/dinov2_head.py:66-71,85-95 head MLP and prototype layer; and the
+ *        autograd backward of all of them)
+ *   C[M,N] = opA(A) . opB(B), bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
+ *   trans_a = 0: A is [M][K] (lda = row stride, K contiguous); 1: A is [K][M] (M contiguous)
+ *   trans_b = 0: B is [N][K] (nn.Linear weight layout);          1: B is [K][N]
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  LT_EPI_BF16 = 0,          /* C(bf16) = alpha*acc + bias                                        */
+  LT_EPI_BF16_GELU = 1,     /* C2(bf16, optional) = pre = alpha*acc + bias; C(bf16) = gelu(pre)   */
+  LT_EPI_RESID = 2,         /* y = alpha*acc + bias; C2(bf16, optional) = y; C(f32) = resid + gamma*y */
+  LT_EPI_F32 = 3,           /* C(f32) = alpha*acc + bias                                         */
+  LT_EPI_BF16_GELUGRAD = 4, /* C(bf16) = alpha*acc * gelu'(aux(bf16))                            */
+  LT_EPI_F32_ACCUM = 5      /* C(f32) += alpha*acc   (split_k > 1 -> atomic adds)                */
+};
+
+typedef struct lt_gemm_desc {
+  const void* A; const void* B;   /* bf16 */
+  int M, N, K;
+  int lda, ldb;
+  int trans_a, trans_b;
+  int epilogue;
+  void* C; int ldc;               /* primary output (dtype by epilogue) */
+  void* C2; int ldc2;             /* optional secondary bf16 output */
+  const float* bias;              /* [N] or NULL */
+  const float* gamma;             /* [N] LayerScale (LT_EPI_RESID) or NULL (=1) */
+  const float* resid; int ldr;    /* [M][N] f32 residual (LT_EPI_RESID) or NULL (=0) */
+  const void* aux; int ldaux;     /* [M][N] bf16 pre-activation (LT_EPI_BF16_GELUGRAD) */
+  float alpha;
+  int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
+} lt_gemm_desc;
+
+int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);
+/* one-thread-per-output fp32-accumulate GEMM on the same bf16 operands (cross-check only) */
+int lt_gemm_bf16_naive(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int trans_a, int trans_b, void* stream);
+/* tiny fp32 matmul C[M,N] (+)= op(A)[M,K] . B[K,N]  (pos-embed bicubic map, vision_transformer.py:251-305) */
+int lt_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Token path (vision_transformer.py:307-329 prepare_tokens_with_masks; patch_embed.py:86-114)
+ * ------------------------------------------------------------------------------------------ */
+/* img f32 [B,C,H,W] -> cols bf16 [B*gh*gw, kpad], k = (c*p + py)*p + px, zero padded to kpad */
+int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H, int W, int p, int kpad, void* stream);
+/* x[b,0]=cls+pos[0]; x[b,1+i]=(mask[b,i]?mask_token:patch[b*n_p+i])+pos[1+i]; masks may be NULL */
+int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
+                       const uint8_t* masks, float* x, int B, int n_p, int D, void* stream);
+/* backward: dpatch bf16 [B*n_p,D] (0 where masked); dcls[D], dpos[(1+n_p),D], dmask_token[D] accumulate */
+int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_bf16, float* dcls, float* dpos,
+                           float* dmask_token, int B, int n_p, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm eps=1e-6 (vision_transformer.py:138; block.py:60,74)  x f32 [rows,D]
+ * ------------------------------------------------------------------------------------------ */
+int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                     float* rstd, int rows, int D, float eps, void* stream);
+/* dx = (dres ? dres : 0) + LN'(dy); dw/db accumulate (atomics). dy is bf16 unless dy_is_f32 */
+int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                     int dy_is_f32, const float* dres, float* dx, float* dw, float* db, int rows, int D, void* stream);
+
+/* LayerScale backward (layer_scale.py:27-28): dy(bf16) = dout*gamma; dgamma += sum_rows dout*y.
+ * gamma == NULL: dy = bf16(dout) only. */
+int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
+                      int rows, int D, void* stream);
+/* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */
+int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream);
+/* out[N] (+)= column sums of an f32 [rows,N] matrix (teacher center, dinov2_loss.py:139-145,274-282) */
+int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream);
+/* row gather: out[m,:] = src[idx[m],:]  (index_select, dinov2.py:427-431,496-500; cls rows incl. the
+ * teacher half-swap dinov2.py:414-420).  Either output may be NULL. */
+int lt_gather_rows(const float* src, int ld_src, const int64_t* idx, void* out_bf16, float* out_f32, int M, int D,
+                   void* stream);
+/* dst[idx[m],:] += src[m,:] (unique idx) */
+int lt_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int ld_dst, int M, int D, void* stream);
+int lt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int lt_fill_f32(float* dst, float value, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention (attention.py:49-66): softmax(q*scale k^T) v on the packed qkv bf16 [B,N,3,H,dh].
+ * head_dim 64 runs the MFMA flash kernels; other head dims run the generic kernels.
+ * ------------------------------------------------------------------------------------------ */
+int lt_attention_fwd(const void* qkv, void* out_bf16, float* lse, int B, int N, int H, int dh, float scale, void* stream);
+/* dqkv bf16 [B,N,3,H,dh]; ws = f32 workspace of lt_attention_bwd_ws_floats(B,N,H,dh) floats */
+int64_t lt_attention_bwd_ws_floats(int B, int N, int H, int dh);
+int lt_attention_bwd(const void* qkv, const void* out_bf16, const void* dout_bf16, const float* lse, float* ws,
+                     void* dqkv, int B, int N, int H, int dh, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Projection head pieces (dinov2_head.py:54-58,66-71)
+ * ------------------------------------------------------------------------------------------ */
+/* y = x / max(||x||, eps) per row; outputs bf16 y and the f32 inverse norm */
+int lt_l2norm_fwd(const float* x, void* y_bf16, float* inv_norm, int rows, int D, float eps, void* stream);
+/* dx(bf16) = (dy - y*(y.dy)) * inv_norm with y = x*inv_norm */
+int lt_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, void* dx_bf16, int rows, int D, void* stream);
+/* weight_norm(dim=0): w[k,:] = v[k,:]*g[k]/||v[k,:]|| -> bf16 */
+int lt_weightnorm_fwd(const float* v, const float* g, void* w_bf16, int K, int D, void* stream);
+/* dv += g/||v|| * (dw - v*(v.dw)/||v||^2);  dg += (v.dw)/||v|| */
+int lt_weightnorm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int K, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses (LT/_methods/dinov2/dinov2_loss.py)
+ * ------------------------------------------------------------------------------------------ */
+/* probs = softmax((logits - center) * inv_temp) per row (:76-82, :178-186); center may be NULL */
+int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream);
+/* center = center*momentum + colsum*scale*(1-momentum) (:147-160, :284-297) */
+int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream);
+/* student CE against 1 or 2 teacher rows (:117-133, :246-268):
+ *   lsm = log_softmax(s*inv_temp);  l_r = -sum_k (t_a + t_b) * lsm
+ *   *loss += coef_r * l_r ;  dlogits(bf16)[r,:] = coef_r * inv_temp * (softmax(s*inv_temp)*sum(t) - (t_a+t_b))
+ *   coef_r = scale * (row_weight ? row_weight[r] : 1);  t_a = teacher[ta[r]], t_b = tb ? teacher[tb[r]] : 0 */
+int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
+                  float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K, void* stream);
+/* Sinkhorn-Knopp pieces (:84-115, :188-224); Q f32 [rows,K] holds exp(logits*inv_temp) */
+int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream);
+/* Q[r,k] *= 1/(colsum[k]*K); then row-normalise: Q[r,:] /= (rowsum(r) * n_total); final: Q *= final_mul */
+int lt_sk_iter(float* Q, const float* colsum, int rows, int K, float n_total, float final_mul, void* stream);
+/* KoLeo (lightly.loss.KoLeoLoss, call site dinov2.py:377-380): *loss += weight*L(x), dx += weight*dL/dx.
+ * ws: f32 workspace of 2*n*D + 2*n floats, nn: int32 workspace [n] */
+int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, int ld_dx, int n, int D, float eps, float weight,
+                     float* ws, int32_t* nn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer / EMA on flat parameter storage (LT/_methods/dinov2/utils.py:191-250 AdamW groups,
+ * dinov2.py:588-660 clip / WD schedule / EMA; LT/_torch_helpers.py:75-96)
+ * The flat f32 buffer is split into segments; seg_of_chunk[i] gives the segment of 1024-element chunk i.
+ * ------------------------------------------------------------------------------------------ */
+/* out[0] += sum(g^2) */
+int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
+/* AdamW (torch.optim.AdamW semantics, decoupled wd). clip_coef = min(1, max_norm/(||g||+1e-6)) is computed on
+ * device from *sumsq.  lr = seg_lr[seg]*lr_factor (0 if seg_frozen[seg] && freeze); wd = seg_wd_on[seg] ? wd : 0.
+ * Also writes the bf16 shadow copy of the updated parameters. */
+int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int32_t* seg_of_chunk,
+                  const float* seg_lr, const uint8_t* seg_wd_on, const uint8_t* seg_frozen, int freeze,
+                  float lr_factor, float wd, float beta1, float beta2, float eps, int step, const float* sumsq,
+                  float max_norm, void* stream);
+/* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow */
+int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, float m, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LT_AMD_H */

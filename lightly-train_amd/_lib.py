@@ -1,0 +1,97 @@
+"""ctypes binding of liblt_amd.so (C ABI declared in include/lt_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblt_amd.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32),
+        ("trans_a", i32), ("trans_b", i32), ("epilogue", i32), ("C", vp), ("ldc", i32), ("C2", vp), ("ldc2", i32),
+        ("bias", vp), ("gamma", vp), ("resid", vp), ("ldr", i32), ("aux", vp), ("ldaux", i32),
+        ("alpha", f32), ("split_k", i32),
+    ]
+
+
+EPI_BF16, EPI_BF16_GELU, EPI_RESID, EPI_F32, EPI_BF16_GELUGRAD, EPI_F32_ACCUM = range(6)
+
+# name -> argtypes (every function returns int status except lt_last_error)
+SIGNATURES: dict[str, list[Any]] = {
+    "lt_abi_version": [],
+    "lt_device_info": [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)],
+    "lt_gemm_bf16": [C.POINTER(GemmDesc), vp],
+    "lt_gemm_bf16_naive": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lt_matmul_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lt_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "lt_layernorm_bwd": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp],
+    "lt_layerscale_bwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "lt_colsum_bf16": [vp, vp, i32, i32, vp],
+    "lt_colsum_f32": [vp, vp, i32, i32, i32, vp],
+    "lt_gather_rows": [vp, i32, vp, vp, vp, i32, i32, vp],
+    "lt_scatter_add_rows": [vp, vp, vp, i32, i32, i32, vp],
+    "lt_cast_f32_to_bf16": [vp, vp, i64, vp],
+    "lt_fill_f32": [vp, f32, i64, vp],
+    "lt_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lt_attention_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lt_l2norm_fwd": [vp, vp, vp, i32, i32, f32, vp],
+    "lt_l2norm_bwd": [vp, vp, vp, vp, i32, i32, vp],
+    "lt_weightnorm_fwd": [vp, vp, vp, i32, i32, vp],
+    "lt_weightnorm_bwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "lt_softmax_center": [vp, vp, vp, i32, i32, f32, vp],
+    "lt_center_ema": [vp, vp, f32, f32, i32, vp],
+    "lt_ce_fwd_bwd": [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp],
+    "lt_sk_exp": [vp, vp, i64, f32, vp],
+    "lt_sk_iter": [vp, vp, i32, i32, f32, f32, vp],
+    "lt_koleo_fwd_bwd": [vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],
+    "lt_sumsq_f32": [vp, vp, i64, vp],
+    "lt_adamw_flat": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, vp, f32, vp],
+    "lt_ema_flat": [vp, vp, vp, i64, f32, vp],
+}
+
+_lib: C.CDLL | None = None
+
+
+class LtAmdError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load liblt_amd.so; raise loudly when it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LtAmdError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback for the MI355X kernels."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.lt_last_error.restype = C.c_char_p
+    lib.lt_last_error.argtypes = []
+    lib.lt_attention_bwd_ws_floats.restype = C.c_int64
+    lib.lt_attention_bwd_ws_floats.argtypes = [i32, i32, i32, i32]
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, also loud
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().lt_last_error().decode("utf-8", "replace")
+        raise LtAmdError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,485 @@
+// Fused multi-head self-attention for gfx950, forward and backward, on the packed qkv activation
+// [B, N, 3, H, dh] (bf16) produced by the qkv GEMM  (replaces Attention.forward,
+// LT/_models/dinov2_vit/dinov2_vit_src/layers/attention.py:49-66: q*scale @ k^T -> softmax -> @ v,
+// and its autograd backward; the [B,H,N,N] score matrix never reaches HBM).
+//
+// head_dim 64 path (ViT-S/B/L/g): v_mfma_f32_32x32x16_bf16, "swapped" products so that every softmax
+// statistic is lane-local:
+//   forward   S^T = K Q^T  (C layout: lane -> query column, registers -> keys), online softmax over the
+//             registers (+1 shuffle with lane^32), P^T registers ARE the B fragments of O^T = V^T P^T.
+//   backward  dK/dV kernel (waves own key tiles): S = Q K^T, P, dP = dO V^T, dS; P^T/dS^T are read as A
+//             fragments straight from the C layout;  dQ kernel (waves own query tiles): S^T, dP^T, dS^T as B.
+//   Operands whose contraction index is the slow (token) index are staged in LDS as [4 tok][16 d] 128-B
+//   pieces and fetched with ds_read_b64_tr_b16 (hardware transpose); the others as XOR-swizzled rows
+//   read with ds_read_b128.  The k-slot permutation implied by the C layout (keys {0-3,8-11 | 4-7,12-15})
+//   is applied to both operands of every such MFMA.
+// Other head dims (toy models of the reference's tests, head_dim 4) run plain one-block-per-row kernels.
+#include "lt_common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int CH = 128;  // tokens staged per LDS chunk
+constexpr int IMG = CH * DH * 2;  // 16 KiB per LDS image
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct QkvPtr {
+  const bf16_t* base; long tok_stride;  // elements between consecutive tokens = 3*H*dh
+  __device__ __forceinline__ const bf16_t* row(long tok) const { return base + tok * tok_stride; }
+};
+
+// ---- LDS images ----------------------------------------------------------------------------------
+// row image ("N-mode"): [CH tok][64 d] bf16, 128 B per token, 16-B chunk c stored at c ^ ((tok>>1)&7)
+__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* src, long tok_stride, int tok0, int ntok_valid) {
+  const int t = threadIdx.x, c = t & 7, rr = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rr + 32 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tok0 + r < ntok_valid) v = *reinterpret_cast<const uint4*>(src + (long)(tok0 + r) * tok_stride + c * 8);
+    *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+  }
+}
+// transposable image ("T-mode"): piece(q = tok/4, b = d/16) of [4 tok][16 d] at (q*4+b)*128, token rows rotated by b
+__device__ __forceinline__ void stage_tr(char* lds, const bf16_t* src, long tok_stride, int tok0, int ntok_valid) {
+  const int t = threadIdx.x, c = t & 7, rr = t >> 3;
+  const int b = c >> 1, half = c & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rr + 32 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tok0 + r < ntok_valid) v = *reinterpret_cast<const uint4*>(src + (long)(tok0 + r) * tok_stride + c * 8);
+    *reinterpret_cast<uint4*>(lds + ((r >> 2) * 4 + b) * 128 + ((((r & 3) + b) & 3) << 5) + (half << 4)) = v;
+  }
+}
+// A/B fragment of a row image: 32 tokens (tile tt of the chunk) x 16 d (k16 step ks)
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tt, int ks) {
+  const int l = threadIdx.x & 63;
+  const int r = tt * 32 + (l & 31), c = ks * 2 + (l >> 5);
+  return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+}
+// fragment of a T image: rows = 32 d (block db), k-slots = 16 tokens starting at tok16 (multiple of 16), in the
+// C-layout slot order: lane half hi gets tokens {4hi..4hi+3, 8+4hi..8+4hi+3}
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int db, int tok16) {
+  const int l = threadIdx.x & 63;
+  const int i = l & 15, cb = (l >> 4) & 1, hi = l >> 5;
+  const int b = db * 2 + cb;
+  const int inner = ((((i >> 2) + b) & 3) << 5) + ((i & 3) << 3);
+  const int q = (tok16 >> 2) + hi;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (q * 4 + b) * 128 + inner));
+  s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((q + 2) * 4 + b) * 128 + inner));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi4;
+  return u.v;
+}
+// 16-B global fragment: token (tok0 + lane&31), d = ks*16 + (lane>>5)*8 .. +8
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* src, long tok_stride, int tok0, int ntok_valid, int ks) {
+  const int l = threadIdx.x & 63;
+  const int tok = tok0 + (l & 31);
+  union { uint4 u; bf16x8 v; } x;
+  x.u = make_uint4(0, 0, 0, 0);
+  if (tok < ntok_valid) x.u = *reinterpret_cast<const uint4*>(src + (long)tok * tok_stride + ks * 16 + (l >> 5) * 8);
+  return x.v;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& p, int off) {
+  union { uint4 u; bf16x8 v; } x;
+  x.u = make_uint4(pack_bf2(p[off + 0], p[off + 1]), pack_bf2(p[off + 2], p[off + 3]), pack_bf2(p[off + 4], p[off + 5]),
+                   pack_bf2(p[off + 6], p[off + 7]));
+  return x.v;
+}
+// C-layout row index of register e for lane half hi
+__device__ __forceinline__ int crow(int e, int hi) { return (e & 3) + 8 * (e >> 2) + 4 * hi; }
+
+// write a [64 d][32 q] accumulator pair (C layout: lane -> q, regs -> d) as bf16 rows dst[q][0..63]
+// through a per-wave LDS scratch (32 x 144 B), so global stores are 16 B and row-contiguous.
+__device__ __forceinline__ void store_qd_tile(char* scratch, const f32x16 (&o)[2], float mul_lane, bf16_t* dst, long tok_stride,
+                                              int tok0, int ntok_valid) {
+  const int l = threadIdx.x & 63, q = l & 31, hi = l >> 5;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = db * 32 + 8 * g + 4 * hi;
+      *reinterpret_cast<uint2*>(scratch + q * 144 + d * 2) =
+          make_uint2(pack_bf2(o[db][4 * g] * mul_lane, o[db][4 * g + 1] * mul_lane),
+                     pack_bf2(o[db][4 * g + 2] * mul_lane, o[db][4 * g + 3] * mul_lane));
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private scratch, no barrier needed
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + (l >> 3), c = l & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(scratch + r * 144 + c * 16);
+    if (tok0 + r < ntok_valid) *reinterpret_cast<uint4*>(dst + (long)(tok0 + r) * tok_stride + c * 8) = v;
+  }
+}
+
+// ================================================================================================ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + IMG;
+  char* scratch = smem + 2 * IMG + (threadIdx.x >> 6) * (32 * 144);
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const long ts = 3L * H * DH;
+  const bf16_t* qb = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* kb = qb + (long)H * DH;
+  const bf16_t* vb = qb + 2L * H * DH;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = q0 < N;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ts, q0, N, ks);
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+
+  for (int c0 = 0; c0 < N; c0 += CH) {
+    __syncthreads();
+    stage_rows(ldsK, kb, ts, c0, N);
+    stage_tr(ldsV, vb, ts, c0, N);
+    __syncthreads();
+    if (!active) continue;
+    const int ntile = min(4, (N - c0 + 31) / 32);
+    for (int t = 0; t < ntile; ++t) {
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, t, ks), qf[ks], s, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = c0 + t * 32 + crow(e, hi);
+        s[e] = key < N ? s[e] * scale : -INFINITY;
+        mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __expf(m - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = __expf(s[e] - mnew); rs += s[e]; }
+      rs += __shfl_xor(rs, 32, 64);
+      lsum = lsum * alpha + rs;
+      m = mnew;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+      const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, t * 32), p0, o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, t * 32 + 16), p1, o[db], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  const int q = q0 + (l & 31);
+  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
+  store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
+}
+
+// ================================================================================================ backward
+// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d]
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int N,
+                                  int H, int dh, long total) {
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // (b*N + q)*H + h
+  if (wid >= total) return;
+  const int l = threadIdx.x & 63;
+  float s = 0.f;
+  for (int d = l; d < dh; d += 64) s += bf2f(o[wid * dh + d]) * bf2f(dout[wid * dh + d]);
+  s = wave_sum(s);
+  if (l == 0) {
+    const long tokq = wid / H; const int h = wid % H;
+    const long b = tokq / N, q = tokq % N;
+    delta[(b * H + h) * N + q] = s;
+  }
+}
+
+// dK, dV: waves own key tiles; query side streamed through LDS in chunks of 128 tokens
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsQ = smem;            // row image of Q
+  char* ldsQt = smem + IMG;     // T image of Q
+  char* ldsD = smem + 2 * IMG;  // row image of dO
+  char* ldsDt = smem + 3 * IMG; // T image of dO
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * IMG);  // lse [CH], delta [CH]
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qb = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* kb = qb + (long)H * DH;
+  const bf16_t* vb = qb + 2L * H * DH;
+  const bf16_t* dob = dout + (long)b * N * tso + h * DH;
+  const float* lseb = lse + ((long)b * H + h) * N;
+  const float* delb = delta + ((long)b * H + h) * N;
+  const int nkt = (N + 31) / 32;
+
+  for (int round = blockIdx.x * 4; round < nkt; round += gridDim.x * 4) {
+    const int kt = round + wave;
+    const bool active = kt < nkt;
+    const int k0 = kt * 32;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global(kb, ts, k0, N, ks); vf[ks] = frag_global(vb, ts, k0, N, ks); }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+    const bool key_ok = k0 + (l & 31) < N;
+
+    for (int c0 = 0; c0 < N; c0 += CH) {
+      __syncthreads();
+      stage_rows(ldsQ, qb, ts, c0, N);
+      stage_tr(ldsQt, qb, ts, c0, N);
+      stage_rows(ldsD, dob, tso, c0, N);
+      stage_tr(ldsDt, dob, tso, c0, N);
+      if (threadIdx.x < CH) {
+        const int q = c0 + threadIdx.x;
+        ldsL[threadIdx.x] = q < N ? lseb[q] : INFINITY;
+        ldsL[CH + threadIdx.x] = q < N ? delb[q] : 0.f;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int ntile = min(4, (N - c0 + 31) / 32);
+      for (int t = 0; t < ntile; ++t) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, t, ks), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, t, ks), vf[ks], dp, 0, 0, 0);
+        }
+        // rows = queries crow(e,hi), col = key lane
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[t * 32 + 8 * g + 4 * hi]);
+          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[CH + t * 32 + 8 * g + 4 * hi]);
+          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g + j;
+            const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - dlv[j]) * scale;
+          }
+        }
+        const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8), d0 = pack8(dp, 0), d1 = pack8(dp, 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, frag_tr(ldsDt, db, t * 32), dv[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, frag_tr(ldsDt, db, t * 32 + 16), dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, frag_tr(ldsQt, db, t * 32), dk[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, frag_tr(ldsQt, db, t * 32 + 16), dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (active) {
+      // acc layout D[key][d]: lane -> d column, regs -> key rows
+      bf16_t* dkb = dqkv + (long)b * N * ts + (long)H * DH + h * DH;
+      bf16_t* dvb = dqkv + (long)b * N * ts + 2L * H * DH + h * DH;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + crow(e, hi);
+          if (key < N) {
+            dkb[(long)key * ts + db * 32 + (l & 31)] = f2bf(dk[db][e]);
+            dvb[(long)key * ts + db * 32 + (l & 31)] = f2bf(dv[db][e]);
+          }
+        }
+    }
+  }
+}
+
+// dQ: waves own query tiles; key side streamed through LDS in chunks of 128 tokens
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsKt = smem + IMG;
+  char* ldsV = smem + 2 * IMG;
+  char* scratch = smem + 3 * IMG + (threadIdx.x >> 6) * (32 * 144);
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qb = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* kb = qb + (long)H * DH;
+  const bf16_t* vb = qb + 2L * H * DH;
+  const bf16_t* dob = dout + (long)b * N * tso + h * DH;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = q0 < N;
+  const int q = q0 + (l & 31);
+  const float lse_q = (q < N) ? lse[((long)b * H + h) * N + q] : INFINITY;
+  const float del_q = (q < N) ? delta[((long)b * H + h) * N + q] : 0.f;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_global(qb, ts, q0, N, ks); dof[ks] = frag_global(dob, tso, q0, N, ks); }
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+
+  for (int c0 = 0; c0 < N; c0 += CH) {
+    __syncthreads();
+    stage_rows(ldsK, kb, ts, c0, N);
+    stage_tr(ldsKt, kb, ts, c0, N);
+    stage_rows(ldsV, vb, ts, c0, N);
+    __syncthreads();
+    if (!active) continue;
+    const int ntile = min(4, (N - c0 + 31) / 32);
+    for (int t = 0; t < ntile; ++t) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, t, ks), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsV, t, ks), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = c0 + t * 32 + crow(e, hi);
+        const float p = key < N ? __expf(s[e] * scale - lse_q) : 0.f;
+        dp[e] = p * (dp[e] - del_q) * scale;
+      }
+      const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, t * 32), d0, dq[db], 0, 0, 0);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, t * 32 + 16), d1, dq[db], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  store_qd_tile(scratch, dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, q0, N);
+}
+
+// ================================================================================================ generic head dims
+// one block (64 threads) per (b, h, q); scores in LDS (N <= 4096)
+__global__ void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N,
+                                        int H, int dh, float scale) {
+  extern __shared__ float sc[];
+  __shared__ float red[16];
+  const int q = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
+  const long ts = 3L * H * dh;
+  const bf16_t* qp = qkv + ((long)b * N + q) * ts + h * dh;
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    const bf16_t* kp = qkv + ((long)b * N + k) * ts + (long)H * dh + h * dh;
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s = fmaf(bf2f(qp[d]), bf2f(kp[d]), s);
+    s *= scale;
+    sc[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_max(mx, red);
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) { const float p = __expf(sc[k] - mx); sc[k] = p; sum += p; }
+  sum = block_sum(sum, red);
+  __syncthreads();
+  if (threadIdx.x == 0 && lse) lse[((long)b * H + h) * N + q] = mx + __logf(sum);
+  for (int d = threadIdx.x; d < dh; d += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < N; ++k) acc = fmaf(sc[k] / sum, bf2f(qkv[((long)b * N + k) * ts + 2L * H * dh + h * dh + d]), acc);
+    out[((long)b * N + q) * H * dh + h * dh + d] = f2bf(acc);
+  }
+}
+// per (b,h,q): p, ds rows into scratch [B,H,N,N] and dQ
+__global__ void attn_bwd_generic_q_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                          const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ P,
+                                          float* __restrict__ dS, bf16_t* __restrict__ dqkv, int N, int H, int dh, float scale) {
+  const int q = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
+  const long ts = 3L * H * dh;
+  const bf16_t* qp = qkv + ((long)b * N + q) * ts + h * dh;
+  const bf16_t* dop = dout + ((long)b * N + q) * H * dh + h * dh;
+  const float l = lse[((long)b * H + h) * N + q], dl = delta[((long)b * H + h) * N + q];
+  float* prow = P + (((long)b * H + h) * N + q) * N;
+  float* dsrow = dS + (((long)b * H + h) * N + q) * N;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    const bf16_t* kp = qkv + ((long)b * N + k) * ts + (long)H * dh + h * dh;
+    const bf16_t* vp = qkv + ((long)b * N + k) * ts + 2L * H * dh + h * dh;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < dh; ++d) { s = fmaf(bf2f(qp[d]), bf2f(kp[d]), s); dp = fmaf(bf2f(dop[d]), bf2f(vp[d]), dp); }
+    const float p = __expf(s * scale - l);
+    prow[k] = p;
+    dsrow[k] = p * (dp - dl) * scale;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dh; d += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < N; ++k) acc = fmaf(dsrow[k], bf2f(qkv[((long)b * N + k) * ts + (long)H * dh + h * dh + d]), acc);
+    dqkv[((long)b * N + q) * ts + h * dh + d] = f2bf(acc);
+  }
+}
+// per (b,h,key): dK, dV
+__global__ void attn_bwd_generic_k_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ P,
+                                          const float* __restrict__ dS, bf16_t* __restrict__ dqkv, int N, int H, int dh) {
+  const int k = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
+  const long ts = 3L * H * dh;
+  for (int d = threadIdx.x; d < dh; d += blockDim.x) {
+    float ak = 0.f, av = 0.f;
+    for (int q = 0; q < N; ++q) {
+      const long o = (((long)b * H + h) * N + q) * N + k;
+      ak = fmaf(dS[o], bf2f(qkv[((long)b * N + q) * ts + h * dh + d]), ak);
+      av = fmaf(P[o], bf2f(dout[((long)b * N + q) * H * dh + h * dh + d]), av);
+    }
+    dqkv[((long)b * N + k) * ts + (long)H * dh + h * dh + d] = f2bf(ak);
+    dqkv[((long)b * N + k) * ts + 2L * H * dh + h * dh + d] = f2bf(av);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int64_t lt_attention_bwd_ws_floats(int B, int N, int H, int dh) {
+  const int64_t rows = (int64_t)B * H * N;
+  return dh == DH ? rows : rows * (1 + 2 * (int64_t)N);
+}
+
+extern "C" int lt_attention_fwd(const void* qkv, void* out_bf16, float* lse, int B, int N, int H, int dh, float scale, void* stream) {
+  LT_CHECK_ARG(qkv && out_bf16 && B > 0 && N > 0 && H > 0 && dh > 0, "lt_attention_fwd: bad arguments");
+  if (dh == DH) {
+    LT_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out_bf16 & 15) == 0, "lt_attention_fwd: 16-byte alignment required");
+    dim3 grid(lt_cdiv(N, 128), B * H);
+    const size_t smem = 2 * IMG + 4 * 32 * 144;
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), smem, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse, N, H, scale);
+  } else {
+    LT_CHECK_ARG(N <= 8192, "lt_attention_fwd: generic path supports N <= 8192 (N=%d)", N);
+    hipLaunchKernelGGL(attn_fwd_generic_kernel, dim3(N, B * H), dim3(64), N * sizeof(float), ST, (const bf16_t*)qkv,
+                       (bf16_t*)out_bf16, lse, N, H, dh, scale);
+  }
+  LT_CHECK_LAUNCH("lt_attention_fwd");
+}
+
+extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const void* dout_bf16, const float* lse, float* ws,
+                                void* dqkv, int B, int N, int H, int dh, float scale, void* stream) {
+  LT_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && ws && dqkv && B > 0 && N > 0 && H > 0 && dh > 0,
+               "lt_attention_bwd: bad arguments");
+  const long total = (long)B * N * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(lt_cdiv(total * 64, 256)), dim3(256), 0, ST, (const bf16_t*)out_bf16,
+                     (const bf16_t*)dout_bf16, ws, N, H, dh, total);
+  if (dh == DH) {
+    const int nkt = lt_cdiv(N, 32);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(min(lt_cdiv(nkt, 4), 4), B * H), dim3(256), 4 * IMG + 2 * CH * sizeof(float), ST,
+                       (const bf16_t*)qkv, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(lt_cdiv(N, 128), B * H), dim3(256), 3 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
+                       (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+  } else {
+    float* P = ws + (long)B * H * N;
+    float* dS = P + (long)B * H * N * N;
+    hipLaunchKernelGGL(attn_bwd_generic_q_kernel, dim3(N, B * H), dim3(64), 0, ST, (const bf16_t*)qkv, (const bf16_t*)dout_bf16, lse,
+                       ws, P, dS, (bf16_t*)dqkv, N, H, dh, scale);
+    hipLaunchKernelGGL(attn_bwd_generic_k_kernel, dim3(N, B * H), dim3(64), 0, ST, (const bf16_t*)qkv, (const bf16_t*)dout_bf16, P, dS,
+                       (bf16_t*)dqkv, N, H, dh);
+  }
+  LT_CHECK_LAUNCH("lt_attention_bwd");
+}

@@ -1,0 +1,469 @@
+// HBM-bound kernels of the ViT token path: im2col, token assembly, LayerNorm fwd/bwd, LayerScale bwd,
+// column sums, row gather/scatter, casts, L2-normalise, weight-norm.  All are coalesced 16-byte
+// (4 x f32 / 8 x bf16) streams, one wave (64 lanes) per row where a row reduction is needed.
+#include "lt_common.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane cached in registers: rows up to 2048 wide
+
+// ------------------------------------------------------------------------------------ im2col
+__global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int B, int C, int H, int W, int p,
+                              int kpad) {
+  const int gh = H / p, gw = W / p;
+  const long row = blockIdx.x;  // b*gh*gw + gy*gw + gx
+  const int b = row / (gh * gw), rem = row % (gh * gw), gy = rem / gw, gx = rem % gw;
+  const int kreal = C * p * p;
+  for (int k = threadIdx.x; k < kpad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < kreal) {
+      const int c = k / (p * p), r = k % (p * p), py = r / p, px = r % p;
+      v = img[(((long)b * C + c) * H + gy * p + py) * W + gx * p + px];
+    }
+    cols[row * kpad + k] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------ tokens
+__global__ void assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                const float* __restrict__ mask_token, const uint8_t* __restrict__ masks, float* __restrict__ x,
+                                int B, int n_p, int D) {
+  const long tok = blockIdx.x;  // b*(n_p+1) + t
+  const int N = n_p + 1;
+  const int b = tok / N, t = tok % N;
+  const float* src;
+  if (t == 0) src = cls;
+  else if (masks && masks[(long)b * n_p + t - 1]) src = mask_token;
+  else src = patch + ((long)b * n_p + t - 1) * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) x[tok * D + d] = src[d] + pos[(long)t * D + d];
+}
+
+// one thread per (t, d): loops over the batch (coalesced over d)
+__global__ void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t* __restrict__ masks, bf16_t* __restrict__ dpatch,
+                                    float* __restrict__ dcls, float* __restrict__ dpos, float* __restrict__ dmask, int B, int n_p,
+                                    int D) {
+  const int N = n_p + 1;
+  const int t = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float sum = 0.f, msum = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = dx[((long)b * N + t) * D + d];
+      sum += g;
+      if (t > 0) {
+        const bool m = masks && masks[(long)b * n_p + t - 1];
+        if (m) msum += g;
+        dpatch[((long)b * n_p + t - 1) * D + d] = m ? (bf16_t)0 : f2bf(g);
+      }
+    }
+    dpos[(long)t * D + d] += sum;
+    if (t == 0) dcls[d] += sum;
+    else if (masks && msum != 0.f) atomicAdd(&dmask[d], msum);
+  }
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+__device__ __forceinline__ void load_row(float4 (&v)[MAXV], const float* __restrict__ p, int D, int lane) {
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = (c < D) ? *reinterpret_cast<const float4*>(p + c) : make_float4(0, 0, 0, 0);
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, bf16_t* __restrict__ yb,
+                                                            float* __restrict__ yf, float* __restrict__ mean_o,
+                                                            float* __restrict__ rstd_o, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  if (VEC) {
+    float4 v[MAXV];
+    load_row(v, xr, D, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+        q += a * a + bb * bb + cc * cc + dd * dd;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        const float4 bb = *reinterpret_cast<const float4*>(b + c);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+        o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+        o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+        if (yf) *reinterpret_cast<float4*>(yf + row * D + c) = o;
+        if (yb) *reinterpret_cast<uint2*>(yb + row * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+      }
+    }
+  } else {
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float a = xr[c] - mean; q += a * a; }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
+    }
+    for (int c = lane; c < D; c += 64) {
+      const float o = (xr[c] - mean) * rstd * w[c] + b[c];
+      if (yf) yf[row * D + c] = o;
+      if (yb) yb[row * D + c] = f2bf(o);
+    }
+  }
+}
+
+// generic (scalar-column) backward; each wave walks rows with stride, keeps dw/db partials per lane-column
+// in registers for up to 32 columns per lane (D <= 2048), reduces over the block's 4 waves in LDS,
+// then one atomicAdd per column per block.
+template <bool DYF32>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const void* __restrict__ dyv, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                            int rows, int D) {
+  constexpr int MAXC = 32;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float aw[MAXC], ab[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + row * D;
+    float xh[MAXC], gy[MAXC];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      xh[i] = 0.f; gy[i] = 0.f;
+      if (c < D) {
+        const float dyv_ = DYF32 ? ((const float*)dyv)[row * D + c] : bf2f(((const bf16_t*)dyv)[row * D + c]);
+        xh[i] = (xr[c] - mu) * rs;
+        gy[i] = dyv_ * w[c];
+        c1 += gy[i];
+        c2 += gy[i] * xh[i];
+        aw[i] += dyv_ * xh[i];
+        ab[i] += dyv_;
+      }
+    }
+    c1 = wave_sum(c1) / D;
+    c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < D) {
+        float o = rs * (gy[i] - c1 - xh[i] * c2);
+        if (dres) o += dres[row * D + c];
+        dx[row * D + c] = o;
+      }
+    }
+  }
+  // cross-wave reduction, one column group (64 columns) at a time
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    if (i * 64 >= D) break;
+    __syncthreads();
+    red[0][wv][lane] = aw[i];
+    red[1][wv][lane] = ab[i];
+    __syncthreads();
+    if (wv == 0) {
+      const int c = i * 64 + lane;
+      if (c < D) {
+        atomicAdd(&dw[c], red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+        atomicAdd(&db[c], red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ LayerScale bwd
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                             const float* __restrict__ gamma, bf16_t* __restrict__ dy,
+                                                             float* __restrict__ dgamma, int rows, int D) {
+  // block = 256 threads: 64 column-lanes x 4 row-lanes; grid.x over column groups of 64, grid.y over row slabs
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < D) {
+    const float gm = gamma ? gamma[c] : 1.f;
+    for (long r = (long)blockIdx.y * 4 + rl; r < rows; r += (long)gridDim.y * 4) {
+      const float g = dout[r * D + c];
+      dy[r * D + c] = f2bf(g * gm);
+      if (gamma) acc += g * bf2f(y[r * D + c]);
+    }
+  }
+  if (gamma) {
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < D) atomicAdd(&dgamma[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int N) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < N) {
+    for (long r = (long)blockIdx.y * 4 + rl; r < rows; r += (long)gridDim.y * 4) {
+      if (sizeof(T) == 2) acc += bf2f(((const bf16_t*)x)[r * N + c]);
+      else acc += ((const float*)x)[r * N + c];
+    }
+  }
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+// ------------------------------------------------------------------------------------ gather / scatter / cast
+__global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const int64_t* __restrict__ idx, bf16_t* __restrict__ ob,
+                                   float* __restrict__ of, int M, int D) {
+  const long m = blockIdx.x;
+  const float* s = src + idx[m] * ld;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float v = s[d];
+    if (of) of[m * D + d] = v;
+    if (ob) ob[m * D + d] = f2bf(v);
+  }
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
+                                        int ld, int M, int D) {
+  const long m = blockIdx.x;
+  float* o = dst + idx[m] * ld;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) o[d] += src[m * D + d];
+}
+__global__ void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(s + i);
+    *reinterpret_cast<uint2*>(d + i) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+  if (i < n) for (long j = i; j < n && j < i + 4; ++j) d[j] = f2bf(s[j]);
+}
+__global__ void fill_kernel(float* d, float v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = v;
+}
+
+// ------------------------------------------------------------------------------------ L2 normalise / weight-norm
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                         float* __restrict__ inv, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+  const float nrm = sqrtf(wave_sum(s));
+  const float iv = 1.f / fmaxf(nrm, eps);
+  if (lane == 0) inv[row] = iv;
+  for (int c = lane; c < D; c += 64) y[row * D + c] = f2bf(xr[c] * iv);
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ inv, bf16_t* __restrict__ dx, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float iv = inv[row];
+  float dot = 0.f;
+  for (int c = lane; c < D; c += 64) dot += dy[row * D + c] * x[row * D + c] * iv;
+  dot = wave_sum(dot);
+  for (int c = lane; c < D; c += 64) {
+    const float yv = x[row * D + c] * iv;
+    dx[row * D + c] = f2bf((dy[row * D + c] - yv * dot) * iv);
+  }
+}
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                             bf16_t* __restrict__ w, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= K) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float a = v[row * D + c]; s += a * a; }
+  const float sc = g[row] / sqrtf(wave_sum(s));
+  for (int c = lane; c < D; c += 64) w[row * D + c] = f2bf(v[row * D + c] * sc);
+}
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                             const float* __restrict__ g, float* __restrict__ dv,
+                                                             float* __restrict__ dg, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= K) return;
+  float s = 0.f, dot = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float a = v[row * D + c];
+    s += a * a;
+    dot += a * dw[row * D + c];
+  }
+  s = wave_sum(s);
+  dot = wave_sum(dot);
+  const float nrm = sqrtf(s), gg = g[row];
+  if (lane == 0) dg[row] += dot / nrm;
+  for (int c = lane; c < D; c += 64)
+    dv[row * D + c] += gg / nrm * (dw[row * D + c] - v[row * D + c] * dot / s);
+}
+
+// tiny fp32 matmul (pos-embed interpolation map): C[M,N] (+)= op(A)[M,K] B[K,N]
+__global__ void matmul_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
+                                  int K, int ta, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(ta ? A[(long)k * M + m] : A[(long)m * K + k], B[(long)k * N + n], s);
+  if (accumulate) C[(long)m * N + n] += s;
+  else C[(long)m * N + n] = s;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H, int W, int p, int kpad, void* stream) {
+  LT_CHECK_ARG(img && cols && B > 0 && p > 0 && H % p == 0 && W % p == 0 && kpad >= C * p * p,
+               "lt_im2col_bf16: bad arguments (H=%d W=%d p=%d kpad=%d)", H, W, p, kpad);
+  hipLaunchKernelGGL(im2col_kernel, dim3(B * (H / p) * (W / p)), dim3(256), 0, ST, img, (bf16_t*)cols, B, C, H, W, p, kpad);
+  LT_CHECK_LAUNCH("lt_im2col_bf16");
+}
+extern "C" int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
+                                  const uint8_t* masks, float* x, int B, int n_p, int D, void* stream) {
+  LT_CHECK_ARG(patch && cls && pos && x && (!masks || mask_token), "lt_assemble_tokens: null pointer");
+  hipLaunchKernelGGL(assemble_kernel, dim3(B * (n_p + 1)), dim3(256), 0, ST, patch, cls, pos, mask_token, masks, x, B, n_p, D);
+  LT_CHECK_LAUNCH("lt_assemble_tokens");
+}
+extern "C" int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_bf16, float* dcls, float* dpos,
+                                      float* dmask_token, int B, int n_p, int D, void* stream) {
+  LT_CHECK_ARG(dx && dpatch_bf16 && dcls && dpos && (!masks || dmask_token), "lt_assemble_tokens_bwd: null pointer");
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(n_p + 1), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls, dpos,
+                     dmask_token, B, n_p, D);
+  LT_CHECK_LAUNCH("lt_assemble_tokens_bwd");
+}
+extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                                float* rstd, int rows, int D, float eps, void* stream) {
+  LT_CHECK_ARG(x && w && b && (y_bf16 || y_f32) && rows >= 0 && D > 0 && D <= MAXV * 256, "lt_layernorm_fwd: bad arguments (D=%d)", D);
+  if (rows == 0) return LT_OK;
+  if (D % 4 == 0)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(lt_cdiv(rows, 4)), dim3(256), 0, ST, x, w, b, (bf16_t*)y_bf16, y_f32,
+                       mean, rstd, rows, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(lt_cdiv(rows, 4)), dim3(256), 0, ST, x, w, b, (bf16_t*)y_bf16, y_f32,
+                       mean, rstd, rows, D, eps);
+  LT_CHECK_LAUNCH("lt_layernorm_fwd");
+}
+extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                                int dy_is_f32, const float* dres, float* dx, float* dw, float* db, int rows, int D, void* stream) {
+  LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
+  if (rows == 0) return LT_OK;
+  const int grid = min(lt_cdiv(rows, 4), 1024);
+  if (dy_is_f32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
+  LT_CHECK_LAUNCH("lt_layernorm_bwd");
+}
+extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
+                                 int rows, int D, void* stream) {
+  LT_CHECK_ARG(dout && dy_bf16 && (!gamma || (y_bf16 && dgamma)), "lt_layerscale_bwd: null pointer");
+  if (rows == 0) return LT_OK;
+  dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
+  hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
+                     dgamma, rows, D);
+  LT_CHECK_LAUNCH("lt_layerscale_bwd");
+}
+extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream) {
+  LT_CHECK_ARG(x && out, "lt_colsum_bf16: null pointer");
+  if (rows == 0) return LT_OK;
+  dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
+  hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
+  LT_CHECK_LAUNCH("lt_colsum_bf16");
+}
+extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream) {
+  LT_CHECK_ARG(x && out, "lt_colsum_f32: null pointer");
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, ST);
+    if (e != hipSuccess) { lt_set_error("lt_colsum_f32: memset failed"); return LT_ERR_HIP; }
+  }
+  if (rows == 0) return LT_OK;
+  dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
+  hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, x, out, rows, N);
+  LT_CHECK_LAUNCH("lt_colsum_f32");
+}
+extern "C" int lt_gather_rows(const float* src, int ld_src, const int64_t* idx, void* out_bf16, float* out_f32, int M, int D,
+                              void* stream) {
+  LT_CHECK_ARG(src && idx && (out_bf16 || out_f32), "lt_gather_rows: null pointer");
+  if (M == 0) return LT_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, ST, src, ld_src, idx, (bf16_t*)out_bf16, out_f32, M, D);
+  LT_CHECK_LAUNCH("lt_gather_rows");
+}
+extern "C" int lt_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int ld_dst, int M, int D, void* stream) {
+  LT_CHECK_ARG(src && idx && dst, "lt_scatter_add_rows: null pointer");
+  if (M == 0) return LT_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(M), dim3(256), 0, ST, src, idx, dst, ld_dst, M, D);
+  LT_CHECK_LAUNCH("lt_scatter_add_rows");
+}
+extern "C" int lt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  LT_CHECK_ARG(src && dst && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "lt_cast_f32_to_bf16: bad pointer/alignment");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)2048, (long)lt_cdiv(n, 1024));
+  hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, ST, src, (bf16_t*)dst, (long)n);
+  LT_CHECK_LAUNCH("lt_cast_f32_to_bf16");
+}
+extern "C" int lt_fill_f32(float* dst, float value, int64_t n, void* stream) {
+  LT_CHECK_ARG(dst, "lt_fill_f32: null pointer");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)2048, (long)lt_cdiv(n, 256));
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, ST, dst, value, (long)n);
+  LT_CHECK_LAUNCH("lt_fill_f32");
+}
+extern "C" int lt_l2norm_fwd(const float* x, void* y_bf16, float* inv_norm, int rows, int D, float eps, void* stream) {
+  LT_CHECK_ARG(x && y_bf16 && inv_norm, "lt_l2norm_fwd: null pointer");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(lt_cdiv(rows, 4)), dim3(256), 0, ST, x, (bf16_t*)y_bf16, inv_norm, rows, D, eps);
+  LT_CHECK_LAUNCH("lt_l2norm_fwd");
+}
+extern "C" int lt_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, void* dx_bf16, int rows, int D, void* stream) {
+  LT_CHECK_ARG(dy && x && inv_norm && dx_bf16, "lt_l2norm_bwd: null pointer");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(lt_cdiv(rows, 4)), dim3(256), 0, ST, dy, x, inv_norm, (bf16_t*)dx_bf16, rows, D);
+  LT_CHECK_LAUNCH("lt_l2norm_bwd");
+}
+extern "C" int lt_weightnorm_fwd(const float* v, const float* g, void* w_bf16, int K, int D, void* stream) {
+  LT_CHECK_ARG(v && g && w_bf16, "lt_weightnorm_fwd: null pointer");
+  hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(lt_cdiv(K, 4)), dim3(256), 0, ST, v, g, (bf16_t*)w_bf16, K, D);
+  LT_CHECK_LAUNCH("lt_weightnorm_fwd");
+}
+extern "C" int lt_weightnorm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int K, int D, void* stream) {
+  LT_CHECK_ARG(dw && v && g && dv && dg, "lt_weightnorm_bwd: null pointer");
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(lt_cdiv(K, 4)), dim3(256), 0, ST, dw, v, g, dv, dg, K, D);
+  LT_CHECK_LAUNCH("lt_weightnorm_bwd");
+}
+extern "C" int lt_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate, void* stream) {
+  LT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "lt_matmul_f32: bad arguments");
+  hipLaunchKernelGGL(matmul_f32_kernel, dim3(lt_cdiv(N, 128), M), dim3(128), 0, ST, A, B, C, M, N, K, trans_a, accumulate);
+  LT_CHECK_LAUNCH("lt_matmul_f32");
+}

@@ -1,0 +1,232 @@
+// DINO / iBOT prototype losses over K = 65 536 prototypes (LT/_methods/dinov2/dinov2_loss.py) and KoLeo.
+// One 256-thread block per logits row; rows are streamed as float4 with an online (max, sum-exp) so each
+// row is read twice (second pass from L2: one row = 256 KiB) instead of three times.
+#include "lt_common.h"
+
+namespace {
+
+struct MaxSum { float m, s; };
+__device__ __forceinline__ MaxSum ms_combine(MaxSum a, MaxSum b) {
+  const float m = fmaxf(a.m, b.m);
+  MaxSum r;
+  r.m = m;
+  r.s = (a.m == -INFINITY ? 0.f : a.s * __expf(a.m - m)) + (b.m == -INFINITY ? 0.f : b.s * __expf(b.m - m));
+  return r;
+}
+__device__ __forceinline__ void ms_push(MaxSum& a, float z) {
+  if (z > a.m) { a.s = a.s * __expf(a.m - z) + 1.f; a.m = z; }
+  else a.s += __expf(z - a.m);
+}
+__device__ __forceinline__ MaxSum block_ms(MaxSum v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxSum other;
+    other.m = __shfl_xor(v.m, o, 64);
+    other.s = __shfl_xor(v.s, o, 64);
+    v = ms_combine(v, other);
+  }
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[2 * w] = v.m; red[2 * w + 1] = v.s; }
+  __syncthreads();
+  MaxSum r; r.m = red[0]; r.s = red[1];
+  for (int i = 1; i < nw; ++i) { MaxSum o; o.m = red[2 * i]; o.s = red[2 * i + 1]; r = ms_combine(r, o); }
+  return r;
+}
+
+// probs = softmax((logits - center) * inv_temp)
+__global__ __launch_bounds__(256) void softmax_center_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+                                                             float* __restrict__ probs, int K, float inv_temp) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* x = logits + row * K;
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) ms_push(a, (x[k] - (center ? center[k] : 0.f)) * inv_temp);
+  a = block_ms(a, red);
+  const float inv = 1.f / a.s;
+  for (int k = threadIdx.x; k < K; k += 256)
+    probs[row * K + k] = __expf((x[k] - (center ? center[k] : 0.f)) * inv_temp - a.m) * inv;
+}
+
+__global__ void center_ema_kernel(float* center, const float* colsum, float scale, float momentum, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) center[k] = center[k] * momentum + colsum[k] * scale * (1.f - momentum);
+}
+
+// fused CE forward + d(logits)
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, const float* __restrict__ teacher,
+                                                 const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
+                                                 const float* __restrict__ row_weight, float scale, float inv_temp,
+                                                 float* __restrict__ loss, bf16_t* __restrict__ dlogits, int K) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* z = s + row * K;
+  const float* t0 = teacher + (long)ta[row] * K;
+  const float* t1 = tb ? teacher + (long)tb[row] * K : nullptr;
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  float dot = 0.f, tsum = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float zk = z[k] * inv_temp;
+    const float tk = t0[k] + (t1 ? t1[k] : 0.f);
+    ms_push(a, zk);
+    dot += tk * zk;
+    tsum += tk;
+  }
+  a = block_ms(a, red);
+  dot = block_sum(dot, red);
+  tsum = block_sum(tsum, red);
+  const float lse = a.m + __logf(a.s);
+  const float coef = scale * (row_weight ? row_weight[row] : 1.f);
+  if (threadIdx.x == 0) atomicAdd(loss, -coef * (dot - lse * tsum));
+  if (dlogits) {
+    const float c2 = coef * inv_temp;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float zk = z[k] * inv_temp;
+      const float tk = t0[k] + (t1 ? t1[k] : 0.f);
+      dlogits[row * K + k] = f2bf(c2 * (__expf(zk - lse) * tsum - tk));
+    }
+  }
+}
+
+__global__ void sk_exp_kernel(const float* __restrict__ x, float* __restrict__ q, long n, float inv_temp) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) q[i] = __expf(x[i] * inv_temp);
+}
+__global__ __launch_bounds__(256) void sk_iter_kernel(float* __restrict__ Q, const float* __restrict__ colsum, int K, float n_total,
+                                                      float final_mul) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  float* q = Q + row * K;
+  const float invK = 1.f / (float)K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += q[k] / colsum[k] * invK;
+  s = block_sum(s, red);
+  const float mul = final_mul / (s * n_total);
+  for (int k = threadIdx.x; k < K; k += 256) q[k] = q[k] / colsum[k] * invK * mul;
+}
+
+// ------------------------------------------------------------------------------------ KoLeo
+// ws layout: xn [n*D], inv_norm [n], coef [n]
+__global__ __launch_bounds__(256) void koleo_normalize_kernel(const float* __restrict__ x, int ld, float* __restrict__ xn,
+                                                              float* __restrict__ inv, int D, float eps) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) { const float a = x[(long)i * ld + d]; s += a * a; }
+  s = block_sum(s, red);
+  const float iv = 1.f / fmaxf(sqrtf(s), eps);
+  if (threadIdx.x == 0) inv[i] = iv;
+  for (int d = threadIdx.x; d < D; d += 256) xn[(long)i * D + d] = x[(long)i * ld + d] * iv;
+}
+// one block per row i: nearest neighbour by max cosine (diag excluded), distance, loss, per-row coefficient
+__global__ __launch_bounds__(256) void koleo_nn_kernel(const float* __restrict__ xn, int32_t* __restrict__ nn, float* __restrict__ coef,
+                                                       float* __restrict__ loss, int n, int D, float eps, float weight) {
+  __shared__ float sval[256];
+  __shared__ int sidx[256];
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  float best = -INFINITY; int bj = 0x7fffffff;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (j == i) continue;
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot = fmaf(xn[(long)i * D + d], xn[(long)j * D + d], dot);
+    if (dot > best) { best = dot; bj = j; }
+  }
+  sval[threadIdx.x] = best; sidx[threadIdx.x] = bj;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float v2 = sval[threadIdx.x + o]; const int i2 = sidx[threadIdx.x + o];
+      if (v2 > sval[threadIdx.x] || (v2 == sval[threadIdx.x] && i2 < sidx[threadIdx.x])) { sval[threadIdx.x] = v2; sidx[threadIdx.x] = i2; }
+    }
+    __syncthreads();
+  }
+  const int j = sidx[0];
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) { const float u = xn[(long)i * D + d] - xn[(long)j * D + d] + eps; s += u * u; }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float dist = sqrtf(s);
+    nn[i] = j;
+    // L = -(1/n) sum log(dist + eps);  dL/du = -(1/n) * 1/(dist+eps) * u/dist
+    coef[i] = -weight / ((float)n * (dist + eps) * fmaxf(dist, 1e-30f));
+    atomicAdd(loss, -weight * __logf(dist + eps) / (float)n);
+  }
+}
+// dxn[i] += c_i*u_i ; dxn[nn(i)] -= c_i*u_i  (atomics: several i may share a neighbour)
+__global__ __launch_bounds__(256) void koleo_dxn_kernel(const float* __restrict__ xn, const int32_t* __restrict__ nn,
+                                                        const float* __restrict__ coef, float* __restrict__ dxn, int D, float eps) {
+  const int i = blockIdx.x, j = nn[i];
+  const float c = coef[i];
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float g = c * (xn[(long)i * D + d] - xn[(long)j * D + d] + eps);
+    atomicAdd(&dxn[(long)i * D + d], g);
+    atomicAdd(&dxn[(long)j * D + d], -g);
+  }
+}
+// through x/max(||x||,eps): dx += (dxn - xn*(xn.dxn)) * inv
+__global__ __launch_bounds__(256) void koleo_dx_kernel(const float* __restrict__ xn, const float* __restrict__ dxn,
+                                                       const float* __restrict__ inv, float* __restrict__ dx, int ld_dx, int D) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  float dot = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) dot += xn[(long)i * D + d] * dxn[(long)i * D + d];
+  dot = block_sum(dot, red);
+  const float iv = inv[i];
+  for (int d = threadIdx.x; d < D; d += 256)
+    dx[(long)i * ld_dx + d] += (dxn[(long)i * D + d] - xn[(long)i * D + d] * dot) * iv;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream) {
+  LT_CHECK_ARG(logits && probs && K > 0, "lt_softmax_center: bad arguments");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(softmax_center_kernel, dim3(rows), dim3(256), 0, ST, logits, center, probs, K, inv_temp);
+  LT_CHECK_LAUNCH("lt_softmax_center");
+}
+extern "C" int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream) {
+  LT_CHECK_ARG(center && colsum, "lt_center_ema: null pointer");
+  hipLaunchKernelGGL(center_ema_kernel, dim3(lt_cdiv(K, 256)), dim3(256), 0, ST, center, colsum, scale, momentum, K);
+  LT_CHECK_LAUNCH("lt_center_ema");
+}
+extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
+                             float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K, void* stream) {
+  LT_CHECK_ARG(s && teacher && ta && loss && K > 0, "lt_ce_fwd_bwd: bad arguments");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, scale, inv_temp, loss,
+                     (bf16_t*)dlogits_bf16, K);
+  LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
+}
+extern "C" int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream) {
+  LT_CHECK_ARG(logits && Q, "lt_sk_exp: null pointer");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)4096, (long)lt_cdiv(n, 256));
+  hipLaunchKernelGGL(sk_exp_kernel, dim3(grid), dim3(256), 0, ST, logits, Q, (long)n, inv_temp);
+  LT_CHECK_LAUNCH("lt_sk_exp");
+}
+extern "C" int lt_sk_iter(float* Q, const float* colsum, int rows, int K, float n_total, float final_mul, void* stream) {
+  LT_CHECK_ARG(Q && colsum && K > 0, "lt_sk_iter: bad arguments");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(sk_iter_kernel, dim3(rows), dim3(256), 0, ST, Q, colsum, K, n_total, final_mul);
+  LT_CHECK_LAUNCH("lt_sk_iter");
+}
+extern "C" int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, int ld_dx, int n, int D, float eps, float weight,
+                                float* ws, int32_t* nn, void* stream) {
+  LT_CHECK_ARG(x && loss && dx && ws && nn && n > 1 && D > 0, "lt_koleo_fwd_bwd: bad arguments (n=%d)", n);
+  float* xn = ws;
+  float* inv = ws + (size_t)n * D;
+  float* coef = inv + n;
+  // dxn is accumulated in place of a second buffer: reuse dx? no -- separate scratch after coef
+  float* dxn = coef + n;
+  hipError_t e = hipMemsetAsync(dxn, 0, sizeof(float) * (size_t)n * D, ST);
+  if (e != hipSuccess) { lt_set_error("lt_koleo_fwd_bwd: memset failed"); return LT_ERR_HIP; }
+  hipLaunchKernelGGL(koleo_normalize_kernel, dim3(n), dim3(256), 0, ST, x, ld, xn, inv, D, eps);
+  hipLaunchKernelGGL(koleo_nn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, loss, n, D, eps, weight);
+  hipLaunchKernelGGL(koleo_dxn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, D, eps);
+  hipLaunchKernelGGL(koleo_dx_kernel, dim3(n), dim3(256), 0, ST, xn, dxn, inv, dx, ld_dx, D);
+  LT_CHECK_LAUNCH("lt_koleo_fwd_bwd");
+}

@@ -1,0 +1,91 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the DINOv2 hot path.
+// wave = 64 lanes; all kernels are written for gfx950 only (no dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lt_amd.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type in HBM / LDS)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LT_WAVE 64
+
+// ---- error plumbing (host) -----------------------------------------------------------
+void lt_set_error(const char* fmt, ...);
+#define LT_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      lt_set_error(__VA_ARGS__);            \
+      return LT_ERR_INVALID;                \
+    }                                       \
+  } while (0)
+#define LT_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      lt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return LT_ERR_HIP;                                                        \
+    }                                                                           \
+    return LT_OK;                                                               \
+  } while (0)
+
+// ---- bf16 <-> f32 (device) -----------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave / block reductions ---------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reductions; `red` = LDS scratch of >= 32 floats; result broadcast to all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = red[0];
+  for (int i = 1; i < nw; ++i) s = fmaxf(s, red[i]);
+  return s;
+}
+
+// exact-erf GELU (nn.GELU default, layers/mlp.py:36-42) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int lt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,106 @@
+// Multi-tensor optimizer kernels on flat parameter storage: global grad-norm, AdamW (+clip, +bf16 shadow),
+// EMA teacher update (+bf16 shadow).  Pure HBM streams: AdamW moves 28 B/param, EMA 14 B/param.
+// Replaces torch.optim.AdamW(foreach) + clip_grad_norm_ + _foreach_mul_/_foreach_add_
+// (LT/_methods/dinov2/utils.py:191-250, dinov2.py:588-660, LT/_torch_helpers.py:75-96).
+#include "lt_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n) {
+  __shared__ float red[16];
+  float s = 0.f;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(g + i);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (i < n) for (long j = i; j < n; ++j) s += g[j] * g[j];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// one block per 1024-element chunk (a chunk never straddles two parameter tensors)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n,
+                                                    const int32_t* __restrict__ seg_of_chunk, const float* __restrict__ seg_lr,
+                                                    const uint8_t* __restrict__ seg_wd_on, const uint8_t* __restrict__ seg_frozen,
+                                                    int freeze, float lr_factor, float wd, float beta1, float beta2, float eps,
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ sumsq, float max_norm) {
+  const long chunk = blockIdx.x;
+  const int seg = seg_of_chunk[chunk];
+  float lr = seg_lr[seg] * lr_factor;
+  if (freeze && seg_frozen[seg]) lr = 0.f;
+  const float wdv = seg_wd_on[seg] ? wd : 0.f;
+  float clip = 1.f;
+  if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+  const long i = chunk * 1024 + threadIdx.x * 4;
+  if (i >= n) return;
+  float4 pp = *reinterpret_cast<float4*>(p + i);
+  float4 gg = *reinterpret_cast<const float4*>(g + i);
+  float4 mm = *reinterpret_cast<float4*>(m + i);
+  float4 vv = *reinterpret_cast<float4*>(v + i);
+  float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gr = G[e] * clip;
+    P[e] *= 1.f - lr * wdv;                      // decoupled weight decay (torch AdamW order)
+    M[e] = M[e] + (gr - M[e]) * (1.f - beta1);   // lerp form used by torch
+    V[e] = V[e] * beta2 + gr * gr * (1.f - beta2);
+    const float denom = sqrtf(V[e]) / bc2_sqrt + eps;
+    P[e] -= (lr / bc1) * (M[e] / denom);
+  }
+  *reinterpret_cast<float4*>(p + i) = pp;
+  *reinterpret_cast<float4*>(m + i) = mm;
+  *reinterpret_cast<float4*>(v + i) = vv;
+  if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf2(pp.x, pp.y), pack_bf2(pp.z, pp.w));
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, bf16_t* __restrict__ tb, long n,
+                                                  float mom) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  const float om = 1.f - mom;
+  for (; i + 3 < n; i += stride) {
+    float4 a = *reinterpret_cast<float4*>(t + i);
+    const float4 b = *reinterpret_cast<const float4*>(s + i);
+    a.x = a.x * mom + b.x * om; a.y = a.y * mom + b.y * om; a.z = a.z * mom + b.z * om; a.w = a.w * mom + b.w * om;
+    *reinterpret_cast<float4*>(t + i) = a;
+    if (tb) *reinterpret_cast<uint2*>(tb + i) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream) {
+  LT_CHECK_ARG(g && out && ((uintptr_t)g & 15) == 0, "lt_sumsq_f32: bad pointer/alignment");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)1024, (long)lt_cdiv(n, 1024));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, out, (long)n);
+  LT_CHECK_LAUNCH("lt_sumsq_f32");
+}
+
+extern "C" int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int32_t* seg_of_chunk,
+                             const float* seg_lr, const uint8_t* seg_wd_on, const uint8_t* seg_frozen, int freeze,
+                             float lr_factor, float wd, float beta1, float beta2, float eps, int step, const float* sumsq,
+                             float max_norm, void* stream) {
+  LT_CHECK_ARG(p && g && m && v && seg_of_chunk && seg_lr && seg_wd_on && seg_frozen, "lt_adamw_flat: null pointer");
+  LT_CHECK_ARG(n % 1024 == 0, "lt_adamw_flat: n must be a multiple of the 1024-element chunk (n=%ld)", (long)n);
+  LT_CHECK_ARG(step >= 1 && (max_norm <= 0.f || sumsq), "lt_adamw_flat: step must be >= 1 and sumsq given when clipping");
+  if (n == 0) return LT_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, m, v, (bf16_t*)p_bf16, (long)n, seg_of_chunk,
+                     seg_lr, seg_wd_on, seg_frozen, freeze, lr_factor, wd, beta1, beta2, eps, bc1, bc2_sqrt, sumsq, max_norm);
+  LT_CHECK_LAUNCH("lt_adamw_flat");
+}
+
+extern "C" int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, float m, void* stream) {
+  LT_CHECK_ARG(teacher && student && n % 4 == 0, "lt_ema_flat: bad arguments");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)2048, (long)lt_cdiv(n, 1024));
+  hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, ST, teacher, student, (bf16_t*)teacher_bf16, (long)n, m);
+  LT_CHECK_LAUNCH("lt_ema_flat");
+}

@@ -1,0 +1,238 @@
+"""torch-tensor front-ends of the C ABI (include/lt_amd.h).  torch is plumbing only: it owns the HBM
+allocations and the HIP stream; every arithmetic op below runs in liblt_amd.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import (EPI_BF16, EPI_BF16_GELU, EPI_BF16_GELUGRAD, EPI_F32, EPI_F32_ACCUM, EPI_RESID, GemmDesc, check)
+
+__all__ = ["EPI_BF16", "EPI_BF16_GELU", "EPI_RESID", "EPI_F32", "EPI_BF16_GELUGRAD", "EPI_F32_ACCUM"]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "lightly_train_amd ops need device tensors (no CPU fallback)"
+    return t.data_ptr()
+
+
+def _chk(t: Tensor, dtype: torch.dtype, name: str) -> None:
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"{name}: expected contiguous device tensor of {dtype}, got {t.dtype} contiguous={t.is_contiguous()} cuda={t.is_cuda}")
+
+
+def device_info() -> dict:
+    lib = _lib.load()
+    name = C.create_string_buffer(128)
+    cu, clk = C.c_int(0), C.c_int(0)
+    check(lib.lt_device_info(name, 128, C.byref(cu), C.byref(clk)), "lt_device_info")
+    return {"name": name.value.decode(), "compute_units": cu.value, "clock_khz": clk.value}
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = False,
+         epilogue: int = EPI_BF16, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
+         resid: Optional[Tensor] = None, out2: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+         alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
+         ldc: Optional[int] = None) -> Tensor:
+    """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h."""
+    _chk(a, torch.bfloat16, "gemm.a")
+    _chk(b, torch.bfloat16, "gemm.b")
+    d = GemmDesc()
+    d.A, d.B, d.M, d.N, d.K = _p(a), _p(b), M, N, K
+    d.lda = lda if lda is not None else (M if trans_a else K)
+    d.ldb = ldb if ldb is not None else (N if trans_b else K)
+    d.trans_a, d.trans_b, d.epilogue = int(trans_a), int(trans_b), epilogue
+    want = torch.float32 if epilogue in (EPI_RESID, EPI_F32, EPI_F32_ACCUM) else torch.bfloat16
+    _chk(out, want, "gemm.out")
+    d.C, d.ldc = _p(out), (ldc if ldc is not None else N)
+    if out2 is not None:
+        _chk(out2, torch.bfloat16, "gemm.out2")
+    d.C2, d.ldc2 = _p(out2), N
+    for t, nm in ((bias, "bias"), (gamma, "gamma"), (resid, "resid")):
+        if t is not None:
+            _chk(t, torch.float32, "gemm." + nm)
+    d.bias, d.gamma, d.resid, d.ldr = _p(bias), _p(gamma), _p(resid), N
+    if aux is not None:
+        _chk(aux, torch.bfloat16, "gemm.aux")
+    d.aux, d.ldaux = _p(aux), N
+    d.alpha, d.split_k = alpha, split_k
+    check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
+    return out
+
+
+def gemm_naive(a: Tensor, b: Tensor, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = False) -> Tensor:
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    check(_lib.load().lt_gemm_bf16_naive(_p(a), _p(b), _p(out), M, N, K, M if trans_a else K, N if trans_b else K, N,
+                                         int(trans_a), int(trans_b), _stream()), "lt_gemm_bf16_naive")
+    return out
+
+
+def matmul_f32(a: Tensor, b: Tensor, out: Tensor, M: int, N: int, K: int, trans_a: bool = False, accumulate: bool = False) -> Tensor:
+    for t in (a, b, out):
+        _chk(t, torch.float32, "matmul_f32")
+    check(_lib.load().lt_matmul_f32(_p(a), _p(b), _p(out), M, N, K, int(trans_a), int(accumulate), _stream()), "lt_matmul_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ tokens
+def im2col(img: Tensor, p: int, kpad: int) -> Tensor:
+    _chk(img, torch.float32, "im2col.img")
+    B, Cc, H, W = img.shape
+    cols = torch.empty(B * (H // p) * (W // p), kpad, device=img.device, dtype=torch.bfloat16)
+    check(_lib.load().lt_im2col_bf16(_p(img), _p(cols), B, Cc, H, W, p, kpad, _stream()), "lt_im2col_bf16")
+    return cols
+
+
+def assemble_tokens(patch: Tensor, cls: Tensor, pos: Tensor, mask_token: Tensor, masks: Optional[Tensor], B: int, n_p: int,
+                    D: int, out: Optional[Tensor] = None) -> Tensor:
+    x = out if out is not None else torch.empty(B, n_p + 1, D, device=patch.device, dtype=torch.float32)
+    if masks is not None:
+        _chk(masks, torch.uint8, "assemble.masks")
+    check(_lib.load().lt_assemble_tokens(_p(patch), _p(cls), _p(pos), _p(mask_token), _p(masks), _p(x), B, n_p, D, _stream()),
+          "lt_assemble_tokens")
+    return x
+
+
+def assemble_tokens_bwd(dx: Tensor, masks: Optional[Tensor], dpatch: Tensor, dcls: Tensor, dpos: Tensor, dmask: Tensor, B: int,
+                        n_p: int, D: int) -> None:
+    check(_lib.load().lt_assemble_tokens_bwd(_p(dx), _p(masks), _p(dpatch), _p(dcls), _p(dpos), _p(dmask), B, n_p, D, _stream()),
+          "lt_assemble_tokens_bwd")
+
+
+# ------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, rows: int, D: int, y_bf16: Optional[Tensor] = None,
+                  y_f32: Optional[Tensor] = None, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None,
+                  eps: float = 1e-6) -> None:
+    _chk(x, torch.float32, "layernorm.x")
+    check(_lib.load().lt_layernorm_fwd(_p(x), _p(w), _p(b), _p(y_bf16), _p(y_f32), _p(mean), _p(rstd), rows, D, eps, _stream()),
+          "lt_layernorm_fwd")
+
+
+def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, dres: Optional[Tensor], dx: Tensor, dw: Tensor,
+                  db: Tensor, rows: int, D: int) -> None:
+    check(_lib.load().lt_layernorm_bwd(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx),
+                                       _p(dw), _p(db), rows, D, _stream()), "lt_layernorm_bwd")
+
+
+def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,
+                   D: int) -> None:
+    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), rows, D, _stream()), "lt_layerscale_bwd")
+
+
+def colsum_bf16(x: Tensor, out: Tensor, rows: int, N: int) -> None:
+    check(_lib.load().lt_colsum_bf16(_p(x), _p(out), rows, N, _stream()), "lt_colsum_bf16")
+
+
+def colsum_f32(x: Tensor, out: Tensor, rows: int, N: int, accumulate: bool = False) -> None:
+    check(_lib.load().lt_colsum_f32(_p(x), _p(out), rows, N, int(accumulate), _stream()), "lt_colsum_f32")
+
+
+def gather_rows(src: Tensor, ld: int, idx: Tensor, M: int, D: int, out_bf16: Optional[Tensor] = None,
+                out_f32: Optional[Tensor] = None) -> None:
+    _chk(idx, torch.int64, "gather_rows.idx")
+    check(_lib.load().lt_gather_rows(_p(src), ld, _p(idx), _p(out_bf16), _p(out_f32), M, D, _stream()), "lt_gather_rows")
+
+
+def scatter_add_rows(src: Tensor, idx: Tensor, dst: Tensor, ld: int, M: int, D: int) -> None:
+    _chk(idx, torch.int64, "scatter_add_rows.idx")
+    check(_lib.load().lt_scatter_add_rows(_p(src), _p(idx), _p(dst), ld, M, D, _stream()), "lt_scatter_add_rows")
+
+
+def cast_bf16(src: Tensor, dst: Tensor) -> None:
+    check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
+
+
+def fill_f32(dst: Tensor, value: float) -> None:
+    check(_lib.load().lt_fill_f32(_p(dst), value, dst.numel(), _stream()), "lt_fill_f32")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv: Tensor, out: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> None:
+    _chk(qkv, torch.bfloat16, "attention.qkv")
+    check(_lib.load().lt_attention_fwd(_p(qkv), _p(out), _p(lse), B, N, H, dh, scale, _stream()), "lt_attention_fwd")
+
+
+def attention_bwd_ws_floats(B: int, N: int, H: int, dh: int) -> int:
+    return int(_lib.load().lt_attention_bwd_ws_floats(B, N, H, dh))
+
+
+def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, ws: Tensor, dqkv: Tensor, B: int, N: int, H: int, dh: int,
+                  scale: float) -> None:
+    assert ws.numel() >= attention_bwd_ws_floats(B, N, H, dh)
+    check(_lib.load().lt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(ws), _p(dqkv), B, N, H, dh, scale, _stream()),
+          "lt_attention_bwd")
+
+
+# ------------------------------------------------------------------------------------------ head pieces
+def l2norm_fwd(x: Tensor, y: Tensor, inv: Tensor, rows: int, D: int, eps: float = 1e-12) -> None:
+    check(_lib.load().lt_l2norm_fwd(_p(x), _p(y), _p(inv), rows, D, eps, _stream()), "lt_l2norm_fwd")
+
+
+def l2norm_bwd(dy: Tensor, x: Tensor, inv: Tensor, dx: Tensor, rows: int, D: int) -> None:
+    check(_lib.load().lt_l2norm_bwd(_p(dy), _p(x), _p(inv), _p(dx), rows, D, _stream()), "lt_l2norm_bwd")
+
+
+def weightnorm_fwd(v: Tensor, g: Tensor, w: Tensor, K: int, D: int) -> None:
+    check(_lib.load().lt_weightnorm_fwd(_p(v), _p(g), _p(w), K, D, _stream()), "lt_weightnorm_fwd")
+
+
+def weightnorm_bwd(dw: Tensor, v: Tensor, g: Tensor, dv: Tensor, dg: Tensor, K: int, D: int) -> None:
+    check(_lib.load().lt_weightnorm_bwd(_p(dw), _p(v), _p(g), _p(dv), _p(dg), K, D, _stream()), "lt_weightnorm_bwd")
+
+
+# ------------------------------------------------------------------------------------------ losses
+def softmax_center(logits: Tensor, center: Optional[Tensor], probs: Tensor, rows: int, K: int, inv_temp: float) -> None:
+    check(_lib.load().lt_softmax_center(_p(logits), _p(center), _p(probs), rows, K, inv_temp, _stream()), "lt_softmax_center")
+
+
+def center_ema(center: Tensor, colsum: Tensor, scale: float, momentum: float, K: int) -> None:
+    check(_lib.load().lt_center_ema(_p(center), _p(colsum), scale, momentum, K, _stream()), "lt_center_ema")
+
+
+def ce_fwd_bwd(s: Tensor, teacher: Tensor, ta: Tensor, tb: Optional[Tensor], row_weight: Optional[Tensor], scale: float,
+               inv_temp: float, loss: Tensor, dlogits: Optional[Tensor], rows: int, K: int) -> None:
+    _chk(ta, torch.int32, "ce.ta")
+    check(_lib.load().lt_ce_fwd_bwd(_p(s), _p(teacher), _p(ta), _p(tb), _p(row_weight), scale, inv_temp, _p(loss), _p(dlogits),
+                                    rows, K, _stream()), "lt_ce_fwd_bwd")
+
+
+def sk_exp(logits: Tensor, Q: Tensor, inv_temp: float) -> None:
+    check(_lib.load().lt_sk_exp(_p(logits), _p(Q), logits.numel(), inv_temp, _stream()), "lt_sk_exp")
+
+
+def sk_iter(Q: Tensor, colsum: Tensor, rows: int, K: int, n_total: float, final_mul: float) -> None:
+    check(_lib.load().lt_sk_iter(_p(Q), _p(colsum), rows, K, n_total, final_mul, _stream()), "lt_sk_iter")
+
+
+def koleo_fwd_bwd(x: Tensor, ld: int, loss: Tensor, dx: Tensor, ld_dx: int, n: int, D: int, weight: float, ws: Tensor, nn: Tensor,
+                  eps: float = 1e-8) -> None:
+    assert ws.numel() >= 2 * n * D + 2 * n and nn.dtype == torch.int32
+    check(_lib.load().lt_koleo_fwd_bwd(_p(x), ld, _p(loss), _p(dx), ld_dx, n, D, eps, weight, _p(ws), _p(nn), _stream()),
+          "lt_koleo_fwd_bwd")
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def sumsq(g: Tensor, out: Tensor) -> None:
+    check(_lib.load().lt_sumsq_f32(_p(g), _p(out), g.numel(), _stream()), "lt_sumsq_f32")
+
+
+def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], seg_of_chunk: Tensor, seg_lr: Tensor,
+               seg_wd_on: Tensor, seg_frozen: Tensor, freeze: bool, lr_factor: float, wd: float, beta1: float, beta2: float,
+               eps: float, step: int, sumsq_t: Optional[Tensor], max_norm: float) -> None:
+    check(_lib.load().lt_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(seg_of_chunk), _p(seg_lr), _p(seg_wd_on),
+                                    _p(seg_frozen), int(freeze), lr_factor, wd, beta1, beta2, eps, step, _p(sumsq_t), max_norm,
+                                    _stream()), "lt_adamw_flat")
+
+
+def ema_flat(teacher: Tensor, student: Tensor, teacher_bf16: Optional[Tensor], m: float) -> None:
+    check(_lib.load().lt_ema_flat(_p(teacher), _p(student), _p(teacher_bf16), teacher.numel(), m, _stream()), "lt_ema_flat")

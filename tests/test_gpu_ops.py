@@ -1,0 +1,379 @@
+"""-m gpu: every HIP op of the C ABI against a plain PyTorch fp32 reference of the same op.
+
+bf16 tolerances: operands are rounded to bf16 before both paths, accumulation is fp32 in both, so GEMM-like
+ops agree to ~1e-5 relative (summation order); outputs stored as bf16 add 2^-9 relative rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd import ops as o
+
+    return o
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (197 * 3, 2304, 768), (37, 72, 40), (1, 8, 8), (300, 136, 1000)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_layouts(M, N, K, ta, tb):
+    o = ops()
+    if ta and M % 8:
+        pytest.skip("transposed A needs M % 8 == 0")
+    if tb and N % 8:
+        pytest.skip("transposed B needs N % 8 == 0")
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g)).to(DEV)
+    ref = A.float() @ B.float().t()
+    a_in = A.t().contiguous() if ta else A
+    b_in = B.t().contiguous() if tb else B
+    out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    o.gemm(a_in, b_in, out, M=M, N=N, K=K, trans_a=ta, trans_b=tb, epilogue=o.EPI_F32)
+    naive = o.gemm_naive(a_in, b_in, M, N, K, ta, tb)
+    torch.cuda.synchronize()
+    assert rel_err(naive, ref) < 1e-5
+    assert rel_err(out, ref) < 1e-5, f"mfma gemm mismatch ta={ta} tb={tb}"
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with asymmetric B catches row/col swaps in the C write (guide G9)."""
+    o = ops()
+    n = 128
+    A = bf(torch.eye(n)).to(DEV)
+    Bm = bf((torch.arange(n)[:, None] * 2 + torch.arange(n)[None, :] % 7).float() / 16).to(DEV)  # B[n][k]
+    out = torch.empty(n, n, device=DEV, dtype=torch.float32)
+    o.gemm(A, Bm, out, M=n, N=n, K=n, epilogue=o.EPI_F32)
+    assert torch.equal(out, Bm.float().t())
+
+
+def test_gemm_epilogues():
+    o = ops()
+    M, N, K = 200, 256, 192
+    g = torch.Generator().manual_seed(0)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    gamma = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    y = A.float() @ W.float().t() + bias
+    # BF16
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm(A, W, out, M=M, N=N, K=K, epilogue=o.EPI_BF16, bias=bias)
+    assert rel_err(out, y) < 6e-3
+    # GELU + pre
+    pre = torch.empty_like(out)
+    o.gemm(A, W, out, M=M, N=N, K=K, epilogue=o.EPI_BF16_GELU, bias=bias, out2=pre)
+    assert rel_err(pre, y) < 6e-3
+    assert rel_err(out, F.gelu(y)) < 6e-3
+    # RESID
+    outf = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    ybf = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm(A, W, outf, M=M, N=N, K=K, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, out2=ybf)
+    assert rel_err(outf, resid + gamma * y) < 1e-5
+    assert rel_err(ybf, y) < 6e-3
+    # GELUGRAD
+    aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+    o.gemm(A, W, out, M=M, N=N, K=K, epilogue=o.EPI_BF16_GELUGRAD, aux=aux)
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel_err(out, (A.float() @ W.float().t()) * x.grad) < 6e-3
+    # ACCUM with split-k (atomics) and alpha
+    acc = torch.ones(M, N, device=DEV, dtype=torch.float32)
+    o.gemm(A, W, acc, M=M, N=N, K=K, epilogue=o.EPI_F32_ACCUM, split_k=3, alpha=0.5)
+    assert rel_err(acc, 1 + 0.5 * (A.float() @ W.float().t())) < 1e-5
+
+
+def test_gemm_wgrad_shape():
+    """dW[N,K] += dY[M,N]^T X[M,K] with a long token dimension and split-k."""
+    o = ops()
+    M, N, K = 3000, 256, 128
+    g = torch.Generator().manual_seed(1)
+    dY = bf(torch.randn(M, N, generator=g)).to(DEV)
+    X = bf(torch.randn(M, K, generator=g)).to(DEV)
+    dW = torch.zeros(N, K, device=DEV, dtype=torch.float32)
+    o.gemm(dY, X, dW, M=N, N=K, K=M, trans_a=True, trans_b=True, epilogue=o.EPI_F32_ACCUM, split_k=4, lda=N, ldb=K)
+    assert rel_err(dW, dY.float().t() @ X.float()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,D", [(1000, 768), (37, 384), (50, 8), (129, 1024), (5, 64)])
+def test_layernorm(rows, D):
+    o = ops()
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(DEV)
+    w = (torch.randn(D, generator=g) * 0.2 + 1).to(DEV)
+    b = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    yb = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    yf = torch.empty(rows, D, device=DEV)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    o.layernorm_fwd(x, w, b, rows, D, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), wr, br, 1e-6)
+    assert (yf - ref).abs().max().item() < 2e-5
+    assert rel_err(yb, ref) < 5e-3
+    # backward (bf16 dy and f32 dy)
+    dy = torch.randn(rows, D, generator=g).to(DEV)
+    dres = torch.randn(rows, D, generator=g).to(DEV)
+    for dyt in (dy, bf(dy)):
+        dx = torch.empty(rows, D, device=DEV)
+        dw = torch.zeros(D, device=DEV)
+        db = torch.zeros(D, device=DEV)
+        o.layernorm_bwd(x, w, mean, rstd, dyt, dres, dx, dw, db, rows, D)
+        for t in (xr, wr, br):
+            t.grad = None
+        ref.backward(dyt.float(), retain_graph=True)
+        assert rel_err(dx, xr.grad + dres) < 2e-5
+        assert rel_err(dw, wr.grad) < 2e-5
+        assert rel_err(db, br.grad) < 2e-5
+
+
+def test_im2col_and_tokens():
+    o = ops()
+    B, C, H, W, p, D = 3, 3, 32, 48, 16, 24
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(B, C, H, W, generator=g).to(DEV)
+    cols = o.im2col(img, p, C * p * p + 8)
+    ref = F.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(B * (H // p) * (W // p), C * p * p)
+    assert torch.equal(cols[:, : C * p * p].float(), bf(ref).float())
+    assert cols[:, C * p * p:].abs().max().item() == 0
+    n_p = (H // p) * (W // p)
+    patch = torch.randn(B * n_p, D, generator=g).to(DEV)
+    cls = torch.randn(D, generator=g).to(DEV)
+    pos = torch.randn(n_p + 1, D, generator=g).to(DEV)
+    mt = torch.randn(D, generator=g).to(DEV)
+    masks = (torch.rand(B, n_p, generator=g) < 0.4).to(DEV)
+    x = o.assemble_tokens(patch, cls, pos, mt, masks.to(torch.uint8), B, n_p, D)
+    t = torch.where(masks.unsqueeze(-1), mt.view(1, 1, D), patch.view(B, n_p, D))
+    refx = torch.cat([cls.view(1, 1, D).expand(B, -1, -1), t], 1) + pos.unsqueeze(0)
+    assert torch.allclose(x, refx)
+    dx = torch.randn(B, n_p + 1, D, generator=g).to(DEV)
+    dpatch = torch.empty(B * n_p, D, device=DEV, dtype=torch.bfloat16)
+    dcls = torch.zeros(D, device=DEV); dpos = torch.zeros(n_p + 1, D, device=DEV); dmask = torch.zeros(D, device=DEV)
+    o.assemble_tokens_bwd(dx, masks.to(torch.uint8), dpatch, dcls, dpos, dmask, B, n_p, D)
+    assert torch.allclose(dcls, dx[:, 0].sum(0), atol=1e-5)
+    assert torch.allclose(dpos, dx.sum(0), atol=1e-5)
+    assert torch.allclose(dmask, (dx[:, 1:] * masks.unsqueeze(-1)).sum((0, 1)), atol=1e-5)
+    assert torch.equal(dpatch.float().view(B, n_p, D), bf(dx[:, 1:] * (~masks).unsqueeze(-1)).float())
+
+
+def test_layerscale_colsum_gather():
+    o = ops()
+    rows, D = 333, 136
+    g = torch.Generator().manual_seed(3)
+    dout = torch.randn(rows, D, generator=g).to(DEV)
+    y = bf(torch.randn(rows, D, generator=g)).to(DEV)
+    gamma = torch.randn(D, generator=g).to(DEV)
+    dy = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    dg = torch.zeros(D, device=DEV)
+    o.layerscale_bwd(dout, y, gamma, dy, dg, rows, D)
+    assert torch.equal(dy.float(), bf(dout * gamma).float())
+    assert rel_err(dg, (dout * y.float()).sum(0)) < 1e-5
+    cs = torch.zeros(D, device=DEV)
+    o.colsum_bf16(y, cs, rows, D)
+    assert rel_err(cs, y.float().sum(0)) < 1e-5
+    cs2 = torch.empty(D, device=DEV)
+    o.colsum_f32(dout, cs2, rows, D)
+    assert rel_err(cs2, dout.sum(0)) < 1e-5
+    idx = torch.randperm(rows, generator=g)[:57].to(DEV)
+    gb = torch.empty(57, D, device=DEV, dtype=torch.bfloat16); gf = torch.empty(57, D, device=DEV)
+    o.gather_rows(dout, D, idx, 57, D, out_bf16=gb, out_f32=gf)
+    assert torch.equal(gf, dout[idx]) and torch.equal(gb.float(), bf(dout[idx]).float())
+    dst = torch.zeros(rows, D, device=DEV)
+    o.scatter_add_rows(gf, idx, dst, D, 57, D)
+    ref = torch.zeros(rows, D, device=DEV); ref[idx] = gf
+    assert torch.equal(dst, ref)
+
+
+def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
+    q, k, v = qkv.float().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    q = q.detach().requires_grad_(True); k = k.detach().requires_grad_(True); v = v.detach().requires_grad_(True)
+    s = (q * scale) @ k.transpose(-2, -1)
+    a = s.softmax(-1)
+    out = (a @ v).transpose(1, 2).reshape(B, N, H * dh)
+    lse = torch.logsumexp(s, -1)
+    if dout is None:
+        return out, lse, None
+    out.backward(dout.float().view(B, N, H * dh))
+    dqkv = torch.stack([q.grad, k.grad, v.grad], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * dh)
+    return out, lse, dqkv
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (3, 37, 2, 64), (2, 50, 1, 64), (1, 300, 2, 64), (2, 128, 2, 64),
+                                       (4, 17, 2, 4), (2, 5, 2, 8)])
+def test_attention(B, N, H, dh):
+    o = ops()
+    g = torch.Generator().manual_seed(N + dh)
+    qkv = bf(torch.randn(B, N, 3 * H * dh, generator=g)).to(DEV)
+    scale = dh ** -0.5
+    out = torch.zeros(B, N, H * dh, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device=DEV)
+    o.attention_fwd(qkv, out, lse, B, N, H, dh, scale)
+    dout = bf(torch.randn(B, N, H * dh, generator=g)).to(DEV)
+    ref_out, ref_lse, ref_dqkv = _attn_ref(qkv, B, N, H, dh, scale, dout)
+    assert rel_err(lse, ref_lse) < 1e-4
+    assert rel_err(out, ref_out) < 1.5e-2, "attention forward"
+    ws = torch.zeros(o.attention_bwd_ws_floats(B, N, H, dh), device=DEV)
+    dqkv = torch.zeros(B, N, 3 * H * dh, device=DEV, dtype=torch.bfloat16)
+    o.attention_bwd(qkv, out, dout, lse, ws, dqkv, B, N, H, dh, scale)
+    d = dqkv.float().view(B, N, 3, H * dh)
+    r = ref_dqkv.view(B, N, 3, H * dh)
+    for i, nm in enumerate("qkv"):
+        assert rel_err(d[:, :, i], r[:, :, i]) < 2.5e-2, f"attention backward d{nm}"
+
+
+def test_attention_rescale_branch():
+    """spiked key forces the online-softmax running max to jump at a late tile (guide rule 26)."""
+    o = ops()
+    B, N, H, dh = 1, 160, 1, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, N, 3, H, dh, generator=g) * 0.5
+    x[0, 150, 1] = x[0, 3, 0] * 8  # key 150 aligned with query 3
+    qkv = bf(x.reshape(B, N, -1)).to(DEV)
+    out = torch.zeros(B, N, H * dh, device=DEV, dtype=torch.bfloat16); lse = torch.zeros(B, H, N, device=DEV)
+    o.attention_fwd(qkv, out, lse, B, N, H, dh, dh ** -0.5)
+    ref_out, ref_lse, _ = _attn_ref(qkv, B, N, H, dh, dh ** -0.5)
+    assert rel_err(lse, ref_lse) < 1e-4 and rel_err(out, ref_out) < 1.5e-2
+
+
+def test_head_pieces():
+    o = ops()
+    rows, D, K = 77, 256, 1024
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(rows, D, generator=g).to(DEV)
+    y = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16); inv = torch.empty(rows, device=DEV)
+    o.l2norm_fwd(x, y, inv, rows, D)
+    xr = x.clone().requires_grad_(True)
+    ref = F.normalize(xr, dim=-1, eps=1e-12)
+    assert rel_err(y, ref) < 5e-3
+    dy = torch.randn(rows, D, generator=g).to(DEV)
+    dx = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    o.l2norm_bwd(dy, x, inv, dx, rows, D)
+    ref.backward(dy)
+    assert rel_err(dx, xr.grad) < 5e-3
+    v = torch.randn(K, D, generator=g).to(DEV); gg = (torch.rand(K, 1, generator=g) + 0.5).to(DEV)
+    w = torch.empty(K, D, device=DEV, dtype=torch.bfloat16)
+    o.weightnorm_fwd(v, gg, w, K, D)
+    vr = v.clone().requires_grad_(True); gr = gg.clone().requires_grad_(True)
+    wref = torch._weight_norm(vr, gr, 0)
+    assert rel_err(w, wref) < 5e-3
+    dw = torch.randn(K, D, generator=g).to(DEV)
+    dv = torch.zeros(K, D, device=DEV); dg = torch.zeros(K, 1, device=DEV)
+    o.weightnorm_bwd(dw, v, gg, dv, dg, K, D)
+    wref.backward(dw)
+    assert rel_err(dv, vr.grad) < 1e-5 and rel_err(dg, gr.grad) < 1e-5
+
+
+def test_losses():
+    o = ops()
+    rows, K = 24, 4096
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(rows, K, generator=g) * 0.3).to(DEV)
+    center = (torch.randn(K, generator=g) * 0.05).to(DEV)
+    probs = torch.empty(rows, K, device=DEV)
+    o.softmax_center(logits, center, probs, rows, K, 1 / 0.04)
+    ref = F.softmax((logits - center) / 0.04, -1)
+    assert rel_err(probs, ref) < 1e-5
+    cs = torch.empty(K, device=DEV)
+    o.colsum_f32(logits, cs, rows, K)
+    c2 = center.clone()
+    o.center_ema(c2, cs, 1.0 / rows, 0.9, K)
+    assert torch.allclose(c2, center * 0.9 + logits.mean(0) * 0.1, atol=1e-6)
+    # CE with two teachers and row weights
+    s = (torch.randn(16, K, generator=g)).to(DEV).requires_grad_(True)
+    ta = torch.arange(16, dtype=torch.int32, device=DEV) % 12
+    tb = (torch.arange(16, dtype=torch.int32, device=DEV) % 12) + 12
+    w = torch.rand(16, generator=g).to(DEV)
+    loss = torch.zeros(1, device=DEV); dl = torch.empty(16, K, device=DEV, dtype=torch.bfloat16)
+    o.ce_fwd_bwd(s.detach(), probs, ta, tb, w, 0.37, 10.0, loss, dl, 16, K)
+    t = probs[ta.long()] + probs[tb.long()]
+    ref_loss = -(0.37 * w * (t * F.log_softmax(s * 10.0, -1)).sum(-1)).sum()
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    assert rel_err(dl, s.grad) < 8e-3
+    # Sinkhorn-Knopp (single rank): same recurrence as dinov2_loss.py:84-115
+    Q = torch.empty(rows, K, device=DEV)
+    o.sk_exp(logits, Q, 1 / 0.05)
+    colsum = torch.empty(K, device=DEV)
+    for it in range(3):
+        o.colsum_f32(Q, colsum, rows, K)
+        o.sk_iter(Q, colsum, rows, K, float(rows), float(rows) if it == 2 else 1.0)
+    q = torch.exp(logits / 0.05).t(); q /= q.sum()
+    for _ in range(3):
+        q /= q.sum(1, keepdim=True); q /= K; q /= q.sum(0, keepdim=True); q /= rows
+    q *= rows
+    assert rel_err(Q, q.t()) < 1e-4
+
+
+def test_koleo():
+    o = ops()
+    n, D = 48, 96
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n + 3, D, generator=g).to(DEV)[:n]
+    loss = torch.zeros(1, device=DEV); dx = torch.zeros(n, D, device=DEV)
+    ws = torch.empty(2 * n * D + 2 * n, device=DEV); nn = torch.empty(n, dtype=torch.int32, device=DEV)
+    o.koleo_fwd_bwd(x, D, loss, dx, D, n, D, 0.1, ws, nn)
+    xr = x.clone().requires_grad_(True)
+    xn = F.normalize(xr, p=2, dim=-1, eps=1e-8)
+    cos = (xn @ xn.t()).clone(); cos.fill_diagonal_(-2)
+    idx = cos.argmax(1)
+    ref = -torch.log(torch.linalg.vector_norm(xn - xn[idx] + 1e-8, dim=-1) + 1e-8).mean() * 0.1
+    ref.backward()
+    assert torch.equal(nn.long(), idx)
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert rel_err(dx, xr.grad) < 1e-4
+
+
+def test_adamw_ema_match_torch():
+    o = ops()
+    sizes = [1024 * 3, 1024, 2048]
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(7)
+    p = torch.randn(n, generator=g).to(DEV); p0 = p.clone()
+    seg_of_chunk = torch.tensor([0, 0, 0, 1, 2, 2], dtype=torch.int32, device=DEV)
+    seg_lr = torch.tensor([1e-3, 5e-4, 2e-3], device=DEV)
+    seg_wd = torch.tensor([1, 0, 1], dtype=torch.uint8, device=DEV)
+    seg_fr = torch.tensor([0, 0, 1], dtype=torch.uint8, device=DEV)
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV); pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    views = list(p0.clone().split(sizes))
+    params = [torch.nn.Parameter(t) for t in views]
+    opt = torch.optim.AdamW([{"params": [params[0]], "lr": 1e-3, "weight_decay": 0.04},
+                             {"params": [params[1]], "lr": 5e-4, "weight_decay": 0.0},
+                             {"params": [params[2]], "lr": 2e-3, "weight_decay": 0.04}], betas=(0.9, 0.999), eps=1e-8)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g).to(DEV) * 3
+        ss = torch.zeros(1, device=DEV)
+        o.sumsq(grad, ss)
+        assert abs(ss.item() - (grad ** 2).sum().item()) < 1e-4 * ss.item()
+        freeze = step == 1
+        o.adamw_flat(p, grad, m, v, pb, seg_of_chunk, seg_lr, seg_wd, seg_fr, freeze, 0.5, 0.04, 0.9, 0.999, 1e-8, step, ss, 3.0)
+        for prm, gpart in zip(params, grad.split(sizes)):
+            prm.grad = gpart.clone()
+        torch.nn.utils.clip_grad_norm_(params, 3.0)
+        for gi, grp in enumerate(opt.param_groups):
+            grp["lr"] = [1e-3, 5e-4, 2e-3][gi] * 0.5
+            if gi == 2 and freeze:
+                grp["lr"] = 0.0
+        opt.step()
+        ref = torch.cat([q.detach() for q in params])
+        assert (p - ref).abs().max().item() < 2e-6, f"adamw step {step}"
+        assert torch.equal(pb.float(), ref.to(torch.bfloat16).float()) or (pb.float() - ref).abs().max().item() < 1e-2
+    t = torch.randn(n, generator=g).to(DEV); t0 = t.clone(); tb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    o.ema_flat(t, p, tb, 0.992)
+    assert torch.allclose(t, t0 * 0.992 + p * (1 - 0.992), atol=1e-6)
