@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: DINOv2 training step throughput (images/sec, whole job) on MI355X.
+
+Workload (BASELINE.json metric): DINOv2 ViT-B/16, 2 x 224^2 global + 8 x 96^2 local crops per image,
+per-GPU batch 128, K = 65 536 prototypes, bf16 MFMA compute / fp32 master weights, drop-path 0
+(96^2 locals instead of the literal 98^2: patch 16 needs a multiple of 16 -- SURVEY.md 8(d) caveat).
+One "step" = mask sampling + teacher forward + student forward/backward (global+local) + DINO/iBOT/KoLeo
+losses + grad clip + AdamW + EMA (+ gradient all-reduce over RCCL when N > 1).  Synthetic N(0,1) views are
+resident in HBM before the timed region; random-init weights with the reference's initialisers.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N > 1 launched by torch.distributed.run
+(one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MODELS = {
+    "vit_base": dict(embed_dim=768, depth=12, num_heads=12),
+    "vit_small": dict(embed_dim=384, depth=12, num_heads=6),
+    "vit_large": dict(embed_dim=1024, depth=24, num_heads=16),
+    "vit_tiny": dict(embed_dim=192, depth=12, num_heads=3),
+}
+
+
+def step_flops_per_image(D: int, depth: int, hidden: int, n_g: int, n_l: int, n_local: int, K: int, head_hidden: int,
+                         bottleneck: int, m_tokens: float, p: int = 16, in_chans: int = 3) -> float:
+    """Algorithmic FLOPs (2*MAC) per image, SURVEY.md 8(d): teacher fwd + heads_t + 3*(student fwd + heads_s)."""
+    def backbone(T: float, n_p: float) -> float:
+        lin = 2 * T * (3 * D * D + D * D + 2 * D * hidden)
+        att = 4 * T * T * D
+        return depth * (lin + att) + 2 * n_p * D * in_chans * p * p
+
+    def head(rows: float) -> float:
+        return 2 * rows * (D * head_hidden + head_hidden * head_hidden + head_hidden * bottleneck + bottleneck * K)
+
+    teacher = 2 * backbone(n_g, n_g - 1) + head(2 + m_tokens)
+    student = 2 * backbone(n_g, n_g - 1) + n_local * backbone(n_l, n_l - 1) + head(2 + m_tokens + n_local)
+    return teacher + 3 * student
+
+
+def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int) -> dict:
+    """The oracle (CPU port of the reference step, oracle/dinov2_oracle.py) timed on the host cores: a bounded
+    sample (batch 4, 1 warm-up + 1 timed step).  Reported baseline only."""
+    from oracle import dinov2_oracle as O
+
+    b = 4
+    g = torch.Generator().manual_seed(0)
+    name = {768: "vit_base", 384: "vit_small", 1024: "vit_large", 192: "vit_tiny"}[arch["embed_dim"]]
+    sb, cfg = O.init_vit_params(name, patch_size=16, img_size=g_size, generator=g)
+    sh = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
+    th = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
+    o = O.OracleDINOv2(sb, sh, cfg, args=dict(output_dim=K), global_batch_size=b, total_steps=1000, teacher_head=th)
+    views = [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
+        torch.randn(b, 3, l_size, l_size, generator=g) for _ in range(n_local)]
+    random.seed(0)
+    o.train_step(views)
+    t0 = time.perf_counter()
+    o.train_step(views)
+    dt = time.perf_counter() - t0
+    return {"value": b / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/dinov2_oracle.py fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, 1 warm-up + 1 timed step"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="vit_base", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (images)")
+    ap.add_argument("--global-size", type=int, default=224)
+    ap.add_argument("--local-size", type=int, default=96)
+    ap.add_argument("--n-local", type=int, default=8)
+    ap.add_argument("--out-dim", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP kernels)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd import ops
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig
+
+    arch = MODELS[args.model]
+    cfg = ViTConfig(patch_size=16, img_size=args.global_size, init_values=1e-5, **arch)
+    margs = DINOv2Args(output_dim=args.out_dim)
+    B = args.batch
+    method = DINOv2(cfg, margs, global_batch_size=B * world, total_steps=125_000, device=dev, seed=0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [
+        torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
+    random.seed(100 + rank)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        method.train_step(views)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = method.train_step(views)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(res.loss)
+    ms_per_step = dt / args.steps * 1e3
+    img_per_s = B * world * args.steps / dt
+
+    n_g = (args.global_size // 16) ** 2 + 1
+    n_l = (args.local_size // 16) ** 2 + 1
+    m_tokens = method._last["M"] / B
+    gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
+                                  2048, 256, m_tokens) / 1e9
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # one instrumented step: HIP events (torch.cuda.Event on the launch stream = torch's current stream)
+        # around every MFMA GEMM launch; achieved = algorithmic GEMM FLOPs / summed GEMM time.
+        recs = []
+        orig = ops.gemm
+
+        def timed_gemm(a, b, out, *, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(a, b, out, M=M, N=N, K=K, **kw)
+            e1.record()
+            recs.append((e0, e1, 2.0 * M * N * K))
+            return r
+
+        ops.gemm = timed_gemm
+        try:
+            method.train_step(views)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm = orig
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        fl = sum(f for _, _, f in recs)
+        achieved = fl / (t_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA,TB,EPI> (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
+                    "gemm_flops_per_step": fl, "step_algorithmic_gflop_per_image": round(gf_img, 1),
+                    "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(arch, args.out_dim, args.global_size, args.local_size, args.n_local)
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops",
+            "value": round(img_per_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "
+                                   f"K={args.out_dim} prototypes, softmax centering, drop-path 0",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

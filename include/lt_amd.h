@@ -109,6 +109,7 @@ int lt_gather_rows(const float* src, int ld_src, const int64_t* idx, void* out_b
 int lt_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int ld_dst, int M, int D, void* stream);
 int lt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int lt_fill_f32(float* dst, float value, int64_t n, void* stream);
+int lt_scale_f32(float* dst, float alpha, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention (attention.py:49-66): softmax(q*scale k^T) v on the packed qkv bf16 [B,N,3,H,dh].
@@ -141,10 +142,11 @@ int lt_softmax_center(const float* logits, const float* center, float* probs, in
 int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream);
 /* student CE against 1 or 2 teacher rows (:117-133, :246-268):
  *   lsm = log_softmax(s*inv_temp);  l_r = -sum_k (t_a + t_b) * lsm
- *   *loss += coef_r * l_r ;  dlogits(bf16)[r,:] = coef_r * inv_temp * (softmax(s*inv_temp)*sum(t) - (t_a+t_b))
- *   coef_r = scale * (row_weight ? row_weight[r] : 1);  t_a = teacher[ta[r]], t_b = tb ? teacher[tb[r]] : 0 */
+ *   loss[slot ? slot[r] : 0] += coef_r * l_r ;  dlogits(bf16)[r,:] = coef_r * inv_temp * (softmax(s*inv_temp)*sum(t) - (t_a+t_b))
+ *   coef_r = scale * (row_weight ? row_weight[r] : 1);  t_a = teacher[ta[r]], t_b = (tb && tb[r] >= 0) ? teacher[tb[r]] : 0 */
 int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
-                  float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K, void* stream);
+                  const int32_t* slot, float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K,
+                  void* stream);
 /* Sinkhorn-Knopp pieces (:84-115, :188-224); Q f32 [rows,K] holds exp(logits*inv_temp) */
 int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream);
 /* Q[r,k] *= 1/(colsum[k]*K); then row-normalise: Q[r,:] /= (rowsum(r) * n_total); final: Q *= final_mul */

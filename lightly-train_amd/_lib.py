@@ -44,6 +44,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_scatter_add_rows": [vp, vp, vp, i32, i32, i32, vp],
     "lt_cast_f32_to_bf16": [vp, vp, i64, vp],
     "lt_fill_f32": [vp, f32, i64, vp],
+    "lt_scale_f32": [vp, f32, i64, vp],
     "lt_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "lt_attention_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "lt_l2norm_fwd": [vp, vp, vp, i32, i32, f32, vp],
@@ -52,7 +53,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_weightnorm_bwd": [vp, vp, vp, vp, vp, i32, i32, vp],
     "lt_softmax_center": [vp, vp, vp, i32, i32, f32, vp],
     "lt_center_ema": [vp, vp, f32, f32, i32, vp],
-    "lt_ce_fwd_bwd": [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp],
+    "lt_ce_fwd_bwd": [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp],
     "lt_sk_exp": [vp, vp, i64, f32, vp],
     "lt_sk_iter": [vp, vp, i32, i32, f32, f32, vp],
     "lt_koleo_fwd_bwd": [vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],

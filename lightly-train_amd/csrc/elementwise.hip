@@ -265,6 +265,11 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d,
   }
   if (i < n) for (long j = i; j < n && j < i + 4; ++j) d[j] = f2bf(s[j]);
 }
+__global__ void scale_kernel(float* d, float a, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] *= a;
+}
 __global__ void fill_kernel(float* d, float v, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -439,6 +444,13 @@ extern "C" int lt_fill_f32(float* dst, float value, int64_t n, void* stream) {
   const int grid = (int)min((long)2048, (long)lt_cdiv(n, 256));
   hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, ST, dst, value, (long)n);
   LT_CHECK_LAUNCH("lt_fill_f32");
+}
+extern "C" int lt_scale_f32(float* dst, float alpha, int64_t n, void* stream) {
+  LT_CHECK_ARG(dst, "lt_scale_f32: null pointer");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)2048, (long)lt_cdiv(n, 256));
+  hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(256), 0, ST, dst, alpha, (long)n);
+  LT_CHECK_LAUNCH("lt_scale_f32");
 }
 extern "C" int lt_l2norm_fwd(const float* x, void* y_bf16, float* inv_norm, int rows, int D, float eps, void* stream) {
   LT_CHECK_ARG(x && y_bf16 && inv_norm, "lt_l2norm_fwd: null pointer");

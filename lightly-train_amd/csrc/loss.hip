@@ -56,13 +56,14 @@ __global__ void center_ema_kernel(float* center, const float* colsum, float scal
 // fused CE forward + d(logits)
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, const float* __restrict__ teacher,
                                                  const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
-                                                 const float* __restrict__ row_weight, float scale, float inv_temp,
-                                                 float* __restrict__ loss, bf16_t* __restrict__ dlogits, int K) {
+                                                 const float* __restrict__ row_weight, const int32_t* __restrict__ slot,
+                                                 float scale, float inv_temp, float* __restrict__ loss,
+                                                 bf16_t* __restrict__ dlogits, int K) {
   __shared__ float red[16];
   const long row = blockIdx.x;
   const float* z = s + row * K;
   const float* t0 = teacher + (long)ta[row] * K;
-  const float* t1 = tb ? teacher + (long)tb[row] * K : nullptr;
+  const float* t1 = (tb && tb[row] >= 0) ? teacher + (long)tb[row] * K : nullptr;
   MaxSum a; a.m = -INFINITY; a.s = 0.f;
   float dot = 0.f, tsum = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, co
   tsum = block_sum(tsum, red);
   const float lse = a.m + __logf(a.s);
   const float coef = scale * (row_weight ? row_weight[row] : 1.f);
-  if (threadIdx.x == 0) atomicAdd(loss, -coef * (dot - lse * tsum));
+  if (threadIdx.x == 0) atomicAdd(loss + (slot ? slot[row] : 0), -coef * (dot - lse * tsum));
   if (dlogits) {
     const float c2 = coef * inv_temp;
     for (int k = threadIdx.x; k < K; k += 256) {
@@ -194,10 +195,11 @@ extern "C" int lt_center_ema(float* center, const float* colsum, float scale, fl
   LT_CHECK_LAUNCH("lt_center_ema");
 }
 extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
-                             float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K, void* stream) {
+                             const int32_t* slot, float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K,
+                             void* stream) {
   LT_CHECK_ARG(s && teacher && ta && loss && K > 0, "lt_ce_fwd_bwd: bad arguments");
   if (rows == 0) return LT_OK;
-  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, scale, inv_temp, loss,
+  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
                      (bf16_t*)dlogits_bf16, K);
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
 }

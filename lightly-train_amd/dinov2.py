@@ -1,0 +1,506 @@
+"""DINOv2 method on the MI355X kernels -- mirrors lightly_train's `DINOv2(Method)`
+(LT/_methods/dinov2/dinov2.py:179-660): same hyper-parameters (DINOv2Args), same step semantics
+(training_step_impl -> on_before_optimizer_step -> clip -> AdamW -> LR schedule -> EMA), same parameter /
+state_dict names, but the forward-backward underneath is hand-written HIP (no autograd, no Lightning).
+
+Differences that are part of the design (all documented in DESIGN.md):
+  * `training_step_impl` runs forward AND backward: gradients are written straight into the flat grad
+    buffer ("a whole-step fwd+bwd call that writes .grad directly"); the returned loss is a
+    detached device scalar.
+  * student global+patch+local head rows go through the projection head as ONE batch of rows (the head is
+    shared, dinov2.py:230-234), teacher cls+patch rows likewise.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Literal, Mapping, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops
+from .masking import MaskingGenerator, create_collated_masks
+from .params import FlatParams
+from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
+from .vit import ViTConfig, ViTEngine, Workspace, init_vit_state, vit_param_shapes
+
+
+@dataclass
+class DINOv2Args:
+    """Field-for-field the reference's DINOv2Args (dinov2.py:70-153) + DINOv2AdamWViTArgs (:156-164)."""
+    ibot_separate_head: bool = False
+    hidden_dim: int = 2048
+    dino_bottleneck_dim: int = 256
+    ibot_bottleneck_dim: int = 256
+    output_dim: int = 65536
+    batch_norm: bool = False
+    student_freeze_last_layer_steps: int = 1250
+    student_freeze_backbone_steps: int = 0
+    dino_loss_weight: float = 1.0
+    ibot_loss_weight: float = 1.0
+    koleo_loss_weight: float = 0.1
+    center_method: Literal["softmax", "sinkhorn_knopp"] = "softmax"
+    center_momentum: float = 0.9
+    momentum_start: float = 0.992
+    momentum_end: float = 1.0
+    student_temp: float = 0.1
+    teacher_temp_start: float = 0.04
+    teacher_temp_end: float = 0.07
+    teacher_temp_warmup_steps: int = 37500
+    mask_ratio_min: float = 0.1
+    mask_ratio_max: float = 0.5
+    mask_probability: float = 0.5
+    min_lr: float = 1.0e-06
+    warmup_steps: int = 12500
+    layerwise_decay: float = 0.9
+    patch_embed_lr_multiplier: float = 0.2
+    lr_scale_method: Literal["linear", "sqrt"] = "sqrt"
+    reference_batch_size: int = 1024
+    weight_decay_start: float = 0.04
+    weight_decay_end: float = 0.4
+    gradient_clip_val: float = 3.0
+    # optimizer (DINOv2AdamWViTArgs)
+    lr: float = 0.004
+    betas: Tuple[float, float] = (0.9, 0.999)
+    eps: float = 1e-8
+
+
+@dataclass
+class TrainingStepResult:
+    loss: Tensor
+    log_dict: Optional[Mapping[str, Any]] = None
+
+
+HEAD_KEYS = ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias",
+             "last_layer.parametrizations.weight.original0", "last_layer.parametrizations.weight.original1")
+
+
+def head_param_shapes(in_dim: int, hidden: int, bottleneck: int, out_dim: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    return [("mlp.0.weight", (hidden, in_dim)), ("mlp.0.bias", (hidden,)), ("mlp.2.weight", (hidden, hidden)),
+            ("mlp.2.bias", (hidden,)), ("mlp.4.weight", (bottleneck, hidden)), ("mlp.4.bias", (bottleneck,)),
+            ("last_layer.parametrizations.weight.original0", (out_dim, 1)),
+            ("last_layer.parametrizations.weight.original1", (out_dim, bottleneck))]
+
+
+def init_head_state(in_dim: int, hidden: int, bottleneck: int, out_dim: int, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """DINOv2ProjectionHead init (dinov2_head.py:32-65): trunc-normal(0.02)/zero-bias MLP, weight-norm g=1,
+    v = nn.Linear default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in)))."""
+    sd: Dict[str, Tensor] = {}
+    for name, shape in head_param_shapes(in_dim, hidden, bottleneck, out_dim):
+        if name.endswith("original0"):
+            sd[name] = torch.ones(shape)
+        elif name.endswith("original1"):
+            bound = 1 / math.sqrt(bottleneck)
+            sd[name] = torch.empty(shape).uniform_(-bound, bound, generator=generator)
+        elif name.endswith(".weight"):
+            sd[name] = torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=generator)
+        else:
+            sd[name] = torch.zeros(shape)
+    return sd
+
+
+def vit_lr_decay_rate(name: str, lr_decay_rate: float, num_layers: int) -> float:
+    """get_vit_lr_decay_rate (utils.py:155-188), un-chunked blocks."""
+    layer_id = num_layers + 1
+    if any(k in name for k in ("pos_embed", "patch_embed", "mask_token", "cls_token", "register_tokens")):
+        layer_id = 0
+    elif "blocks." in name and "residual." not in name:
+        layer_id = int(name[name.find("blocks."):].split(".")[1]) + 1
+    return lr_decay_rate ** (num_layers + 1 - layer_id)
+
+
+def param_group_hparams(name: str, is_backbone: bool, depth: int, lr: float, args: DINOv2Args) -> Dict[str, Any]:
+    """One entry of get_optimizer_with_decay's param groups (utils.py:191-250)."""
+    rate = vit_lr_decay_rate(name, args.layerwise_decay, depth) if is_backbone else 1.0
+    out = {"name": name, "lr": lr * rate, "weight_decay": args.weight_decay_start,
+           "last_layer": "last_layer" in name, "head": "head" in name}
+    if name.endswith(".bias") or "norm" in name or "gamma" in name:
+        out["weight_decay"] = 0.0
+    if "patch_embed" in name:
+        out["lr"] = out["lr"] * args.patch_embed_lr_multiplier
+    return out
+
+
+class HeadEngine:
+    """DINOv2ProjectionHead forward/backward (dinov2_head.py:66-71) on rows of bf16 features."""
+
+    def __init__(self, params: FlatParams, prefix: str, in_dim: int, args: DINOv2Args) -> None:
+        self.P, self.prefix = params, prefix
+        self.in_dim, self.hid, self.bn, self.K = in_dim, args.hidden_dim, args.dino_bottleneck_dim, args.output_dim
+        dev = params.device
+        self.wn = torch.empty(self.K, self.bn, dtype=torch.bfloat16, device=dev)        # normalised prototype matrix (bf16)
+        self.dwn = torch.zeros(self.K, self.bn, dtype=torch.float32, device=dev) if params.grad is not None else None
+
+    def w(self, n: str) -> Tensor:
+        return self.P.p[self.prefix + n]
+
+    def wb(self, n: str) -> Tensor:
+        return self.P.b[self.prefix + n]
+
+    def gw(self, n: str) -> Tensor:
+        return self.P.g[self.prefix + n]
+
+    def refresh_weightnorm(self) -> None:
+        ops.weightnorm_fwd(self.w(HEAD_KEYS[7]), self.w(HEAD_KEYS[6]), self.wn, self.K, self.bn)
+
+    def forward(self, ws: Workspace, tag: str, x: Tensor, R: int, cap: int, save: bool) -> Dict[str, Tensor]:
+        hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
+        h1 = ws.get(tag + ".h1", (cap, hid), torch.bfloat16)
+        h1p = ws.get(tag + ".h1p", (cap, hid), torch.bfloat16) if save else None
+        ops.gemm(x, self.wb("mlp.0.weight"), h1, M=R, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w("mlp.0.bias"), out2=h1p)
+        h2 = ws.get(tag + ".h2", (cap, hid), torch.bfloat16)
+        h2p = ws.get(tag + ".h2p", (cap, hid), torch.bfloat16) if save else None
+        ops.gemm(h1, self.wb("mlp.2.weight"), h2, M=R, N=hid, K=hid, epilogue=ops.EPI_BF16_GELU, bias=self.w("mlp.2.bias"), out2=h2p)
+        z = ws.get(tag + ".z", (cap, bn), torch.float32)
+        ops.gemm(h2, self.wb("mlp.4.weight"), z, M=R, N=bn, K=hid, epilogue=ops.EPI_F32, bias=self.w("mlp.4.bias"))
+        zn = ws.get(tag + ".zn", (cap, bn), torch.bfloat16)
+        inv = ws.get(tag + ".inv", (cap,), torch.float32)
+        ops.l2norm_fwd(z, zn, inv, R, bn, 1e-12)
+        logits = ws.get(tag + ".logits", (cap, K), torch.float32)
+        ops.gemm(zn, self.wn, logits, M=R, N=K, K=bn, epilogue=ops.EPI_F32)
+        return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, zn=zn, inv=inv, logits=logits, R=R, cap=cap, tag=tag)
+
+    def backward(self, ws: Workspace, c: Dict[str, Any], dlogits: Tensor) -> Tensor:
+        """dlogits bf16 [R,K] -> returns d(x) f32 [R, in_dim]; accumulates parameter grads."""
+        R, cap, tag = c["R"], c["cap"], c["tag"]
+        hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
+
+        def split(n_out: int, k_in: int) -> int:
+            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            want = max(1, (512 + tiles - 1) // tiles)
+            return max(1, min(want, 32, R // 512 if R >= 1024 else 1))
+
+        ops.gemm(dlogits, c["zn"], self.dwn, M=K, N=bn, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                 split_k=split(K, bn), lda=K, ldb=bn)
+        dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
+        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32)
+        dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
+        ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
+        ops.colsum_bf16(dz, self.gw("mlp.4.bias"), R, bn)
+        ops.gemm(dz, c["h2"], self.gw("mlp.4.weight"), M=bn, N=hid, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                 split_k=split(bn, hid), lda=bn, ldb=hid)
+        dh2 = ws.get(tag + ".dh2", (cap, hid), torch.bfloat16)
+        ops.gemm(dz, self.wb("mlp.4.weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
+        ops.colsum_bf16(dh2, self.gw("mlp.2.bias"), R, hid)
+        ops.gemm(dh2, c["h1"], self.gw("mlp.2.weight"), M=hid, N=hid, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                 split_k=split(hid, hid), lda=hid, ldb=hid)
+        dh1 = ws.get(tag + ".dh1", (cap, hid), torch.bfloat16)
+        ops.gemm(dh2, self.wb("mlp.2.weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
+        ops.colsum_bf16(dh1, self.gw("mlp.0.bias"), R, hid)
+        ops.gemm(dh1, c["x"], self.gw("mlp.0.weight"), M=hid, N=D, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                 split_k=split(hid, D), lda=hid, ldb=D)
+        dx = ws.get(tag + ".dx", (cap, D), torch.float32)
+        ops.gemm(dh1, self.wb("mlp.0.weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
+        return dx
+
+    def finish_weightnorm_grad(self) -> None:
+        ops.weightnorm_bwd(self.dwn, self.w(HEAD_KEYS[7]), self.w(HEAD_KEYS[6]), self.gw(HEAD_KEYS[7]), self.gw(HEAD_KEYS[6]), self.K, self.bn)
+        self.dwn.zero_()
+
+
+class MockTrainerState:
+    """global_step / estimated_stepping_batches as the reference reads them from Lightning's Trainer."""
+
+    def __init__(self, total_steps: int) -> None:
+        self.global_step = 0
+        self.max_epochs = 1
+        self.estimated_stepping_batches = total_steps
+
+
+class DINOv2:
+    """The method object.  Attribute / state_dict layout follows the reference."""
+
+    def __init__(self, vit_cfg: ViTConfig, method_args: Optional[DINOv2Args] = None, global_batch_size: int = 128,
+                 total_steps: int = 125_000, device: str | torch.device = "cuda",
+                 backbone_state: Optional[Dict[str, Tensor]] = None, student_head_state: Optional[Dict[str, Tensor]] = None,
+                 teacher_head_state: Optional[Dict[str, Tensor]] = None, teacher_backbone_state: Optional[Dict[str, Tensor]] = None,
+                 seed: int = 0) -> None:
+        self.method_args = method_args or DINOv2Args()
+        a = self.method_args
+        if a.ibot_separate_head:
+            raise NotImplementedError("ibot_separate_head=True is not implemented (reference default is a shared head)")
+        if a.batch_norm:
+            raise NotImplementedError("batch_norm heads are not implemented (reference default False)")
+        if a.center_method not in ("softmax", "sinkhorn_knopp"):
+            raise ValueError(f"Unknown centering method: {a.center_method}")
+        self.cfg = vit_cfg
+        self.device = torch.device(device)
+        self.global_batch_size = global_batch_size
+        self.trainer = MockTrainerState(total_steps)
+        g = torch.Generator().manual_seed(seed)
+        D = vit_cfg.embed_dim
+        bsd = backbone_state if backbone_state is not None else init_vit_state(vit_cfg, g)
+        shs = student_head_state if student_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+        ths = teacher_head_state if teacher_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+        tbs = teacher_backbone_state if teacher_backbone_state is not None else bsd
+        order_b = [n for n, _ in vit_param_shapes(vit_cfg)]
+        order_h = [n for n, _ in head_param_shapes(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim)]
+        self.student = FlatParams([("backbone." + n, bsd[n]) for n in order_b] + [("head." + n, shs[n]) for n in order_h], self.device, True)
+        self.teacher = FlatParams([("backbone." + n, tbs[n]) for n in order_b] + [("head." + n, ths[n]) for n in order_h], self.device, False)
+        self.s_vit = ViTEngine(vit_cfg, self.student, "backbone.")
+        self.t_vit = ViTEngine(vit_cfg, self.teacher, "backbone.")
+        self.s_head = HeadEngine(self.student, "head.", D, a)
+        self.t_head = HeadEngine(self.teacher, "head.", D, a)
+        self.s_head.refresh_weightnorm()
+        self.t_head.refresh_weightnorm()
+        K = a.output_dim
+        self.dino_center = torch.zeros(1, K, device=self.device)
+        self.ibot_center = torch.zeros(1, 1, K, device=self.device)
+        self._pending: Dict[str, Tuple[Tensor, float]] = {}
+        self.ws = Workspace(self.device)
+        # optimizer state
+        self.exp_avg = torch.zeros_like(self.student.data)
+        self.exp_avg_sq = torch.zeros_like(self.student.data)
+        self.opt_step = 0
+        lr_scale = global_batch_size / a.reference_batch_size
+        if a.lr_scale_method == "sqrt":
+            lr_scale = math.sqrt(lr_scale)
+        self.base_lr = a.lr * lr_scale
+        self.param_groups: List[Dict[str, Any]] = []
+        for n in self.student.names:
+            is_bb = n.startswith("backbone.")
+            ref_name = n[len("backbone."):] if is_bb else "dino_head." + n[len("head."):]
+            self.param_groups.append(param_group_hparams(ref_name, is_bb, vit_cfg.depth, self.base_lr, a))
+        dev = self.device
+        self.seg_lr = torch.tensor([g_["lr"] for g_ in self.param_groups], dtype=torch.float32, device=dev)
+        self.seg_wd_on = torch.tensor([1 if g_["weight_decay"] != 0.0 else 0 for g_ in self.param_groups], dtype=torch.uint8, device=dev)
+        self.seg_frozen = torch.tensor([1 if g_["last_layer"] else 0 for g_ in self.param_groups], dtype=torch.uint8, device=dev)
+        self.warmup_steps = min(total_steps - 1, a.warmup_steps)
+        self._sumsq = torch.zeros(1, device=dev)
+        self._loss_slots = torch.zeros(4, device=dev)
+        self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
+        self.last_grad_norm: Optional[Tensor] = None
+
+    # ------------------------------------------------------------------ reference-compatible views
+    def state_dict(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for role, fp in (("teacher", self.teacher), ("student", self.student)):
+            for n in fp.names:
+                if n.startswith("backbone."):
+                    out[f"{role}_embedding_model.wrapped_model._model.{n[9:]}"] = fp.p[n].detach().clone()
+                else:
+                    for hname in ("dino_head", "ibot_head"):
+                        out[f"{role}_head.{hname}.{n[5:]}"] = fp.p[n].detach().clone()
+        out["dino_loss.center"] = self.dino_center.clone()
+        out["ibot_loss.center"] = self.ibot_center.clone()
+        return out
+
+    def export_backbone_state_dict(self) -> Dict[str, Tensor]:
+        """What the reference exports (EMA teacher backbone, dinov2_vit_package.py:146-162)."""
+        return {n[9:]: self.teacher.p[n].detach().clone() for n in self.teacher.names if n.startswith("backbone.")}
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # ------------------------------------------------------------------ helpers
+    def _apply_center_updates(self) -> None:
+        m = self.method_args.center_momentum
+        for key, center in (("dino", self.dino_center), ("ibot", self.ibot_center)):
+            if key in self._pending:
+                colsum, scale, handle = self._pending.pop(key)
+                if handle is not None:
+                    handle.wait()
+                ops.center_ema(center.view(-1), colsum, scale / self.world, m, center.numel())
+
+    def _indices(self, B: int, n_p_g: int, n_local: int, n_p_l: int) -> Dict[str, Tensor]:
+        key = (B, n_p_g, n_local, n_p_l)
+        if key not in self._static_idx:
+            Ng, Nl = n_p_g + 1, n_p_l + 1
+            r = torch.arange(2 * B)
+            d = dict(
+                t_cls=(((r + B) % (2 * B)) * Ng).to(torch.int64),   # teacher cls rows, halves swapped (dinov2.py:414-420)
+                s_cls=(r * Ng).to(torch.int64),
+                l_cls=(torch.arange(n_local * B) * Nl).to(torch.int64),
+            )
+            self._static_idx[key] = {k: v.to(self.device) for k, v in d.items()}
+        return self._static_idx[key]
+
+    # ------------------------------------------------------------------ the step
+    def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:
+        a, cfg, ws, dev = self.method_args, self.cfg, self.ws, self.device
+        step = self.trainer.global_step
+        teacher_temp = linear_warmup_schedule(step, a.teacher_temp_warmup_steps, a.teacher_temp_start, a.teacher_temp_end)
+        views: List[Tensor] = batch["views"]
+        n_global = 2
+        n_local = len(views) - n_global
+        terms = (n_global - 1) * n_global + max(n_local * n_global, 1)
+        gv = torch.cat(views[:n_global]).to(dev, torch.float32)
+        n_crops = gv.shape[0]
+        B = n_crops // n_global
+        p = cfg.patch_size
+        gh, gw = gv.shape[2] // p, gv.shape[3] // p
+        n_p = gh * gw
+        Ng = n_p + 1
+        D, K = cfg.embed_dim, a.output_dim
+
+        if masks is None:
+            gen = MaskingGenerator(input_size=(gh, gw), max_num_patches=int(0.5 * gh * gw))
+            masks = create_collated_masks(a.mask_ratio_min, a.mask_ratio_max, int(n_crops * a.mask_probability), n_crops, gen)
+        cm = masks["collated_masks"]
+        mask_u8 = cm.to(torch.uint8).to(dev, non_blocking=True)
+        midx = masks["mask_indices_list"].to(torch.int64)
+        M = int(midx.shape[0])
+        mw = masks["masks_weight"].to(torch.float32)
+        patch_rows = ((midx // n_p) * Ng + 1 + midx % n_p).to(dev, non_blocking=True)
+        cap_M = int(n_crops * a.mask_probability) * max(int(0.5 * n_p), 1)
+        assert M <= cap_M
+
+        lv = torch.cat(views[n_global:]).to(dev, torch.float32) if n_local > 0 else None
+        n_p_l = (lv.shape[2] // p) * (lv.shape[3] // p) if lv is not None else 0
+        Nl = n_p_l + 1
+        ix = self._indices(B, n_p, n_local, n_p_l)
+        self.student.grad.zero_()
+        self._loss_slots.zero_()
+
+        # ---------------- teacher (no grad) : dinov2.py:399-472
+        if a.center_method == "softmax":
+            self._apply_center_updates()
+        tctx = self.t_vit.forward(ws, "t", gv, None, save=False)
+        Rt, cap_t = 2 * B + M, 2 * B + cap_M
+        t_in = ws.get("t.head_in", (cap_t, D), torch.bfloat16)
+        txn = tctx["xn"].view(-1, D)
+        ops.gather_rows(txn, D, ix["t_cls"], 2 * B, D, out_bf16=t_in[:2 * B])
+        ops.gather_rows(txn, D, patch_rows, M, D, out_bf16=t_in[2 * B:2 * B + M])
+        th = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False)
+        t_logits = th["logits"]
+        t_probs = ws.get("t.probs", (cap_t, K), torch.float32)
+        if a.center_method == "softmax":
+            ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
+            ops.softmax_center(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_probs[2 * B:Rt], M, K, 1.0 / teacher_temp)
+            cs_d = ws.get("t.colsum_dino", (K,), torch.float32)
+            cs_i = ws.get("t.colsum_ibot", (K,), torch.float32)
+            ops.colsum_f32(t_logits[:2 * B], cs_d, 2 * B, K)
+            ops.colsum_f32(t_logits[2 * B:Rt], cs_i, M, K)
+            # dinov2_loss.py:139-145 / :274-282 -- DINO: sum over 2B rows / (2B*world); iBOT: per-rank mean over M / world
+            ops.scale_f32(cs_i, 1.0 / max(M, 1))
+            hd = hi = None
+            if self.world > 1:
+                hd = dist.all_reduce(cs_d, async_op=True)
+                hi = dist.all_reduce(cs_i, async_op=True)
+            self._pending["dino"] = (cs_d, 1.0 / (2 * B), hd)
+            self._pending["ibot"] = (cs_i, 1.0, hi)
+        else:
+            self._sinkhorn(t_logits[:2 * B], t_probs[:2 * B], 2 * B, K, teacher_temp, float(2 * B * self.world), "skd")
+            n_masked_total = torch.tensor([float(M)], device=dev)
+            if self.world > 1:
+                dist.all_reduce(n_masked_total)
+            self._sinkhorn(t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, K, teacher_temp, n_masked_total, "ski")
+
+        # ---------------- student forward : dinov2.py:474-519
+        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True)
+        sl = self.s_vit.forward(ws, "sl", lv, None, save=True) if lv is not None else None
+        Rl = n_local * B
+        Rs, cap_s = 2 * B + M + Rl, 2 * B + cap_M + Rl
+        s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16)
+        sxn = sg["xn"].view(-1, D)
+        ops.gather_rows(sxn, D, ix["s_cls"], 2 * B, D, out_bf16=s_in[:2 * B])
+        ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in[2 * B:2 * B + M])
+        if sl is not None:
+            ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B + M:Rs])
+        sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True)
+
+        # ---------------- losses : dinov2.py:335-387, dinov2_loss.py:117-133,246-268
+        r2 = torch.arange(2 * B, dtype=torch.int32)
+        ta = torch.cat([r2, 2 * B + torch.arange(M, dtype=torch.int32), torch.arange(B, dtype=torch.int32).repeat(n_local)])
+        tb = torch.cat([torch.full((2 * B + M,), -1, dtype=torch.int32), (B + torch.arange(B, dtype=torch.int32)).repeat(n_local)])
+        coef = torch.cat([torch.full((2 * B,), a.dino_loss_weight * 2.0 / terms / (2 * B)), a.ibot_loss_weight * mw / n_crops,
+                          torch.full((Rl,), a.dino_loss_weight / terms / B)])
+        slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32)])
+        ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
+        dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16)
+        ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, 1.0 / a.student_temp, self._loss_slots, dlogits, Rs, K, slot=slot)
+
+        dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
+        dxn_g.zero_()
+        kws = ws.get("koleo.ws", (2 * B * D + 2 * B,), torch.float32)
+        knn = ws.get("koleo.nn", (B,), torch.int32)
+        if a.koleo_loss_weight != 0.0 and B > 1:
+            for c in range(2):  # per global-crop chunk, dinov2.py:377-380
+                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, self._loss_slots[3:], dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
+
+        # ---------------- backward
+        dx_head = self.s_head.backward(ws, sh, dlogits)
+        self.s_head.finish_weightnorm_grad()
+        ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
+        ops.scatter_add_rows(dx_head[2 * B:2 * B + M], patch_rows, dxn_g, D, M, D)
+        if sl is not None:
+            dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
+            dxn_l.zero_()
+            ops.scatter_add_rows(dx_head[2 * B + M:Rs], ix["l_cls"], dxn_l, D, Rl, D)
+            self.s_vit.backward(ws, sl, dxn_l)
+        self.s_vit.backward(ws, sg, dxn_g)
+
+        ls = self._loss_slots
+        # slots hold weighted terms; report the unweighted terms like the reference's log_dict
+        logs = {
+            "train_loss/dino_global_loss": ls[0] / a.dino_loss_weight if a.dino_loss_weight else ls[0],
+            "train_loss/dino_local_loss": ls[1] / a.dino_loss_weight if a.dino_loss_weight else ls[1],
+            "train_loss/ibot_loss": ls[2] / a.ibot_loss_weight if a.ibot_loss_weight else ls[2],
+            "train_loss/koleo_loss": ls[3] / a.koleo_loss_weight if a.koleo_loss_weight else ls[3],
+        }
+        self._last_masks = masks
+        self._last = dict(t_logits=t_logits[:Rt], t_probs=t_probs[:Rt], s_logits=sh["logits"][:Rs], B=B, M=M, Rl=Rl)
+        return TrainingStepResult(loss=ls.sum(), log_dict=logs)
+
+    def _sinkhorn(self, logits: Tensor, out: Tensor, rows: int, K: int, temp: float, n_total: Any, tag: str) -> None:
+        """dinov2_loss.py:84-115 / :188-224.  The initial Q /= sum(Q) is a global scalar that cancels in the first
+        row normalisation, so it is skipped (same value up to fp32 rounding)."""
+        nt = float(n_total.item()) if isinstance(n_total, Tensor) else float(n_total)
+        ops.sk_exp(logits, out, 1.0 / temp)
+        cs = self.ws.get(tag + ".colsum", (K,), torch.float32)
+        for it in range(3):
+            ops.colsum_f32(out, cs, rows, K)
+            if self.world > 1:
+                dist.all_reduce(cs)
+            ops.sk_iter(out, cs, rows, K, nt, nt if it == 2 else 1.0)
+
+    # ------------------------------------------------------------------ optimizer / EMA hooks
+    def allreduce_gradients(self) -> None:
+        """DDP gradient mean over ranks (C1 in SURVEY.md 2c) on the flat grad buffer, in 64 MiB buckets."""
+        if self.world == 1:
+            return
+        g = self.student.grad
+        bucket = 16 * 1024 * 1024
+        handles = []
+        for o in range(0, g.numel(), bucket):
+            handles.append(dist.all_reduce(g[o:o + bucket], async_op=True))
+        for h in handles:
+            h.wait()
+        ops.scale_f32(g, 1.0 / self.world)
+
+    def optimizer_step(self) -> Dict[str, float]:
+        """on_before_optimizer_step + configure_gradient_clipping + AdamW + CosineWarmupScheduler (dinov2.py:576-639)."""
+        a = self.method_args
+        k = self.trainer.global_step
+        total = self.trainer.estimated_stepping_batches
+        wd = cosine_schedule(k, total, a.weight_decay_start, a.weight_decay_end)
+        lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, a.min_lr / self.base_lr)
+        freeze = k < a.student_freeze_last_layer_steps
+        self.allreduce_gradients()
+        self._sumsq.zero_()
+        ops.sumsq(self.student.grad, self._sumsq)
+        self.opt_step += 1
+        ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
+                       self.seg_lr, self.seg_wd_on, self.seg_frozen, freeze, lr_factor, wd, a.betas[0], a.betas[1], a.eps,
+                       self.opt_step, self._sumsq, a.gradient_clip_val)
+        self.s_head.refresh_weightnorm()
+        self.last_grad_norm = self._sumsq  # squared norm, device scalar
+        self.trainer.global_step += 1
+        return {"weight_decay": wd, "lr_factor": lr_factor}
+
+    def on_train_batch_end(self) -> float:
+        """EMA teacher update with momentum evaluated at the already-incremented global_step (dinov2.py:641-660)."""
+        a = self.method_args
+        m = cosine_schedule(self.trainer.global_step, self.trainer.estimated_stepping_batches, a.momentum_start, a.momentum_end)
+        ops.ema_flat(self.teacher.data, self.student.data, self.teacher.bf16, m)
+        self.t_head.refresh_weightnorm()
+        return m
+
+    def train_step(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:
+        res = self.training_step_impl({"views": views}, 0, masks=masks)
+        self.optimizer_step()
+        self.on_train_batch_end()
+        return res

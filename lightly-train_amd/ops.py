@@ -152,6 +152,10 @@ def cast_bf16(src: Tensor, dst: Tensor) -> None:
     check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
 
 
+def scale_f32(dst: Tensor, alpha: float) -> None:
+    check(_lib.load().lt_scale_f32(_p(dst), alpha, dst.numel(), _stream()), "lt_scale_f32")
+
+
 def fill_f32(dst: Tensor, value: float) -> None:
     check(_lib.load().lt_fill_f32(_p(dst), value, dst.numel(), _stream()), "lt_fill_f32")
 
@@ -200,10 +204,10 @@ def center_ema(center: Tensor, colsum: Tensor, scale: float, momentum: float, K:
 
 
 def ce_fwd_bwd(s: Tensor, teacher: Tensor, ta: Tensor, tb: Optional[Tensor], row_weight: Optional[Tensor], scale: float,
-               inv_temp: float, loss: Tensor, dlogits: Optional[Tensor], rows: int, K: int) -> None:
+               inv_temp: float, loss: Tensor, dlogits: Optional[Tensor], rows: int, K: int, slot: Optional[Tensor] = None) -> None:
     _chk(ta, torch.int32, "ce.ta")
-    check(_lib.load().lt_ce_fwd_bwd(_p(s), _p(teacher), _p(ta), _p(tb), _p(row_weight), scale, inv_temp, _p(loss), _p(dlogits),
-                                    rows, K, _stream()), "lt_ce_fwd_bwd")
+    check(_lib.load().lt_ce_fwd_bwd(_p(s), _p(teacher), _p(ta), _p(tb), _p(row_weight), _p(slot), scale, inv_temp, _p(loss),
+                                    _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd")
 
 
 def sk_exp(logits: Tensor, Q: Tensor, inv_temp: float) -> None:

@@ -1,0 +1,322 @@
+"""ViT backbone forward / backward on the HIP ops -- the MI355X replacement for
+DinoVisionTransformer.forward_features (LT/_models/dinov2_vit/dinov2_vit_src/models/vision_transformer.py:307-384)
+and Block / Attention / Mlp / LayerScale / PatchEmbed (layers/*.py), with an explicit backward pass (no autograd).
+
+Parameter names equal the reference's DinoVisionTransformer.state_dict() keys (no register tokens, ffn "mlp").
+Numerics follow the reference under `precision="bf16-mixed"`: fp32 master weights, bf16 MFMA operands,
+fp32 accumulation, fp32 residual stream / LayerNorm / softmax statistics.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import ops
+from .params import FlatParams
+
+
+@dataclass
+class ViTConfig:
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: float = 4.0
+    patch_size: int = 16
+    img_size: int = 224
+    in_chans: int = 3
+    init_values: Optional[float] = 1e-5
+    interpolate_offset: float = 0.1
+    interpolate_antialias: bool = False
+
+    @property
+    def hidden(self) -> int:
+        return int(self.embed_dim * self.mlp_ratio)
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+ARCHS: Dict[str, Dict[str, Any]] = {
+    "_vit_test": dict(embed_dim=8, depth=3, num_heads=2, mlp_ratio=1.0),
+    "vit_tiny": dict(embed_dim=192, depth=12, num_heads=3),
+    "vit_small": dict(embed_dim=384, depth=12, num_heads=6),
+    "vit_base": dict(embed_dim=768, depth=12, num_heads=12),
+    "vit_large": dict(embed_dim=1024, depth=24, num_heads=16),
+    "vit_giant2": dict(embed_dim=1536, depth=40, num_heads=24),
+}
+
+
+def vit_param_shapes(cfg: ViTConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    D, hid, p = cfg.embed_dim, cfg.hidden, cfg.patch_size
+    n_p = (cfg.img_size // p) ** 2
+    out: List[Tuple[str, Tuple[int, ...]]] = [
+        ("cls_token", (1, 1, D)), ("pos_embed", (1, n_p + 1, D)), ("mask_token", (1, D)),
+        ("patch_embed.proj.weight", (D, cfg.in_chans, p, p)), ("patch_embed.proj.bias", (D,)),
+    ]
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        out += [(b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)), (b + "attn.qkv.weight", (3 * D, D)),
+                (b + "attn.qkv.bias", (3 * D,)), (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,))]
+        if cfg.init_values:
+            out.append((b + "ls1.gamma", (D,)))
+        out += [(b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)), (b + "mlp.fc1.weight", (hid, D)),
+                (b + "mlp.fc1.bias", (hid,)), (b + "mlp.fc2.weight", (D, hid)), (b + "mlp.fc2.bias", (D,))]
+        if cfg.init_values:
+            out.append((b + "ls2.gamma", (D,)))
+    out += [("norm.weight", (D,)), ("norm.bias", (D,))]
+    return out
+
+
+def init_vit_state(cfg: ViTConfig, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """Random init with the reference's initialisers (vision_transformer.py:243-249, 489-495; Conv2d default)."""
+    sd: Dict[str, Tensor] = {}
+    for name, shape in vit_param_shapes(cfg):
+        if name == "cls_token":
+            t = torch.empty(shape).normal_(std=1e-6, generator=generator)
+        elif name == "pos_embed" or (name.endswith(".weight") and len(shape) == 2):
+            t = torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=generator)
+        elif name == "patch_embed.proj.weight":
+            bound = 1 / math.sqrt(shape[1] * shape[2] * shape[3])
+            t = torch.empty(shape).uniform_(-bound, bound, generator=generator)
+        elif name == "patch_embed.proj.bias":
+            bound = 1 / math.sqrt(cfg.in_chans * cfg.patch_size ** 2)
+            t = torch.empty(shape).uniform_(-bound, bound, generator=generator)
+        elif name.endswith("gamma"):
+            t = torch.full(shape, float(cfg.init_values))
+        elif "norm" in name and name.endswith(".weight"):
+            t = torch.ones(shape)
+        else:
+            t = torch.zeros(shape)
+        sd[name] = t
+    return sd
+
+
+class Workspace:
+    """Named, shape-checked HBM buffers reused across steps (288 GB HBM: activations are kept, not recomputed)."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.bufs: Dict[str, Tensor] = {}
+
+    def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype) -> Tensor:
+        t = self.bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+def _split_k(tiles: int, k: int) -> int:
+    """split-K factor for wgrad GEMMs: enough workgroups for 256 CUs, at least 8 k-tiles (512) per slice."""
+    want = max(1, (2 * 256 + tiles - 1) // tiles)
+    return max(1, min(want, 32, k // 512 if k >= 1024 else 1))
+
+
+class ViTEngine:
+    """Runs one backbone (student or teacher) whose parameters live in a FlatParams under `prefix`."""
+
+    def __init__(self, cfg: ViTConfig, params: FlatParams, prefix: str = "") -> None:
+        self.cfg = cfg
+        self.P = params
+        self.prefix = prefix
+        self.dev = params.device
+        self._pos_maps: Dict[Tuple[int, int], Optional[Tensor]] = {}
+        D = cfg.embed_dim
+        kreal = cfg.in_chans * cfg.patch_size ** 2
+        self.kpad = (kreal + 7) // 8 * 8
+        if self.kpad != kreal:
+            raise NotImplementedError("patch_size with in_chans*p*p % 8 != 0 (e.g. /14) not supported yet")
+        assert D % 8 == 0 and cfg.hidden % 8 == 0, "embed_dim and mlp hidden must be multiples of 8"
+
+    # ---- parameter access -------------------------------------------------------------------
+    def w(self, name: str) -> Tensor:
+        return self.P.p[self.prefix + name]
+
+    def wb(self, name: str) -> Tensor:
+        return self.P.b[self.prefix + name]
+
+    def gw(self, name: str) -> Tensor:
+        return self.P.g[self.prefix + name]
+
+    def has(self, name: str) -> bool:
+        return (self.prefix + name) in self.P.p
+
+    # ---- positional embedding for a gh x gw grid ------------------------------------------------
+    def _pos_map(self, gh: int, gw: int) -> Optional[Tensor]:
+        """Linear map [gh*gw, M*M] with pos_grid = map @ pos_native, obtained by pushing an identity basis through
+        the reference's bicubic F.interpolate call (vision_transformer.py:283-300) once on the host."""
+        key = (gh, gw)
+        if key in self._pos_maps:
+            return self._pos_maps[key]
+        n_native = self.w("pos_embed").shape[1] - 1
+        m = int(math.sqrt(n_native))
+        assert m * m == n_native
+        if gh * gw == n_native and gh == gw:
+            self._pos_maps[key] = None
+            return None
+        basis = torch.eye(n_native).reshape(1, m, m, n_native).permute(0, 3, 1, 2)  # [1, M*M chans, M, M]
+        kw: Dict[str, Any] = {}
+        if self.cfg.interpolate_offset:
+            kw["scale_factor"] = (float(gh + self.cfg.interpolate_offset) / m, float(gw + self.cfg.interpolate_offset) / m)
+        else:
+            kw["size"] = (gh, gw)
+        out = F.interpolate(basis, mode="bicubic", antialias=self.cfg.interpolate_antialias, **kw)
+        assert out.shape[-2:] == (gh, gw)
+        mp = out.permute(0, 2, 3, 1).reshape(gh * gw, n_native).contiguous().to(self.dev)
+        self._pos_maps[key] = mp
+        return mp
+
+    def _pos_for_grid(self, ws: Workspace, tag: str, gh: int, gw: int) -> Tensor:
+        D = self.cfg.embed_dim
+        pe = self.w("pos_embed").view(-1, D)
+        mp = self._pos_map(gh, gw)
+        if mp is None:
+            return pe
+        pos = ws.get(tag + ".pos", (gh * gw + 1, D), torch.float32)
+        pos[0].copy_(pe[0])
+        ops.matmul_f32(mp, pe[1:], pos[1:], gh * gw, D, mp.shape[1])
+        return pos
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool) -> Dict[str, Any]:
+        """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens)."""
+        cfg = self.cfg
+        B, C, H, W = img.shape
+        p, D, Hh, dh, hid = cfg.patch_size, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
+        if H % p or W % p:
+            raise NotImplementedError("image size must be a multiple of patch_size (bicubic pad-resize of patch_embed.py:90-99 not implemented)")
+        gh, gw = H // p, W // p
+        n_p, N = gh * gw, gh * gw + 1
+        T = B * N
+        scale = dh ** -0.5
+        ctx: Dict[str, Any] = dict(B=B, N=N, n_p=n_p, gh=gh, gw=gw, T=T, masks=masks, tag=tag)
+
+        cols = ops.im2col(img.contiguous(), p, self.kpad)
+        patch = ws.get(tag + ".patch", (B * n_p, D), torch.float32)
+        ops.gemm(cols, self.wb("patch_embed.proj.weight").view(D, -1), patch, M=B * n_p, N=D, K=self.kpad,
+                 epilogue=ops.EPI_F32, bias=self.w("patch_embed.proj.bias"))
+        pos = self._pos_for_grid(ws, tag, gh, gw)
+        x = ws.get(tag + ".x0" if save else tag + ".xa", (T, D), torch.float32)
+        ops.assemble_tokens(patch, self.w("cls_token").view(D), pos, self.w("mask_token").view(D), masks, B, n_p, D, out=x)
+        ctx["cols"] = cols
+
+        blocks: List[Dict[str, Tensor]] = []
+        for i in range(cfg.depth):
+            s = f"{tag}.b{i}." if save else f"{tag}.tmp."
+            pre = f"blocks.{i}."
+            g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
+            g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
+            bk: Dict[str, Tensor] = {"x": x}
+            ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16)
+            bk["mean1"], bk["rstd1"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
+            ops.layernorm_fwd(x, self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), T, D, y_bf16=ln1, mean=bk["mean1"], rstd=bk["rstd1"])
+            qkv = ws.get(s + "qkv", (T, 3 * D), torch.bfloat16)
+            ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=T, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
+            att = ws.get(s + "att", (T, D), torch.bfloat16)
+            lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
+            ops.attention_fwd(qkv, att, lse, B, N, Hh, dh, scale)
+            y1 = ws.get(s + "y1", (T, D), torch.bfloat16) if (save and g1 is not None) else None
+            xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
+            ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
+                     gamma=g1, resid=x, out2=y1)
+            ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16)
+            bk["mean2"], bk["rstd2"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
+            ops.layernorm_fwd(xm, self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), T, D, y_bf16=ln2, mean=bk["mean2"], rstd=bk["rstd2"])
+            act = ws.get(s + "act", (T, hid), torch.bfloat16)
+            hpre = ws.get(s + "hpre", (T, hid), torch.bfloat16) if save else None
+            ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=T, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
+            y2 = ws.get(s + "y2", (T, D), torch.bfloat16) if (save and g2 is not None) else None
+            xo = ws.get(f"{tag}.b{i}.xo" if save else (tag + ".xa"), (T, D), torch.float32)
+            ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
+                     gamma=g2, resid=xm, out2=y2)
+            if save:
+                bk.update(ln1=ln1, qkv=qkv, att=att, lse=lse, y1=y1, xm=xm, ln2=ln2, act=act, hpre=hpre, y2=y2)
+                blocks.append(bk)
+            x = xo
+        xn = ws.get(tag + ".xn", (B, N, D), torch.float32)
+        mean = ws.get(tag + ".meanf", (T,), torch.float32)
+        rstd = ws.get(tag + ".rstdf", (T,), torch.float32)
+        ops.layernorm_fwd(x, self.w("norm.weight"), self.w("norm.bias"), T, D, y_f32=xn, mean=mean, rstd=rstd)
+        ctx.update(blocks=blocks, x_last=x, meanf=mean, rstdf=rstd, xn=xn)
+        return ctx
+
+    # ---- backward -------------------------------------------------------------------------------
+    def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor) -> None:
+        """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views."""
+        cfg = self.cfg
+        B, N, n_p, T, tag = ctx["B"], ctx["N"], ctx["n_p"], ctx["T"], ctx["tag"]
+        D, Hh, dh, hid = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
+        scale = dh ** -0.5
+        dxa = ws.get(tag + ".dxa", (T, D), torch.float32)
+        dxb = ws.get(tag + ".dxb", (T, D), torch.float32)
+        dD = ws.get(tag + ".dD", (T, D), torch.bfloat16)        # bf16 [T,D] gradient scratch
+        dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16)
+        dH = ws.get(tag + ".dH", (T, hid), torch.bfloat16)
+        dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
+        aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
+
+        ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
+                          self.gw("norm.weight"), self.gw("norm.bias"), T, D)
+        dx = dxa
+        other = dxb
+
+        def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int) -> None:
+            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=T, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                     split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in)
+
+        for i in reversed(range(cfg.depth)):
+            bk = ctx["blocks"][i]
+            pre = f"blocks.{i}."
+            g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
+            g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
+            # ---- MLP branch: xo = xm + g2 * (fc2(gelu(fc1(ln2))))
+            ops.layerscale_bwd(dx, bk["y2"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, T, D)
+            ops.colsum_bf16(dD, self.gw(pre + "mlp.fc2.bias"), T, D)
+            wgrad(dD, bk["act"], pre + "mlp.fc2.weight", D, hid)
+            ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=T, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=bk["hpre"])
+            ops.colsum_bf16(dH, self.gw(pre + "mlp.fc1.bias"), T, hid)
+            wgrad(dH, bk["ln2"], pre + "mlp.fc1.weight", hid, D)
+            ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=T, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
+            ops.layernorm_bwd(bk["xm"], self.w(pre + "norm2.weight"), bk["mean2"], bk["rstd2"], dD2, dx, other,
+                              self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D)
+            dx, other = other, dx
+            # ---- attention branch: xm = x + g1 * proj(attn(qkv(ln1)))
+            ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D)
+            ops.colsum_bf16(dD, self.gw(pre + "attn.proj.bias"), T, D)
+            wgrad(dD, bk["att"], pre + "attn.proj.weight", D, D)
+            ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=T, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+            ops.attention_bwd(bk["qkv"], bk["att"], dD2, bk["lse"], aws, dQ, B, N, Hh, dh, scale)
+            ops.colsum_bf16(dQ, self.gw(pre + "attn.qkv.bias"), T, 3 * D)
+            wgrad(dQ, bk["ln1"], pre + "attn.qkv.weight", 3 * D, D)
+            ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=T, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
+            ops.layernorm_bwd(bk["x"], self.w(pre + "norm1.weight"), bk["mean1"], bk["rstd1"], dD, dx, other,
+                              self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D)
+            dx, other = other, dx
+
+        # ---- token assembly + patch embedding
+        dpatch = ws.get(tag + ".dpatch", (B * n_p, D), torch.bfloat16)
+        mp = self._pos_map(ctx["gh"], ctx["gw"])
+        gpos = self.gw("pos_embed").view(-1, D)
+        if mp is None:
+            dpos = gpos
+        else:
+            dpos = ws.get(tag + ".dpos", (n_p + 1, D), torch.float32)
+            dpos.zero_()
+        ops.assemble_tokens_bwd(dx, ctx["masks"], dpatch, self.gw("cls_token").view(D), dpos, self.gw("mask_token").view(D), B, n_p, D)
+        if mp is not None:
+            gpos[0].add_(dpos[0])  # cls position row (plumbing: one D-vector add)
+            ops.matmul_f32(mp, dpos[1:], gpos[1:], mp.shape[1], D, n_p, trans_a=True, accumulate=True)
+        ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
+        tiles = ((D + 127) // 128) * ((self.kpad + 127) // 128)
+        ops.gemm(dpatch, ctx["cols"], self.gw("patch_embed.proj.weight").view(D, -1), M=D, N=self.kpad, K=B * n_p, trans_a=True,
+                 trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=_split_k(tiles, B * n_p), lda=D, ldb=self.kpad, ldc=self.kpad)
