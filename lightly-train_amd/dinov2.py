@@ -22,6 +22,7 @@ from torch import Tensor
 
 from . import ops
 from .masking import MaskingGenerator, create_collated_masks
+from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
 from .vit import ViTConfig, ViTEngine, Workspace, init_vit_state, vit_param_shapes
@@ -121,6 +122,19 @@ def param_group_hparams(name: str, is_backbone: bool, depth: int, lr: float, arg
     if "patch_embed" in name:
         out["lr"] = out["lr"] * args.patch_embed_lr_multiplier
     return out
+
+
+def fuse_param_groups(groups: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+    """get_fused_param_groups (utils.py:253-273): merge groups with identical lr / weight_decay / head / last_layer
+    properties, named after (and ordered by) their first member."""
+    fused: Dict[Tuple[Any, ...], Dict[str, Any]] = {}
+    for g in groups:
+        key = (g["lr"], g["weight_decay"], g["head"], g["last_layer"])
+        if key not in fused:
+            fused[key] = dict(g, names=[g["name"]])
+        else:
+            fused[key]["names"].append(g["name"])
+    return list(fused.values())
 
 
 class HeadEngine:
@@ -272,6 +286,7 @@ class DINOv2:
         self._loss_slots = torch.zeros(4, device=dev)
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
+        self._grad_sync: Optional[GradSync] = None
 
     # ------------------------------------------------------------------ reference-compatible views
     def state_dict(self) -> Dict[str, Tensor]:
@@ -459,17 +474,13 @@ class DINOv2:
 
     # ------------------------------------------------------------------ optimizer / EMA hooks
     def allreduce_gradients(self) -> None:
-        """DDP gradient mean over ranks (C1 in SURVEY.md 2c) on the flat grad buffer, in 64 MiB buckets."""
+        """DDP gradient mean over ranks (C1 in SURVEY.md 2c) on the flat grad buffer (parallel.GradSync)."""
         if self.world == 1:
             return
-        g = self.student.grad
-        bucket = 16 * 1024 * 1024
-        handles = []
-        for o in range(0, g.numel(), bucket):
-            handles.append(dist.all_reduce(g[o:o + bucket], async_op=True))
-        for h in handles:
-            h.wait()
-        ops.scale_f32(g, 1.0 / self.world)
+        if self._grad_sync is None:
+            self._grad_sync = GradSync(self.student.grad)
+        self._grad_sync.start()
+        self._grad_sync.finish()
 
     def optimizer_step(self) -> Dict[str, float]:
         """on_before_optimizer_step + configure_gradient_clipping + AdamW + CosineWarmupScheduler (dinov2.py:576-639)."""

@@ -1,0 +1,70 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The DINOv2 step shards by images: every rank runs the full step on its own B images, masks and RNG; the only
+exchanges are:
+  C1   gradient mean over ranks        -> GradSync (bucketed async all-reduce on the flat fp32 grad buffer)
+  C3/4 DINO / iBOT center sums         -> async all-reduce, consumed at the next step (dinov2.py, _pending)
+  C5/6 Sinkhorn-Knopp row sums         -> synchronous all-reduce inside the teacher path
+No parameter broadcast is needed after init: every rank builds identical weights from the same seed and the
+EMA teacher of identical students stays identical.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def per_rank_batch(global_batch: int, world: int) -> int:
+    """common_helpers.py:665-719 semantics: the global batch must divide evenly over ranks."""
+    if global_batch % world != 0:
+        raise ValueError(f"Batch size {global_batch} must be divisible by (num_nodes * devices) = {world}.")
+    return global_batch // world
+
+
+def bucket_ranges(numel: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    return [(o, min(o + bucket_elems, numel)) for o in range(0, numel, bucket_elems)]
+
+
+class GradSync:
+    """Mean-all-reduce of a flat gradient buffer in fixed-size buckets.  xGMI is point-to-point (7 links/GPU), so
+    large buckets (64 MiB fp32) keep RCCL on its bandwidth-optimal direct algorithms; buckets are issued async and
+    back-to-back so RCCL pipelines them on its own stream while the caller continues."""
+
+    def __init__(self, flat_grad: Tensor, bucket_bytes: int = 64 << 20) -> None:
+        self.g = flat_grad
+        self.ranges = bucket_ranges(flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size()))
+        self.handles: List = []
+
+    def start(self, lo: int = 0, hi: Optional[int] = None) -> None:
+        """Launch the all-reduce of every bucket that lies inside [lo, hi) (call as gradients become final)."""
+        if world_size() == 1:
+            return
+        hi = self.g.numel() if hi is None else hi
+        for a, b in self.ranges:
+            if a >= lo and b <= hi:
+                self.handles.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        w = world_size()
+        if w == 1:
+            return
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        if self.g.is_cuda:
+            from . import ops
+
+            ops.scale_f32(self.g, 1.0 / w)
+        else:
+            self.g.mul_(1.0 / w)

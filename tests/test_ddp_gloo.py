@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the N>1 data-parallel path (gradient mean in buckets, batch sharding rule)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.parallel import GradSync, per_rank_batch, world_size
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert world_size() == 2 and per_rank_batch(256, world) == 128
+        g = torch.Generator().manual_seed(100 + rank)
+        grad = torch.randn(10_000, generator=g)
+        mine = grad.clone()
+        sync = GradSync(grad, bucket_bytes=4096 * 4)  # 3 buckets: 4096 + 4096 + 1808
+        assert len(sync.ranges) == 3 and sync.ranges[-1] == (8192, 10_000)
+        sync.start(0, 8192)      # buckets that are already final
+        sync.start(8192, 10_000)  # the tail
+        sync.finish()
+        others = [torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        expect = sum(others) / world
+        assert torch.allclose(grad, expect, atol=1e-6)
+        assert torch.equal(others[rank], mine)
+        # center sums: async all-reduce consumed later (dinov2_loss.py:139-160 semantics)
+        cs = torch.full((8,), float(rank + 1))
+        h = dist.all_reduce(cs, async_op=True)
+        h.wait()
+        assert torch.equal(cs, torch.full((8,), 3.0))
+        torch.save(grad, os.path.join(out_dir, f"grad{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_two_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "grad0.pt")
+    b = torch.load(tmp_path / "grad1.pt")
+    assert torch.equal(a, b), "ranks disagree after the gradient all-reduce"
+
+
+def test_batch_must_divide():
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.parallel import bucket_ranges, per_rank_batch
+
+    with pytest.raises(ValueError):
+        per_rank_batch(100, 8)
+    assert bucket_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]

@@ -1,0 +1,166 @@
+"""-m gpu: the HIP DINOv2 step against (a) golden fixtures produced by the reference's own code on CPU fp32 and
+(b) the oracle restatement on identical seeded inputs.
+
+Stated tolerances (bf16 MFMA operands / fp32 accumulate vs an fp32 reference):
+  logits                     2e-2 of max|logit|   (observed 3e-3 .. 8e-3)
+  DINO / iBOT loss terms     5e-3 relative        (observed 2e-4 .. 2.4e-3)
+  KoLeo term                 3e-2 relative        (distances of near-identical cls tokens: ill-conditioned at init,
+                                                   the reference's own bf16-mixed path has the same sensitivity)
+  gradients, KoLeo off       5e-2 of max|grad| per tensor (observed <= 1.8e-2 at D=64, 3.5e-2 on the D=8 toy)
+  gradients, KoLeo on        5e-2 for the well-conditioned tensors (head, final norm, cls/pos tokens); the in-branch
+                             tensors are sums that cancel to ~1e-3 of their terms (LayerScale 1e-5 * +-KoLeo pairs) and are
+                             checked through the grad-norm (8e-2, D=64 fixture) instead."""
+import os
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def synth_views(seed, b, g_size, l_size, n_local):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
+        torch.randn(b, 3, l_size, l_size, generator=g) for _ in range(n_local)]
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+
+
+def build(fx, **over):
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig
+
+    cfgd, mk = fx["cfg"], fx["method_kwargs"]
+    sb = fx["init"]["student_backbone"]
+    D = sb["cls_token"].shape[-1]
+    hid = sb["blocks.0.mlp.fc1.weight"].shape[0]
+    vc = ViTConfig(embed_dim=D, depth=cfgd["depth"], num_heads=cfgd["num_heads"], mlp_ratio=hid / D, patch_size=cfgd["patch_size"],
+                   img_size=fx["g_size"])
+    args = DINOv2Args(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"],
+                      center_method=mk.get("center_method", "softmax"), **over)
+    return DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=sb,
+                  student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"])
+
+
+def oracle_for(fx, **over):
+    from oracle import dinov2_oracle as O
+
+    mk = fx["method_kwargs"]
+    a = dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], bottleneck_dim=mk["dino_bottleneck_dim"],
+             center_method=mk.get("center_method", "softmax"))
+    a.update(over)
+    return O.OracleDINOv2(fx["init"]["student_backbone"], fx["init"]["student_head"], fx["cfg"], args=a, global_batch_size=fx["b"],
+                          total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"])
+
+
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_d64_softmax"])
+def test_step_matches_reference_fixture(name):
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    m = build(fx)
+    for si, rec in enumerate(fx["steps"]):
+        views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+        L = m._last
+        B, M = L["B"], L["M"]
+        assert rel(L["t_logits"][:2 * B], rec["teacher_cls_logits"]) < 2e-2
+        assert rel(L["t_logits"][2 * B:], rec["teacher_patch_logits"]) < 2e-2
+        assert rel(L["s_logits"][:2 * B], rec["student_cls_logits"]) < 2e-2
+        assert rel(L["s_logits"][2 * B:2 * B + M], rec["student_patch_logits"]) < 2e-2
+        assert rel(L["s_logits"][2 * B + M:], rec["student_local_logits"]) < 2e-2
+        logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+            assert logs[k] == pytest.approx(rec["logs"][k], rel=5e-3), (si, k)
+        assert logs["koleo_loss"] == pytest.approx(rec["logs"]["koleo_loss"], rel=3e-2)
+        assert float(res.loss) == pytest.approx(rec["logs"]["loss"], rel=1e-2)
+        m.optimizer_step()
+        assert float(m.last_grad_norm.sqrt()) == pytest.approx(rec["logs"]["grad_norm"], rel=6e-2)
+        m.on_train_batch_end()
+        if si > 0 and m.method_args.center_method == "softmax":
+            # centers are applied lazily: after step si the center holds the update computed at step si-1
+            assert rel(m.dino_center, rec["dino_center"]) < 2e-2
+            assert rel(m.ibot_center, rec["ibot_center"]) < 2e-2
+    sd = m.state_dict()
+    assert "student_embedding_model.wrapped_model._model.blocks.0.attn.qkv.weight" in sd
+    assert "teacher_head.ibot_head.last_layer.parametrizations.weight.original1" in sd and "dino_loss.center" in sd
+
+
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_d64_softmax"])
+def test_gradients_match_oracle(name):
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    for koleo_w in (0.0, 0.1):
+        m = build(fx, koleo_loss_weight=koleo_w)
+        o = oracle_for(fx, koleo_loss_weight=koleo_w)
+        res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+        loss, _ = o.forward_loss(views, rec["masks"])
+        loss.backward()
+        assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3 if koleo_w == 0 else 1e-2)
+        well = ("head.", "backbone.norm.", "backbone.cls_token", "backbone.pos_embed")
+        sq_o = sq_r = 0.0
+        for n in m.student.names:
+            ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+            ours = m.student.g[n].cpu()
+            sq_o += float((ours.double() ** 2).sum()); sq_r += float((ref.double() ** 2).sum())
+            if koleo_w == 0.0 or n.startswith(well):
+                assert rel(ours, ref) < 5e-2, (koleo_w, n)
+        if koleo_w == 0.0 or name == "step_d64_softmax":  # the D=8 toy + KoLeo is chaotic (nearest-neighbour flips between CPUs)
+            assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2 if koleo_w == 0.0 else 8e-2)
+
+
+def test_parameter_update_and_ema_match_oracle():
+    """One full optimizer step (clip + AdamW + EMA) on identical gradients-by-construction (KoLeo off):
+    Adam's first step is sign-like (|update| = lr), so per-element agreement is measured as a fraction."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    m = build(fx, koleo_loss_weight=0.0)
+    o = oracle_for(fx, koleo_loss_weight=0.0)
+    m.train_step(views, masks=rec["masks"])
+    o.train_step(views, rec["masks"])
+    agree = tot = 0
+    for n in m.student.names:
+        ref_p = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).detach()
+        init = (fx["init"]["student_backbone"][n[9:]] if n.startswith("backbone.") else fx["init"]["student_head"][n[5:]])
+        d_ref, d_our = ref_p - init, m.student.p[n].cpu() - init
+        lr_t = d_ref.abs().max().item()
+        if lr_t == 0:
+            assert d_our.abs().max().item() == 0, n   # frozen last layer (lr = 0 for the first 1250 steps)
+            continue
+        assert d_our.abs().max().item() <= 1.05 * lr_t + 1e-9, n
+        agree += int(((d_our - d_ref).abs() <= 0.1 * lr_t).sum()); tot += d_ref.numel()
+        ref_t = (o.tb[n[9:]] if n.startswith("backbone.") else o.th[n[5:]])
+        assert torch.allclose(m.teacher.p[n].cpu(), ref_t, atol=2e-7 + 0.02 * lr_t), n
+    assert agree / tot > 0.97, f"only {agree / tot:.3f} of the parameter updates agree with the oracle"
+
+
+def test_full_size_head_properties():
+    """K = 65 536 at bench size: probabilities are normalised, Sinkhorn rows sum to 1, CE of t against itself >= entropy."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd import ops
+
+    rows, K = 64, 65536
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(rows, K, generator=g) * 0.3).cuda()
+    probs = torch.empty_like(logits)
+    ops.softmax_center(logits, None, probs, rows, K, 1 / 0.04)
+    assert torch.allclose(probs.sum(-1), torch.ones(rows, device="cuda"), atol=1e-4)
+    Q = torch.empty_like(logits); cs = torch.empty(K, device="cuda")
+    ops.sk_exp(logits, Q, 1 / 0.04)
+    for it in range(3):
+        ops.colsum_f32(Q, cs, rows, K)
+        ops.sk_iter(Q, cs, rows, K, float(rows), float(rows) if it == 2 else 1.0)
+    assert torch.allclose(Q.sum(-1), torch.ones(rows, device="cuda"), atol=1e-4)
+    assert torch.allclose(Q.sum(0), torch.full((K,), rows / K, device="cuda"), rtol=0.2)  # prototypes roughly balanced
+    loss = torch.zeros(1, device="cuda")
+    ta = torch.arange(rows, dtype=torch.int32, device="cuda")
+    ops.ce_fwd_bwd(logits, probs, ta, None, None, 1.0 / rows, 10.0, loss, None, rows, K)
+    ref = -(probs * torch.log_softmax(logits * 10.0, -1)).sum(-1).mean()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-4)

