@@ -15,6 +15,7 @@
  */
 #ifndef LT_AMD_H
 #define LT_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -63,6 +64,8 @@ typedef struct lt_gemm_desc {
   const void* aux; int ldaux;     /* [M][N] bf16 pre-activation (LT_EPI_BF16_GELUGRAD) */
   float alpha;
   int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
+  int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged kernel, 2 = 256-row LDS-DMA kernel */
+  void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */
 } lt_gemm_desc;
 
 int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);
@@ -93,10 +96,11 @@ int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
 int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
                      int dy_is_f32, const float* dres, float* dx, float* dw, float* db, int rows, int D, void* stream);
 
-/* LayerScale backward (layer_scale.py:27-28): dy(bf16) = dout*gamma; dgamma += sum_rows dout*y.
- * gamma == NULL: dy = bf16(dout) only. */
+/* LayerScale backward (layer_scale.py:27-28): dy(bf16) = dout*gamma; dgamma += sum_rows dout*y;
+ * dbias (optional) += sum_rows dy  (bias gradient of the Linear in front of LayerScale, fused).
+ * gamma == NULL: dy = bf16(dout). */
 int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
-                      int rows, int D, void* stream);
+                      float* dbias, int rows, int D, void* stream);
 /* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */
 int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream);
 /* out[N] (+)= column sums of an f32 [rows,N] matrix (teacher center, dinov2_loss.py:139-145,274-282) */

@@ -38,15 +38,18 @@ __global__ void assemble_kernel(const float* __restrict__ patch, const float* __
   for (int d = threadIdx.x; d < D; d += blockDim.x) x[tok * D + d] = src[d] + pos[(long)t * D + d];
 }
 
-// one thread per (t, d): loops over the batch (coalesced over d)
-__global__ void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t* __restrict__ masks, bf16_t* __restrict__ dpatch,
-                                    float* __restrict__ dcls, float* __restrict__ dpos, float* __restrict__ dmask, int B, int n_p,
-                                    int D) {
+// block = 64 columns x 4 batch-lanes for one token position t; the batch reduction goes through LDS
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t* __restrict__ masks,
+                                                           bf16_t* __restrict__ dpatch, float* __restrict__ dcls, float* __restrict__ dpos,
+                                                           float* __restrict__ dmask, int B, int n_p, int D) {
+  __shared__ float red[2][4][64];
   const int N = n_p + 1;
   const int t = blockIdx.x;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float sum = 0.f, msum = 0.f;
-    for (int b = 0; b < B; ++b) {
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int d = blockIdx.y * 64 + cl;
+  float sum = 0.f, msum = 0.f;
+  if (d < D) {
+    for (int b = bl; b < B; b += 4) {
       const float g = dx[((long)b * N + t) * D + d];
       sum += g;
       if (t > 0) {
@@ -55,9 +58,15 @@ __global__ void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t*
         dpatch[((long)b * n_p + t - 1) * D + d] = m ? (bf16_t)0 : f2bf(g);
       }
     }
-    dpos[(long)t * D + d] += sum;
-    if (t == 0) dcls[d] += sum;
-    else if (masks && msum != 0.f) atomicAdd(&dmask[d], msum);
+  }
+  red[0][bl][cl] = sum; red[1][bl][cl] = msum;
+  __syncthreads();
+  if (bl == 0 && d < D) {
+    const float s2 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    const float m2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    dpos[(long)t * D + d] += s2;
+    if (t == 0) dcls[d] += s2;
+    else if (masks && m2 != 0.f) atomicAdd(&dmask[d], m2);
   }
 }
 
@@ -134,6 +143,84 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Vector backward for D % 4 == 0 (D <= 2048): lane owns float4 column groups c = (i*64 + lane)*4; per-lane dw/db partials
+// live in registers across the wave's rows, are reduced over the block's 4 waves in LDS, then one atomicAdd per column.
+template <bool DYF32>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const void* __restrict__ dyv, const float* __restrict__ dres,
+                                                                float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                                int rows, int D) {
+  __shared__ float4 red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 aw[MAXV], ab[MAXV], wv4[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    const int c = (i * 64 + lane) * 4;
+    wv4[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
+  }
+  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[MAXV], gy[MAXV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      xh[i] = make_float4(0, 0, 0, 0); gy[i] = make_float4(0, 0, 0, 0);
+      if (c < D) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c);
+        float4 d;
+        if (DYF32) d = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
+        else {
+          const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
+          d = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+        }
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gy[i] = make_float4(d.x * wv4[i].x, d.y * wv4[i].y, d.z * wv4[i].z, d.w * wv4[i].w);
+        c1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
+        c2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
+        aw[i].x += d.x * xh[i].x; aw[i].y += d.y * xh[i].y; aw[i].z += d.z * xh[i].z; aw[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      }
+    }
+    c1 = wave_sum(c1) / D;
+    c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        float4 o = make_float4(rs * (gy[i].x - c1 - xh[i].x * c2), rs * (gy[i].y - c1 - xh[i].y * c2),
+                               rs * (gy[i].z - c1 - xh[i].z * c2), rs * (gy[i].w - c1 - xh[i].w * c2));
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + row * D + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i * 256 >= D) break;
+    __syncthreads();
+    red[0][wv][lane] = aw[i];
+    red[1][wv][lane] = ab[i];
+    __syncthreads();
+    if (wv == 0) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const float4 a0 = red[0][0][lane], a1 = red[0][1][lane], a2 = red[0][2][lane], a3 = red[0][3][lane];
+        const float4 b0 = red[1][0][lane], b1 = red[1][1][lane], b2 = red[1][2][lane], b3 = red[1][3][lane];
+        atomicAdd(&dw[c], a0.x + a1.x + a2.x + a3.x); atomicAdd(&dw[c + 1], a0.y + a1.y + a2.y + a3.y);
+        atomicAdd(&dw[c + 2], a0.z + a1.z + a2.z + a3.z); atomicAdd(&dw[c + 3], a0.w + a1.w + a2.w + a3.w);
+        atomicAdd(&db[c], b0.x + b1.x + b2.x + b3.x); atomicAdd(&db[c + 1], b0.y + b1.y + b2.y + b3.y);
+        atomicAdd(&db[c + 2], b0.z + b1.z + b2.z + b3.z); atomicAdd(&db[c + 3], b0.w + b1.w + b2.w + b3.w);
+      }
+    }
+  }
+}
+
 // generic (scalar-column) backward; each wave walks rows with stride, keeps dw/db partials per lane-column
 // in registers for up to 32 columns per lane (D <= 2048), reduces over the block's 4 waves in LDS,
 // then one atomicAdd per column per block.
@@ -199,29 +286,99 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------ LayerScale bwd
+// block = 32 column-chunks (4 columns each = 128 columns) x 8 row-lanes; grid.x over 128-column groups, grid.y row slabs.
+// dy(bf16) = dout*gamma; dgamma += sum_rows dout*y; dbias += sum_rows dout*gamma (bias of the Linear feeding LayerScale).
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
                                                              const float* __restrict__ gamma, bf16_t* __restrict__ dy,
-                                                             float* __restrict__ dgamma, int rows, int D) {
-  // block = 256 threads: 64 column-lanes x 4 row-lanes; grid.x over column groups of 64, grid.y over row slabs
-  __shared__ float red[4][64];
+                                                             float* __restrict__ dgamma, float* __restrict__ dbias, int rows, int D) {
+  __shared__ float4 red[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cl) * 4;
+  float4 ag = make_float4(0, 0, 0, 0), abias = make_float4(0, 0, 0, 0);
+  if (c < D) {
+    const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    for (long r = (long)blockIdx.y * 8 + rl; r < rows; r += (long)gridDim.y * 8) {
+      const float4 g = *reinterpret_cast<const float4*>(dout + r * D + c);
+      const float4 o = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
+      *reinterpret_cast<uint2*>(dy + r * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+      abias.x += o.x; abias.y += o.y; abias.z += o.z; abias.w += o.w;
+      if (gamma) {
+        const uint2 u = *reinterpret_cast<const uint2*>(y + r * D + c);
+        ag.x += g.x * bf2f((bf16_t)(u.x & 0xffff)); ag.y += g.y * bf2f((bf16_t)(u.x >> 16));
+        ag.z += g.z * bf2f((bf16_t)(u.y & 0xffff)); ag.w += g.w * bf2f((bf16_t)(u.y >> 16));
+      }
+    }
+  }
+  red[0][rl][cl] = ag;
+  red[1][rl][cl] = abias;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float4 a = red[0][0][cl], b = red[1][0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      const float4 a2 = red[0][i][cl], b2 = red[1][i][cl];
+      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+    }
+    if (gamma) { atomicAdd(&dgamma[c], a.x); atomicAdd(&dgamma[c + 1], a.y); atomicAdd(&dgamma[c + 2], a.z); atomicAdd(&dgamma[c + 3], a.w); }
+    if (dbias) { atomicAdd(&dbias[c], b.x); atomicAdd(&dbias[c + 1], b.y); atomicAdd(&dbias[c + 2], b.z); atomicAdd(&dbias[c + 3], b.w); }
+  }
+}
+// scalar fallback for D % 4 != 0
+__global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                                    const float* __restrict__ gamma, bf16_t* __restrict__ dy,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbias, int rows, int D) {
+  __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float acc = 0.f;
+  float acc = 0.f, accb = 0.f;
   if (c < D) {
     const float gm = gamma ? gamma[c] : 1.f;
     for (long r = (long)blockIdx.y * 4 + rl; r < rows; r += (long)gridDim.y * 4) {
       const float g = dout[r * D + c];
       dy[r * D + c] = f2bf(g * gm);
+      accb += g * gm;
       if (gamma) acc += g * bf2f(y[r * D + c]);
     }
   }
-  if (gamma) {
-    red[rl][cl] = acc;
-    __syncthreads();
-    if (rl == 0 && c < D) atomicAdd(&dgamma[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  red[0][rl][cl] = acc; red[1][rl][cl] = accb;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    if (gamma) atomicAdd(&dgamma[c], red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    if (dbias) atomicAdd(&dbias[c], red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
   }
 }
 
+// column sums: bf16 rows read as 16-byte vectors (8 columns per thread); block = 32 column-chunks x 8 row-lanes
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int N) {
+  __shared__ float red[8][32][9];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cl) * 8;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  if (c < N) {
+    for (long r = (long)blockIdx.y * 8 + rl; r < rows; r += (long)gridDim.y * 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + r * N + c);
+      a[0] += bf2f((bf16_t)(u.x & 0xffff)); a[1] += bf2f((bf16_t)(u.x >> 16));
+      a[2] += bf2f((bf16_t)(u.y & 0xffff)); a[3] += bf2f((bf16_t)(u.y >> 16));
+      a[4] += bf2f((bf16_t)(u.z & 0xffff)); a[5] += bf2f((bf16_t)(u.z >> 16));
+      a[6] += bf2f((bf16_t)(u.w & 0xffff)); a[7] += bf2f((bf16_t)(u.w >> 16));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cl][j] = a[j];
+  __syncthreads();
+  // 256 threads reduce 32 chunks x 8 columns over the 8 row-lanes
+  const int cc = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const int col = (blockIdx.x * 32 + cc) * 8 + j;
+  if (col < N) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s2 += red[i][cc][j];
+    atomicAdd(&out[col], s2);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int N) {
   __shared__ float red[4][64];
@@ -364,7 +521,7 @@ extern "C" int lt_assemble_tokens(const float* patch, const float* cls, const fl
 extern "C" int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_bf16, float* dcls, float* dpos,
                                       float* dmask_token, int B, int n_p, int D, void* stream) {
   LT_CHECK_ARG(dx && dpatch_bf16 && dcls && dpos && (!masks || dmask_token), "lt_assemble_tokens_bwd: null pointer");
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(n_p + 1), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls, dpos,
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(n_p + 1, lt_cdiv(D, 64)), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls, dpos,
                      dmask_token, B, n_p, D);
   LT_CHECK_LAUNCH("lt_assemble_tokens_bwd");
 }
@@ -385,26 +542,44 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
   LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
   if (rows == 0) return LT_OK;
   const int grid = min(lt_cdiv(rows, 4), 1024);
-  if (dy_is_f32)
+  const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
+                   (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)w % 16 == 0);
+  if (vec && dy_is_f32)
+    hipLaunchKernelGGL(layernorm_bwd_vec_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
+  else if (vec)
+    hipLaunchKernelGGL(layernorm_bwd_vec_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
+  else if (dy_is_f32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
   LT_CHECK_LAUNCH("lt_layernorm_bwd");
 }
 extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
-                                 int rows, int D, void* stream) {
+                                 float* dbias, int rows, int D, void* stream) {
   LT_CHECK_ARG(dout && dy_bf16 && (!gamma || (y_bf16 && dgamma)), "lt_layerscale_bwd: null pointer");
   if (rows == 0) return LT_OK;
-  dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
-  hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
-                     dgamma, rows, D);
+  if (D % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dy_bf16 % 8 == 0 && (!y_bf16 || (uintptr_t)y_bf16 % 8 == 0) &&
+      (!gamma || (uintptr_t)gamma % 16 == 0)) {
+    dim3 grid(lt_cdiv(D, 128), min(lt_cdiv(rows, 8), 256));
+    hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16, dgamma,
+                       dbias, rows, D);
+  } else {
+    dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
+    hipLaunchKernelGGL(layerscale_bwd_scalar_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
+                       dgamma, dbias, rows, D);
+  }
   LT_CHECK_LAUNCH("lt_layerscale_bwd");
 }
 extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream) {
   LT_CHECK_ARG(x && out, "lt_colsum_bf16: null pointer");
   if (rows == 0) return LT_OK;
-  dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
-  hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
+  if (N % 8 == 0 && (uintptr_t)x % 16 == 0) {
+    dim3 grid(lt_cdiv(N, 256), min(lt_cdiv(rows, 8), 256));
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
+  } else {
+    dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
+  }
   LT_CHECK_LAUNCH("lt_colsum_bf16");
 }
 extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream) {

@@ -124,7 +124,50 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rb, int ks) {
   }
 }
 
-template <bool TA, bool TB, int EPI>
+// ---- vector epilogue: emit a [64 x 64] fp32 sub-tile staged in wave-private LDS `wl` (row-major, 64 floats/row) --------
+template <int EPI>
+__device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl, int row_base, int col_base, int l, bool atomic) {
+  const int cc = (l & 15) * 4, rs = l >> 4;
+  const int col = col_base + cc;
+  if (col >= g.N) return;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (EPI != EPI_F32_ACCUM && EPI != EPI_BF16_GELUGRAD && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + col);
+  if (EPI == EPI_RESID && g.gamma) gam4 = *reinterpret_cast<const float4*>(g.gamma + col);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int rl = it * 4 + rs;
+    const int row = row_base + rl;
+    if (row >= g.M) continue;
+    float4 v = *reinterpret_cast<const float4*>(wl + rl * 64 + cc);
+    v.x = v.x * g.alpha + bias4.x; v.y = v.y * g.alpha + bias4.y; v.z = v.z * g.alpha + bias4.z; v.w = v.w * g.alpha + bias4.w;
+    const size_t o = (size_t)row * g.ldc + col;
+    if (EPI == EPI_BF16) {
+      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    } else if (EPI == EPI_BF16_GELU) {
+      if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(gelu_f(v.x), gelu_f(v.y)), pack_bf2(gelu_f(v.z), gelu_f(v.w)));
+    } else if (EPI == EPI_RESID) {
+      if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.resid) r4 = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldr + col);
+      *reinterpret_cast<float4*>((float*)g.C + o) =
+          make_float4(r4.x + gam4.x * v.x, r4.y + gam4.y * v.y, r4.z + gam4.z * v.z, r4.w + gam4.w * v.w);
+    } else if (EPI == EPI_F32) {
+      *reinterpret_cast<float4*>((float*)g.C + o) = v;
+    } else if (EPI == EPI_BF16_GELUGRAD) {
+      const uint2 a = *reinterpret_cast<const uint2*>(g.aux + (size_t)row * g.ldaux + col);
+      const float p0 = bf2f((bf16_t)(a.x & 0xffff)), p1 = bf2f((bf16_t)(a.x >> 16)), p2 = bf2f((bf16_t)(a.y & 0xffff)), p3 = bf2f((bf16_t)(a.y >> 16));
+      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) =
+          make_uint2(pack_bf2(v.x * gelu_grad_f(p0), v.y * gelu_grad_f(p1)), pack_bf2(v.z * gelu_grad_f(p2), v.w * gelu_grad_f(p3)));
+    } else if (EPI == EPI_F32_ACCUM) {
+      float* c = (float*)g.C + o;
+      if (atomic) { atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w); }
+      else { float4 old = *reinterpret_cast<float4*>(c); *reinterpret_cast<float4*>(c) = make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w); }
+    }
+  }
+}
+
+template <bool TA, bool TB, int EPI, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // stage s: A image at smem + 2*s*TILE_BYTES, B image right behind it
@@ -190,7 +233,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // ---- epilogue
+  if (VEC) {
+    // Stage the wave's 64x64 fp32 sub-tile through its private 16 KiB of LDS (the operand images are dead after the
+    // loop's last barrier) so that every global access of the epilogue is a 16-byte, row-contiguous vector:
+    // the C layout (lane -> column, regs -> rows) would otherwise issue one 4-byte store per element.
+    float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wl[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    emit_subtile<EPI>(g, wl, m0 + wm * 64, n0 + wn * 64, l, gridDim.y > 1);
+    return;
+  }
+  // scalar fallback (N or a leading dimension not a multiple of 4): C layout of the 32x32 MFMA is
+  // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + (l & 31);
@@ -229,6 +291,197 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
   }
 }
 
+// =====================================================================================================================
+// 256 x 256 x 64 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA 32x32 tiles), one workgroup per CU, operands brought in
+// by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without the VGPR round trip or the ds_write pass, which at
+// ~80 B/clk/CU costs as many LDS cycles as all fragment reads of the 128^2 kernel).  The DMA destination is
+// wave-linear (M0 base + lane*16), so both LDS images are produced by permuting the per-lane SOURCE address:
+//   row image  : lane -> (row = blk*8 + lane/8, slot = lane%8), source chunk = slot ^ ((row>>1)&7)
+//   T image    : lane -> (piece = blk*8 + lane/8, slot), source k-row = (slot/2 - piece%16) & 3, 8-column half = slot&1
+// Two LDS stages (128 KiB): tile k+1 streams in while tile k feeds 256 MFMAs; one barrier per k-tile.
+// Used for the large token-major GEMMs (forward and dgrad); requires K % 64 == 0 and the vector epilogue;
+// out-of-range rows/columns are clamped at the source (their products are never stored).
+namespace g256 {
+constexpr int BM2 = 256, NT2 = 512;
+constexpr int LDS_BYTES = 131072;  // 2 stages x (A 32 KiB + B <=32 KiB); also 8 x 16 KiB epilogue scratch
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// DMA one [ROWS x 64] operand tile into its LDS image (ROWS/8 one-KiB wave-instructions, ROWS/64 per wave)
+template <bool TR, int ROWS>
+__device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  constexpr int PER_WAVE = ROWS / 64, NB = ROWS / 16;
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int blk = w * PER_WAVE + j;
+    const bf16_t* src;
+    if (!TR) {
+      const int row = blk * 8 + (l >> 3), slot = l & 7;
+      const int c = slot ^ ((row >> 1) & 7);
+      const int gr = min(row0 + row, rows - 1);
+      src = P + (size_t)gr * ld + k0 + c * 8;
+    } else {
+      const int p = blk * 8 + (l >> 3), slot = l & 7;
+      const int q = p / NB, b = p % NB;
+      const int kr = ((slot >> 1) - b) & 3;
+      int col = row0 + b * 16 + (slot & 1) * 8;
+      if (col >= rows) col = 0;
+      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
+  }
+}
+
+template <bool TR, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int rb, int ks) {
+  const int l = threadIdx.x & 63;
+  if (!TR) {
+    const int row = rb * 32 + (l & 31);
+    const int c = ks * 2 + (l >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    constexpr int NB = ROWS / 16;
+    const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
+    const int b = rb * 2 + cb;
+    const int inner = ((((i >> 2) + b) & 3) << 5) + ((i & 3) << 3);
+    const int q0 = ks * 4 + kh * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (q0 * NB + b) * 128 + inner));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((q0 + 1) * NB + b) * 128 + inner));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+  }
+}
+
+// BN = 256: waves 2(M) x 4(N), wave tile 128 x 64;  BN = 128: waves 4 x 2, wave tile 64 x 64.
+// SLAB: split-K slice blockIdx.y writes its fp32 partial tile to slab[blockIdx.y] (C2 = slab base), no atomics.
+template <bool TA, bool TB, int EPI, int BN, bool SLAB>
+__global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WN = BN / 64, WM = 8 / WN, MI = BM2 / (WM * 32);
+  constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * BM2, n0 = tn * BN;
+  const int kbeg = blockIdx.y * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg) / BK;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wm = wave / WN, wn = wave % WN;
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0) {
+    stage_dma<TA, BM2>(smem, g.A, g.lda, g.M, m0, kbeg);
+    stage_dma<TB, BN>(smem + A_BYTES, g.B, g.ldb, g.N, n0, kbeg);
+  }
+  __syncthreads();  // hipcc drains the outstanding LDS-DMA (vmcnt(0)) in front of the barrier
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* la = smem + (kt & 1) * STAGE;
+    const char* lb = la + A_BYTES;
+    if (kt + 1 < nk) {
+      char* na = smem + ((kt + 1) & 1) * STAGE;
+      stage_dma<TA, BM2>(na, g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK);
+      stage_dma<TB, BN>(na + A_BYTES, g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[MI], fb[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag2<TA, BM2>(la, wm * MI + i, ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag2<TB, BN>(lb, wn * 2 + j, ks);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: 64-row halves of the wave tile through the wave's private 16 KiB of LDS
+  GemmArgs ge = g;
+  if (SLAB) {  // partial tile -> slab of this k-slice, plain fp32 stores
+    ge.C = (float*)g.C2 + (size_t)blockIdx.y * g.M * g.N;
+    ge.ldc = g.N; ge.alpha = 1.f; ge.bias = nullptr;
+  }
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int h = 0; h < MI / 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (SLAB) emit_subtile<EPI_F32>(ge, wl, m0 + wm * (MI * 32) + h * 64, n0 + wn * 64, l, false);
+    else emit_subtile<EPI>(ge, wl, m0 + wm * (MI * 32) + h * 64, n0 + wn * 64, l, gridDim.y > 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// out[i] (+)= alpha * sum_s slab[s][i]   (deterministic split-K reduction)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int S, float alpha) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i < n; i += stride) {
+    float4 a = *reinterpret_cast<const float4*>(slabs + i);
+    for (int s2 = 1; s2 < S; ++s2) {
+      const float4 b = *reinterpret_cast<const float4*>(slabs + (long)s2 * n + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float4 o = *reinterpret_cast<float4*>(out + i);
+    o.x += alpha * a.x; o.y += alpha * a.y; o.z += alpha * a.z; o.w += alpha * a.w;
+    *reinterpret_cast<float4*>(out + i) = o;
+  }
+}
+
+template <bool TA, bool TB, int EPI, int BN, bool SLAB>
+int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TA, TB, EPI, BN, SLAB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<TA, TB, EPI, BN, SLAB>), grid, dim3(NT2), LDS_BYTES, st, g);
+  return LT_OK;
+}
+
+template <bool TA, bool TB, int BN>
+int launch(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_one<TA, TB, EPI_BF16, BN, false>(g, grid, st);
+    case EPI_BF16_GELU: return launch_one<TA, TB, EPI_BF16_GELU, BN, false>(g, grid, st);
+    case EPI_RESID: return launch_one<TA, TB, EPI_RESID, BN, false>(g, grid, st);
+    case EPI_F32: return launch_one<TA, TB, EPI_F32, BN, false>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_one<TA, TB, EPI_BF16_GELUGRAD, BN, false>(g, grid, st);
+    case EPI_F32_ACCUM:
+      return slab ? launch_one<TA, TB, EPI_F32_ACCUM, BN, true>(g, grid, st) : launch_one<TA, TB, EPI_F32_ACCUM, BN, false>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: unknown epilogue %d", epi); return LT_ERR_INVALID;
+  }
+}
+}  // namespace g256
+
 // ---- plain reference-grade GEMM (one thread per output; cross-check for the MFMA kernel) -------
 __global__ void gemm_naive_kernel(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, int lda, int ldb,
                                   int ldc, int ta, int tb) {
@@ -245,11 +498,12 @@ __global__ void gemm_naive_kernel(const bf16_t* A, const bf16_t* B, float* C, in
 }
 
 template <bool TA, bool TB>
-int launch_epi(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+int launch_epi(const GemmArgs& g, int epi, bool vec, dim3 grid, hipStream_t st) {
   const size_t smem = 4 * TILE_BYTES;
-#define LT_CASE(E)                                                              \
-  case E:                                                                        \
-    hipLaunchKernelGGL((gemm_kernel<TA, TB, E>), grid, dim3(NTHREADS), smem, st, g); \
+#define LT_CASE(E)                                                                                \
+  case E:                                                                                          \
+    if (vec) hipLaunchKernelGGL((gemm_kernel<TA, TB, E, true>), grid, dim3(NTHREADS), smem, st, g);  \
+    else hipLaunchKernelGGL((gemm_kernel<TA, TB, E, false>), grid, dim3(NTHREADS), smem, st, g);     \
     break;
   switch (epi) {
     LT_CASE(EPI_BF16)
@@ -296,10 +550,62 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   dim3 grid(g.tiles_m * g.tiles_n, split);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (!d->trans_a && !d->trans_b) rc = launch_epi<false, false>(g, d->epilogue, grid, st);
-  else if (!d->trans_a && d->trans_b) rc = launch_epi<false, true>(g, d->epilogue, grid, st);
-  else if (d->trans_a && d->trans_b) rc = launch_epi<true, true>(g, d->epilogue, grid, st);
-  else rc = launch_epi<true, false>(g, d->epilogue, grid, st);
+  // vector epilogue needs 4-element alignment of every row it touches
+  auto al = [](const void* p, int ld, int bytes) { return p == nullptr || (ld % 4 == 0 && ((uintptr_t)p % (4 * bytes)) == 0); };
+  const bool f32out = d->epilogue == LT_EPI_RESID || d->epilogue == LT_EPI_F32 || d->epilogue == LT_EPI_F32_ACCUM;
+  const bool vec = d->N % 4 == 0 && al(d->C, d->ldc, f32out ? 4 : 2) && al(d->C2, d->ldc2, 2) && al(d->resid, d->ldr, 4) &&
+                   al(d->aux, d->ldaux, 2) && al(d->bias, 4, 4) && al(d->gamma, 4, 4);
+  // ---- 256-row LDS-DMA kernel for the large GEMMs (forward / dgrad over tokens; wgrad with slab split-K)
+  const bool same_t = d->trans_a == d->trans_b || !d->trans_a;  // (N,N), (N,T), (T,T)
+  const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
+  bool big = eligible && d->force_kernel != 1 && d->N >= 128 &&
+             ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
+  if (d->force_kernel == 2) {
+    LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
+    big = true;
+  }
+  if (big) {
+    const int cus = 256;
+    // tile width: 256 unless the 256-wide grid quantises badly on 256 CUs and the 128-wide one does not
+    auto eff = [&](int bn, int sp) { const long b = (long)lt_cdiv(d->M, 256) * lt_cdiv(d->N, bn) * sp; return (double)b / ((double)((b + cus - 1) / cus) * cus); };
+    int sp = 1;
+    const bool accum = d->epilogue == LT_EPI_F32_ACCUM;
+    int bn = d->N >= 256 ? 256 : 128;  // measured: the 4x2-wave 128-wide variant only pays when N < 256
+    if (accum) {
+      // few output tiles, long contraction: choose the slice count that fills whole waves of 256 workgroups
+      const int kt = d->K / BK;
+      double best = 0.0;
+      for (int cand_bn : {256, 128}) {
+        if (cand_bn == 256 && d->N < 256) continue;
+        for (int c = 1; c <= 64 && kt / c >= 8; ++c) {
+          const double e2 = eff(cand_bn, c) * (cand_bn == 256 ? 1.0 : 0.93);
+          if (e2 > best + 0.03) { best = e2; sp = c; bn = cand_bn; }
+        }
+      }
+      if (d->split_k == 1) sp = 1;
+    }
+    const bool slab = accum && sp > 1 && d->workspace && d->workspace_bytes >= (size_t)sp * d->M * d->N * sizeof(float);
+    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, bn);
+    const int ktiles2 = d->K / BK;
+    g.k_per_split = lt_cdiv(ktiles2, sp) * BK;
+    sp = lt_cdiv(d->K, g.k_per_split);
+    if (slab) g.C2 = d->workspace;
+    dim3 grid2(g.tiles_m * g.tiles_n, sp);
+    if (!d->trans_a && !d->trans_b) rc = bn == 256 ? g256::launch<false, false, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, false, 128>(g, d->epilogue, slab, grid2, st);
+    else if (!d->trans_a) rc = bn == 256 ? g256::launch<false, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, true, 128>(g, d->epilogue, slab, grid2, st);
+    else rc = bn == 256 ? g256::launch<true, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<true, true, 128>(g, d->epilogue, slab, grid2, st);
+    if (rc != LT_OK) return rc;
+    if (slab) {
+      const long n = (long)d->M * d->N;
+      hipLaunchKernelGGL(g256::slab_reduce_kernel, dim3((unsigned)min((long)2048, (n / 4 + 255) / 256)), dim3(256), 0, st,
+                         (const float*)d->workspace, (float*)d->C, n, sp, d->alpha);
+    }
+    LT_CHECK_LAUNCH("lt_gemm_bf16");
+  }
+  if (!d->trans_a && !d->trans_b) rc = launch_epi<false, false>(g, d->epilogue, vec, grid, st);
+  else if (!d->trans_a && d->trans_b) rc = launch_epi<false, true>(g, d->epilogue, vec, grid, st);
+  else if (d->trans_a && d->trans_b) rc = launch_epi<true, true>(g, d->epilogue, vec, grid, st);
+  else rc = launch_epi<true, false>(g, d->epilogue, vec, grid, st);
   if (rc != LT_OK) return rc;
   LT_CHECK_LAUNCH("lt_gemm_bf16");
 }

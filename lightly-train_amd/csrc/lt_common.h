@@ -80,12 +80,30 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
-// exact-erf GELU (nn.GELU default, layers/mlp.py:36-42) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf-based GELU (nn.GELU default, layers/mlp.py:36-42) and its derivative.  erf by Abramowitz-Stegun 7.1.26
+// (|abs error| <= 1.5e-7, below fp32 epilogue noise and far below the bf16 store) with ONE v_exp_f32:
+// exp(-(x/sqrt2)^2) = exp(-x^2/2) is also the Gaussian pdf the derivative needs.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_unnorm) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  const float ex = __expf(-z * z);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfc_abs = poly * t * ex;               // erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.f - 0.5f * erfc_abs : 0.5f * erfc_abs;
+  pdf_unnorm = ex;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 static inline int lt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

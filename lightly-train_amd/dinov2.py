@@ -25,7 +25,7 @@ from .masking import MaskingGenerator, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, init_vit_state, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, vit_param_shapes
 
 
 @dataclass
@@ -182,9 +182,7 @@ class HeadEngine:
         hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
 
         def split(n_out: int, k_in: int) -> int:
-            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-            want = max(1, (512 + tiles - 1) // tiles)
-            return max(1, min(want, 32, R // 512 if R >= 1024 else 1))
+            return _split_k(((n_out + 127) // 128) * ((k_in + 127) // 128), R)
 
         ops.gemm(dlogits, c["zn"], self.dwn, M=K, N=bn, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
                  split_k=split(K, bn), lda=K, ldb=bn)

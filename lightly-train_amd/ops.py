@@ -43,7 +43,7 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
          epilogue: int = EPI_BF16, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
          resid: Optional[Tensor] = None, out2: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None) -> Tensor:
+         ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h."""
     _chk(a, torch.bfloat16, "gemm.a")
     _chk(b, torch.bfloat16, "gemm.b")
@@ -65,7 +65,9 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
     if aux is not None:
         _chk(aux, torch.bfloat16, "gemm.aux")
     d.aux, d.ldaux = _p(aux), N
-    d.alpha, d.split_k = alpha, split_k
+    d.alpha, d.split_k, d.force_kernel = alpha, split_k, force_kernel
+    d.workspace = _p(workspace)
+    d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
     check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
     return out
 
@@ -125,8 +127,9 @@ def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, 
 
 
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,
-                   D: int) -> None:
-    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), rows, D, _stream()), "lt_layerscale_bwd")
+                   D: int, dbias: Optional[Tensor] = None) -> None:
+    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), rows, D, _stream()),
+          "lt_layerscale_bwd")
 
 
 def colsum_bf16(x: Tensor, out: Tensor, rows: int, N: int) -> None:

@@ -115,10 +115,19 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
-def _split_k(tiles: int, k: int) -> int:
-    """split-K factor for wgrad GEMMs: enough workgroups for 256 CUs, at least 8 k-tiles (512) per slice."""
-    want = max(1, (2 * 256 + tiles - 1) // tiles)
-    return max(1, min(want, 32, k // 512 if k >= 1024 else 1))
+def _split_k(tiles: int, k: int, slots: int = 512) -> int:
+    """split-K factor for wgrad GEMMs (few output tiles, very long contraction): pick the slice count whose
+    workgroup count best fills whole waves of the chip (256 CUs x 2 resident 128x128 workgroups), keeping at
+    least 8 k-tiles (512 rows) per slice; ties go to fewer slices (fewer fp32 atomics)."""
+    best, best_eff = 2 if k >= 4096 else 1, 0.0   # >1 also enables the auto slice count of the 256-row kernel
+    for s in range(best, 33):
+        if s > 1 and k // s < 512:
+            break
+        blocks = tiles * s
+        eff = blocks / (((blocks + slots - 1) // slots) * slots)
+        if eff > best_eff + 0.02:
+            best, best_eff = s, eff
+    return best
 
 
 class ViTEngine:
@@ -269,10 +278,12 @@ class ViTEngine:
         dx = dxa
         other = dxb
 
+        slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)  # 128 MiB split-K scratch (deterministic reduction)
+
         def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int) -> None:
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
             ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=T, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                     split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in)
+                     split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
 
         for i in reversed(range(cfg.depth)):
             bk = ctx["blocks"][i]
@@ -280,8 +291,8 @@ class ViTEngine:
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
             # ---- MLP branch: xo = xm + g2 * (fc2(gelu(fc1(ln2))))
-            ops.layerscale_bwd(dx, bk["y2"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, T, D)
-            ops.colsum_bf16(dD, self.gw(pre + "mlp.fc2.bias"), T, D)
+            ops.layerscale_bwd(dx, bk["y2"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, T, D,
+                               dbias=self.gw(pre + "mlp.fc2.bias"))
             wgrad(dD, bk["act"], pre + "mlp.fc2.weight", D, hid)
             ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=T, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=bk["hpre"])
             ops.colsum_bf16(dH, self.gw(pre + "mlp.fc1.bias"), T, hid)
@@ -291,8 +302,8 @@ class ViTEngine:
                               self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D)
             dx, other = other, dx
             # ---- attention branch: xm = x + g1 * proj(attn(qkv(ln1)))
-            ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D)
-            ops.colsum_bf16(dD, self.gw(pre + "attn.proj.bias"), T, D)
+            ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D,
+                               dbias=self.gw(pre + "attn.proj.bias"))
             wgrad(dD, bk["att"], pre + "attn.proj.weight", D, D)
             ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=T, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             ops.attention_bwd(bk["qkv"], bk["att"], dD2, bk["lse"], aws, dQ, B, N, Hh, dh, scale)
@@ -319,4 +330,5 @@ class ViTEngine:
         ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
         tiles = ((D + 127) // 128) * ((self.kpad + 127) // 128)
         ops.gemm(dpatch, ctx["cols"], self.gw("patch_embed.proj.weight").view(D, -1), M=D, N=self.kpad, K=B * n_p, trans_a=True,
-                 trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=_split_k(tiles, B * n_p), lda=D, ldb=self.kpad, ldc=self.kpad)
+                 trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=max(2, _split_k(tiles, B * n_p)), lda=D, ldb=self.kpad, ldc=self.kpad,
+                 workspace=slab)

@@ -50,6 +50,53 @@ def test_gemm_layouts(M, N, K, ta, tb):
     assert rel_err(out, ref) < 1e-5, f"mfma gemm mismatch ta={ta} tb={tb}"
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)])
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_256_kernel(M, N, K, tb):
+    """the 256x256 LDS-DMA kernel (forced) against the fp32 reference, incl. M/N tails and every epilogue it serves."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    ref = A.float() @ B.float().t()
+    b_in = B.t().contiguous() if tb else B
+    out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_F32, force_kernel=2)
+    assert rel_err(out, ref) < 1e-5
+    bias = torch.randn(N, generator=g).to(DEV); gamma = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV); aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+    y = ref + bias
+    ob = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); pre = torch.empty_like(ob)
+    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELU, bias=bias, out2=pre, force_kernel=2)
+    assert rel_err(pre, y) < 6e-3 and rel_err(ob, F.gelu(y)) < 6e-3
+    y2 = torch.empty_like(ob)
+    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, out2=y2, force_kernel=2)
+    assert rel_err(out, resid + gamma * y) < 1e-5 and rel_err(y2, y) < 6e-3
+    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELUGRAD, aux=aux, force_kernel=2)
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel_err(ob, ref * x.grad) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)])
+def test_gemm_256_wgrad_slab_and_atomic(M, N, K):
+    """dW[M,N] += dY[K,M]^T X[K,N] on the 256-row kernel: deterministic slab split-K and the atomic variant."""
+    o = ops()
+    g = torch.Generator().manual_seed(K)
+    dY = bf(torch.randn(K, M, generator=g)).to(DEV)
+    X = bf(torch.randn(K, N, generator=g)).to(DEV)
+    ref = 1.0 + 0.5 * (dY.float().t() @ X.float())
+    slab = torch.empty(64 * 1024 * 1024, device=DEV)
+    outs = []
+    for ws in (slab, None, slab):
+        dW = torch.ones(M, N, device=DEV)
+        o.gemm(dY, X, dW, M=M, N=N, K=K, trans_a=True, trans_b=True, epilogue=o.EPI_F32_ACCUM, split_k=2, alpha=0.5, lda=M, ldb=N,
+               force_kernel=2, workspace=ws)
+        assert rel_err(dW, ref) < 2e-5
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[2]), "slab split-K must be bit-reproducible"
+
+
 def test_gemm_asymmetric_identity():
     """A = I with asymmetric B catches row/col swaps in the C write (guide G9)."""
     o = ops()
@@ -181,10 +228,14 @@ def test_layerscale_colsum_gather():
     y = bf(torch.randn(rows, D, generator=g)).to(DEV)
     gamma = torch.randn(D, generator=g).to(DEV)
     dy = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
-    dg = torch.zeros(D, device=DEV)
-    o.layerscale_bwd(dout, y, gamma, dy, dg, rows, D)
+    dg = torch.zeros(D, device=DEV); dbias = torch.zeros(D, device=DEV)
+    o.layerscale_bwd(dout, y, gamma, dy, dg, rows, D, dbias=dbias)
     assert torch.equal(dy.float(), bf(dout * gamma).float())
     assert rel_err(dg, (dout * y.float()).sum(0)) < 1e-5
+    assert rel_err(dbias, (dout * gamma).sum(0)) < 1e-5
+    dy2 = torch.empty(rows, 10, device=DEV, dtype=torch.bfloat16)  # scalar fallback, no gamma
+    o.layerscale_bwd(dout[:, :10].contiguous(), None, None, dy2, None, rows, 10)
+    assert torch.equal(dy2.float(), bf(dout[:, :10]).float())
     cs = torch.zeros(D, device=DEV)
     o.colsum_bf16(y, cs, rows, D)
     assert rel_err(cs, y.float().sum(0)) < 1e-5
