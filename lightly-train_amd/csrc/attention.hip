@@ -201,7 +201,7 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __
 }
 
 // dK, dV: waves own key tiles; query side streamed through LDS in chunks of 128 tokens
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 }
 
 // dQ: waves own query tiles; key side streamed through LDS in chunks of 128 tokens
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsK = smem;
   char* ldsKt = smem + IMG;
@@ -315,14 +315,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* kb = qb + (long)H * DH;
   const bf16_t* vb = qb + 2L * H * DH;
   const bf16_t* dob = dout + (long)b * N * tso + h * DH;
+  const bf16_t* ob = out + (long)b * N * tso + h * DH;
   const int q0 = (blockIdx.x * 4 + wave) * 32;
   const bool active = q0 < N;
   const int q = q0 + (l & 31);
   const float lse_q = (q < N) ? lse[((long)b * H + h) * N + q] : INFINITY;
-  const float del_q = (q < N) ? delta[((long)b * H + h) * N + q] : 0.f;
   bf16x8 qf[4], dof[4];
+  // delta[q] = sum_d dO[q,d] * O[q,d]: this lane holds d = ks*16 + hi*8 .. +8 of its query row, lane^32 the other half
+  float del_q = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_global(qb, ts, q0, N, ks); dof[ks] = frag_global(dob, tso, q0, N, ks); }
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = frag_global(qb, ts, q0, N, ks);
+    dof[ks] = frag_global(dob, tso, q0, N, ks);
+    const bf16x8 of = frag_global(ob, tso, q0, N, ks);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) del_q += (float)dof[ks][j] * (float)of[j];
+  }
+  del_q += __shfl_xor(del_q, 32, 64);
+  if (active && hi == 0 && q < N) delta[((long)b * H + h) * N + q] = del_q;
   f32x16 dq[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
@@ -465,15 +475,16 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
   LT_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && ws && dqkv && B > 0 && N > 0 && H > 0 && dh > 0,
                "lt_attention_bwd: bad arguments");
   const long total = (long)B * N * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(lt_cdiv(total * 64, 256)), dim3(256), 0, ST, (const bf16_t*)out_bf16,
-                     (const bf16_t*)dout_bf16, ws, N, H, dh, total);
   if (dh == DH) {
     const int nkt = lt_cdiv(N, 32);
+    // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(lt_cdiv(N, 128), B * H), dim3(256), 3 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
+                       (const bf16_t*)out_bf16, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(min(lt_cdiv(nkt, 4), 4), B * H), dim3(256), 4 * IMG + 2 * CH * sizeof(float), ST,
                        (const bf16_t*)qkv, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(lt_cdiv(N, 128), B * H), dim3(256), 3 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
-                       (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
   } else {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(lt_cdiv(total * 64, 256)), dim3(256), 0, ST, (const bf16_t*)out_bf16,
+                       (const bf16_t*)dout_bf16, ws, N, H, dh, total);
     float* P = ws + (long)B * H * N;
     float* dS = P + (long)B * H * N * N;
     hipLaunchKernelGGL(attn_bwd_generic_q_kernel, dim3(N, B * H), dim3(64), 0, ST, (const bf16_t*)qkv, (const bf16_t*)dout_bf16, lse,

@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-// Vector backward for D % 4 == 0 (D <= 2048): lane owns float4 column groups c = (i*64 + lane)*4; per-lane dw/db partials
-// live in registers across the wave's rows, are reduced over the block's 4 waves in LDS, then one atomicAdd per column.
-template <bool DYF32>
+// Vector backward for D % 4 == 0, D <= NV*256: lane owns float4 column groups c = (i*64 + lane)*4.  Each wave walks its rows
+// two at a time (both rows' loads are issued before either row's reductions, hiding the HBM latency a single dependent
+// row chain would expose); per-lane dw/db partials stay in registers, are reduced over the block's 4 waves in LDS, then
+// one atomicAdd per column per block.
+template <bool DYF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const void* __restrict__ dyv, const float* __restrict__ dres,
@@ -153,55 +155,77 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 int rows, int D) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float4 aw[MAXV], ab[MAXV], wv4[MAXV];
+  float4 aw[NV], ab[NV], wv4[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
     const int c = (i * 64 + lane) * 4;
     wv4[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
   }
-  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float4 xh[MAXV], gy[MAXV];
-    float c1 = 0.f, c2 = 0.f;
+  const long stride = (long)gridDim.x * 4;
+  for (long row0 = (long)blockIdx.x * 4 + wv; row0 < rows; row0 += 2 * stride) {
+    float4 xv[2][NV], dv[2][NV];
+    float mu[2], rs[2];
+    bool ok[2];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      xh[i] = make_float4(0, 0, 0, 0); gy[i] = make_float4(0, 0, 0, 0);
-      if (c < D) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + row * D + c);
-        float4 d;
-        if (DYF32) d = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
-        else {
-          const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
-          d = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+    for (int r = 0; r < 2; ++r) {
+      const long row = row0 + r * stride;
+      ok[r] = row < rows;
+      mu[r] = ok[r] ? mean[row] : 0.f;
+      rs[r] = ok[r] ? rstd[row] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        xv[r][i] = make_float4(0, 0, 0, 0); dv[r][i] = make_float4(0, 0, 0, 0);
+        if (ok[r] && c < D) {
+          xv[r][i] = *reinterpret_cast<const float4*>(x + row * D + c);
+          if (DYF32) dv[r][i] = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
+          else {
+            const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
+            dv[r][i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+          }
         }
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        gy[i] = make_float4(d.x * wv4[i].x, d.y * wv4[i].y, d.z * wv4[i].z, d.w * wv4[i].w);
-        c1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
-        c2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
-        aw[i].x += d.x * xh[i].x; aw[i].y += d.y * xh[i].y; aw[i].z += d.z * xh[i].z; aw[i].w += d.w * xh[i].w;
-        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
       }
     }
-    c1 = wave_sum(c1) / D;
-    c2 = wave_sum(c2) / D;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < D) {
-        float4 o = make_float4(rs * (gy[i].x - c1 - xh[i].x * c2), rs * (gy[i].y - c1 - xh[i].y * c2),
-                               rs * (gy[i].z - c1 - xh[i].z * c2), rs * (gy[i].w - c1 - xh[i].w * c2));
-        if (dres) {
-          const float4 r = *reinterpret_cast<const float4*>(dres + row * D + c);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    for (int r = 0; r < 2; ++r) {
+      if (!ok[r]) continue;
+      const long row = row0 + r * stride;
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+          const float4 d = dv[r][i];
+          const float4 xh = make_float4((xv[r][i].x - mu[r]) * rs[r], (xv[r][i].y - mu[r]) * rs[r], (xv[r][i].z - mu[r]) * rs[r], (xv[r][i].w - mu[r]) * rs[r]);
+          const float4 gy = make_float4(d.x * wv4[i].x, d.y * wv4[i].y, d.z * wv4[i].z, d.w * wv4[i].w);
+          c1 += gy.x + gy.y + gy.z + gy.w;
+          c2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
+          aw[i].x += d.x * xh.x; aw[i].y += d.y * xh.y; aw[i].z += d.z * xh.z; aw[i].w += d.w * xh.w;
+          ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+          xv[r][i] = xh; dv[r][i] = gy;
         }
-        *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      }
+      c1 = wave_sum(c1) / D;
+      c2 = wave_sum(c2) / D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+          const float4 xh = xv[r][i], gy = dv[r][i];
+          float4 o = make_float4(rs[r] * (gy.x - c1 - xh.x * c2), rs[r] * (gy.y - c1 - xh.y * c2),
+                                 rs[r] * (gy.z - c1 - xh.z * c2), rs[r] * (gy.w - c1 - xh.w * c2));
+          if (dres) {
+            const float4 rr = *reinterpret_cast<const float4*>(dres + row * D + c);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+          }
+          *reinterpret_cast<float4*>(dx + row * D + c) = o;
+        }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i * 256 >= D) break;
     __syncthreads();
     red[0][wv][lane] = aw[i];
@@ -544,10 +568,13 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
   const int grid = min(lt_cdiv(rows, 4), 1024);
   const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
                    (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)w % 16 == 0);
-  if (vec && dy_is_f32)
-    hipLaunchKernelGGL(layernorm_bwd_vec_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
-  else if (vec)
-    hipLaunchKernelGGL(layernorm_bwd_vec_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
+#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D)
+  if (vec) {
+    const int nv = (D + 255) / 256;
+    if (dy_is_f32) { if (nv <= 2) LT_LNB(true, 2); else if (nv <= 3) LT_LNB(true, 3); else if (nv <= 4) LT_LNB(true, 4); else LT_LNB(true, 8); }
+    else { if (nv <= 2) LT_LNB(false, 2); else if (nv <= 3) LT_LNB(false, 3); else if (nv <= 4) LT_LNB(false, 4); else LT_LNB(false, 8); }
+  }
+#undef LT_LNB
   else if (dy_is_f32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
   else

@@ -20,6 +20,8 @@
 // Tails: M, N arbitrary (predicated loads/stores); contiguous dims must be multiples of 8 elements.
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so the id is
 // remapped to give each XCD's L2 a contiguous band of tiles sharing A-rows.
+#include <algorithm>
+
 #include "lt_common.h"
 
 namespace {
@@ -571,18 +573,20 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     int sp = 1;
     const bool accum = d->epilogue == LT_EPI_F32_ACCUM;
     int bn = d->N >= 256 ? 256 : 128;  // measured: the 4x2-wave 128-wide variant only pays when N < 256
-    if (accum) {
-      // few output tiles, long contraction: choose the slice count that fills whole waves of 256 workgroups
+    if (accum && d->split_k != 1) {
+      // few output tiles, long contraction: choose the slice count that fills whole waves of 256 workgroups.
+      // Slices are capped so the fp32 slabs fit the caller's workspace (without one: <= 4 slices of atomics).
       const int kt = d->K / BK;
+      const size_t mn = (size_t)d->M * d->N;
+      const int cap = d->workspace ? (int)std::min<size_t>(64, d->workspace_bytes / (mn * sizeof(float))) : 4;
       double best = 0.0;
       for (int cand_bn : {256, 128}) {
         if (cand_bn == 256 && d->N < 256) continue;
-        for (int c = 1; c <= 64 && kt / c >= 8; ++c) {
-          const double e2 = eff(cand_bn, c) * (cand_bn == 256 ? 1.0 : 0.93);
-          if (e2 > best + 0.03) { best = e2; sp = c; bn = cand_bn; }
+        for (int c = 1; c <= cap && kt / c >= 8; ++c) {
+          const double e2 = eff(cand_bn, c) * (cand_bn == 256 ? 1.0 : 0.9);
+          if (e2 > best + 0.04) { best = e2; sp = c; bn = cand_bn; }
         }
       }
-      if (d->split_k == 1) sp = 1;
     }
     const bool slab = accum && sp > 1 && d->workspace && d->workspace_bytes >= (size_t)sp * d->M * d->N * sizeof(float);
     g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, bn);
