@@ -311,10 +311,10 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
 // DMA one [ROWS x 64] operand tile into its LDS image (ROWS/8 one-KiB wave-instructions, ROWS/64 per wave)
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int NWAVES = 8>
 __device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  constexpr int PER_WAVE = ROWS / 64, NB = ROWS / 16;
+  constexpr int PER_WAVE = ROWS / 8 / NWAVES, NB = ROWS / 16;
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int blk = w * PER_WAVE + j;
@@ -482,6 +482,79 @@ int launch(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
     default: lt_set_error("lt_gemm_bf16: unknown epilogue %d", epi); return LT_ERR_INVALID;
   }
 }
+
+// 128 x 128 x 64 tile, 4 waves, LDS-DMA staged, 64 KiB LDS -> TWO workgroups per CU: one workgroup's epilogue (GELU / residual
+// traffic) overlaps the other's MFMA main loop.  Used where the epilogue is heavy relative to a short K loop.
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm128dma_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int OP = 128 * 128, STAGE = 2 * OP;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int nk = g.K / BK;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  stage_dma<TA, 128, 4>(smem, g.A, g.lda, g.M, m0, 0);
+  stage_dma<TB, 128, 4>(smem + OP, g.B, g.ldb, g.N, n0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* la = smem + (kt & 1) * STAGE;
+    const char* lb = la + OP;
+    if (kt + 1 < nk) {
+      char* na = smem + ((kt + 1) & 1) * STAGE;
+      stage_dma<TA, 128, 4>(na, g.A, g.lda, g.M, m0, (kt + 1) * BK);
+      stage_dma<TB, 128, 4>(na + OP, g.B, g.ldb, g.N, n0, (kt + 1) * BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag2<TA, 128>(la, wm * 2 + i, ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag2<TB, 128>(lb, wn * 2 + j, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        wl[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[i][j][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  emit_subtile<EPI>(g, wl, m0 + wm * 64, n0 + wn * 64, l, false);
+}
+
+template <bool TA, bool TB>
+int launch128(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+#define LT_C(E) case E: hipLaunchKernelGGL((gemm128dma_kernel<TA, TB, E>), grid, dim3(256), 65536, st, g); return LT_OK;
+  switch (epi) {
+    LT_C(EPI_BF16) LT_C(EPI_BF16_GELU) LT_C(EPI_RESID) LT_C(EPI_F32) LT_C(EPI_BF16_GELUGRAD)
+    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the 128x128 LDS-DMA kernel", epi); return LT_ERR_INVALID;
+  }
+#undef LT_C
+}
 }  // namespace g256
 
 // ---- plain reference-grade GEMM (one thread per output; cross-check for the MFMA kernel) -------
@@ -562,6 +635,14 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
   bool big = eligible && d->force_kernel != 1 && d->N >= 128 &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
+  if (d->force_kernel == 3) {
+    LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM, "lt_gemm_bf16: not eligible for the 128x128 LDS-DMA kernel");
+    g.tiles_m = lt_cdiv(d->M, 128); g.tiles_n = lt_cdiv(d->N, 128);
+    dim3 grid3(g.tiles_m * g.tiles_n);
+    rc = d->trans_b ? g256::launch128<false, true>(g, d->epilogue, grid3, st) : g256::launch128<false, false>(g, d->epilogue, grid3, st);
+    if (rc != LT_OK) return rc;
+    LT_CHECK_LAUNCH("lt_gemm_bf16");
+  }
   if (d->force_kernel == 2) {
     LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
