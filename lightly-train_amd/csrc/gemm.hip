@@ -400,18 +400,27 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
       stage_dma<TA, BM2>(na, g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK);
       stage_dma<TB, BN>(na + A_BYTES, g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK);
     }
+    // fragments double-buffered in registers: the ds_reads of k16-step ks+1 are in flight while step ks feeds the MFMAs
+    bf16x8 fa[2][MI], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[0][i] = read_frag2<TA, BM2>(la, wm * MI + i, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = read_frag2<TB, BN>(lb, wn * 2 + j, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[MI], fb[2];
+      if (ks < 3) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag2<TA, BM2>(la, wm * MI + i, ks);
+        for (int i = 0; i < MI; ++i) fa[(ks + 1) & 1][i] = read_frag2<TA, BM2>(la, wm * MI + i, ks + 1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = read_frag2<TB, BN>(lb, wn * 2 + j, ks);
+        for (int j = 0; j < 2; ++j) fb[(ks + 1) & 1][j] = read_frag2<TB, BN>(lb, wn * 2 + j, ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this step's MFMAs (the scheduler would sink it to its use)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -555,6 +564,145 @@ int launch128(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
   }
 #undef LT_C
 }
+// ---- deeper pipeline variant: BK = 32, FOUR 32-KiB LDS stages, DMA issued three k-tiles ahead, counted vmcnt + raw s_barrier
+// (never vmcnt(0) in the steady state): ~96 KiB of operand bytes in flight per CU instead of 64 KiB.
+template <bool TR, int ROWS>
+__device__ __forceinline__ void stage_dma32(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  constexpr int PER_WAVE = ROWS / 16 / 8, NB = ROWS / 16;
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int blk = w * PER_WAVE + j;
+    const bf16_t* src;
+    if (!TR) {
+      const int row = blk * 16 + (l >> 2), slot = l & 3;
+      const int c = slot ^ ((row >> 2) & 3);
+      const int gr = min(row0 + row, rows - 1);
+      src = P + (size_t)gr * ld + k0 + c * 8;
+    } else {
+      const int p = blk * 8 + (l >> 3), slot = l & 7;
+      const int q = p / NB, b = p % NB;
+      const int kr = ((slot >> 1) - b) & 3;
+      int col = row0 + b * 16 + (slot & 1) * 8;
+      if (col >= rows) col = 0;
+      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
+  }
+}
+template <bool TR, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag32(const char* lds, int rb, int ks) {
+  const int l = threadIdx.x & 63;
+  if (!TR) {
+    const int row = rb * 32 + (l & 31);
+    const int c = ks * 2 + (l >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+  } else {
+    return read_frag2<true, ROWS>(lds, rb, ks);
+  }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(NT2) void gemm256p_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKP = 32, OPB = 256 * BKP * 2, STAGE = 2 * OPB, NS = 4;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = g.K / BKP;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 1; ++s2)
+    if (s2 < nk) {
+      stage_dma32<TA, 256>(smem + s2 * STAGE, g.A, g.lda, g.M, m0, s2 * BKP);
+      stage_dma32<TB, 256>(smem + s2 * STAGE + OPB, g.B, g.ldb, g.N, n0, s2 * BKP);
+    }
+  for (int kt = 0; kt < nk; ++kt) {
+    // each wave issues 4 DMA instructions per k-tile; tiles kt+1, kt+2 (8 instructions) may stay in flight
+    const int ahead = nk - 1 - kt;
+    if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0xF78);       // vmcnt(8)
+    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0xF74);  // vmcnt(4)
+    else __builtin_amdgcn_s_waitcnt(0xF70);                  // vmcnt(0)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) {
+      char* na = smem + ((kt + NS - 1) % NS) * STAGE;
+      stage_dma32<TA, 256>(na, g.A, g.lda, g.M, m0, (kt + NS - 1) * BKP);
+      stage_dma32<TB, 256>(na + OPB, g.B, g.ldb, g.N, n0, (kt + NS - 1) * BKP);
+    }
+    const char* la = smem + (kt % NS) * STAGE;
+    const char* lb = la + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag32<TA, 256>(la, wm * 4 + i, ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag32<TB, 256>(lb, wn * 2 + j, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    emit_subtile<EPI>(g, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool TA, bool TB, int EPI>
+int launch_p_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<TA, TB, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm256p_kernel<TA, TB, EPI>), grid, dim3(NT2), LDS_BYTES, st, g);
+  return LT_OK;
+}
+template <bool TA, bool TB>
+int launch_p(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_p_one<TA, TB, EPI_BF16>(g, grid, st);
+    case EPI_BF16_GELU: return launch_p_one<TA, TB, EPI_BF16_GELU>(g, grid, st);
+    case EPI_RESID: return launch_p_one<TA, TB, EPI_RESID>(g, grid, st);
+    case EPI_F32: return launch_p_one<TA, TB, EPI_F32>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_p_one<TA, TB, EPI_BF16_GELUGRAD>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the pipelined kernel", epi); return LT_ERR_INVALID;
+  }
+}
 }  // namespace g256
 
 // ---- plain reference-grade GEMM (one thread per output; cross-check for the MFMA kernel) -------
@@ -635,6 +783,14 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
   bool big = eligible && d->force_kernel != 1 && d->N >= 128 &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
+  if (d->force_kernel == 4) {
+    LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM && d->N >= 256, "lt_gemm_bf16: not eligible for the pipelined 256x256 kernel");
+    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 256);
+    dim3 grid4(g.tiles_m * g.tiles_n);
+    rc = d->trans_b ? g256::launch_p<false, true>(g, d->epilogue, grid4, st) : g256::launch_p<false, false>(g, d->epilogue, grid4, st);
+    if (rc != LT_OK) return rc;
+    LT_CHECK_LAUNCH("lt_gemm_bf16");
+  }
   if (d->force_kernel == 3) {
     LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM, "lt_gemm_bf16: not eligible for the 128x128 LDS-DMA kernel");
     g.tiles_m = lt_cdiv(d->M, 128); g.tiles_n = lt_cdiv(d->N, 128);

@@ -52,7 +52,8 @@ def test_gemm_layouts(M, N, K, ta, tb):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)])
 @pytest.mark.parametrize("tb", [False, True])
-def test_gemm_256_kernel(M, N, K, tb):
+@pytest.mark.parametrize("fk", [2, 3, 4])
+def test_gemm_256_kernel(M, N, K, tb, fk):
     """the 256x256 LDS-DMA kernel (forced) against the fp32 reference, incl. M/N tails and every epilogue it serves."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -61,18 +62,18 @@ def test_gemm_256_kernel(M, N, K, tb):
     ref = A.float() @ B.float().t()
     b_in = B.t().contiguous() if tb else B
     out = torch.empty(M, N, device=DEV, dtype=torch.float32)
-    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_F32, force_kernel=2)
+    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_F32, force_kernel=fk)
     assert rel_err(out, ref) < 1e-5
     bias = torch.randn(N, generator=g).to(DEV); gamma = torch.randn(N, generator=g).to(DEV)
     resid = torch.randn(M, N, generator=g).to(DEV); aux = bf(torch.randn(M, N, generator=g)).to(DEV)
     y = ref + bias
     ob = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); pre = torch.empty_like(ob)
-    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELU, bias=bias, out2=pre, force_kernel=2)
+    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELU, bias=bias, out2=pre, force_kernel=fk)
     assert rel_err(pre, y) < 6e-3 and rel_err(ob, F.gelu(y)) < 6e-3
     y2 = torch.empty_like(ob)
-    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, out2=y2, force_kernel=2)
+    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, out2=y2, force_kernel=fk)
     assert rel_err(out, resid + gamma * y) < 1e-5 and rel_err(y2, y) < 6e-3
-    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELUGRAD, aux=aux, force_kernel=2)
+    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELUGRAD, aux=aux, force_kernel=fk)
     x = aux.float().requires_grad_(True)
     F.gelu(x).sum().backward()
     assert rel_err(ob, ref * x.grad) < 6e-3

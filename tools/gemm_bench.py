@@ -32,7 +32,7 @@ def bench(name, M, N, K, ta, tb, epi, split=1, iters=10, fk=0, ws=None):
 
 T = 256 * 197
 D = 768
-for fk in (2, 3):
+for fk in (2, 4):
     bench("square 4096 NN bf16", 4096, 4096, 4096, False, False, ops.EPI_BF16, fk=fk)
     bench("square 8192 NN bf16", 8192, 8192, 8192, False, False, ops.EPI_BF16, fk=fk)
     bench("square 4096 NT(tb) bf16", 4096, 4096, 4096, False, True, ops.EPI_BF16, fk=fk)
