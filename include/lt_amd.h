@@ -92,9 +92,11 @@ int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_b
  * ------------------------------------------------------------------------------------------ */
 int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                      float* rstd, int rows, int D, float eps, void* stream);
-/* dx = (dres ? dres : 0) + LN'(dy); dw/db accumulate (atomics). dy is bf16 unless dy_is_f32 */
+/* dx = (dres ? dres : 0) + LN'(dy); dw/db accumulate. dy is bf16 unless dy_is_f32.
+ * ws (optional, ws_floats >= 128*D): per-block partial sums + deterministic reduce instead of atomics. */
 int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
-                     int dy_is_f32, const float* dres, float* dx, float* dw, float* db, int rows, int D, void* stream);
+                     int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                     int rows, int D, void* stream);
 
 /* LayerScale backward (layer_scale.py:27-28): dy(bf16) = dout*gamma; dgamma += sum_rows dout*y;
  * dbias (optional) += sum_rows dy  (bias gradient of the Linear in front of LayerScale, fused).

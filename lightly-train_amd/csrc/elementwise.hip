@@ -1,6 +1,8 @@
 // HBM-bound kernels of the ViT token path: im2col, token assembly, LayerNorm fwd/bwd, LayerScale bwd,
 // column sums, row gather/scatter, casts, L2-normalise, weight-norm.  All are coalesced 16-byte
 // (4 x f32 / 8 x bf16) streams, one wave (64 lanes) per row where a row reduction is needed.
+#include <algorithm>
+
 #include "lt_common.h"
 
 namespace {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const void* __restrict__ dyv, const float* __restrict__ dres,
                                                                 float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-                                                                int rows, int D) {
+                                                                float* __restrict__ partial, int rows, int D) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float4 aw[NV], ab[NV], wv4[NV];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   }
   const long stride = (long)gridDim.x * 4;
   for (long row0 = (long)blockIdx.x * 4 + wv; row0 < rows; row0 += 2 * stride) {
-    float4 xv[2][NV], dv[2][NV];
+    float4 xv[2][NV], dv[2][NV], rv[2][NV];
     float mu[2], rs[2];
     bool ok[2];
 #pragma unroll
@@ -176,9 +178,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        xv[r][i] = make_float4(0, 0, 0, 0); dv[r][i] = make_float4(0, 0, 0, 0);
+        xv[r][i] = make_float4(0, 0, 0, 0); dv[r][i] = make_float4(0, 0, 0, 0); rv[r][i] = make_float4(0, 0, 0, 0);
         if (ok[r] && c < D) {
           xv[r][i] = *reinterpret_cast<const float4*>(x + row * D + c);
+          if (dres) rv[r][i] = *reinterpret_cast<const float4*>(dres + row * D + c);  // residual gradient prefetched with the row
           if (DYF32) dv[r][i] = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
           else {
             const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
@@ -215,10 +218,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
           const float4 xh = xv[r][i], gy = dv[r][i];
           float4 o = make_float4(rs[r] * (gy.x - c1 - xh.x * c2), rs[r] * (gy.y - c1 - xh.y * c2),
                                  rs[r] * (gy.z - c1 - xh.z * c2), rs[r] * (gy.w - c1 - xh.w * c2));
-          if (dres) {
-            const float4 rr = *reinterpret_cast<const float4*>(dres + row * D + c);
-            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-          }
+          const float4 rr = rv[r][i];
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
           *reinterpret_cast<float4*>(dx + row * D + c) = o;
         }
       }
@@ -236,12 +237,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
       if (c < D) {
         const float4 a0 = red[0][0][lane], a1 = red[0][1][lane], a2 = red[0][2][lane], a3 = red[0][3][lane];
         const float4 b0 = red[1][0][lane], b1 = red[1][1][lane], b2 = red[1][2][lane], b3 = red[1][3][lane];
-        atomicAdd(&dw[c], a0.x + a1.x + a2.x + a3.x); atomicAdd(&dw[c + 1], a0.y + a1.y + a2.y + a3.y);
-        atomicAdd(&dw[c + 2], a0.z + a1.z + a2.z + a3.z); atomicAdd(&dw[c + 3], a0.w + a1.w + a2.w + a3.w);
-        atomicAdd(&db[c], b0.x + b1.x + b2.x + b3.x); atomicAdd(&db[c + 1], b0.y + b1.y + b2.y + b3.y);
-        atomicAdd(&db[c + 2], b0.z + b1.z + b2.z + b3.z); atomicAdd(&db[c + 3], b0.w + b1.w + b2.w + b3.w);
+        const float4 sa = make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
+        const float4 sb = make_float4(b0.x + b1.x + b2.x + b3.x, b0.y + b1.y + b2.y + b3.y, b0.z + b1.z + b2.z + b3.z, b0.w + b1.w + b2.w + b3.w);
+        if (partial) {  // per-block partial rows [gridDim.x][2][D], summed by ln_partial_reduce_kernel (deterministic, no atomics)
+          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2) * D + c) = sa;
+          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 1) * D + c) = sb;
+        } else {
+          atomicAdd(&dw[c], sa.x); atomicAdd(&dw[c + 1], sa.y); atomicAdd(&dw[c + 2], sa.z); atomicAdd(&dw[c + 3], sa.w);
+          atomicAdd(&db[c], sb.x); atomicAdd(&db[c + 1], sb.y); atomicAdd(&db[c + 2], sb.z); atomicAdd(&db[c + 3], sb.w);
+        }
       }
     }
+  }
+}
+// dw[c] += sum_b partial[b][0][c]; db[c] += sum_b partial[b][1][c]
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                float* __restrict__ db, int nblk, int D) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, which = blockIdx.y;
+  float a = 0.f;
+  if (c < D)
+    for (int b = rl; b < nblk; b += 4) a += partial[((size_t)b * 2 + which) * D + c];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float* o = which ? db : dw;
+    o[c] += red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
   }
 }
 
@@ -562,20 +584,30 @@ extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, 
   LT_CHECK_LAUNCH("lt_layernorm_fwd");
 }
 extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
-                                int dy_is_f32, const float* dres, float* dx, float* dw, float* db, int rows, int D, void* stream) {
+                                int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                                int rows, int D, void* stream) {
   LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
   if (rows == 0) return LT_OK;
-  const int grid = min(lt_cdiv(rows, 4), 1024);
+  int grid = min(lt_cdiv(rows, 4), 512);
+  const bool vec_ok = D % 4 == 0;
+  float* partial = nullptr;
+  if (vec_ok && ws && ws_floats >= (int64_t)2 * D * 64) {  // workspace given: more blocks, no same-address atomics
+    grid = (int)std::min<int64_t>(std::min<int64_t>(lt_cdiv(rows, 4), 2048), ws_floats / (2 * D));
+    partial = ws;
+  }
   const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
                    (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)w % 16 == 0);
-#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D)
+#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, rows, D)
   if (vec) {
     const int nv = (D + 255) / 256;
     if (dy_is_f32) { if (nv <= 2) LT_LNB(true, 2); else if (nv <= 3) LT_LNB(true, 3); else if (nv <= 4) LT_LNB(true, 4); else LT_LNB(true, 8); }
     else { if (nv <= 2) LT_LNB(false, 2); else if (nv <= 3) LT_LNB(false, 3); else if (nv <= 4) LT_LNB(false, 4); else LT_LNB(false, 8); }
   }
 #undef LT_LNB
-  else if (dy_is_f32)
+  if (vec && partial)
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(lt_cdiv(D, 64), 2), dim3(256), 0, ST, partial, dw, db, grid, D);
+  if (vec) { LT_CHECK_LAUNCH("lt_layernorm_bwd"); }
+  if (dy_is_f32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);

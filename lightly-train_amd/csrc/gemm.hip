@@ -135,7 +135,23 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
   if (EPI != EPI_F32_ACCUM && EPI != EPI_BF16_GELUGRAD && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + col);
   if (EPI == EPI_RESID && g.gamma) gam4 = *reinterpret_cast<const float4*>(g.gamma + col);
-#pragma unroll 4
+  // operands the epilogue has to fetch from HBM (residual rows / GELU pre-activations): issue all 16 loads up front so
+  // their latency overlaps instead of being paid once per row group
+  float4 r4[16];
+  uint2 a2[16];
+  if (EPI == EPI_RESID || EPI == EPI_BF16_GELUGRAD) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = row_base + it * 4 + rs;
+      r4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a2[it] = make_uint2(0, 0);
+      if (row < g.M) {
+        if (EPI == EPI_RESID && g.resid) r4[it] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldr + col);
+        if (EPI == EPI_BF16_GELUGRAD) a2[it] = *reinterpret_cast<const uint2*>(g.aux + (size_t)row * g.ldaux + col);
+      }
+    }
+  }
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int rl = it * 4 + rs;
     const int row = row_base + rl;
@@ -150,14 +166,12 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
       *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(gelu_f(v.x), gelu_f(v.y)), pack_bf2(gelu_f(v.z), gelu_f(v.w)));
     } else if (EPI == EPI_RESID) {
       if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.resid) r4 = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldr + col);
       *reinterpret_cast<float4*>((float*)g.C + o) =
-          make_float4(r4.x + gam4.x * v.x, r4.y + gam4.y * v.y, r4.z + gam4.z * v.z, r4.w + gam4.w * v.w);
+          make_float4(r4[it].x + gam4.x * v.x, r4[it].y + gam4.y * v.y, r4[it].z + gam4.z * v.z, r4[it].w + gam4.w * v.w);
     } else if (EPI == EPI_F32) {
       *reinterpret_cast<float4*>((float*)g.C + o) = v;
     } else if (EPI == EPI_BF16_GELUGRAD) {
-      const uint2 a = *reinterpret_cast<const uint2*>(g.aux + (size_t)row * g.ldaux + col);
+      const uint2 a = a2[it];
       const float p0 = bf2f((bf16_t)(a.x & 0xffff)), p1 = bf2f((bf16_t)(a.x >> 16)), p2 = bf2f((bf16_t)(a.y & 0xffff)), p3 = bf2f((bf16_t)(a.y >> 16));
       *reinterpret_cast<uint2*>((bf16_t*)g.C + o) =
           make_uint2(pack_bf2(v.x * gelu_grad_f(p0), v.y * gelu_grad_f(p1)), pack_bf2(v.z * gelu_grad_f(p2), v.w * gelu_grad_f(p3)));

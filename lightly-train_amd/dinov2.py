@@ -187,7 +187,10 @@ class HeadEngine:
         ops.gemm(dlogits, c["zn"], self.dwn, M=K, N=bn, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
                  split_k=split(K, bn), lda=K, ldb=bn)
         dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
-        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32)
+        # [R, bn] output = only ~35 tiles but a 65 536-long contraction: split-K into slabs, accumulate into zeros
+        dzn.zero_()
+        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=2,
+                 workspace=ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32))
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         ops.colsum_bf16(dz, self.gw("mlp.4.bias"), R, bn)

@@ -121,9 +121,10 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, rows: int, D: int, y_bf16: Op
 
 
 def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, dres: Optional[Tensor], dx: Tensor, dw: Tensor,
-                  db: Tensor, rows: int, D: int) -> None:
+                  db: Tensor, rows: int, D: int, ws: Optional[Tensor] = None) -> None:
     check(_lib.load().lt_layernorm_bwd(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx),
-                                       _p(dw), _p(db), rows, D, _stream()), "lt_layernorm_bwd")
+                                       _p(dw), _p(db), _p(ws), ws.numel() if ws is not None else 0, rows, D, _stream()),
+          "lt_layernorm_bwd")
 
 
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,

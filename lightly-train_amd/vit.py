@@ -273,8 +273,9 @@ class ViTEngine:
         dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
+        lnws = None  # per-block partial sums (deterministic) measured slower than 512 blocks + atomics on MI355X
         ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
-                          self.gw("norm.weight"), self.gw("norm.bias"), T, D)
+                          self.gw("norm.weight"), self.gw("norm.bias"), T, D, ws=lnws)
         dx = dxa
         other = dxb
 
@@ -299,7 +300,7 @@ class ViTEngine:
             wgrad(dH, bk["ln2"], pre + "mlp.fc1.weight", hid, D)
             ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=T, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
             ops.layernorm_bwd(bk["xm"], self.w(pre + "norm2.weight"), bk["mean2"], bk["rstd2"], dD2, dx, other,
-                              self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D)
+                              self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D, ws=lnws)
             dx, other = other, dx
             # ---- attention branch: xm = x + g1 * proj(attn(qkv(ln1)))
             ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D,
@@ -311,7 +312,7 @@ class ViTEngine:
             wgrad(dQ, bk["ln1"], pre + "attn.qkv.weight", 3 * D, D)
             ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=T, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
             ops.layernorm_bwd(bk["x"], self.w(pre + "norm1.weight"), bk["mean1"], bk["rstd1"], dD, dx, other,
-                              self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D)
+                              self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, ws=lnws)
             dx, other = other, dx
 
         # ---- token assembly + patch embedding

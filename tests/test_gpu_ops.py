@@ -179,11 +179,12 @@ def test_layernorm(rows, D):
     # backward (bf16 dy and f32 dy)
     dy = torch.randn(rows, D, generator=g).to(DEV)
     dres = torch.randn(rows, D, generator=g).to(DEV)
-    for dyt in (dy, bf(dy)):
+    wsb = torch.empty(2048 * 2 * D, device=DEV)
+    for dyt, wsx in ((dy, None), (bf(dy), None), (bf(dy), wsb)):
         dx = torch.empty(rows, D, device=DEV)
         dw = torch.zeros(D, device=DEV)
         db = torch.zeros(D, device=DEV)
-        o.layernorm_bwd(x, w, mean, rstd, dyt, dres, dx, dw, db, rows, D)
+        o.layernorm_bwd(x, w, mean, rstd, dyt, dres, dx, dw, db, rows, D, ws=wsx)
         for t in (xr, wr, br):
             t.grad = None
         ref.backward(dyt.float(), retain_graph=True)
