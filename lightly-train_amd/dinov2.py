@@ -287,7 +287,11 @@ class DINOv2:
         self._loss_slots = torch.zeros(4, device=dev)
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
+        self.overlap_streams = True
         self._grad_sync: Optional[GradSync] = None
+        use_streams = self.device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(device=self.device) if use_streams else None     # weight-gradient GEMMs
+        self.teacher_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # teacher forward
 
     # ------------------------------------------------------------------ reference-compatible views
     def state_dict(self) -> Dict[str, Tensor]:
@@ -371,7 +375,11 @@ class DINOv2:
         self.student.grad.zero_()
         self._loss_slots.zero_()
 
-        # ---------------- teacher (no grad) : dinov2.py:399-472
+        # ---------------- teacher (no grad) : dinov2.py:399-472 -- on its own stream, concurrent with the student forward
+        main = torch.cuda.current_stream()
+        tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
+        tstream.wait_event(main.record_event())
+        torch.cuda.set_stream(tstream)
         if a.center_method == "softmax":
             self._apply_center_updates()
         tctx = self.t_vit.forward(ws, "t", gv, None, save=False)
@@ -405,9 +413,23 @@ class DINOv2:
                 dist.all_reduce(n_masked_total)
             self._sinkhorn(t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, K, teacher_temp, n_masked_total, "ski")
 
+        teacher_done = tstream.record_event()
+        torch.cuda.set_stream(main)
+
         # ---------------- student forward : dinov2.py:474-519
+        # local-crop forward on the side stream, concurrent with the global-crop forward (disjoint activation buffers)
+        lstream = self.side_stream if (self.side_stream is not None and self.overlap_streams and lv is not None) else None
+        sl = None
+        if lstream is not None:
+            lstream.wait_event(main.record_event())
+            with torch.cuda.stream(lstream):
+                sl = self.s_vit.forward(ws, "sl", lv, None, save=True)
+                local_done = lstream.record_event()
         sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True)
-        sl = self.s_vit.forward(ws, "sl", lv, None, save=True) if lv is not None else None
+        if lstream is not None:
+            main.wait_event(local_done)
+        elif lv is not None:
+            sl = self.s_vit.forward(ws, "sl", lv, None, save=True)
         Rl = n_local * B
         Rs, cap_s = 2 * B + M + Rl, 2 * B + cap_M + Rl
         s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16)
@@ -427,6 +449,7 @@ class DINOv2:
         slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32)])
         ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
         dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16)
+        main.wait_event(teacher_done)
         ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, 1.0 / a.student_temp, self._loss_slots, dlogits, Rs, K, slot=slot)
 
         dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
@@ -438,6 +461,7 @@ class DINOv2:
                 ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, self._loss_slots[3:], dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
 
         # ---------------- backward
+        side = self.side_stream if self.overlap_streams else None
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
@@ -446,8 +470,10 @@ class DINOv2:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B + M:Rs], ix["l_cls"], dxn_l, D, Rl, D)
-            self.s_vit.backward(ws, sl, dxn_l)
-        self.s_vit.backward(ws, sg, dxn_g)
+            self.s_vit.backward(ws, sl, dxn_l, side=side)
+        self.s_vit.backward(ws, sg, dxn_g, side=side)
+        if side is not None:
+            main.wait_stream(side)
 
         ls = self._loss_slots
         # slots hold weighted terms; report the unweighted terms like the reference's log_dict

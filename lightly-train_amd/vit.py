@@ -259,8 +259,13 @@ class ViTEngine:
         return ctx
 
     # ---- backward -------------------------------------------------------------------------------
-    def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor) -> None:
-        """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views."""
+    def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> None:
+        """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
+
+        `side`: optional second HIP stream for the weight-gradient GEMMs and bias column sums.  They depend only on
+        tensors the main (dgrad) chain has already produced and feed nothing but the optimizer, so running them beside
+        the dgrad chain fills the CUs the 591-tile dgrad GEMMs leave idle in their last wave.  The caller must make the
+        optimizer wait for `side`."""
         cfg = self.cfg
         B, N, n_p, T, tag = ctx["B"], ctx["N"], ctx["n_p"], ctx["T"], ctx["tag"]
         D, Hh, dh, hid = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
@@ -280,11 +285,30 @@ class ViTEngine:
         other = dxb
 
         slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)  # 128 MiB split-K scratch (deterministic reduction)
+        main = torch.cuda.current_stream()
+        consumed: Dict[int, Any] = {}  # buffer data_ptr -> event after which the side stream no longer reads it
 
-        def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int) -> None:
+        def before_write(buf: Tensor) -> None:
+            ev = consumed.pop(buf.data_ptr(), None)
+            if ev is not None:
+                main.wait_event(ev)
+
+        def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int, bias: Optional[str] = None) -> None:
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-            ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=T, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                     split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
+
+            def run() -> None:
+                if bias is not None:
+                    ops.colsum_bf16(dy, self.gw(bias), T, n_out)
+                ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=T, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                         split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
+
+            if side is None:
+                run()
+                return
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                run()
+                consumed[dy.data_ptr()] = side.record_event()
 
         for i in reversed(range(cfg.depth)):
             bk = ctx["blocks"][i]
@@ -292,24 +316,27 @@ class ViTEngine:
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
             # ---- MLP branch: xo = xm + g2 * (fc2(gelu(fc1(ln2))))
+            before_write(dD)
             ops.layerscale_bwd(dx, bk["y2"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, T, D,
                                dbias=self.gw(pre + "mlp.fc2.bias"))
             wgrad(dD, bk["act"], pre + "mlp.fc2.weight", D, hid)
+            before_write(dH)
             ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=T, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=bk["hpre"])
-            ops.colsum_bf16(dH, self.gw(pre + "mlp.fc1.bias"), T, hid)
-            wgrad(dH, bk["ln2"], pre + "mlp.fc1.weight", hid, D)
+            wgrad(dH, bk["ln2"], pre + "mlp.fc1.weight", hid, D, bias=pre + "mlp.fc1.bias")
             ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=T, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
             ops.layernorm_bwd(bk["xm"], self.w(pre + "norm2.weight"), bk["mean2"], bk["rstd2"], dD2, dx, other,
                               self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D, ws=lnws)
             dx, other = other, dx
             # ---- attention branch: xm = x + g1 * proj(attn(qkv(ln1)))
+            before_write(dD)
             ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D,
                                dbias=self.gw(pre + "attn.proj.bias"))
             wgrad(dD, bk["att"], pre + "attn.proj.weight", D, D)
             ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=T, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+            before_write(dQ)
             ops.attention_bwd(bk["qkv"], bk["att"], dD2, bk["lse"], aws, dQ, B, N, Hh, dh, scale)
-            ops.colsum_bf16(dQ, self.gw(pre + "attn.qkv.bias"), T, 3 * D)
-            wgrad(dQ, bk["ln1"], pre + "attn.qkv.weight", 3 * D, D)
+            wgrad(dQ, bk["ln1"], pre + "attn.qkv.weight", 3 * D, D, bias=pre + "attn.qkv.bias")
+            before_write(dD)
             ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=T, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
             ops.layernorm_bwd(bk["x"], self.w(pre + "norm1.weight"), bk["mean1"], bk["rstd1"], dD, dx, other,
                               self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, ws=lnws)
@@ -328,8 +355,17 @@ class ViTEngine:
         if mp is not None:
             gpos[0].add_(dpos[0])  # cls position row (plumbing: one D-vector add)
             ops.matmul_f32(mp, dpos[1:], gpos[1:], mp.shape[1], D, n_p, trans_a=True, accumulate=True)
-        ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
         tiles = ((D + 127) // 128) * ((self.kpad + 127) // 128)
-        ops.gemm(dpatch, ctx["cols"], self.gw("patch_embed.proj.weight").view(D, -1), M=D, N=self.kpad, K=B * n_p, trans_a=True,
-                 trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=max(2, _split_k(tiles, B * n_p)), lda=D, ldb=self.kpad, ldc=self.kpad,
-                 workspace=slab)
+
+        def patch_wgrad() -> None:
+            ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
+            ops.gemm(dpatch, ctx["cols"], self.gw("patch_embed.proj.weight").view(D, -1), M=D, N=self.kpad, K=B * n_p, trans_a=True,
+                     trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=max(2, _split_k(tiles, B * n_p)), lda=D, ldb=self.kpad,
+                     ldc=self.kpad, workspace=slab)
+
+        if side is None:
+            patch_wgrad()
+        else:
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                patch_wgrad()
