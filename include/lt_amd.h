@@ -44,7 +44,7 @@ int lt_device_info(char* name, int name_len, int* compute_units, int* clock_khz)
 enum {
   LT_EPI_BF16 = 0,          /* C(bf16) = alpha*acc + bias                                        */
   LT_EPI_BF16_GELU = 1,     /* C2(bf16, optional) = pre = alpha*acc + bias; C(bf16) = gelu(pre)   */
-  LT_EPI_RESID = 2,         /* y = alpha*acc + bias; C2(bf16, optional) = y; C(f32) = resid + gamma*y */
+  LT_EPI_RESID = 2,         /* y = alpha*acc + bias; C2(bf16, optional) = y; C(f32) = resid + branch_scale*rowscale[m]*gamma*y */
   LT_EPI_F32 = 3,           /* C(f32) = alpha*acc + bias                                         */
   LT_EPI_BF16_GELUGRAD = 4, /* C(bf16) = alpha*acc * gelu'(aux(bf16))                            */
   LT_EPI_F32_ACCUM = 5      /* C(f32) += alpha*acc   (split_k > 1 -> atomic adds)                */
@@ -65,6 +65,8 @@ typedef struct lt_gemm_desc {
   float alpha;
   int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
   int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged kernel, 2 = 256-row LDS-DMA kernel */
+  const float* rowscale;          /* [M] per-row multiplier of the LayerScale branch (LT_EPI_RESID; per-sample DropPath) or NULL */
+  float branch_scale;             /* scalar multiplier of the branch (LT_EPI_RESID; batch-subset stochastic depth b/s); 0 = 1 */
   void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */
 } lt_gemm_desc;
 
@@ -98,11 +100,12 @@ int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const fl
                      int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
                      int rows, int D, void* stream);
 
-/* LayerScale backward (layer_scale.py:27-28): dy(bf16) = dout*gamma; dgamma += sum_rows dout*y;
- * dbias (optional) += sum_rows dy  (bias gradient of the Linear in front of LayerScale, fused).
- * gamma == NULL: dy = bf16(dout). */
+/* LayerScale (+ stochastic depth) backward (layer_scale.py:27-28, block.py:118-141, drop_path.py:16-28):
+ *   m_r = scale * (rowscale ? rowscale[r] : 1);  dy(bf16) = dout*gamma*m_r;  dgamma += sum_r dout*y*m_r;
+ *   dbias (optional) += sum_r dy  (bias gradient of the Linear in front of LayerScale, fused).
+ * gamma == NULL: dy = bf16(dout*m_r). */
 int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
-                      float* dbias, int rows, int D, void* stream);
+                      float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
 /* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */
 int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream);
 /* out[N] (+)= column sums of an f32 [rows,N] matrix (teacher center, dinov2_loss.py:139-145,274-282) */

@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
         ("A", vp), ("B", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32),
         ("trans_a", i32), ("trans_b", i32), ("epilogue", i32), ("C", vp), ("ldc", i32), ("C2", vp), ("ldc2", i32),
         ("bias", vp), ("gamma", vp), ("resid", vp), ("ldr", i32), ("aux", vp), ("ldaux", i32),
-        ("alpha", f32), ("split_k", i32), ("force_kernel", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
+        ("alpha", f32), ("split_k", i32), ("force_kernel", i32), ("rowscale", vp), ("branch_scale", f32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -37,7 +37,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lt_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lt_layernorm_bwd": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
-    "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],
     "lt_colsum_bf16": [vp, vp, i32, i32, vp],
     "lt_colsum_f32": [vp, vp, i32, i32, i32, vp],
     "lt_gather_rows": [vp, i32, vp, vp, vp, i32, i32, vp],

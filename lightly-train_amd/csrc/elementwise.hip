@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // dy(bf16) = dout*gamma; dgamma += sum_rows dout*y; dbias += sum_rows dout*gamma (bias of the Linear feeding LayerScale).
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
                                                              const float* __restrict__ gamma, bf16_t* __restrict__ dy,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbias, int rows, int D) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbias,
+                                                             const float* __restrict__ rowscale, float scale, int rows, int D) {
   __shared__ float4 red[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cl) * 4;
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   if (c < D) {
     const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     for (long r = (long)blockIdx.y * 8 + rl; r < rows; r += (long)gridDim.y * 8) {
-      const float4 g = *reinterpret_cast<const float4*>(dout + r * D + c);
+      const float m_r = scale * (rowscale ? rowscale[r] : 1.f);
+      float4 g = *reinterpret_cast<const float4*>(dout + r * D + c);
+      g.x *= m_r; g.y *= m_r; g.z *= m_r; g.w *= m_r;
       const float4 o = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
       *reinterpret_cast<uint2*>(dy + r * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
       abias.x += o.x; abias.y += o.y; abias.z += o.z; abias.w += o.w;
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
 // scalar fallback for D % 4 != 0
 __global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dy,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbias, int rows, int D) {
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbias,
+                                                                    const float* __restrict__ rowscale, float scale, int rows, int D) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float*
   if (c < D) {
     const float gm = gamma ? gamma[c] : 1.f;
     for (long r = (long)blockIdx.y * 4 + rl; r < rows; r += (long)gridDim.y * 4) {
-      const float g = dout[r * D + c];
+      const float g = dout[r * D + c] * scale * (rowscale ? rowscale[r] : 1.f);
       dy[r * D + c] = f2bf(g * gm);
       accb += g * gm;
       if (gamma) acc += g * bf2f(y[r * D + c]);
@@ -614,18 +618,18 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
   LT_CHECK_LAUNCH("lt_layernorm_bwd");
 }
 extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
-                                 float* dbias, int rows, int D, void* stream) {
+                                 float* dbias, const float* rowscale, float scale, int rows, int D, void* stream) {
   LT_CHECK_ARG(dout && dy_bf16 && (!gamma || (y_bf16 && dgamma)), "lt_layerscale_bwd: null pointer");
   if (rows == 0) return LT_OK;
   if (D % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dy_bf16 % 8 == 0 && (!y_bf16 || (uintptr_t)y_bf16 % 8 == 0) &&
       (!gamma || (uintptr_t)gamma % 16 == 0)) {
     dim3 grid(lt_cdiv(D, 128), min(lt_cdiv(rows, 8), 256));
     hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16, dgamma,
-                       dbias, rows, D);
+                       dbias, rowscale, scale, rows, D);
   } else {
     dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
     hipLaunchKernelGGL(layerscale_bwd_scalar_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
-                       dgamma, dbias, rows, D);
+                       dgamma, dbias, rowscale, scale, rows, D);
   }
   LT_CHECK_LAUNCH("lt_layerscale_bwd");
 }

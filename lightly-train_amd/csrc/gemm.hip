@@ -46,6 +46,7 @@ struct GemmArgs {
   const float* bias; const float* gamma;
   const float* resid; int ldr;
   const bf16_t* aux; int ldaux;
+  const float* rowscale; float branch_scale;
   float alpha;
   int tiles_m, tiles_n, k_per_split;
 };
@@ -166,8 +167,9 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
       *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(gelu_f(v.x), gelu_f(v.y)), pack_bf2(gelu_f(v.z), gelu_f(v.w)));
     } else if (EPI == EPI_RESID) {
       if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      *reinterpret_cast<float4*>((float*)g.C + o) =
-          make_float4(r4[it].x + gam4.x * v.x, r4[it].y + gam4.y * v.y, r4[it].z + gam4.z * v.z, r4[it].w + gam4.w * v.w);
+      const float rsc = g.branch_scale * (g.rowscale ? g.rowscale[row] : 1.f);  // stochastic depth: subset b/s or per-sample mask/keep
+      *reinterpret_cast<float4*>((float*)g.C + o) = make_float4(r4[it].x + rsc * gam4.x * v.x, r4[it].y + rsc * gam4.y * v.y,
+                                                                r4[it].z + rsc * gam4.z * v.z, r4[it].w + rsc * gam4.w * v.w);
     } else if (EPI == EPI_F32) {
       *reinterpret_cast<float4*>((float*)g.C + o) = v;
     } else if (EPI == EPI_BF16_GELUGRAD) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
         } else if (EPI == EPI_RESID) {
           if (g.C2) ((bf16_t*)g.C2)[(size_t)row * g.ldc2 + col] = f2bf(v);
           const float rs = g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f;
-          ((float*)g.C)[o] = rs + gam * v;
+          ((float*)g.C)[o] = rs + g.branch_scale * (g.rowscale ? g.rowscale[row] : 1.f) * gam * v;
         } else if (EPI == EPI_F32) {
           ((float*)g.C)[o] = v;
         } else if (EPI == EPI_BF16_GELUGRAD) {
@@ -776,6 +778,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   g.C = d->C; g.ldc = d->ldc; g.C2 = d->C2; g.ldc2 = d->ldc2;
   g.bias = d->bias; g.gamma = d->gamma; g.resid = d->resid; g.ldr = d->ldr;
   g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux;
+  g.rowscale = d->rowscale; g.branch_scale = d->branch_scale == 0.f ? 1.f : d->branch_scale;
   g.alpha = d->alpha;
   g.tiles_m = lt_cdiv(d->M, BM); g.tiles_n = lt_cdiv(d->N, BN);
   int split = d->split_k > 0 ? d->split_k : 1;

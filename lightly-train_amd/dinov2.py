@@ -25,7 +25,7 @@ from .masking import MaskingGenerator, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, make_drop_plan, vit_param_shapes
 
 
 @dataclass
@@ -288,6 +288,7 @@ class DINOv2:
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
+        self._drop_gen = torch.Generator().manual_seed(seed + 7919)  # host RNG of the stochastic-depth draws
         self._grad_sync: Optional[GradSync] = None
         use_streams = self.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device=self.device) if use_streams else None     # weight-gradient GEMMs
@@ -417,19 +418,26 @@ class DINOv2:
         torch.cuda.set_stream(main)
 
         # ---------------- student forward : dinov2.py:474-519
+        # stochastic depth draws (student, training): injected (parity tests) or drawn from the host generator
+        plan_g = batch.get("drop_plan_global", None) if isinstance(batch, dict) else None
+        plan_l = batch.get("drop_plan_local", None) if isinstance(batch, dict) else None
+        if plan_g is None:
+            plan_g = make_drop_plan(cfg, n_crops, self._drop_gen)
+        if plan_l is None and lv is not None:
+            plan_l = make_drop_plan(cfg, lv.shape[0], self._drop_gen)
         # local-crop forward on the side stream, concurrent with the global-crop forward (disjoint activation buffers)
         lstream = self.side_stream if (self.side_stream is not None and self.overlap_streams and lv is not None) else None
         sl = None
         if lstream is not None:
             lstream.wait_event(main.record_event())
             with torch.cuda.stream(lstream):
-                sl = self.s_vit.forward(ws, "sl", lv, None, save=True)
+                sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l)
                 local_done = lstream.record_event()
-        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True)
+        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g)
         if lstream is not None:
             main.wait_event(local_done)
         elif lv is not None:
-            sl = self.s_vit.forward(ws, "sl", lv, None, save=True)
+            sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l)
         Rl = n_local * B
         Rs, cap_s = 2 * B + M + Rl, 2 * B + cap_M + Rl
         s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16)

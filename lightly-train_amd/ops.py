@@ -43,7 +43,8 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
          epilogue: int = EPI_BF16, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
          resid: Optional[Tensor] = None, out2: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None) -> Tensor:
+         ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None,
+         rowscale: Optional[Tensor] = None, branch_scale: float = 1.0) -> Tensor:
     """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h."""
     _chk(a, torch.bfloat16, "gemm.a")
     _chk(b, torch.bfloat16, "gemm.b")
@@ -66,6 +67,7 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
         _chk(aux, torch.bfloat16, "gemm.aux")
     d.aux, d.ldaux = _p(aux), N
     d.alpha, d.split_k, d.force_kernel = alpha, split_k, force_kernel
+    d.rowscale, d.branch_scale = _p(rowscale), branch_scale
     d.workspace = _p(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
     check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
@@ -128,9 +130,9 @@ def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, 
 
 
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,
-                   D: int, dbias: Optional[Tensor] = None) -> None:
-    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), rows, D, _stream()),
-          "lt_layerscale_bwd")
+                   D: int, dbias: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, scale: float = 1.0) -> None:
+    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), _p(rowscale), scale, rows, D,
+                                        _stream()), "lt_layerscale_bwd")
 
 
 def colsum_bf16(x: Tensor, out: Tensor, rows: int, N: int) -> None:

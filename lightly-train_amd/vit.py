@@ -32,6 +32,8 @@ class ViTConfig:
     init_values: Optional[float] = 1e-5
     interpolate_offset: float = 0.1
     interpolate_antialias: bool = False
+    drop_path_rate: float = 0.0
+    drop_path_uniform: bool = False
 
     @property
     def hidden(self) -> int:
@@ -95,6 +97,38 @@ def init_vit_state(cfg: ViTConfig, generator: Optional[torch.Generator] = None) 
             t = torch.zeros(shape)
         sd[name] = t
     return sd
+
+
+def block_drop_rates(cfg: ViTConfig) -> List[float]:
+    """Per-block stochastic-depth rate (vision_transformer.py:150-157): uniform or linspace(0, rate, depth)."""
+    if cfg.drop_path_uniform:
+        return [float(cfg.drop_path_rate)] * cfg.depth
+    return [x.item() for x in torch.linspace(0, cfg.drop_path_rate, cfg.depth)]
+
+
+def make_drop_plan(cfg: ViTConfig, batch: int, generator: Optional[torch.Generator] = None) -> Optional[List[Any]]:
+    """Host-side draws for one training forward of the student (one entry per residual branch, attn then ffn):
+    rate > 0.1 -> ("subset", randperm(b)[:max(int(b(1-rate)),1)])   (block.py:118-141, batch-subset stochastic depth)
+    0 < rate <= 0.1 -> ("persample", bernoulli(keep)/keep)          (block.py:108-111 + drop_path.py:16-28)
+    The reference draws from the device RNG; we draw from a host generator (same distribution, different stream)."""
+    rates = block_drop_rates(cfg)
+    if not any(r > 0 for r in rates):
+        return None
+    plan: List[Any] = []
+    for r in rates:
+        for _branch in range(2):
+            if r == 0.0:
+                plan.append(None)
+            elif r > 0.1:
+                s = max(int(batch * (1 - r)), 1)
+                plan.append(("subset", torch.randperm(batch, generator=generator)[:s]))
+            else:
+                keep = 1 - r
+                sc = torch.empty(batch).bernoulli_(keep, generator=generator)
+                if keep > 0.0:
+                    sc.div_(keep)
+                plan.append(("persample", sc))
+    return plan
 
 
 class Workspace:
@@ -196,8 +230,12 @@ class ViTEngine:
         return pos
 
     # ---- forward --------------------------------------------------------------------------------
-    def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool) -> Dict[str, Any]:
-        """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens)."""
+    def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
+                drop_plan: Optional[List[Any]] = None) -> Dict[str, Any]:
+        """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
+
+        drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
+        ("subset", brange int64[s]) | ("persample", scale f32[B]) -- see make_drop_plan / layers/block.py:90-141."""
         cfg = self.cfg
         B, C, H, W = img.shape
         p, D, Hh, dh, hid = cfg.patch_size, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
@@ -217,39 +255,80 @@ class ViTEngine:
         x = ws.get(tag + ".x0" if save else tag + ".xa", (T, D), torch.float32)
         ops.assemble_tokens(patch, self.w("cls_token").view(D), pos, self.w("mask_token").view(D), masks, B, n_p, D, out=x)
         ctx["cols"] = cols
+        tok = torch.arange(N, dtype=torch.int64)
 
-        blocks: List[Dict[str, Tensor]] = []
+        def branch_setup(entry: Any, s: str, which: str, xin: Tensor) -> Dict[str, Any]:
+            """Decide the rows a residual branch runs on: all T rows, or the gathered rows of a batch subset."""
+            br: Dict[str, Any] = {"mode": "plain", "rows": T, "nb": B, "x": xin, "rowscale": None, "scale": 1.0}
+            if entry is None:
+                return br
+            kind, val = entry
+            if kind == "persample":   # DropPath: per-image mask/keep expanded over the image's tokens
+                br["mode"] = "persample"
+                br["rowscale"] = val.to(torch.float32).repeat_interleave(N).to(self.dev, non_blocking=True)
+                return br
+            sb = int(val.numel())      # batch-subset stochastic depth
+            Ts = sb * N
+            idx = (val.to(torch.int64).view(-1, 1) * N + tok.view(1, -1)).reshape(-1).to(self.dev, non_blocking=True)
+            xs = ws.get(s + which + ".xs", (T, D), torch.float32)[:Ts]
+            ops.gather_rows(xin, D, idx, Ts, D, out_f32=xs)
+            br.update(mode="subset", rows=Ts, nb=sb, x=xs, idx=idx, scale=B / sb)
+            return br
+
+        blocks: List[Dict[str, Any]] = []
         for i in range(cfg.depth):
             s = f"{tag}.b{i}." if save else f"{tag}.tmp."
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
-            bk: Dict[str, Tensor] = {"x": x}
+            e1 = drop_plan[2 * i] if drop_plan is not None else None
+            e2 = drop_plan[2 * i + 1] if drop_plan is not None else None
+            # ---------------- attention branch
+            a = branch_setup(e1, s, "a", x)
+            R, nb = a["rows"], a["nb"]
             ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16)
-            bk["mean1"], bk["rstd1"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
-            ops.layernorm_fwd(x, self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), T, D, y_bf16=ln1, mean=bk["mean1"], rstd=bk["rstd1"])
+            a["mean"], a["rstd"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
+            ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"])
             qkv = ws.get(s + "qkv", (T, 3 * D), torch.bfloat16)
-            ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=T, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
+            ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=R, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
             att = ws.get(s + "att", (T, D), torch.bfloat16)
             lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
-            ops.attention_fwd(qkv, att, lse, B, N, Hh, dh, scale)
+            ops.attention_fwd(qkv, att, lse, nb, N, Hh, dh, scale)
             y1 = ws.get(s + "y1", (T, D), torch.bfloat16) if (save and g1 is not None) else None
-            xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
-            ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
-                     gamma=g1, resid=x, out2=y1)
+            if a["mode"] == "subset":
+                delta = ws.get(tag + ".delta", (T, D), torch.float32)
+                ops.gemm(att, self.wb(pre + "attn.proj.weight"), delta, M=R, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
+                         gamma=g1, resid=None, out2=y1, branch_scale=a["scale"])
+                ops.scatter_add_rows(delta, a["idx"], x, D, R, D)   # x += (b/s) * g1 * branch on the subset rows, in place
+                xm = x
+            else:
+                xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
+                ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
+                         gamma=g1, resid=x, out2=y1, rowscale=a["rowscale"])
+            # ---------------- MLP branch
+            m = branch_setup(e2, s, "m", xm)
+            R2 = m["rows"]
             ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16)
-            bk["mean2"], bk["rstd2"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
-            ops.layernorm_fwd(xm, self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), T, D, y_bf16=ln2, mean=bk["mean2"], rstd=bk["rstd2"])
+            m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
+            ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"])
             act = ws.get(s + "act", (T, hid), torch.bfloat16)
             hpre = ws.get(s + "hpre", (T, hid), torch.bfloat16) if save else None
-            ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=T, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
+            ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=R2, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
             y2 = ws.get(s + "y2", (T, D), torch.bfloat16) if (save and g2 is not None) else None
-            xo = ws.get(f"{tag}.b{i}.xo" if save else (tag + ".xa"), (T, D), torch.float32)
-            ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
-                     gamma=g2, resid=xm, out2=y2)
+            if m["mode"] == "subset":
+                delta = ws.get(tag + ".delta", (T, D), torch.float32)
+                ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), delta, M=R2, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
+                         gamma=g2, resid=None, out2=y2, branch_scale=m["scale"])
+                ops.scatter_add_rows(delta, m["idx"], xm, D, R2, D)
+                xo = xm
+            else:
+                xo = ws.get(f"{tag}.b{i}.xo" if save else (tag + ".xa"), (T, D), torch.float32)
+                ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
+                         gamma=g2, resid=xm, out2=y2, rowscale=m["rowscale"])
             if save:
-                bk.update(ln1=ln1, qkv=qkv, att=att, lse=lse, y1=y1, xm=xm, ln2=ln2, act=act, hpre=hpre, y2=y2)
-                blocks.append(bk)
+                a.update(ln=ln1, qkv=qkv, att=att, lse=lse, y=y1)
+                m.update(ln=ln2, act=act, hpre=hpre, y=y2)
+                blocks.append({"attn": a, "mlp": m})
             x = xo
         xn = ws.get(tag + ".xn", (B, N, D), torch.float32)
         mean = ws.get(tag + ".meanf", (T,), torch.float32)
@@ -278,9 +357,8 @@ class ViTEngine:
         dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
-        lnws = None  # per-block partial sums (deterministic) measured slower than 512 blocks + atomics on MI355X
         ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
-                          self.gw("norm.weight"), self.gw("norm.bias"), T, D, ws=lnws)
+                          self.gw("norm.weight"), self.gw("norm.bias"), T, D)
         dx = dxa
         other = dxb
 
@@ -293,14 +371,20 @@ class ViTEngine:
             if ev is not None:
                 main.wait_event(ev)
 
-        def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int, bias: Optional[str] = None) -> None:
+        def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int, rows: int, bias: Optional[str] = None) -> None:
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            kpad = (rows + 63) // 64 * 64
+            if kpad != rows and kpad <= dy.shape[0] and kpad <= xin.shape[0]:
+                dy[rows:kpad].zero_()   # zero the <=63 pad rows so the contraction can run in whole 64-row k-tiles
+                xin[rows:kpad].zero_()  # (both operands: stale pad rows could hold NaN bit patterns)
+            else:
+                kpad = rows
 
             def run() -> None:
                 if bias is not None:
-                    ops.colsum_bf16(dy, self.gw(bias), T, n_out)
-                ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=T, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                         split_k=_split_k(tiles, T), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
+                    ops.colsum_bf16(dy, self.gw(bias), rows, n_out)
+                ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                         split_k=_split_k(tiles, kpad), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
 
             if side is None:
                 run()
@@ -310,37 +394,62 @@ class ViTEngine:
                 run()
                 consumed[dy.data_ptr()] = side.record_event()
 
+        def branch_grad_in(br: Dict[str, Any], tagx: str) -> Tensor:
+            """Upstream gradient rows of a branch: all of dx, or the gathered subset rows."""
+            if br["mode"] != "subset":
+                return dx
+            dxs = ws.get(tag + tagx, (T, D), torch.float32)[:br["rows"]]
+            ops.gather_rows(dx, D, br["idx"], br["rows"], D, out_f32=dxs)
+            return dxs
+
         for i in reversed(range(cfg.depth)):
-            bk = ctx["blocks"][i]
+            blk = ctx["blocks"][i]
+            a, m = blk["attn"], blk["mlp"]
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
-            # ---- MLP branch: xo = xm + g2 * (fc2(gelu(fc1(ln2))))
+            # ---- MLP branch: xo = xm + scale * g2 * (fc2(gelu(fc1(ln2(rows)))))
+            R2 = m["rows"]
+            din = branch_grad_in(m, ".dxs")
             before_write(dD)
-            ops.layerscale_bwd(dx, bk["y2"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, T, D,
-                               dbias=self.gw(pre + "mlp.fc2.bias"))
-            wgrad(dD, bk["act"], pre + "mlp.fc2.weight", D, hid)
+            ops.layerscale_bwd(din, m["y"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, R2, D,
+                               dbias=self.gw(pre + "mlp.fc2.bias"), rowscale=m["rowscale"], scale=m["scale"])
+            wgrad(dD, m["act"], pre + "mlp.fc2.weight", D, hid, R2)
             before_write(dH)
-            ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=T, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=bk["hpre"])
-            wgrad(dH, bk["ln2"], pre + "mlp.fc1.weight", hid, D, bias=pre + "mlp.fc1.bias")
-            ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=T, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
-            ops.layernorm_bwd(bk["xm"], self.w(pre + "norm2.weight"), bk["mean2"], bk["rstd2"], dD2, dx, other,
-                              self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D, ws=lnws)
-            dx, other = other, dx
-            # ---- attention branch: xm = x + g1 * proj(attn(qkv(ln1)))
+            ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=R2, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=m["hpre"])
+            wgrad(dH, m["ln"], pre + "mlp.fc1.weight", hid, D, R2, bias=pre + "mlp.fc1.bias")
+            ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=R2, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
+            if m["mode"] == "subset":
+                lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R2]
+                ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, None, lng,
+                                  self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), R2, D)
+                ops.scatter_add_rows(lng, m["idx"], dx, D, R2, D)   # dx += LN'(.) on the subset rows; identity path untouched
+            else:
+                ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, dx, other,
+                                  self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D)
+                dx, other = other, dx
+            # ---- attention branch: xm = x + scale * g1 * proj(attn(qkv(ln1(rows))))
+            R1, nb = a["rows"], a["nb"]
+            din = branch_grad_in(a, ".dxs")
             before_write(dD)
-            ops.layerscale_bwd(dx, bk["y1"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, T, D,
-                               dbias=self.gw(pre + "attn.proj.bias"))
-            wgrad(dD, bk["att"], pre + "attn.proj.weight", D, D)
-            ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=T, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+            ops.layerscale_bwd(din, a["y"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, R1, D,
+                               dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
+            wgrad(dD, a["att"], pre + "attn.proj.weight", D, D, R1)
+            ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             before_write(dQ)
-            ops.attention_bwd(bk["qkv"], bk["att"], dD2, bk["lse"], aws, dQ, B, N, Hh, dh, scale)
-            wgrad(dQ, bk["ln1"], pre + "attn.qkv.weight", 3 * D, D, bias=pre + "attn.qkv.bias")
+            ops.attention_bwd(a["qkv"], a["att"], dD2, a["lse"], aws, dQ, nb, N, Hh, dh, scale)
+            wgrad(dQ, a["ln"], pre + "attn.qkv.weight", 3 * D, D, R1, bias=pre + "attn.qkv.bias")
             before_write(dD)
-            ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=T, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
-            ops.layernorm_bwd(bk["x"], self.w(pre + "norm1.weight"), bk["mean1"], bk["rstd1"], dD, dx, other,
-                              self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, ws=lnws)
-            dx, other = other, dx
+            ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
+            if a["mode"] == "subset":
+                lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R1]
+                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, None, lng,
+                                  self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), R1, D)
+                ops.scatter_add_rows(lng, a["idx"], dx, D, R1, D)
+            else:
+                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, dx, other,
+                                  self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D)
+                dx, other = other, dx
 
         # ---- token assembly + patch embedding
         dpatch = ws.get(tag + ".dpatch", (B * n_p, D), torch.bfloat16)

@@ -203,9 +203,21 @@ def pos_embed_for_grid(pos_embed: Tensor, gh: int, gw: int, interpolate_offset: 
     return torch.cat([cls_pe, grid.permute(0, 2, 3, 1).reshape(1, gh * gw, d)], dim=1).to(pos_embed.dtype)
 
 
+def block_drop_rates(cfg: Dict[str, Any]) -> List[float]:
+    """vision_transformer.py:150-157: uniform rate or linspace(0, rate, depth)."""
+    rate, depth = float(cfg.get("drop_path_rate", 0.0)), cfg["depth"]
+    if cfg.get("drop_path_uniform", False):
+        return [rate] * depth
+    return [x.item() for x in torch.linspace(0, rate, depth)]
+
+
 def vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], masks: Optional[Tensor] = None,
-                capture: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
-    """x [B,C,H,W] -> {"cls":[B,D], "patch":[B,n_p,D], "prenorm":[B,N,D]}."""
+                capture: Optional[Dict[str, Tensor]] = None, drop: Any = None) -> Dict[str, Tensor]:
+    """x [B,C,H,W] -> {"cls":[B,D], "patch":[B,n_p,D], "prenorm":[B,N,D]}.
+
+    drop: None (eval / teacher), "torch" (training: draw like the reference from torch's global RNG,
+    layers/block.py:118-141 + drop_path.py:16-28), or a list (one entry per residual branch, attn then ffn per block)
+    of None | ("subset", brange LongTensor) | ("persample", scale FloatTensor[B]) to inject the draws."""
     ps, heads, depth = cfg["patch_size"], cfg["num_heads"], cfg["depth"]
     B, _, H, W = x.shape
     nh, nw = math.ceil(H / ps) * ps, math.ceil(W / ps) * ps
@@ -226,26 +238,60 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], masks: Opt
     D = t.shape[-1]
     dh = D // heads
     has_ls = "blocks.0.ls1.gamma" in p
-    for i in range(depth):
-        pre = f"blocks.{i}."
-        y = F.layer_norm(t, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)
+    rates = block_drop_rates(cfg)
+    used_draws: List[Any] = []
+
+    def attn_branch(z: Tensor, pre: str) -> Tensor:
+        b_ = z.shape[0]
+        y = F.layer_norm(z, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)
         qkv = F.linear(y, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
-        qkv = qkv.reshape(B, -1, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        qkv = qkv.reshape(b_, -1, 3, heads, dh).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0] * dh ** -0.5, qkv[1], qkv[2]
         a = (q @ k.transpose(-2, -1)).softmax(dim=-1)
-        y = (a @ v).transpose(1, 2).reshape(B, -1, D)
+        y = (a @ v).transpose(1, 2).reshape(b_, -1, D)
         y = F.linear(y, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"])
-        if has_ls:
-            y = y * p[pre + "ls1.gamma"]
-        t = t + y
-        y = F.layer_norm(t, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-6)
+        return y * p[pre + "ls1.gamma"] if has_ls else y
+
+    def ffn_branch(z: Tensor, pre: str) -> Tensor:
+        y = F.layer_norm(z, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-6)
         y = F.gelu(F.linear(y, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))
         y = F.linear(y, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
-        if has_ls:
-            y = y * p[pre + "ls2.gamma"]
-        t = t + y
+        return y * p[pre + "ls2.gamma"] if has_ls else y
+
+    def residual(z: Tensor, fn, pre: str, rate: float, slot: int) -> Tensor:
+        if drop is None or rate == 0.0:
+            used_draws.append(None)
+            return z + fn(z, pre)
+        b_ = z.shape[0]
+        if rate > 0.1:  # batch-subset stochastic depth, block.py:118-141
+            s_ = max(int(b_ * (1 - rate)), 1)
+            if drop == "torch":
+                br = torch.randperm(b_)[:s_]
+            else:
+                kind, br = drop[slot]
+                assert kind == "subset" and br.numel() == s_
+            used_draws.append(("subset", br))
+            res = fn(z[br], pre)
+            return torch.index_add(z.flatten(1), 0, br, res.flatten(1).to(z.dtype), alpha=b_ / s_).view_as(z)
+        keep = 1 - rate  # per-sample DropPath, drop_path.py:16-28
+        if drop == "torch":
+            sc = z.new_empty((b_,)).bernoulli_(keep)
+            if keep > 0.0:
+                sc.div_(keep)
+        else:
+            kind, sc = drop[slot]
+            assert kind == "persample"
+        used_draws.append(("persample", sc))
+        return z + fn(z, pre) * sc.view(b_, 1, 1)
+
+    for i in range(depth):
+        pre = f"blocks.{i}."
+        t = residual(t, attn_branch, pre, rates[i], 2 * i)
+        t = residual(t, ffn_branch, pre, rates[i], 2 * i + 1)
         if capture is not None:
             capture[f"block{i}"] = t
+    if capture is not None:
+        capture["drop_draws"] = used_draws
     tn = F.layer_norm(t, (D,), p["norm.weight"], p["norm.bias"], 1e-6)
     nreg = p["register_tokens"].shape[1] if "register_tokens" in p else 0
     return {"cls": tn[:, 0], "patch": tn[:, 1 + nreg:], "prenorm": t}
@@ -396,7 +442,8 @@ class OracleDINOv2:
 
     # ---- one forward (loss + logs), mirrors LT/_methods/dinov2/dinov2.py:259-397
     def forward_loss(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None,
-                     capture: Optional[Dict[str, Any]] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+                     capture: Optional[Dict[str, Any]] = None, drop_global: Any = "torch", drop_local: Any = "torch"
+                     ) -> Tuple[Tensor, Dict[str, Tensor]]:
         a, cfg = self.args, self.cfg
         step = self.global_step
         t_temp = linear_warmup_schedule(step, a["teacher_temp_warmup_steps"], a["teacher_temp_start"], a["teacher_temp_end"])
@@ -431,7 +478,9 @@ class OracleDINOv2:
             else:
                 raise ValueError(f"Unknown centering method: {a['center_method']}")
         # student global
-        sg = vit_forward(self.sb, gv, cfg, masks=cm)
+        cap_g: Dict[str, Any] = {}
+        cap_l: Dict[str, Any] = {}
+        sg = vit_forward(self.sb, gv, cfg, masks=cm, drop=drop_global, capture=cap_g)
         s_cls_logits = head_forward(self.sh, sg["cls"])
         s_patch_logits = head_forward(self.sh, sg["patch"].flatten(0, 1)[idx])
         dino_global = dino_ce([s_cls_logits], [t_cls_p.flatten(0, 1)], a["student_temp"]) * 2 / terms
@@ -439,7 +488,7 @@ class OracleDINOv2:
         s_loc_logits = None
         if n_local > 0:
             lv = torch.cat(views[2:])
-            sl = vit_forward(self.sb, lv, cfg)
+            sl = vit_forward(self.sb, lv, cfg, drop=drop_local, capture=cap_l)
             s_loc_logits = head_forward(self.sh, sl["cls"])
             dino_local = dino_ce(s_loc_logits.chunk(n_local), list(t_cls_p), a["student_temp"]) / terms
         ibot = ibot_ce_masked(s_patch_logits, t_patch_p, mw, n_crops, a["student_temp"])
@@ -449,7 +498,8 @@ class OracleDINOv2:
         if capture is not None:
             capture.update(dict(t_cls_logits=t_cls_logits, t_patch_logits=t_patch_logits, t_cls_p=t_cls_p,
                                 t_patch_p=t_patch_p, s_cls_logits=s_cls_logits, s_patch_logits=s_patch_logits,
-                                s_loc_logits=s_loc_logits, s_cls=sg["cls"], masks=masks, teacher_temp=t_temp))
+                                s_loc_logits=s_loc_logits, s_cls=sg["cls"], masks=masks, teacher_temp=t_temp,
+                                drop_global=cap_g.get("drop_draws"), drop_local=cap_l.get("drop_draws")))
         logs = {"dino_global_loss": dino_global.detach(), "dino_local_loss": dino_local.detach(),
                 "ibot_loss": ibot.detach(), "koleo_loss": koleo.detach()}
         return loss, logs
@@ -486,8 +536,8 @@ class OracleDINOv2:
                     d_t[name].mul_(mom).add_(d_s[name].detach(), alpha=1.0 - mom)
         return {"grad_norm": float(gnorm), "weight_decay": wd, "lr_factor": factor, "momentum": mom}
 
-    def train_step(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None) -> Dict[str, float]:
-        loss, logs = self.forward_loss(views, masks)
+    def train_step(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None, **kw: Any) -> Dict[str, float]:
+        loss, logs = self.forward_loss(views, masks, **kw)
         loss.backward()
         info = self.optimizer_step()
         out = {k: float(v) for k, v in logs.items()}

@@ -116,6 +116,53 @@ def test_gradients_match_oracle(name):
             assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2 if koleo_w == 0.0 else 8e-2)
 
 
+@pytest.mark.parametrize("rate,uniform", [(0.3, True), (0.1, True), (0.4, False)])
+def test_stochastic_depth_matches_oracle(rate, uniform):
+    """Batch-subset stochastic depth (rate > 0.1) and per-sample DropPath (rate <= 0.1) of the student
+    (layers/block.py:90-141): same draws injected into the HIP step and the oracle (the oracle itself reproduces the
+    reference bit-exactly under torch.manual_seed, see tests/test_oracle_pin.py)."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig
+    from oracle import dinov2_oracle as O
+
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    sb = fx["init"]["student_backbone"]
+    vc = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"], drop_path_rate=rate,
+                   drop_path_uniform=uniform)
+    args = DINOv2Args(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, koleo_loss_weight=0.0)
+    m = DINOv2(vc, args, global_batch_size=fx["b"], total_steps=50, device="cuda", backbone_state=sb,
+               student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"])
+    cfg = dict(fx["cfg"], drop_path_rate=rate, drop_path_uniform=uniform)
+    o = O.OracleDINOv2(sb, fx["init"]["student_head"], cfg, args=dict(output_dim=512, hidden_dim=128, bottleneck_dim=64, koleo_loss_weight=0.0),
+                       global_batch_size=fx["b"], total_steps=50, teacher_head=fx["init"]["teacher_head"])
+    torch.manual_seed(3)
+    cap = {}
+    loss, _ = o.forward_loss(views, rec["masks"], capture=cap)
+    loss.backward()
+    assert any(d is not None for d in cap["drop_global"])
+    res = m.training_step_impl({"views": views, "drop_plan_global": cap["drop_global"], "drop_plan_local": cap["drop_local"]}, 0,
+                               masks=rec["masks"])
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+    for n in m.student.names:
+        ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+        assert rel(m.student.g[n].cpu(), ref) < 5e-2, n
+    # the method's own host-side draws: shapes / subset sizes follow the reference formulas
+    from lightly_train_amd.vit import make_drop_plan
+    plan = make_drop_plan(vc, 16, torch.Generator().manual_seed(0))
+    rates = [rate, rate] if uniform else [0.0, rate]
+    for i, r in enumerate(rates):
+        for e in plan[2 * i: 2 * i + 2]:
+            if r == 0:
+                assert e is None
+            elif r > 0.1:
+                assert e[0] == "subset" and e[1].numel() == max(int(16 * (1 - r)), 1) and e[1].unique().numel() == e[1].numel()
+            else:
+                assert e[0] == "persample" and all(v == 0.0 or abs(v - 1.0 / (1 - r)) < 1e-6 for v in e[1].tolist())
+
+
 def test_parameter_update_and_ema_match_oracle():
     """One full optimizer step (clip + AdamW + EMA) on identical gradients-by-construction (KoLeo off):
     Adam's first step is sign-like (|update| = lr), so per-element agreement is measured as a fraction."""

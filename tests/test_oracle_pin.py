@@ -141,3 +141,28 @@ def test_oracle_vs_live_reference():
         b = o.train_step(views)
         for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
             assert a[k] == pytest.approx(b[k], rel=2e-5, abs=2e-5), (step, k)
+
+
+@pytest.mark.parametrize("rate,uniform", [(0.3, True), (0.1, True), (0.4, False)])
+def test_oracle_stochastic_depth_vs_live_reference(rate, uniform):
+    """Both stochastic-depth regimes of layers/block.py:90-141: same torch seed -> identical draws and losses."""
+    from oracle import ref_harness as H
+
+    if not H.reference_available():
+        pytest.skip("/root/reference not present (GPU box)")
+    mk = dict(output_dim=256, hidden_dim=32, dino_bottleneck_dim=16)
+    m = H.build_reference_method(arch="_vit_test", patch_size=16, img_size=64, model_kwargs=dict(drop_path_rate=rate, drop_path_uniform=uniform),
+                                 method_kwargs=mk, global_batch_size=8, total_steps=10, seed=3)
+    r = H.ReferenceRunner(m)
+    st = r.split_state()
+    o = O.OracleDINOv2(st["student_backbone"], st["student_head"], dict(patch_size=16, num_heads=2, depth=3, drop_path_rate=rate, drop_path_uniform=uniform),
+                       args=dict(output_dim=256, hidden_dim=32, bottleneck_dim=16), global_batch_size=8, total_steps=10,
+                       teacher_backbone=st["teacher_backbone"], teacher_head=st["teacher_head"])
+    g = torch.Generator().manual_seed(11)
+    views = [torch.randn(8, 3, 64, 64, generator=g) for _ in range(2)] + [torch.randn(8, 3, 32, 32, generator=g) for _ in range(2)]
+    random.seed(0); torch.manual_seed(5)
+    a = r.train_step(views)
+    random.seed(0); torch.manual_seed(5)
+    b = o.train_step(views)
+    for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
+        assert a[k] == pytest.approx(b[k], rel=2e-5, abs=2e-5), k
