@@ -136,8 +136,8 @@ def main() -> None:
     ms_per_step = dt / args.steps * 1e3
     img_per_s = B * world * args.steps / dt
 
-    n_g = (args.global_size // 16) ** 2 + 1
-    n_l = (args.local_size // 16) ** 2 + 1
+    n_g = (-(-args.global_size // 16)) ** 2 + 1
+    n_l = (-(-args.local_size // 16)) ** 2 + 1  # 98 -> 112 (bicubic pad-resize of patch_embed.py:90-99) -> 7x7 patches
     m_tokens = method._last["M"] / B
     gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
                                   2048, 256, m_tokens) / 1e9

@@ -32,6 +32,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_gemm_bf16": [C.POINTER(GemmDesc), vp],
     "lt_gemm_bf16_naive": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lt_matmul_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

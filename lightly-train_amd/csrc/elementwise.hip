@@ -26,6 +26,29 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------ bicubic pad-resize (patch_embed.py:90-99)
+// separable 4-tap resize with host-precomputed taps: out[p,y,x] = sum_a sum_b wy[y,a]*wx[x,b]*in[p, iy[y,a], ix[x,b]]
+__global__ __launch_bounds__(256) void resize4tap_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ iy,
+                                                         const float* __restrict__ wy, const int32_t* __restrict__ ix,
+                                                         const float* __restrict__ wx, int planes, int H, int W, int Ho, int Wo) {
+  const long n = (long)planes * Ho * Wo;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long)gridDim.x * 256) {
+    const int x = o % Wo, y = (o / Wo) % Ho;
+    const long p = o / ((long)Wo * Ho);
+    const float* src = in + p * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float* row = src + (long)iy[y * 4 + a] * W;
+      float r = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) r = fmaf(wx[x * 4 + b], row[ix[x * 4 + b]], r);
+      acc = fmaf(wy[y * 4 + a], r, acc);
+    }
+    out[o] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------ tokens
 __global__ void assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
                                 const float* __restrict__ mask_token, const uint8_t* __restrict__ masks, float* __restrict__ x,
@@ -561,6 +584,14 @@ extern "C" int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H,
                "lt_im2col_bf16: bad arguments (H=%d W=%d p=%d kpad=%d)", H, W, p, kpad);
   hipLaunchKernelGGL(im2col_kernel, dim3(B * (H / p) * (W / p)), dim3(256), 0, ST, img, (bf16_t*)cols, B, C, H, W, p, kpad);
   LT_CHECK_LAUNCH("lt_im2col_bf16");
+}
+extern "C" int lt_resize_4tap(const float* in, float* out, const int32_t* iy, const float* wy, const int32_t* ix, const float* wx,
+                              int planes, int H, int W, int Ho, int Wo, void* stream) {
+  LT_CHECK_ARG(in && out && iy && wy && ix && wx && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "lt_resize_4tap: bad arguments");
+  const long n = (long)planes * Ho * Wo;
+  hipLaunchKernelGGL(resize4tap_kernel, dim3((unsigned)min((long)8192, (n + 255) / 256)), dim3(256), 0, ST, in, out, iy, wy, ix, wx, planes, H, W,
+                     Ho, Wo);
+  LT_CHECK_LAUNCH("lt_resize_4tap");
 }
 extern "C" int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
                                   const uint8_t* masks, float* x, int B, int n_p, int D, void* stream) {

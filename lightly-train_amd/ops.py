@@ -89,6 +89,31 @@ def matmul_f32(a: Tensor, b: Tensor, out: Tensor, M: int, N: int, K: int, trans_
 
 
 # ------------------------------------------------------------------------------------------ tokens
+def bicubic_taps(n_in: int, n_out: int):
+    """4-tap (index, weight) table of torch's 1-D bicubic resize (align_corners=False), read off F.interpolate itself by
+    pushing an identity basis through it (host, once per size pair) so the arithmetic is the reference's by construction."""
+    import torch.nn.functional as F
+
+    basis = torch.eye(n_in).view(1, 1, n_in, n_in)                        # rows = source index, cols = basis id
+    m = F.interpolate(basis, size=(n_out, n_in), mode="bicubic", align_corners=False)[0, 0]  # [n_out, n_in]
+    idx = torch.zeros(n_out, 4, dtype=torch.int32)
+    wts = torch.zeros(n_out, 4, dtype=torch.float32)
+    for o in range(n_out):
+        nz = m[o].nonzero().flatten()
+        assert nz.numel() <= 4, "bicubic row with more than 4 taps"
+        idx[o, : nz.numel()] = nz.to(torch.int32)
+        wts[o, : nz.numel()] = m[o, nz]
+    return idx, wts
+
+
+def resize_4tap(img: Tensor, iy: Tensor, wy: Tensor, ix: Tensor, wx: Tensor, Ho: int, Wo: int) -> Tensor:
+    _chk(img, torch.float32, "resize.img")
+    B, Cc, H, W = img.shape
+    out = torch.empty(B, Cc, Ho, Wo, device=img.device, dtype=torch.float32)
+    check(_lib.load().lt_resize_4tap(_p(img), _p(out), _p(iy), _p(wy), _p(ix), _p(wx), B * Cc, H, W, Ho, Wo, _stream()), "lt_resize_4tap")
+    return out
+
+
 def im2col(img: Tensor, p: int, kpad: int) -> Tensor:
     _chk(img, torch.float32, "im2col.img")
     B, Cc, H, W = img.shape

@@ -173,6 +173,7 @@ class ViTEngine:
         self.prefix = prefix
         self.dev = params.device
         self._pos_maps: Dict[Tuple[int, int], Optional[Tensor]] = {}
+        self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
         D = cfg.embed_dim
         kreal = cfg.in_chans * cfg.patch_size ** 2
         self.kpad = (kreal + 7) // 8 * 8
@@ -240,7 +241,16 @@ class ViTEngine:
         B, C, H, W = img.shape
         p, D, Hh, dh, hid = cfg.patch_size, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
         if H % p or W % p:
-            raise NotImplementedError("image size must be a multiple of patch_size (bicubic pad-resize of patch_embed.py:90-99 not implemented)")
+            # PatchEmbed.forward (layers/patch_embed.py:86-99): bicubic-resize to the next multiple of the patch size
+            nh, nw = math.ceil(H / p) * p, math.ceil(W / p) * p
+            key = (H, W, nh, nw)
+            if key not in self._resize_taps:
+                iy, wy = ops.bicubic_taps(H, nh)
+                ix, wx = ops.bicubic_taps(W, nw)
+                self._resize_taps[key] = tuple(t.to(self.dev) for t in (iy, wy, ix, wx))
+            iy, wy, ix, wx = self._resize_taps[key]
+            img = ops.resize_4tap(img.contiguous(), iy, wy, ix, wx, nh, nw)
+            H, W = nh, nw
         gh, gw = H // p, W // p
         n_p, N = gh * gw, gh * gw + 1
         T = B * N

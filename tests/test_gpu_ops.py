@@ -222,6 +222,18 @@ def test_im2col_and_tokens():
     assert torch.equal(dpatch.float().view(B, n_p, D), bf(dx[:, 1:] * (~masks).unsqueeze(-1)).float())
 
 
+def test_bicubic_pad_resize():
+    """98x98 -> 112x112 (the literal 8 x 98^2 local crops with patch 16): taps read off F.interpolate, applied in HIP."""
+    o = ops()
+    g = torch.Generator().manual_seed(8)
+    img = torch.randn(3, 3, 98, 90, generator=g).to(DEV)
+    iy, wy = o.bicubic_taps(98, 112)
+    ix, wx = o.bicubic_taps(90, 96)
+    out = o.resize_4tap(img, iy.to(DEV), wy.to(DEV), ix.to(DEV), wx.to(DEV), 112, 96)
+    ref = F.interpolate(img.cpu(), size=(112, 96), mode="bicubic", align_corners=False)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
 def test_layerscale_colsum_gather():
     o = ops()
     rows, D = 333, 136

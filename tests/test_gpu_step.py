@@ -163,6 +163,26 @@ def test_stochastic_depth_matches_oracle(rate, uniform):
                 assert e[0] == "persample" and all(v == 0.0 or abs(v - 1.0 / (1 - r)) < 1e-6 for v in e[1].tolist())
 
 
+def test_vit_forward_with_non_multiple_image_size():
+    """98^2 crops with patch 16 (BASELINE config literal): the inner model's 98 -> 112 bicubic pad-resize + 7x7 pos-embed."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.params import FlatParams
+    from lightly_train_amd.vit import ViTConfig, ViTEngine, Workspace, init_vit_state, vit_param_shapes
+    from oracle import dinov2_oracle as O
+
+    cfg = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=0.5)
+    g = torch.Generator().manual_seed(0)
+    sd = init_vit_state(cfg, g)
+    fp = FlatParams([(n, sd[n]) for n, _ in vit_param_shapes(cfg)], "cuda", False)
+    eng = ViTEngine(cfg, fp, "")
+    x = torch.randn(4, 3, 98, 98, generator=g)
+    ctx = eng.forward(Workspace(torch.device("cuda")), "t", x.cuda(), None, save=False)
+    ref = O.vit_forward(sd, x, dict(patch_size=16, num_heads=1, depth=2))
+    assert ctx["N"] == 50
+    ours = ctx["xn"].cpu()
+    assert rel(ours[:, 0], ref["cls"]) < 2e-2 and rel(ours[:, 1:], ref["patch"]) < 2e-2
+
+
 def test_parameter_update_and_ema_match_oracle():
     """One full optimizer step (clip + AdamW + EMA) on identical gradients-by-construction (KoLeo off):
     Adam's first step is sign-like (|update| = lr), so per-element agreement is measured as a fraction."""
