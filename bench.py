@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: DINOv2 training step throughput (images/sec, whole job) on MI355X.
 
-Workload (BASELINE.json metric): DINOv2 ViT-B/16, 2 x 224^2 global + 8 x 96^2 local crops per image,
-per-GPU batch 128, K = 65 536 prototypes, bf16 MFMA compute / fp32 master weights, drop-path 0
-(96^2 locals instead of the literal 98^2: patch 16 needs a multiple of 16 -- SURVEY.md 8(d) caveat).
+Workload (BASELINE.json metric): DINOv2 ViT-B/16, 2 x 224^2 global + 8 x 98^2 local crops per image,
+per-GPU batch 128, K = 65 536 prototypes, bf16 MFMA compute / fp32 master weights, drop-path 0.
+98 is not a multiple of the patch size: like the reference's inner model (patch_embed.py:90-99) the local crops
+are bicubic pad-resized to 112^2 (7x7 patches, 50 tokens); `--local-size 96` gives the upstream DINOv2 default.
 One "step" = mask sampling + teacher forward + student forward/backward (global+local) + DINO/iBOT/KoLeo
 losses + grad clip + AdamW + EMA (+ gradient all-reduce over RCCL when N > 1).  Synthetic N(0,1) views are
 resident in HBM before the timed region; random-init weights with the reference's initialisers.
@@ -81,7 +82,7 @@ def main() -> None:
     ap.add_argument("--model", default="vit_base", choices=sorted(MODELS))
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (images)")
     ap.add_argument("--global-size", type=int, default=224)
-    ap.add_argument("--local-size", type=int, default=96)
+    ap.add_argument("--local-size", type=int, default=98, help="98 = BASELINE config (pad-resized to 112 by PatchEmbed); 96 = upstream DINOv2 default")
     ap.add_argument("--n-local", type=int, default=8)
     ap.add_argument("--out-dim", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")

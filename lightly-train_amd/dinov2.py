@@ -352,7 +352,7 @@ class DINOv2:
         n_crops = gv.shape[0]
         B = n_crops // n_global
         p = cfg.patch_size
-        gh, gw = gv.shape[2] // p, gv.shape[3] // p
+        gh, gw = -(-gv.shape[2] // p), -(-gv.shape[3] // p)  # ceil: PatchEmbed pad-resizes to the next multiple of p
         n_p = gh * gw
         Ng = n_p + 1
         D, K = cfg.embed_dim, a.output_dim
@@ -370,7 +370,7 @@ class DINOv2:
         assert M <= cap_M
 
         lv = torch.cat(views[n_global:]).to(dev, torch.float32) if n_local > 0 else None
-        n_p_l = (lv.shape[2] // p) * (lv.shape[3] // p) if lv is not None else 0
+        n_p_l = (-(-lv.shape[2] // p)) * (-(-lv.shape[3] // p)) if lv is not None else 0
         Nl = n_p_l + 1
         ix = self._indices(B, n_p, n_local, n_p_l)
         self.student.grad.zero_()
