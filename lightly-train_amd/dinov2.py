@@ -231,11 +231,10 @@ class DINOv2:
                  total_steps: int = 125_000, device: str | torch.device = "cuda",
                  backbone_state: Optional[Dict[str, Tensor]] = None, student_head_state: Optional[Dict[str, Tensor]] = None,
                  teacher_head_state: Optional[Dict[str, Tensor]] = None, teacher_backbone_state: Optional[Dict[str, Tensor]] = None,
-                 seed: int = 0) -> None:
+                 seed: int = 0, student_ibot_head_state: Optional[Dict[str, Tensor]] = None,
+                 teacher_ibot_head_state: Optional[Dict[str, Tensor]] = None) -> None:
         self.method_args = method_args or DINOv2Args()
         a = self.method_args
-        if a.ibot_separate_head:
-            raise NotImplementedError("ibot_separate_head=True is not implemented (reference default is a shared head)")
         if a.batch_norm:
             raise NotImplementedError("batch_norm heads are not implemented (reference default False)")
         if a.center_method not in ("softmax", "sinkhorn_knopp"):
@@ -252,14 +251,24 @@ class DINOv2:
         tbs = teacher_backbone_state if teacher_backbone_state is not None else bsd
         order_b = [n for n, _ in vit_param_shapes(vit_cfg)]
         order_h = [n for n, _ in head_param_shapes(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim)]
-        self.student = FlatParams([("backbone." + n, bsd[n]) for n in order_b] + [("head." + n, shs[n]) for n in order_h], self.device, True)
-        self.teacher = FlatParams([("backbone." + n, tbs[n]) for n in order_b] + [("head." + n, ths[n]) for n in order_h], self.device, False)
+        s_named = [("backbone." + n, bsd[n]) for n in order_b] + [("head." + n, shs[n]) for n in order_h]
+        t_named = [("backbone." + n, tbs[n]) for n in order_b] + [("head." + n, ths[n]) for n in order_h]
+        if a.ibot_separate_head:
+            # the reference builds the iBOT head with dino_bottleneck_dim too (dinov2.py:221-228) -- kept bug-compatible
+            sis = student_ibot_head_state if student_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+            tis = teacher_ibot_head_state if teacher_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+            s_named += [("ihead." + n, sis[n]) for n in order_h]
+            t_named += [("ihead." + n, tis[n]) for n in order_h]
+        self.student = FlatParams(s_named, self.device, True)
+        self.teacher = FlatParams(t_named, self.device, False)
         self.s_vit = ViTEngine(vit_cfg, self.student, "backbone.")
         self.t_vit = ViTEngine(vit_cfg, self.teacher, "backbone.")
         self.s_head = HeadEngine(self.student, "head.", D, a)
         self.t_head = HeadEngine(self.teacher, "head.", D, a)
-        self.s_head.refresh_weightnorm()
-        self.t_head.refresh_weightnorm()
+        self.s_ihead = HeadEngine(self.student, "ihead.", D, a) if a.ibot_separate_head else self.s_head
+        self.t_ihead = HeadEngine(self.teacher, "ihead.", D, a) if a.ibot_separate_head else self.t_head
+        for h in {id(x): x for x in (self.s_head, self.t_head, self.s_ihead, self.t_ihead)}.values():
+            h.refresh_weightnorm()
         K = a.output_dim
         self.dino_center = torch.zeros(1, K, device=self.device)
         self.ibot_center = torch.zeros(1, 1, K, device=self.device)
@@ -276,7 +285,7 @@ class DINOv2:
         self.param_groups: List[Dict[str, Any]] = []
         for n in self.student.names:
             is_bb = n.startswith("backbone.")
-            ref_name = n[len("backbone."):] if is_bb else "dino_head." + n[len("head."):]
+            ref_name = n[len("backbone."):] if is_bb else ("ibot_head." + n[len("ihead."):] if n.startswith("ihead.") else "dino_head." + n[len("head."):])
             self.param_groups.append(param_group_hparams(ref_name, is_bb, vit_cfg.depth, self.base_lr, a))
         dev = self.device
         self.seg_lr = torch.tensor([g_["lr"] for g_ in self.param_groups], dtype=torch.float32, device=dev)
@@ -301,8 +310,10 @@ class DINOv2:
             for n in fp.names:
                 if n.startswith("backbone."):
                     out[f"{role}_embedding_model.wrapped_model._model.{n[9:]}"] = fp.p[n].detach().clone()
+                elif n.startswith("ihead."):
+                    out[f"{role}_head.ibot_head.{n[6:]}"] = fp.p[n].detach().clone()
                 else:
-                    for hname in ("dino_head", "ibot_head"):
+                    for hname in (("dino_head",) if self.method_args.ibot_separate_head else ("dino_head", "ibot_head")):
                         out[f"{role}_head.{hname}.{n[5:]}"] = fp.p[n].detach().clone()
         out["dino_loss.center"] = self.dino_center.clone()
         out["ibot_loss.center"] = self.ibot_center.clone()
@@ -389,8 +400,13 @@ class DINOv2:
         txn = tctx["xn"].view(-1, D)
         ops.gather_rows(txn, D, ix["t_cls"], 2 * B, D, out_bf16=t_in[:2 * B])
         ops.gather_rows(txn, D, patch_rows, M, D, out_bf16=t_in[2 * B:2 * B + M])
-        th = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False)
-        t_logits = th["logits"]
+        sep = a.ibot_separate_head
+        t_logits = ws.get("t.logits_all", (cap_t, K), torch.float32) if sep else None
+        if not sep:
+            t_logits = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False)["logits"]
+        else:  # two heads: cls rows through dino_head, masked patch rows through ibot_head
+            t_logits[:2 * B].copy_(self.t_head.forward(ws, "th", t_in, 2 * B, 2 * B, save=False)["logits"][:2 * B])
+            t_logits[2 * B:Rt].copy_(self.t_ihead.forward(ws, "thi", t_in[2 * B:], M, cap_M, save=False)["logits"][:M])
         t_probs = ws.get("t.probs", (cap_t, K), torch.float32)
         if a.center_method == "softmax":
             ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
@@ -439,26 +455,40 @@ class DINOv2:
         elif lv is not None:
             sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l)
         Rl = n_local * B
-        Rs, cap_s = 2 * B + M + Rl, 2 * B + cap_M + Rl
+        Rd = 2 * B + Rl                      # rows of the DINO head: global cls + local cls
+        Rs, cap_s = Rd + M, Rd + cap_M       # student row layout [2B cls | Rl local cls | M masked patches]
         s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16)
         sxn = sg["xn"].view(-1, D)
         ops.gather_rows(sxn, D, ix["s_cls"], 2 * B, D, out_bf16=s_in[:2 * B])
-        ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in[2 * B:2 * B + M])
         if sl is not None:
-            ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B + M:Rs])
-        sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True)
+            ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B:Rd])
+        ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in[Rd:Rs])
+        if not sep:
+            sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True)
+            shi = None
+        else:
+            sh = self.s_head.forward(ws, "sh", s_in, Rd, Rd, save=True)
+            shi = self.s_ihead.forward(ws, "shi", s_in[Rd:], M, cap_M, save=True)
 
         # ---------------- losses : dinov2.py:335-387, dinov2_loss.py:117-133,246-268
         r2 = torch.arange(2 * B, dtype=torch.int32)
-        ta = torch.cat([r2, 2 * B + torch.arange(M, dtype=torch.int32), torch.arange(B, dtype=torch.int32).repeat(n_local)])
-        tb = torch.cat([torch.full((2 * B + M,), -1, dtype=torch.int32), (B + torch.arange(B, dtype=torch.int32)).repeat(n_local)])
-        coef = torch.cat([torch.full((2 * B,), a.dino_loss_weight * 2.0 / terms / (2 * B)), a.ibot_loss_weight * mw / n_crops,
-                          torch.full((Rl,), a.dino_loss_weight / terms / B)])
-        slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32)])
+        ta = torch.cat([r2, torch.arange(B, dtype=torch.int32).repeat(n_local), 2 * B + torch.arange(M, dtype=torch.int32)])
+        tb = torch.cat([torch.full((2 * B,), -1, dtype=torch.int32), (B + torch.arange(B, dtype=torch.int32)).repeat(n_local),
+                        torch.full((M,), -1, dtype=torch.int32)])
+        coef = torch.cat([torch.full((2 * B,), a.dino_loss_weight * 2.0 / terms / (2 * B)), torch.full((Rl,), a.dino_loss_weight / terms / B),
+                          a.ibot_loss_weight * mw / n_crops])
+        slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32)])
         ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
-        dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16)
         main.wait_event(teacher_done)
-        ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, 1.0 / a.student_temp, self._loss_slots, dlogits, Rs, K, slot=slot)
+        inv_ts = 1.0 / a.student_temp
+        if not sep:
+            dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16)
+            ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rs, K, slot=slot)
+        else:
+            dlogits = ws.get("s.dlogits", (Rd, K), torch.bfloat16)
+            dlogits_i = ws.get("s.dlogits_i", (cap_M, K), torch.bfloat16)
+            ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rd, K, slot=slot)
+            ops.ce_fwd_bwd(shi["logits"], t_probs, ta[Rd:], tb[Rd:], coef[Rd:], 1.0, inv_ts, self._loss_slots, dlogits_i, M, K, slot=slot[Rd:])
 
         dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
         dxn_g.zero_()
@@ -473,11 +503,16 @@ class DINOv2:
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
-        ops.scatter_add_rows(dx_head[2 * B:2 * B + M], patch_rows, dxn_g, D, M, D)
+        if not sep:
+            ops.scatter_add_rows(dx_head[Rd:Rs], patch_rows, dxn_g, D, M, D)
+        else:
+            dx_ihead = self.s_ihead.backward(ws, shi, dlogits_i)
+            self.s_ihead.finish_weightnorm_grad()
+            ops.scatter_add_rows(dx_ihead[:M], patch_rows, dxn_g, D, M, D)
         if sl is not None:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
-            ops.scatter_add_rows(dx_head[2 * B + M:Rs], ix["l_cls"], dxn_l, D, Rl, D)
+            ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
             self.s_vit.backward(ws, sl, dxn_l, side=side)
         self.s_vit.backward(ws, sg, dxn_g, side=side)
         if side is not None:
@@ -492,7 +527,10 @@ class DINOv2:
             "train_loss/koleo_loss": ls[3] / a.koleo_loss_weight if a.koleo_loss_weight else ls[3],
         }
         self._last_masks = masks
-        self._last = dict(t_logits=t_logits[:Rt], t_probs=t_probs[:Rt], s_logits=sh["logits"][:Rs], B=B, M=M, Rl=Rl)
+        s_patch_logits = sh["logits"][Rd:Rs] if not sep else shi["logits"][:M]
+        self._last = dict(t_cls_logits=t_logits[:2 * B], t_patch_logits=t_logits[2 * B:Rt], t_probs=t_probs[:Rt],
+                          s_cls_logits=sh["logits"][:2 * B], s_local_logits=sh["logits"][2 * B:Rd], s_patch_logits=s_patch_logits,
+                          B=B, M=M, Rl=Rl)
         return TrainingStepResult(loss=ls.sum(), log_dict=logs)
 
     def _sinkhorn(self, logits: Tensor, out: Tensor, rows: int, K: int, temp: float, n_total: Any, tag: str) -> None:
@@ -533,6 +571,8 @@ class DINOv2:
                        self.seg_lr, self.seg_wd_on, self.seg_frozen, freeze, lr_factor, wd, a.betas[0], a.betas[1], a.eps,
                        self.opt_step, self._sumsq, a.gradient_clip_val)
         self.s_head.refresh_weightnorm()
+        if self.s_ihead is not self.s_head:
+            self.s_ihead.refresh_weightnorm()
         self.last_grad_norm = self._sumsq  # squared norm, device scalar
         self.trainer.global_step += 1
         return {"weight_decay": wd, "lr_factor": lr_factor}
@@ -543,6 +583,8 @@ class DINOv2:
         m = cosine_schedule(self.trainer.global_step, self.trainer.estimated_stepping_batches, a.momentum_start, a.momentum_end)
         ops.ema_flat(self.teacher.data, self.student.data, self.teacher.bf16, m)
         self.t_head.refresh_weightnorm()
+        if self.t_ihead is not self.t_head:
+            self.t_ihead.refresh_weightnorm()
         return m
 
     def train_step(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:

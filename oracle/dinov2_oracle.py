@@ -404,16 +404,21 @@ class OracleDINOv2:
     def __init__(self, student_backbone: Dict[str, Tensor], student_head: Dict[str, Tensor],
                  cfg: Dict[str, Any], args: Optional[Dict[str, Any]] = None, global_batch_size: int = 16,
                  total_steps: int = 100, teacher_backbone: Optional[Dict[str, Tensor]] = None,
-                 teacher_head: Optional[Dict[str, Tensor]] = None, dtype: torch.dtype = torch.float32) -> None:
+                 teacher_head: Optional[Dict[str, Tensor]] = None, dtype: torch.dtype = torch.float32,
+                 student_ibot_head: Optional[Dict[str, Tensor]] = None, teacher_ibot_head: Optional[Dict[str, Tensor]] = None) -> None:
         self.cfg = dict(cfg)
         self.args = dict(DEFAULT_ARGS)
         self.args.update(args or {})
-        assert not self.args["ibot_separate_head"], "oracle restates the shared-head default"
         cast = lambda d: {k: v.detach().clone().to(dtype) for k, v in d.items()}  # noqa: E731
         self.sb = {k: v.requires_grad_(True) for k, v in cast(student_backbone).items()}
         self.sh = {k: v.requires_grad_(True) for k, v in cast(student_head).items()}
         self.tb = cast(teacher_backbone if teacher_backbone is not None else student_backbone)
         self.th = cast(teacher_head if teacher_head is not None else student_head)
+        # ibot_separate_head (dinov2.py:230-234): separate iBOT heads, else the DINO head is shared
+        self.separate = student_ibot_head is not None
+        self.args["ibot_separate_head"] = self.separate
+        self.shi = {k: v.requires_grad_(True) for k, v in cast(student_ibot_head).items()} if self.separate else self.sh
+        self.thi = cast(teacher_ibot_head if teacher_ibot_head is not None else student_ibot_head) if self.separate else self.th
         K = self.sh["last_layer.parametrizations.weight.original1"].shape[0]
         self.dino_center = torch.zeros(1, K, dtype=dtype)
         self.ibot_center = torch.zeros(1, 1, K, dtype=dtype)
@@ -434,6 +439,12 @@ class OracleDINOv2:
             hp = param_hparams(full, False, cfg["depth"], self.base_lr, a["weight_decay_start"])
             groups.append({"name": full, "params": [t], "lr": hp["lr"], "weight_decay": hp["weight_decay"],
                            "last_layer": hp["last_layer"]})
+        if self.separate:
+            for name, t in self.shi.items():
+                full = "ibot_head." + name
+                hp = param_hparams(full, False, cfg["depth"], self.base_lr, a["weight_decay_start"])
+                groups.append({"name": full, "params": [t], "lr": hp["lr"], "weight_decay": hp["weight_decay"],
+                               "last_layer": hp["last_layer"]})
         self.opt = torch.optim.AdamW(groups, lr=self.base_lr, betas=a["betas"], eps=a["eps"])
         for g in self.opt.param_groups:
             g["initial_lr"] = g["lr"]
@@ -464,7 +475,7 @@ class OracleDINOv2:
             tt = vit_forward(self.tb, gv, cfg)
             t_cls = torch.cat([tt["cls"][b:], tt["cls"][:b]])
             t_cls_logits = head_forward(self.th, t_cls)
-            t_patch_logits = head_forward(self.th, tt["patch"].flatten(0, 1)[idx])
+            t_patch_logits = head_forward(self.thi, tt["patch"].flatten(0, 1)[idx])
             if a["center_method"] == "softmax":
                 self._apply_center_updates()
                 t_cls_p = softmax_center(t_cls_logits, self.dino_center, t_temp).view(2, b, -1)
@@ -482,7 +493,7 @@ class OracleDINOv2:
         cap_l: Dict[str, Any] = {}
         sg = vit_forward(self.sb, gv, cfg, masks=cm, drop=drop_global, capture=cap_g)
         s_cls_logits = head_forward(self.sh, sg["cls"])
-        s_patch_logits = head_forward(self.sh, sg["patch"].flatten(0, 1)[idx])
+        s_patch_logits = head_forward(self.shi, sg["patch"].flatten(0, 1)[idx])
         dino_global = dino_ce([s_cls_logits], [t_cls_p.flatten(0, 1)], a["student_temp"]) * 2 / terms
         dino_local = torch.zeros_like(dino_global)
         s_loc_logits = None
@@ -531,7 +542,8 @@ class OracleDINOv2:
         self.global_step += 1
         mom = cosine_schedule(self.global_step, self.total_steps, a["momentum_start"], a["momentum_end"])
         with torch.no_grad():
-            for d_t, d_s in ((self.tb, self.sb), (self.th, self.sh)):
+            pairs = [(self.tb, self.sb), (self.th, self.sh)] + ([(self.thi, self.shi)] if self.separate else [])
+            for d_t, d_s in pairs:
                 for name in d_t:
                     d_t[name].mul_(mom).add_(d_s[name].detach(), alpha=1.0 - mom)
         return {"grad_norm": float(gnorm), "weight_decay": wd, "lr_factor": factor, "momentum": mom}

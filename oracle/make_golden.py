@@ -51,6 +51,10 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
         assert torch.equal(v, init["student_backbone"][k])
     init_small = {"student_backbone": init["student_backbone"], "student_head": init["student_head"],
                   "teacher_head": init["teacher_head"]}
+    separate = bool(method_kwargs.get("ibot_separate_head", False))
+    if separate:
+        init_small["student_ibot_head"] = init["student_ibot_head"]
+        init_small["teacher_ibot_head"] = init["teacher_ibot_head"]
     fixture = {"name": name, "cfg": cfg, "method_kwargs": method_kwargs, "b": b, "g_size": g_size, "l_size": l_size,
                "n_local": n_local, "total_steps": total_steps, "init": init_small, "steps": []}
 
@@ -69,6 +73,10 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
 
     spy_forward(m.teacher_head.dino_head, t_calls)
     spy_forward(m.student_head.dino_head, s_calls)
+    ti_calls, si_calls = [], []
+    if separate:
+        spy_forward(m.teacher_head.ibot_head, ti_calls)
+        spy_forward(m.student_head.ibot_head, si_calls)
     # capture masks the reference sampled
     orig_ccm = ref_utils.create_collated_masks
     import lightly_train._methods.dinov2.dinov2 as ref_dinov2
@@ -87,11 +95,13 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
                                  bottleneck_dim=method_kwargs.get("dino_bottleneck_dim", 256),
                                  center_method=method_kwargs.get("center_method", "softmax")),
                        global_batch_size=b, total_steps=total_steps,
-                       teacher_backbone=init["teacher_backbone"], teacher_head=init["teacher_head"])
+                       teacher_backbone=init["teacher_backbone"], teacher_head=init["teacher_head"],
+                       student_ibot_head=init["student_ibot_head"] if separate else None,
+                       teacher_ibot_head=init["teacher_ibot_head"] if separate else None)
 
     for step in range(n_steps):
         views = synth_views(1000 + step, b, g_size, l_size, n_local)
-        t_calls.clear(); s_calls.clear()
+        t_calls.clear(); s_calls.clear(); ti_calls.clear(); si_calls.clear()
         random.seed(77 + step)
         logs = r.train_step(views)
         random.seed(77 + step)
@@ -103,9 +113,9 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
             "view_checksum": float(sum(v.double().sum() for v in views)),
             "masks": cap["masks"],
             "logs": logs,
-            "teacher_cls_logits": t_calls[0], "teacher_patch_logits": t_calls[1],
-            "student_cls_logits": s_calls[0], "student_patch_logits": s_calls[1],
-            "student_local_logits": s_calls[2] if n_local > 0 else None,
+            "teacher_cls_logits": t_calls[0], "teacher_patch_logits": ti_calls[0] if separate else t_calls[1],
+            "student_cls_logits": s_calls[0], "student_patch_logits": si_calls[0] if separate else s_calls[1],
+            "student_local_logits": (s_calls[1] if separate else s_calls[2]) if n_local > 0 else None,
             "dino_center": m.dino_loss.center.detach().clone(),
             "ibot_center": m.ibot_loss.center.detach().clone(),
         }
@@ -169,6 +179,9 @@ def main() -> None:
     make_step_fixture("step_vittest_sinkhorn", "_vit_test", {}, dict(small_head, center_method="sinkhorn_knopp"),
                       dict(patch_size=16, num_heads=2, depth=3), b=8, g_size=64, l_size=32, n_local=4,
                       n_steps=2, total_steps=20)
+    make_step_fixture("step_vittest_sephead", "_vit_test", {}, dict(small_head, ibot_separate_head=True),
+                      dict(patch_size=16, num_heads=2, depth=3), b=8, g_size=64, l_size=32, n_local=2,
+                      n_steps=1, total_steps=20, keep_params_every_step=False)
     # (b) head_dim 64 (the MFMA attention path): D=64, depth 2, 1 head; 96->6x6 global, 48->3x3 local
     make_step_fixture("step_d64_softmax", "DinoVisionTransformer",
                       dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0),

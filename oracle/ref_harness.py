@@ -250,7 +250,8 @@ class ReferenceRunner:
 
     def split_state(self):  # type: ignore[no-untyped-def]
         sd = self.method.state_dict()
-        out = {"student_backbone": {}, "teacher_backbone": {}, "student_head": {}, "teacher_head": {}}
+        out = {"student_backbone": {}, "teacher_backbone": {}, "student_head": {}, "teacher_head": {},
+               "student_ibot_head": {}, "teacher_ibot_head": {}}
         for k, v in sd.items():
             for role in ("student", "teacher"):
                 pre = f"{role}_embedding_model.wrapped_model._model."
@@ -259,6 +260,9 @@ class ReferenceRunner:
                 pre = f"{role}_head.dino_head."
                 if k.startswith(pre):
                     out[f"{role}_head"][k[len(pre):]] = v.detach().clone()
+                pre = f"{role}_head.ibot_head."
+                if k.startswith(pre) and self.method.student_head.ibot_head is not self.method.student_head.dino_head:
+                    out[f"{role}_ibot_head"][k[len(pre):]] = v.detach().clone()
         return out
 
     def train_step(self, views):  # type: ignore[no-untyped-def]

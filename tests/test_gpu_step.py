@@ -44,9 +44,10 @@ def build(fx, **over):
     vc = ViTConfig(embed_dim=D, depth=cfgd["depth"], num_heads=cfgd["num_heads"], mlp_ratio=hid / D, patch_size=cfgd["patch_size"],
                    img_size=fx["g_size"])
     args = DINOv2Args(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"],
-                      center_method=mk.get("center_method", "softmax"), **over)
+                      center_method=mk.get("center_method", "softmax"), ibot_separate_head=mk.get("ibot_separate_head", False), **over)
     return DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=sb,
-                  student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"])
+                  student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"],
+                  student_ibot_head_state=fx["init"].get("student_ibot_head"), teacher_ibot_head_state=fx["init"].get("teacher_ibot_head"))
 
 
 def oracle_for(fx, **over):
@@ -60,7 +61,7 @@ def oracle_for(fx, **over):
                           total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"])
 
 
-@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_d64_softmax"])
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_vittest_sephead", "step_d64_softmax"])
 def test_step_matches_reference_fixture(name):
     fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     m = build(fx)
@@ -69,11 +70,11 @@ def test_step_matches_reference_fixture(name):
         res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
         L = m._last
         B, M = L["B"], L["M"]
-        assert rel(L["t_logits"][:2 * B], rec["teacher_cls_logits"]) < 2e-2
-        assert rel(L["t_logits"][2 * B:], rec["teacher_patch_logits"]) < 2e-2
-        assert rel(L["s_logits"][:2 * B], rec["student_cls_logits"]) < 2e-2
-        assert rel(L["s_logits"][2 * B:2 * B + M], rec["student_patch_logits"]) < 2e-2
-        assert rel(L["s_logits"][2 * B + M:], rec["student_local_logits"]) < 2e-2
+        assert rel(L["t_cls_logits"], rec["teacher_cls_logits"]) < 2e-2
+        assert rel(L["t_patch_logits"], rec["teacher_patch_logits"]) < 2e-2
+        assert rel(L["s_cls_logits"], rec["student_cls_logits"]) < 2e-2
+        assert rel(L["s_patch_logits"], rec["student_patch_logits"]) < 2e-2
+        assert rel(L["s_local_logits"], rec["student_local_logits"]) < 2e-2
         logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
         for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
             assert logs[k] == pytest.approx(rec["logs"][k], rel=5e-3), (si, k)
@@ -90,6 +91,8 @@ def test_step_matches_reference_fixture(name):
     sd = m.state_dict()
     assert "student_embedding_model.wrapped_model._model.blocks.0.attn.qkv.weight" in sd
     assert "teacher_head.ibot_head.last_layer.parametrizations.weight.original1" in sd and "dino_loss.center" in sd
+    if name == "step_vittest_sephead":  # separate iBOT head: its own parameters, trained and EMA-averaged
+        assert not torch.equal(sd["student_head.ibot_head.mlp.0.weight"], sd["student_head.dino_head.mlp.0.weight"])
 
 
 @pytest.mark.parametrize("name", ["step_vittest_softmax", "step_d64_softmax"])

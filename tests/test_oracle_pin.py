@@ -87,7 +87,7 @@ def test_ema_kat():
     assert torch.equal(t, torch.tensor([[2.5, 3.5], [4.5, 5.5]]))
 
 
-@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_d64_softmax"])
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_vittest_sephead", "step_d64_softmax"])
 def test_oracle_reproduces_reference_steps(name):
     """The restated step reproduces the reference's losses / logits / grad-norm / updated parameters."""
     fx = load(name)
@@ -95,7 +95,8 @@ def test_oracle_reproduces_reference_steps(name):
     o = O.OracleDINOv2(fx["init"]["student_backbone"], fx["init"]["student_head"], fx["cfg"],
                        args=dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], bottleneck_dim=mk["dino_bottleneck_dim"],
                                  center_method=mk.get("center_method", "softmax")),
-                       global_batch_size=fx["b"], total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"])
+                       global_batch_size=fx["b"], total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"],
+                       student_ibot_head=fx["init"].get("student_ibot_head"), teacher_ibot_head=fx["init"].get("teacher_ibot_head"))
     for si, rec in enumerate(fx["steps"]):
         views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
         assert float(sum(v.double().sum() for v in views)) == pytest.approx(rec["view_checksum"], abs=1e-6)

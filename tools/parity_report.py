@@ -31,9 +31,11 @@ def build_from_fixture(fx, device="cuda"):
     vc = ViTConfig(embed_dim=D, depth=cfgd["depth"], num_heads=cfgd["num_heads"], mlp_ratio=hid / D, patch_size=cfgd["patch_size"],
                    img_size=fx["g_size"])
     args = DINOv2Args(output_dim=mk.get("output_dim", 65536), hidden_dim=mk.get("hidden_dim", 2048),
-                      dino_bottleneck_dim=mk.get("dino_bottleneck_dim", 256), center_method=mk.get("center_method", "softmax"))
+                      dino_bottleneck_dim=mk.get("dino_bottleneck_dim", 256), center_method=mk.get("center_method", "softmax"),
+                      ibot_separate_head=mk.get("ibot_separate_head", False))
     m = DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device=device, backbone_state=sb,
-               student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"])
+               student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"],
+               student_ibot_head_state=fx["init"].get("student_ibot_head"), teacher_ibot_head_state=fx["init"].get("teacher_ibot_head"))
     return m
 
 
@@ -49,8 +51,8 @@ def main():
             torch.cuda.synchronize()
             L = m._last
             B, M = L["B"], L["M"]
-            print(f" step {si}: teacher cls logits rel {rel(L['t_logits'][:2*B], rec['teacher_cls_logits']):.3e}  patch {rel(L['t_logits'][2*B:], rec['teacher_patch_logits']):.3e}")
-            print(f"          student cls logits rel {rel(L['s_logits'][:2*B], rec['student_cls_logits']):.3e}  patch {rel(L['s_logits'][2*B:2*B+M], rec['student_patch_logits']):.3e}  local {rel(L['s_logits'][2*B+M:], rec['student_local_logits']):.3e}")
+            print(f" step {si}: teacher cls logits rel {rel(L['t_cls_logits'], rec['teacher_cls_logits']):.3e}  patch {rel(L['t_patch_logits'], rec['teacher_patch_logits']):.3e}")
+            print(f"          student cls logits rel {rel(L['s_cls_logits'], rec['student_cls_logits']):.3e}  patch {rel(L['s_patch_logits'], rec['student_patch_logits']):.3e}  local {rel(L['s_local_logits'], rec['student_local_logits']):.3e}")
             logs = {k.split('/')[-1]: float(v) for k, v in res.log_dict.items()}
             logs["loss"] = float(res.loss)
             print("          losses ours/ref:", {k: (round(logs[k], 5), round(rec["logs"][k], 5)) for k in logs})
