@@ -121,6 +121,10 @@ int lt_gather_rows(const float* src, int ld_src, const int64_t* idx, void* out_b
 /* dst[idx[m],:] += src[m,:] (unique idx) */
 int lt_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int ld_dst, int M, int D, void* stream);
 int lt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst bf16 [R,Cpad] = zero-padded cast of src f32 [R,C]; dst f32 [R,C] += src f32 [R,Cpad][:, :C]  (patch-embed weights whose
+ * 3*p*p is not a multiple of 8, e.g. patch 14: K = 588 -> 592) */
+int lt_cast_pad_rows(const float* src, void* dst_bf16, int R, int C, int Cpad, void* stream);
+int lt_unpad_accumulate(const float* src, float* dst, int R, int C, int Cpad, void* stream);
 int lt_fill_f32(float* dst, float value, int64_t n, void* stream);
 int lt_scale_f32(float* dst, float alpha, int64_t n, void* stream);
 

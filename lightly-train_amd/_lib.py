@@ -44,6 +44,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_gather_rows": [vp, i32, vp, vp, vp, i32, i32, vp],
     "lt_scatter_add_rows": [vp, vp, vp, i32, i32, i32, vp],
     "lt_cast_f32_to_bf16": [vp, vp, i64, vp],
+    "lt_cast_pad_rows": [vp, vp, i32, i32, i32, vp],
+    "lt_unpad_accumulate": [vp, vp, i32, i32, i32, vp],
     "lt_fill_f32": [vp, f32, i64, vp],
     "lt_scale_f32": [vp, f32, i64, vp],
     "lt_attention_fwd": [vp, vp, vp, i32, i32, i32, i32, f32, vp],

@@ -495,6 +495,22 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d,
   }
   if (i < n) for (long j = i; j < n && j < i + 4; ++j) d[j] = f2bf(s[j]);
 }
+// dst bf16 [R, Cpad] = cast(src f32 [R, C]) zero padded (patch-embed weights when 3*p*p is not a multiple of 8, e.g. /14)
+__global__ void cast_pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc, int Cpad) {
+  const long n = (long)R * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % Cpad; const long r = i / Cpad;
+    dst[i] = c < Cc ? f2bf(src[r * Cc + c]) : (bf16_t)0;
+  }
+}
+// dst f32 [R, C] += src f32 [R, Cpad][:, :C]
+__global__ void unpad_accumulate_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc, int Cpad) {
+  const long n = (long)R * Cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % Cc; const long r = i / Cc;
+    dst[i] += src[r * Cpad + c];
+  }
+}
 __global__ void scale_kernel(float* d, float a, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -713,6 +729,16 @@ extern "C" int lt_fill_f32(float* dst, float value, int64_t n, void* stream) {
   const int grid = (int)min((long)2048, (long)lt_cdiv(n, 256));
   hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, ST, dst, value, (long)n);
   LT_CHECK_LAUNCH("lt_fill_f32");
+}
+extern "C" int lt_cast_pad_rows(const float* src, void* dst_bf16, int R, int Cc, int Cpad, void* stream) {
+  LT_CHECK_ARG(src && dst_bf16 && R > 0 && Cc > 0 && Cpad >= Cc, "lt_cast_pad_rows: bad arguments");
+  hipLaunchKernelGGL(cast_pad_rows_kernel, dim3((unsigned)min((long)2048, ((long)R * Cpad + 255) / 256)), dim3(256), 0, ST, src, (bf16_t*)dst_bf16, R, Cc, Cpad);
+  LT_CHECK_LAUNCH("lt_cast_pad_rows");
+}
+extern "C" int lt_unpad_accumulate(const float* src, float* dst, int R, int Cc, int Cpad, void* stream) {
+  LT_CHECK_ARG(src && dst && R > 0 && Cc > 0 && Cpad >= Cc, "lt_unpad_accumulate: bad arguments");
+  hipLaunchKernelGGL(unpad_accumulate_kernel, dim3((unsigned)min((long)2048, ((long)R * Cc + 255) / 256)), dim3(256), 0, ST, src, dst, R, Cc, Cpad);
+  LT_CHECK_LAUNCH("lt_unpad_accumulate");
 }
 extern "C" int lt_scale_f32(float* dst, float alpha, int64_t n, void* stream) {
   LT_CHECK_ARG(dst, "lt_scale_f32: null pointer");

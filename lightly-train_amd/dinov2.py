@@ -573,6 +573,7 @@ class DINOv2:
         self.s_head.refresh_weightnorm()
         if self.s_ihead is not self.s_head:
             self.s_ihead.refresh_weightnorm()
+        self.s_vit.refresh_padded_weights()
         self.last_grad_norm = self._sumsq  # squared norm, device scalar
         self.trainer.global_step += 1
         return {"weight_decay": wd, "lr_factor": lr_factor}
@@ -585,6 +586,7 @@ class DINOv2:
         self.t_head.refresh_weightnorm()
         if self.t_ihead is not self.t_head:
             self.t_ihead.refresh_weightnorm()
+        self.t_vit.refresh_padded_weights()
         return m
 
     def train_step(self, views: List[Tensor], masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:

@@ -183,6 +183,14 @@ def cast_bf16(src: Tensor, dst: Tensor) -> None:
     check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
 
 
+def cast_pad_rows(src: Tensor, dst: Tensor, R: int, Cc: int, Cpad: int) -> None:
+    check(_lib.load().lt_cast_pad_rows(_p(src), _p(dst), R, Cc, Cpad, _stream()), "lt_cast_pad_rows")
+
+
+def unpad_accumulate(src: Tensor, dst: Tensor, R: int, Cc: int, Cpad: int) -> None:
+    check(_lib.load().lt_unpad_accumulate(_p(src), _p(dst), R, Cc, Cpad, _stream()), "lt_unpad_accumulate")
+
+
 def scale_f32(dst: Tensor, alpha: float) -> None:
     check(_lib.load().lt_scale_f32(_p(dst), alpha, dst.numel(), _stream()), "lt_scale_f32")
 

@@ -176,10 +176,21 @@ class ViTEngine:
         self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
         D = cfg.embed_dim
         kreal = cfg.in_chans * cfg.patch_size ** 2
-        self.kpad = (kreal + 7) // 8 * 8
+        self.kreal = kreal
+        self.kpad = (kreal + 7) // 8 * 8   # 16-byte rows for the MFMA GEMM (patch 14: 588 -> 592)
+        self.wpe_pad: Optional[Tensor] = None
         if self.kpad != kreal:
-            raise NotImplementedError("patch_size with in_chans*p*p % 8 != 0 (e.g. /14) not supported yet")
+            self.wpe_pad = torch.zeros(D, self.kpad, dtype=torch.bfloat16, device=self.dev)
+            self.refresh_padded_weights()
         assert D % 8 == 0 and cfg.hidden % 8 == 0, "embed_dim and mlp hidden must be multiples of 8"
+
+    def refresh_padded_weights(self) -> None:
+        """Re-derive the zero-padded bf16 patch-embedding matrix after the fp32 weights changed (optimizer / EMA)."""
+        if self.wpe_pad is not None:
+            ops.cast_pad_rows(self.w("patch_embed.proj.weight").view(self.cfg.embed_dim, -1), self.wpe_pad, self.cfg.embed_dim, self.kreal, self.kpad)
+
+    def _patch_weight_bf16(self) -> Tensor:
+        return self.wpe_pad if self.wpe_pad is not None else self.wb("patch_embed.proj.weight").view(self.cfg.embed_dim, -1)
 
     # ---- parameter access -------------------------------------------------------------------
     def w(self, name: str) -> Tensor:
@@ -259,7 +270,7 @@ class ViTEngine:
 
         cols = ops.im2col(img.contiguous(), p, self.kpad)
         patch = ws.get(tag + ".patch", (B * n_p, D), torch.float32)
-        ops.gemm(cols, self.wb("patch_embed.proj.weight").view(D, -1), patch, M=B * n_p, N=D, K=self.kpad,
+        ops.gemm(cols, self._patch_weight_bf16(), patch, M=B * n_p, N=D, K=self.kpad,
                  epilogue=ops.EPI_F32, bias=self.w("patch_embed.proj.bias"))
         pos = self._pos_for_grid(ws, tag, gh, gw)
         x = ws.get(tag + ".x0" if save else tag + ".xa", (T, D), torch.float32)
@@ -478,9 +489,16 @@ class ViTEngine:
 
         def patch_wgrad() -> None:
             ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
-            ops.gemm(dpatch, ctx["cols"], self.gw("patch_embed.proj.weight").view(D, -1), M=D, N=self.kpad, K=B * n_p, trans_a=True,
+            gview = self.gw("patch_embed.proj.weight").view(D, -1)
+            target = gview
+            if self.kpad != self.kreal:  # accumulate into a padded scratch, then fold the real columns into the gradient
+                target = ws.get(tag + ".dwpe_pad", (D, self.kpad), torch.float32)
+                target.zero_()
+            ops.gemm(dpatch, ctx["cols"], target, M=D, N=self.kpad, K=B * n_p, trans_a=True,
                      trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=max(2, _split_k(tiles, B * n_p)), lda=D, ldb=self.kpad,
                      ldc=self.kpad, workspace=slab)
+            if self.kpad != self.kreal:
+                ops.unpad_accumulate(target, gview, D, self.kreal, self.kpad)
 
         if side is None:
             patch_wgrad()

@@ -186,6 +186,35 @@ def test_vit_forward_with_non_multiple_image_size():
     assert rel(ours[:, 0], ref["cls"]) < 2e-2 and rel(ours[:, 1:], ref["patch"]) < 2e-2
 
 
+def test_patch14_model_step_matches_oracle():
+    """patch 14 (the reference's default models vits14/vitb14/vitl14): 3*14*14 = 588 is padded to 592 for the MFMA GEMM;
+    224/14 -> 16x16 patches (257 tokens), 98/14 -> 7x7 (50 tokens)."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(4)
+    vc = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=14, img_size=56, init_values=0.5)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(64, 128, 64, 512, g), init_head_state(64, 128, 64, 512, g)
+    args = DINOv2Args(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, koleo_loss_weight=0.0)
+    m = DINOv2(vc, args, global_batch_size=4, total_steps=50, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    o = O.OracleDINOv2(bsd, shs, dict(patch_size=14, num_heads=1, depth=2), args=dict(output_dim=512, hidden_dim=128, bottleneck_dim=64, koleo_loss_weight=0.0),
+                       global_batch_size=4, total_steps=50, teacher_head=ths)
+    views = [torch.randn(4, 3, 56, 56, generator=g) for _ in range(2)] + [torch.randn(4, 3, 28, 28, generator=g) for _ in range(2)]
+    random.seed(1)
+    res = m.training_step_impl({"views": views}, 0)
+    loss, _ = o.forward_loss(views, m._last_masks)
+    loss.backward()
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+    for n in ("backbone.patch_embed.proj.weight", "backbone.patch_embed.proj.bias", "backbone.pos_embed", "backbone.blocks.0.attn.qkv.weight"):
+        assert rel(m.student.g[n].cpu(), o.sb[n[9:]].grad) < 5e-2, n
+    m.optimizer_step(); m.on_train_batch_end()   # refreshes the padded bf16 patch-embed matrices
+    assert torch.equal(m.s_vit.wpe_pad[:, :588].float().cpu(), m.student.p["backbone.patch_embed.proj.weight"].view(64, -1).to(torch.bfloat16).float().cpu())
+    assert m.s_vit.wpe_pad[:, 588:].abs().max().item() == 0
+
+
 def test_parameter_update_and_ema_match_oracle():
     """One full optimizer step (clip + AdamW + EMA) on identical gradients-by-construction (KoLeo off):
     Adam's first step is sign-like (|update| = lr), so per-element agreement is measured as a fraction."""
