@@ -86,12 +86,18 @@ int lt_resize_4tap(const float* in, float* out, const int32_t* iy, const float* 
                    int planes, int H, int W, int Ho, int Wo, void* stream);
 /* img f32 [B,C,H,W] -> cols bf16 [B*gh*gw, kpad], k = (c*p + py)*p + px, zero padded to kpad */
 int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H, int W, int p, int kpad, void* stream);
-/* x[b,0]=cls+pos[0]; x[b,1+i]=(mask[b,i]?mask_token:patch[b*n_p+i])+pos[1+i]; masks may be NULL */
+/* SwiGLU FFN gate (reference layers/swiglu_ffn.py:31-35): x12 bf16 [rows, 2H] = [x1 | x2], out bf16 [rows, H] =
+ * silu(x1) * x2.  Backward: d12 bf16 [rows, 2H] = [dh * x2 * silu'(x1) | dh * silu(x1)].  H % 8 == 0. */
+int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream);
+int lt_swiglu_bwd(const void* x12_bf16, const void* dh_bf16, void* d12_bf16, int64_t rows, int H, void* stream);
+
+/* tokens [cls | n_reg registers | n_p patches]: x[b,0]=cls+pos[0]; x[b,1+r]=reg[r] (no pos-embed);
+ * x[b,1+n_reg+i]=(mask[b,i]?mask_token:patch[b*n_p+i])+pos[1+i]; masks / reg may be NULL */
 int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
-                       const uint8_t* masks, float* x, int B, int n_p, int D, void* stream);
-/* backward: dpatch bf16 [B*n_p,D] (0 where masked); dcls[D], dpos[(1+n_p),D], dmask_token[D] accumulate */
+                       const uint8_t* masks, const float* reg, float* x, int B, int n_p, int n_reg, int D, void* stream);
+/* backward: dpatch bf16 [B*n_p,D] (0 where masked); dcls[D], dpos[(1+n_p),D], dmask_token[D], dreg[n_reg,D] accumulate */
 int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_bf16, float* dcls, float* dpos,
-                           float* dmask_token, int B, int n_p, int D, void* stream);
+                           float* dmask_token, float* dreg, int B, int n_p, int n_reg, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm eps=1e-6 (vision_transformer.py:138; block.py:60,74)  x f32 [rows,D]

@@ -34,8 +34,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_matmul_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
+    "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
+    "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "lt_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lt_layernorm_bwd": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],

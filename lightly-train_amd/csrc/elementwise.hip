@@ -51,25 +51,32 @@ __global__ __launch_bounds__(256) void resize4tap_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------ tokens
 __global__ void assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
-                                const float* __restrict__ mask_token, const uint8_t* __restrict__ masks, float* __restrict__ x,
-                                int B, int n_p, int D) {
-  const long tok = blockIdx.x;  // b*(n_p+1) + t
-  const int N = n_p + 1;
+                                const float* __restrict__ mask_token, const uint8_t* __restrict__ masks, const float* __restrict__ reg,
+                                float* __restrict__ x, int B, int n_p, int n_reg, int D) {
+  const long tok = blockIdx.x;  // b*N + t,  token order [cls | registers | patches]
+  const int N = n_p + 1 + n_reg;
   const int b = tok / N, t = tok % N;
   const float* src;
-  if (t == 0) src = cls;
-  else if (masks && masks[(long)b * n_p + t - 1]) src = mask_token;
-  else src = patch + ((long)b * n_p + t - 1) * D;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) x[tok * D + d] = src[d] + pos[(long)t * D + d];
+  const float* pe = nullptr;    // registers get no positional embedding (vision_transformer.py:318-327)
+  if (t == 0) { src = cls; pe = pos; }
+  else if (t <= n_reg) src = reg + (long)(t - 1) * D;
+  else {
+    const int i = t - 1 - n_reg;
+    src = (masks && masks[(long)b * n_p + i]) ? mask_token : patch + ((long)b * n_p + i) * D;
+    pe = pos + (long)(1 + i) * D;
+  }
+  for (int d = threadIdx.x; d < D; d += blockDim.x) x[tok * D + d] = src[d] + (pe ? pe[d] : 0.f);
 }
 
 // block = 64 columns x 4 batch-lanes for one token position t; the batch reduction goes through LDS
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t* __restrict__ masks,
                                                            bf16_t* __restrict__ dpatch, float* __restrict__ dcls, float* __restrict__ dpos,
-                                                           float* __restrict__ dmask, int B, int n_p, int D) {
+                                                           float* __restrict__ dmask, float* __restrict__ dreg, int B, int n_p, int n_reg,
+                                                           int D) {
   __shared__ float red[2][4][64];
-  const int N = n_p + 1;
+  const int N = n_p + 1 + n_reg;
   const int t = blockIdx.x;
+  const int i = t - 1 - n_reg;   // patch index (>= 0 for patch tokens)
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
   const int d = blockIdx.y * 64 + cl;
   float sum = 0.f, msum = 0.f;
@@ -77,10 +84,10 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     for (int b = bl; b < B; b += 4) {
       const float g = dx[((long)b * N + t) * D + d];
       sum += g;
-      if (t > 0) {
-        const bool m = masks && masks[(long)b * n_p + t - 1];
+      if (i >= 0) {
+        const bool m = masks && masks[(long)b * n_p + i];
         if (m) msum += g;
-        dpatch[((long)b * n_p + t - 1) * D + d] = m ? (bf16_t)0 : f2bf(g);
+        dpatch[((long)b * n_p + i) * D + d] = m ? (bf16_t)0 : f2bf(g);
       }
     }
   }
@@ -89,10 +96,85 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
   if (bl == 0 && d < D) {
     const float s2 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
     const float m2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-    dpos[(long)t * D + d] += s2;
-    if (t == 0) dcls[d] += s2;
-    else if (masks && m2 != 0.f) atomicAdd(&dmask[d], m2);
+    if (t == 0) { dcls[d] += s2; dpos[d] += s2; }
+    else if (i < 0) dreg[(long)(t - 1) * D + d] += s2;
+    else {
+      dpos[(long)(1 + i) * D + d] += s2;
+      if (masks && m2 != 0.f) atomicAdd(&dmask[d], m2);
+    }
   }
+}
+
+// ------------------------------------------------------------------------------------ SwiGLU
+// x12 [rows, 2H] bf16 = [x1 | x2];  hidden = silu(x1) * x2   (swiglu_ffn.py:31-35).  8 columns per thread.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ x12, bf16_t* __restrict__ out, long rows, int H) {
+  const int hv = H >> 3;
+  const long n = rows * hv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / hv;
+    const int c = (int)(i - r * hv) << 3;
+    const uint4 a = *reinterpret_cast<const uint4*>(x12 + r * 2 * H + c);
+    const uint4 b = *reinterpret_cast<const uint4*>(x12 + r * 2 * H + H + c);
+    const bf16_t* pa = reinterpret_cast<const bf16_t*>(&a);
+    const bf16_t* pb = reinterpret_cast<const bf16_t*>(&b);
+    uint4 o;
+    bf16_t* po = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x1 = bf2f(pa[j]), x2 = bf2f(pb[j]);
+      po[j] = f2bf(x1 * sigmoid_f(x1) * x2);
+    }
+    *reinterpret_cast<uint4*>(out + r * H + c) = o;
+  }
+}
+
+// d12 = [dh * x2 * silu'(x1) | dh * silu(x1)],  silu'(x) = s(x) * (1 + x * (1 - s(x)))
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ x12, const bf16_t* __restrict__ dh,
+                                                         bf16_t* __restrict__ d12, long rows, int H) {
+  const int hv = H >> 3;
+  const long n = rows * hv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / hv;
+    const int c = (int)(i - r * hv) << 3;
+    const uint4 a = *reinterpret_cast<const uint4*>(x12 + r * 2 * H + c);
+    const uint4 b = *reinterpret_cast<const uint4*>(x12 + r * 2 * H + H + c);
+    const uint4 g = *reinterpret_cast<const uint4*>(dh + r * H + c);
+    const bf16_t* pa = reinterpret_cast<const bf16_t*>(&a);
+    const bf16_t* pb = reinterpret_cast<const bf16_t*>(&b);
+    const bf16_t* pg = reinterpret_cast<const bf16_t*>(&g);
+    uint4 o1, o2;
+    bf16_t* p1 = reinterpret_cast<bf16_t*>(&o1);
+    bf16_t* p2 = reinterpret_cast<bf16_t*>(&o2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x1 = bf2f(pa[j]), x2 = bf2f(pb[j]), gg = bf2f(pg[j]);
+      const float sg = sigmoid_f(x1);
+      p1[j] = f2bf(gg * x2 * sg * (1.f + x1 * (1.f - sg)));
+      p2[j] = f2bf(gg * x1 * sg);
+    }
+    *reinterpret_cast<uint4*>(d12 + r * 2 * H + c) = o1;
+    *reinterpret_cast<uint4*>(d12 + r * 2 * H + H + c) = o2;
+  }
+}
+
+extern "C" int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream) {
+  LT_CHECK_ARG(x12_bf16 && out_bf16 && rows >= 0 && H > 0 && H % 8 == 0, "lt_swiglu_fwd: bad arguments (H must be a multiple of 8)");
+  if (rows == 0) return LT_OK;
+  const long n = rows * (H >> 3);
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((unsigned)min((long)8192, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x12_bf16,
+                     (bf16_t*)out_bf16, rows, H);
+  LT_CHECK_LAUNCH("lt_swiglu_fwd");
+}
+
+extern "C" int lt_swiglu_bwd(const void* x12_bf16, const void* dh_bf16, void* d12_bf16, int64_t rows, int H, void* stream) {
+  LT_CHECK_ARG(x12_bf16 && dh_bf16 && d12_bf16 && rows >= 0 && H > 0 && H % 8 == 0, "lt_swiglu_bwd: bad arguments (H must be a multiple of 8)");
+  if (rows == 0) return LT_OK;
+  const long n = rows * (H >> 3);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)min((long)8192, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x12_bf16,
+                     (const bf16_t*)dh_bf16, (bf16_t*)d12_bf16, rows, H);
+  LT_CHECK_LAUNCH("lt_swiglu_bwd");
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm
@@ -610,16 +692,17 @@ extern "C" int lt_resize_4tap(const float* in, float* out, const int32_t* iy, co
   LT_CHECK_LAUNCH("lt_resize_4tap");
 }
 extern "C" int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
-                                  const uint8_t* masks, float* x, int B, int n_p, int D, void* stream) {
-  LT_CHECK_ARG(patch && cls && pos && x && (!masks || mask_token), "lt_assemble_tokens: null pointer");
-  hipLaunchKernelGGL(assemble_kernel, dim3(B * (n_p + 1)), dim3(256), 0, ST, patch, cls, pos, mask_token, masks, x, B, n_p, D);
+                                  const uint8_t* masks, const float* reg, float* x, int B, int n_p, int n_reg, int D, void* stream) {
+  LT_CHECK_ARG(patch && cls && pos && x && (!masks || mask_token) && n_reg >= 0 && (n_reg == 0 || reg), "lt_assemble_tokens: bad arguments");
+  hipLaunchKernelGGL(assemble_kernel, dim3(B * (n_p + 1 + n_reg)), dim3(256), 0, ST, patch, cls, pos, mask_token, masks, reg, x, B, n_p, n_reg, D);
   LT_CHECK_LAUNCH("lt_assemble_tokens");
 }
 extern "C" int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, void* dpatch_bf16, float* dcls, float* dpos,
-                                      float* dmask_token, int B, int n_p, int D, void* stream) {
-  LT_CHECK_ARG(dx && dpatch_bf16 && dcls && dpos && (!masks || dmask_token), "lt_assemble_tokens_bwd: null pointer");
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(n_p + 1, lt_cdiv(D, 64)), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls, dpos,
-                     dmask_token, B, n_p, D);
+                                      float* dmask_token, float* dreg, int B, int n_p, int n_reg, int D, void* stream) {
+  LT_CHECK_ARG(dx && dpatch_bf16 && dcls && dpos && (!masks || dmask_token) && n_reg >= 0 && (n_reg == 0 || dreg),
+               "lt_assemble_tokens_bwd: bad arguments");
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(n_p + 1 + n_reg, lt_cdiv(D, 64)), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls, dpos,
+                     dmask_token, dreg, B, n_p, n_reg, D);
   LT_CHECK_LAUNCH("lt_assemble_tokens_bwd");
 }
 extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,

@@ -365,7 +365,8 @@ class DINOv2:
         p = cfg.patch_size
         gh, gw = -(-gv.shape[2] // p), -(-gv.shape[3] // p)  # ceil: PatchEmbed pad-resizes to the next multiple of p
         n_p = gh * gw
-        Ng = n_p + 1
+        n_reg = cfg.num_register_tokens
+        Ng = n_p + 1 + n_reg   # tokens per global crop: [cls | registers | patches]
         D, K = cfg.embed_dim, a.output_dim
 
         if masks is None:
@@ -376,14 +377,14 @@ class DINOv2:
         midx = masks["mask_indices_list"].to(torch.int64)
         M = int(midx.shape[0])
         mw = masks["masks_weight"].to(torch.float32)
-        patch_rows = ((midx // n_p) * Ng + 1 + midx % n_p).to(dev, non_blocking=True)
+        patch_rows = ((midx // n_p) * Ng + 1 + n_reg + midx % n_p).to(dev, non_blocking=True)
         cap_M = int(n_crops * a.mask_probability) * max(int(0.5 * n_p), 1)
         assert M <= cap_M
 
         lv = torch.cat(views[n_global:]).to(dev, torch.float32) if n_local > 0 else None
         n_p_l = (-(-lv.shape[2] // p)) * (-(-lv.shape[3] // p)) if lv is not None else 0
-        Nl = n_p_l + 1
-        ix = self._indices(B, n_p, n_local, n_p_l)
+        Nl = n_p_l + 1 + n_reg
+        ix = self._indices(B, n_p + n_reg, n_local, n_p_l + n_reg)
         self.student.grad.zero_()
         self._loss_slots.zero_()
 

@@ -123,19 +123,19 @@ def im2col(img: Tensor, p: int, kpad: int) -> Tensor:
 
 
 def assemble_tokens(patch: Tensor, cls: Tensor, pos: Tensor, mask_token: Tensor, masks: Optional[Tensor], B: int, n_p: int,
-                    D: int, out: Optional[Tensor] = None) -> Tensor:
-    x = out if out is not None else torch.empty(B, n_p + 1, D, device=patch.device, dtype=torch.float32)
+                    D: int, out: Optional[Tensor] = None, reg: Optional[Tensor] = None, n_reg: int = 0) -> Tensor:
+    x = out if out is not None else torch.empty(B, n_p + 1 + n_reg, D, device=patch.device, dtype=torch.float32)
     if masks is not None:
         _chk(masks, torch.uint8, "assemble.masks")
-    check(_lib.load().lt_assemble_tokens(_p(patch), _p(cls), _p(pos), _p(mask_token), _p(masks), _p(x), B, n_p, D, _stream()),
-          "lt_assemble_tokens")
+    check(_lib.load().lt_assemble_tokens(_p(patch), _p(cls), _p(pos), _p(mask_token), _p(masks), _p(reg), _p(x), B, n_p, n_reg, D,
+                                         _stream()), "lt_assemble_tokens")
     return x
 
 
 def assemble_tokens_bwd(dx: Tensor, masks: Optional[Tensor], dpatch: Tensor, dcls: Tensor, dpos: Tensor, dmask: Tensor, B: int,
-                        n_p: int, D: int) -> None:
-    check(_lib.load().lt_assemble_tokens_bwd(_p(dx), _p(masks), _p(dpatch), _p(dcls), _p(dpos), _p(dmask), B, n_p, D, _stream()),
-          "lt_assemble_tokens_bwd")
+                        n_p: int, D: int, dreg: Optional[Tensor] = None, n_reg: int = 0) -> None:
+    check(_lib.load().lt_assemble_tokens_bwd(_p(dx), _p(masks), _p(dpatch), _p(dcls), _p(dpos), _p(dmask), _p(dreg), B, n_p, n_reg, D,
+                                             _stream()), "lt_assemble_tokens_bwd")
 
 
 # ------------------------------------------------------------------------------------------ norms
@@ -181,6 +181,17 @@ def scatter_add_rows(src: Tensor, idx: Tensor, dst: Tensor, ld: int, M: int, D: 
 
 def cast_bf16(src: Tensor, dst: Tensor) -> None:
     check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
+
+
+def swiglu_fwd(x12: Tensor, out: Tensor, rows: int, H: int) -> None:
+    """out[rows, H] = silu(x12[:, :H]) * x12[:, H:]  (bf16, reference swiglu_ffn.py:31-35)."""
+    _chk(x12, torch.bfloat16, "swiglu.x12"); _chk(out, torch.bfloat16, "swiglu.out")
+    check(_lib.load().lt_swiglu_fwd(_p(x12), _p(out), rows, H, _stream()), "lt_swiglu_fwd")
+
+
+def swiglu_bwd(x12: Tensor, dh: Tensor, d12: Tensor, rows: int, H: int) -> None:
+    _chk(x12, torch.bfloat16, "swiglu.x12"); _chk(dh, torch.bfloat16, "swiglu.dh"); _chk(d12, torch.bfloat16, "swiglu.d12")
+    check(_lib.load().lt_swiglu_bwd(_p(x12), _p(dh), _p(d12), rows, H, _stream()), "lt_swiglu_bwd")
 
 
 def cast_pad_rows(src: Tensor, dst: Tensor, R: int, Cc: int, Cpad: int) -> None:

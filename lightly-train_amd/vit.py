@@ -34,10 +34,19 @@ class ViTConfig:
     interpolate_antialias: bool = False
     drop_path_rate: float = 0.0
     drop_path_uniform: bool = False
+    num_register_tokens: int = 0
+    ffn_layer: str = "mlp"   # "mlp" | "swiglu" | "swiglufused" (vision_transformer.py:179-185)
+
+    @property
+    def swiglu(self) -> bool:
+        return self.ffn_layer in ("swiglu", "swiglufused")
 
     @property
     def hidden(self) -> int:
-        return int(self.embed_dim * self.mlp_ratio)
+        h = int(self.embed_dim * self.mlp_ratio)
+        if self.swiglu:   # SwiGLUFFNFused: 2/3 of the MLP width rounded up to 8 (swiglu_ffn.py:61-63)
+            h = (int(h * 2 / 3) + 7) // 8 * 8
+        return h
 
     @property
     def head_dim(self) -> int:
@@ -58,17 +67,24 @@ def vit_param_shapes(cfg: ViTConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     D, hid, p = cfg.embed_dim, cfg.hidden, cfg.patch_size
     n_p = (cfg.img_size // p) ** 2
     out: List[Tuple[str, Tuple[int, ...]]] = [
-        ("cls_token", (1, 1, D)), ("pos_embed", (1, n_p + 1, D)), ("mask_token", (1, D)),
-        ("patch_embed.proj.weight", (D, cfg.in_chans, p, p)), ("patch_embed.proj.bias", (D,)),
+        ("cls_token", (1, 1, D)), ("pos_embed", (1, n_p + 1, D)),
     ]
+    if cfg.num_register_tokens:
+        out.append(("register_tokens", (1, cfg.num_register_tokens, D)))
+    out += [("mask_token", (1, D)), ("patch_embed.proj.weight", (D, cfg.in_chans, p, p)), ("patch_embed.proj.bias", (D,))]
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         out += [(b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)), (b + "attn.qkv.weight", (3 * D, D)),
                 (b + "attn.qkv.bias", (3 * D,)), (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,))]
         if cfg.init_values:
             out.append((b + "ls1.gamma", (D,)))
-        out += [(b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)), (b + "mlp.fc1.weight", (hid, D)),
-                (b + "mlp.fc1.bias", (hid,)), (b + "mlp.fc2.weight", (D, hid)), (b + "mlp.fc2.bias", (D,))]
+        out += [(b + "norm2.weight", (D,)), (b + "norm2.bias", (D,))]
+        if cfg.swiglu:
+            out += [(b + "mlp.w12.weight", (2 * hid, D)), (b + "mlp.w12.bias", (2 * hid,)), (b + "mlp.w3.weight", (D, hid)),
+                    (b + "mlp.w3.bias", (D,))]
+        else:
+            out += [(b + "mlp.fc1.weight", (hid, D)), (b + "mlp.fc1.bias", (hid,)), (b + "mlp.fc2.weight", (D, hid)),
+                    (b + "mlp.fc2.bias", (D,))]
         if cfg.init_values:
             out.append((b + "ls2.gamma", (D,)))
     out += [("norm.weight", (D,)), ("norm.bias", (D,))]
@@ -79,7 +95,7 @@ def init_vit_state(cfg: ViTConfig, generator: Optional[torch.Generator] = None) 
     """Random init with the reference's initialisers (vision_transformer.py:243-249, 489-495; Conv2d default)."""
     sd: Dict[str, Tensor] = {}
     for name, shape in vit_param_shapes(cfg):
-        if name == "cls_token":
+        if name in ("cls_token", "register_tokens"):
             t = torch.empty(shape).normal_(std=1e-6, generator=generator)
         elif name == "pos_embed" or (name.endswith(".weight") and len(shape) == 2):
             t = torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=generator)
@@ -251,6 +267,7 @@ class ViTEngine:
         cfg = self.cfg
         B, C, H, W = img.shape
         p, D, Hh, dh, hid = cfg.patch_size, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
+        fc2 = "mlp.w3" if cfg.swiglu else "mlp.fc2"
         if H % p or W % p:
             # PatchEmbed.forward (layers/patch_embed.py:86-99): bicubic-resize to the next multiple of the patch size
             nh, nw = math.ceil(H / p) * p, math.ceil(W / p) * p
@@ -263,7 +280,8 @@ class ViTEngine:
             img = ops.resize_4tap(img.contiguous(), iy, wy, ix, wx, nh, nw)
             H, W = nh, nw
         gh, gw = H // p, W // p
-        n_p, N = gh * gw, gh * gw + 1
+        n_reg = cfg.num_register_tokens
+        n_p, N = gh * gw, gh * gw + 1 + n_reg
         T = B * N
         scale = dh ** -0.5
         ctx: Dict[str, Any] = dict(B=B, N=N, n_p=n_p, gh=gh, gw=gw, T=T, masks=masks, tag=tag)
@@ -274,7 +292,8 @@ class ViTEngine:
                  epilogue=ops.EPI_F32, bias=self.w("patch_embed.proj.bias"))
         pos = self._pos_for_grid(ws, tag, gh, gw)
         x = ws.get(tag + ".x0" if save else tag + ".xa", (T, D), torch.float32)
-        ops.assemble_tokens(patch, self.w("cls_token").view(D), pos, self.w("mask_token").view(D), masks, B, n_p, D, out=x)
+        ops.assemble_tokens(patch, self.w("cls_token").view(D), pos, self.w("mask_token").view(D), masks, B, n_p, D, out=x,
+                            reg=self.w("register_tokens").view(-1, D) if n_reg else None, n_reg=n_reg)
         ctx["cols"] = cols
         tok = torch.arange(N, dtype=torch.int64)
 
@@ -333,18 +352,23 @@ class ViTEngine:
             m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
             ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"])
             act = ws.get(s + "act", (T, hid), torch.bfloat16)
-            hpre = ws.get(s + "hpre", (T, hid), torch.bfloat16) if save else None
-            ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=R2, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
+            if cfg.swiglu:   # w12 -> silu(x1) * x2 -> w3
+                hpre = ws.get(s + "hpre", (T, 2 * hid), torch.bfloat16)
+                ops.gemm(ln2, self.wb(pre + "mlp.w12.weight"), hpre, M=R2, N=2 * hid, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "mlp.w12.bias"))
+                ops.swiglu_fwd(hpre, act, R2, hid)
+            else:
+                hpre = ws.get(s + "hpre", (T, hid), torch.bfloat16) if save else None
+                ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=R2, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
             y2 = ws.get(s + "y2", (T, D), torch.bfloat16) if (save and g2 is not None) else None
             if m["mode"] == "subset":
                 delta = ws.get(tag + ".delta", (T, D), torch.float32)
-                ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), delta, M=R2, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
+                ops.gemm(act, self.wb(pre + fc2 + ".weight"), delta, M=R2, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + fc2 + ".bias"),
                          gamma=g2, resid=None, out2=y2, branch_scale=m["scale"])
                 ops.scatter_add_rows(delta, m["idx"], xm, D, R2, D)
                 xo = xm
             else:
                 xo = ws.get(f"{tag}.b{i}.xo" if save else (tag + ".xa"), (T, D), torch.float32)
-                ops.gemm(act, self.wb(pre + "mlp.fc2.weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + "mlp.fc2.bias"),
+                ops.gemm(act, self.wb(pre + fc2 + ".weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + fc2 + ".bias"),
                          gamma=g2, resid=xm, out2=y2, rowscale=m["rowscale"])
             if save:
                 a.update(ln=ln1, qkv=qkv, att=att, lse=lse, y=y1)
@@ -374,7 +398,10 @@ class ViTEngine:
         dxb = ws.get(tag + ".dxb", (T, D), torch.float32)
         dD = ws.get(tag + ".dD", (T, D), torch.bfloat16)        # bf16 [T,D] gradient scratch
         dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16)
-        dH = ws.get(tag + ".dH", (T, hid), torch.bfloat16)
+        dH = ws.get(tag + ".dH", (T, 2 * hid if cfg.swiglu else hid), torch.bfloat16)
+        dAct = ws.get(tag + ".dAct", (T, hid), torch.bfloat16) if cfg.swiglu else None
+        fc1, fc2 = ("mlp.w12", "mlp.w3") if cfg.swiglu else ("mlp.fc1", "mlp.fc2")
+        hid1 = 2 * hid if cfg.swiglu else hid
         dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
@@ -434,12 +461,16 @@ class ViTEngine:
             din = branch_grad_in(m, ".dxs")
             before_write(dD)
             ops.layerscale_bwd(din, m["y"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, R2, D,
-                               dbias=self.gw(pre + "mlp.fc2.bias"), rowscale=m["rowscale"], scale=m["scale"])
-            wgrad(dD, m["act"], pre + "mlp.fc2.weight", D, hid, R2)
+                               dbias=self.gw(pre + fc2 + ".bias"), rowscale=m["rowscale"], scale=m["scale"])
+            wgrad(dD, m["act"], pre + fc2 + ".weight", D, hid, R2)
             before_write(dH)
-            ops.gemm(dD, self.wb(pre + "mlp.fc2.weight"), dH, M=R2, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=m["hpre"])
-            wgrad(dH, m["ln"], pre + "mlp.fc1.weight", hid, D, R2, bias=pre + "mlp.fc1.bias")
-            ops.gemm(dH, self.wb(pre + "mlp.fc1.weight"), dD2, M=R2, N=D, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
+            if cfg.swiglu:
+                ops.gemm(dD, self.wb(pre + fc2 + ".weight"), dAct, M=R2, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+                ops.swiglu_bwd(m["hpre"], dAct, dH, R2, hid)
+            else:
+                ops.gemm(dD, self.wb(pre + fc2 + ".weight"), dH, M=R2, N=hid, K=D, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=m["hpre"])
+            wgrad(dH, m["ln"], pre + fc1 + ".weight", hid1, D, R2, bias=pre + fc1 + ".bias")
+            ops.gemm(dH, self.wb(pre + fc1 + ".weight"), dD2, M=R2, N=D, K=hid1, trans_b=True, epilogue=ops.EPI_BF16)
             if m["mode"] == "subset":
                 lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R2]
                 ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, None, lng,
@@ -481,7 +512,9 @@ class ViTEngine:
         else:
             dpos = ws.get(tag + ".dpos", (n_p + 1, D), torch.float32)
             dpos.zero_()
-        ops.assemble_tokens_bwd(dx, ctx["masks"], dpatch, self.gw("cls_token").view(D), dpos, self.gw("mask_token").view(D), B, n_p, D)
+        n_reg = cfg.num_register_tokens
+        ops.assemble_tokens_bwd(dx, ctx["masks"], dpatch, self.gw("cls_token").view(D), dpos, self.gw("mask_token").view(D), B, n_p, D,
+                                dreg=self.gw("register_tokens").view(-1, D) if n_reg else None, n_reg=n_reg)
         if mp is not None:
             gpos[0].add_(dpos[0])  # cls position row (plumbing: one D-vector add)
             ops.matmul_f32(mp, dpos[1:], gpos[1:], mp.shape[1], D, n_p, trans_a=True, accumulate=True)

@@ -254,8 +254,12 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], masks: Opt
 
     def ffn_branch(z: Tensor, pre: str) -> Tensor:
         y = F.layer_norm(z, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-6)
-        y = F.gelu(F.linear(y, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))
-        y = F.linear(y, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+        if pre + "mlp.w12.weight" in p:   # SwiGLUFFNFused, layers/swiglu_ffn.py:31-35
+            x1, x2 = F.linear(y, p[pre + "mlp.w12.weight"], p[pre + "mlp.w12.bias"]).chunk(2, dim=-1)
+            y = F.linear(F.silu(x1) * x2, p[pre + "mlp.w3.weight"], p[pre + "mlp.w3.bias"])
+        else:
+            y = F.gelu(F.linear(y, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))
+            y = F.linear(y, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
         return y * p[pre + "ls2.gamma"] if has_ls else y
 
     def residual(z: Tensor, fn, pre: str, rate: float, slot: int) -> Tensor:
@@ -573,7 +577,8 @@ VIT_CONFIGS: Dict[str, Dict[str, Any]] = {
 
 
 def init_vit_params(arch: str, patch_size: int = 16, img_size: int = 224, in_chans: int = 3,
-                    init_values: float = 1e-5, generator: Optional[torch.Generator] = None) -> Tuple[Dict[str, Tensor], Dict[str, Any]]:
+                    init_values: float = 1e-5, generator: Optional[torch.Generator] = None, num_register_tokens: int = 0,
+                    ffn_layer: str = "mlp") -> Tuple[Dict[str, Tensor], Dict[str, Any]]:
     c = dict(VIT_CONFIGS[arch])
     D, depth = c["embed_dim"], c["depth"]
     hid = int(D * c["mlp_ratio"])
@@ -586,6 +591,8 @@ def init_vit_params(arch: str, patch_size: int = 16, img_size: int = 224, in_cha
     p: Dict[str, Tensor] = {}
     p["cls_token"] = torch.empty(1, 1, D).normal_(std=1e-6, generator=g)
     p["pos_embed"] = tn(1, n_p + 1, D)
+    if num_register_tokens:
+        p["register_tokens"] = torch.empty(1, num_register_tokens, D).normal_(std=1e-6, generator=g)
     p["mask_token"] = torch.zeros(1, D)
     fan_in = in_chans * patch_size * patch_size
     bound = 1 / math.sqrt(fan_in)
@@ -598,8 +605,13 @@ def init_vit_params(arch: str, patch_size: int = 16, img_size: int = 224, in_cha
         p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"] = tn(D, D), torch.zeros(D)
         p[pre + "ls1.gamma"] = torch.full((D,), init_values)
         p[pre + "norm2.weight"], p[pre + "norm2.bias"] = torch.ones(D), torch.zeros(D)
-        p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"] = tn(hid, D), torch.zeros(hid)
-        p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"] = tn(D, hid), torch.zeros(D)
+        if ffn_layer in ("swiglu", "swiglufused"):
+            hs = (int(hid * 2 / 3) + 7) // 8 * 8   # swiglu_ffn.py:61-63
+            p[pre + "mlp.w12.weight"], p[pre + "mlp.w12.bias"] = tn(2 * hs, D), torch.zeros(2 * hs)
+            p[pre + "mlp.w3.weight"], p[pre + "mlp.w3.bias"] = tn(D, hs), torch.zeros(D)
+        else:
+            p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"] = tn(hid, D), torch.zeros(hid)
+            p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"] = tn(D, hid), torch.zeros(D)
         p[pre + "ls2.gamma"] = torch.full((D,), init_values)
     p["norm.weight"], p["norm.bias"] = torch.ones(D), torch.zeros(D)
     cfg = dict(patch_size=patch_size, num_heads=c["num_heads"], depth=depth, embed_dim=D, hidden=hid,

@@ -170,6 +170,9 @@ def make_loss_kats() -> None:
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
+    if "--reg4-only" in sys.argv:
+        make_reg4_swiglu()
+        return
     make_loss_kats()
     small_head = dict(output_dim=512, hidden_dim=64, dino_bottleneck_dim=32)
     # (a) the reference tests' own toy model: D=8, depth 3, 2 heads (head_dim 4)
@@ -188,6 +191,19 @@ def main() -> None:
                       dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64),
                       dict(patch_size=16, num_heads=1, depth=2), b=8, g_size=96, l_size=48, n_local=2,
                       n_steps=2, total_steps=50, keep_params_every_step=False)
+    make_reg4_swiglu()
+
+
+def make_reg4_swiglu() -> None:
+    # (c) the shape of the reference's default pretrained family (dinov2_vit_src/configs: patch 14, 4 register tokens,
+    # antialiased pos-embed interpolation with offset 0) + the SwiGLU FFN of the giant models, at D=64
+    make_step_fixture("step_d64_reg4_swiglu14", "DinoVisionTransformer",
+                      dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, num_register_tokens=4, ffn_layer="swiglu",
+                           interpolate_antialias=True, interpolate_offset=0.0),
+                      dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64),
+                      dict(patch_size=14, num_heads=1, depth=2, mlp_ratio=4.0, ffn_layer="swiglu", num_register_tokens=4,
+                           interpolate_antialias=True, interpolate_offset=0.0),
+                      b=8, g_size=56, l_size=28, n_local=2, n_steps=2, total_steps=50, keep_params_every_step=False)
 
 
 if __name__ == "__main__":

@@ -222,6 +222,46 @@ def test_im2col_and_tokens():
     assert torch.equal(dpatch.float().view(B, n_p, D), bf(dx[:, 1:] * (~masks).unsqueeze(-1)).float())
 
 
+def test_tokens_with_registers_and_swiglu():
+    """Register tokens are inserted after cls without a positional embedding (vision_transformer.py:318-327);
+    SwiGLU gate silu(x1)*x2 and its backward (swiglu_ffn.py:31-35) against torch autograd on the bf16-rounded inputs."""
+    o = ops()
+    B, n_p, R, D = 3, 6, 4, 24
+    g = torch.Generator().manual_seed(12)
+    patch = torch.randn(B * n_p, D, generator=g).to(DEV)
+    cls, mt = torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)
+    pos, reg = torch.randn(n_p + 1, D, generator=g).to(DEV), torch.randn(R, D, generator=g).to(DEV)
+    masks = (torch.rand(B, n_p, generator=g) < 0.4).to(DEV)
+    x = o.assemble_tokens(patch, cls, pos, mt, masks.to(torch.uint8), B, n_p, D, reg=reg, n_reg=R)
+    t = torch.where(masks.unsqueeze(-1), mt.view(1, 1, D), patch.view(B, n_p, D))
+    t = torch.cat([cls.view(1, 1, D).expand(B, -1, -1), t], 1) + pos.unsqueeze(0)
+    refx = torch.cat([t[:, :1], reg.unsqueeze(0).expand(B, -1, -1), t[:, 1:]], 1)
+    assert x.shape == (B, n_p + 1 + R, D) and torch.allclose(x, refx)
+    dx = torch.randn(B, n_p + 1 + R, D, generator=g).to(DEV)
+    dpatch = torch.empty(B * n_p, D, device=DEV, dtype=torch.bfloat16)
+    dcls, dmask = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dpos, dreg = torch.zeros(n_p + 1, D, device=DEV), torch.ones(R, D, device=DEV)   # dreg accumulates onto 1
+    o.assemble_tokens_bwd(dx, masks.to(torch.uint8), dpatch, dcls, dpos, dmask, B, n_p, D, dreg=dreg, n_reg=R)
+    dxp = dx[:, 1 + R:]
+    assert torch.allclose(dcls, dx[:, 0].sum(0), atol=1e-5) and torch.allclose(dreg, 1 + dx[:, 1:1 + R].sum(0), atol=1e-5)
+    assert torch.allclose(dpos, torch.cat([dx[:, :1], dxp], 1).sum(0), atol=1e-5)
+    assert torch.allclose(dmask, (dxp * masks.unsqueeze(-1)).sum((0, 1)), atol=1e-5)
+    assert torch.equal(dpatch.float().view(B, n_p, D), bf(dxp * (~masks).unsqueeze(-1)).float())
+
+    rows, H = 37, 176
+    x12 = bf(torch.randn(rows, 2 * H, generator=g) * 2).to(DEV)
+    dh = bf(torch.randn(rows, H, generator=g)).to(DEV)
+    out = torch.empty(rows, H, device=DEV, dtype=torch.bfloat16)
+    d12 = torch.empty(rows, 2 * H, device=DEV, dtype=torch.bfloat16)
+    o.swiglu_fwd(x12, out, rows, H)
+    o.swiglu_bwd(x12, dh, d12, rows, H)
+    xr = x12.float().requires_grad_(True)
+    ref = F.silu(xr[:, :H]) * xr[:, H:]
+    ref.backward(dh.float())
+    assert (out.float() - ref.detach()).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    assert (d12.float() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
+
+
 def test_bicubic_pad_resize():
     """98x98 -> 112x112 (the literal 8 x 98^2 local crops with patch 16): taps read off F.interpolate, applied in HIP."""
     o = ops()

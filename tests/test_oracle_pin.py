@@ -87,7 +87,8 @@ def test_ema_kat():
     assert torch.equal(t, torch.tensor([[2.5, 3.5], [4.5, 5.5]]))
 
 
-@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_vittest_sephead", "step_d64_softmax"])
+@pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_vittest_sephead", "step_d64_softmax",
+                                  "step_d64_reg4_swiglu14"])
 def test_oracle_reproduces_reference_steps(name):
     """The restated step reproduces the reference's losses / logits / grad-norm / updated parameters."""
     fx = load(name)
