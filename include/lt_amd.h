@@ -74,6 +74,9 @@ int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);
 /* one-thread-per-output fp32-accumulate GEMM on the same bf16 operands (cross-check only) */
 int lt_gemm_bf16_naive(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int trans_a, int trans_b, void* stream);
+/* diagnostics: per-block records [hw_id, xcc_id, priority ticket, start tick, end tick, tiles, -, -] (8 x u64 per block,
+ * 100 MHz ticks) of the last persistent two-blocks-per-CU GEMM launched with force_kernel = 58; synchronises the device */
+int lt_debug_gemm_log(unsigned long long* host_dst, int n_blocks);
 /* tiny fp32 matmul C[M,N] (+)= op(A)[M,K] . B[K,N]  (pos-embed bicubic map, vision_transformer.py:251-305) */
 int lt_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate, void* stream);
 

@@ -34,6 +34,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_matmul_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lt_debug_gemm_log": [vp, i32],
     "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
     "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
     "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

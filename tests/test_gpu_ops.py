@@ -52,7 +52,7 @@ def test_gemm_layouts(M, N, K, ta, tb):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("fk", [2, 3, 4])
+@pytest.mark.parametrize("fk", [2, 3, 4, 5])
 def test_gemm_256_kernel(M, N, K, tb, fk):
     """the 256x256 LDS-DMA kernel (forced) against the fp32 reference, incl. M/N tails and every epilogue it serves."""
     o = ops()
@@ -77,6 +77,29 @@ def test_gemm_256_kernel(M, N, K, tb, fk):
     x = aux.float().requires_grad_(True)
     F.gelu(x).sum().backward()
     assert rel_err(ob, ref * x.grad) < 6e-3
+
+
+def test_gemm_persistent_scheduler_reuse():
+    """The two-blocks-per-CU kernel takes its tiles from self-resetting per-XCD counters in a ring of 1024 slots: run it more
+    often than there are slots, on two streams at once, and require identical results every time."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 3000, 384, 128
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    B = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    ref = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    o.gemm(A, B, ref, M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=2)
+    outs = [torch.zeros(M, N, device=DEV, dtype=torch.float32) for _ in range(2)]
+    side = torch.cuda.Stream()
+    for it in range(600):
+        o.gemm(A, B, outs[0], M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=5)
+        with torch.cuda.stream(side):
+            o.gemm(A, B, outs[1], M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=5)
+        if it % 150 == 149:
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref), it
+            outs[0].zero_(); outs[1].zero_()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("M,N,K", [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)])

@@ -269,3 +269,27 @@ def test_full_size_head_properties():
     ops.ce_fwd_bwd(logits, probs, ta, None, None, 1.0 / rows, 10.0, loss, None, rows, K)
     ref = -(probs * torch.log_softmax(logits * 10.0, -1)).sum(-1).mean()
     assert float(loss) == pytest.approx(float(ref), rel=1e-4)
+
+
+def test_loss_trajectory_100_steps_matches_oracle():
+    """North-star item: the loss trajectory over 100 optimizer steps on identical synthetic batches (same views, same
+    iBOT masks, reference-generated initial state) against the fp32 CPU oracle.  KoLeo off (the ill-conditioned term, see
+    the module docstring): total loss within 2e-3 relative at EVERY step (observed max 9.8e-4), DINO terms 4e-3 (1.5e-3),
+    iBOT 2e-3 (2.8e-4) -- bf16 MFMA operands against fp32, through 100 AdamW + EMA updates."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import trajectory
+
+    worst, rows = trajectory.run("step_d64_softmax", 100, 0.0, quiet=True)
+    assert rows[-1][1] < rows[0][1] - 1.0          # it trains: 12.5 -> 9.8
+    assert worst["loss"] < 2e-3 and worst["dino_global_loss"] < 4e-3 and worst["dino_local_loss"] < 4e-3 and worst["ibot_loss"] < 2e-3, worst
+
+
+def test_loss_trajectory_with_koleo_40_steps():
+    """Same with the default KoLeo weight 0.1: 40 steps, total loss within 8e-3 (observed 2.2e-3), DINO / iBOT terms 6e-3."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import trajectory
+
+    worst, _ = trajectory.run("step_d64_softmax", 40, 0.1, quiet=True)
+    assert worst["loss"] < 8e-3 and worst["dino_global_loss"] < 6e-3 and worst["dino_local_loss"] < 6e-3 and worst["ibot_loss"] < 6e-3, worst
