@@ -254,6 +254,82 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // two at a time (both rows' loads are issued before either row's reductions, hiding the HBM latency a single dependent
 // row chain would expose); per-lane dw/db partials stay in registers, are reduced over the block's 4 waves in LDS, then
 // one atomicAdd per column per block.
+// One row of LayerNorm-backward operands held by a wave (lane owns NV float4 column groups)
+template <bool DYF32, int NV>
+struct LnbRow {
+  float4 xv[NV], rv[NV];
+  float4 dvf[DYF32 ? NV : 1];
+  uint2 dvh[DYF32 ? 1 : NV];
+  float mu, rs;
+  bool ok;
+};
+
+template <bool DYF32, int NV>
+__device__ __forceinline__ void lnb_load(LnbRow<DYF32, NV>& R, long row, int rows, int D, int lane, const float* __restrict__ x,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd, const void* __restrict__ dyv,
+                                         const float* __restrict__ dres) {
+  R.ok = row < rows;
+  R.mu = R.ok ? mean[row] : 0.f;
+  R.rs = R.ok ? rstd[row] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    R.xv[i] = make_float4(0, 0, 0, 0); R.rv[i] = make_float4(0, 0, 0, 0);
+    if (DYF32) R.dvf[i] = make_float4(0, 0, 0, 0); else R.dvh[i] = make_uint2(0, 0);
+    if (R.ok && c < D) {
+      R.xv[i] = *reinterpret_cast<const float4*>(x + row * D + c);
+      if (dres) R.rv[i] = *reinterpret_cast<const float4*>(dres + row * D + c);  // residual gradient travels with the row
+      if (DYF32) R.dvf[i] = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
+      else R.dvh[i] = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
+    }
+  }
+}
+
+template <bool DYF32, int NV>
+__device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int D, int lane, const float4 (&wv4)[NV], float4 (&aw)[NV],
+                                            float4 (&ab)[NV], float* __restrict__ dx) {
+  if (!R.ok) return;
+  float c1 = 0.f, c2 = 0.f;
+  float4 gyv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    gyv[i] = make_float4(0, 0, 0, 0);
+    if (c < D) {
+      float4 d;
+      if (DYF32) d = R.dvf[i];
+      else {
+        const uint2 u = R.dvh[i];
+        d = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+      }
+      const float4 xh = make_float4((R.xv[i].x - R.mu) * R.rs, (R.xv[i].y - R.mu) * R.rs, (R.xv[i].z - R.mu) * R.rs, (R.xv[i].w - R.mu) * R.rs);
+      const float4 gy = make_float4(d.x * wv4[i].x, d.y * wv4[i].y, d.z * wv4[i].z, d.w * wv4[i].w);
+      c1 += gy.x + gy.y + gy.z + gy.w;
+      c2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
+      aw[i].x += d.x * xh.x; aw[i].y += d.y * xh.y; aw[i].z += d.z * xh.z; aw[i].w += d.w * xh.w;
+      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      R.xv[i] = xh; gyv[i] = gy;
+    }
+  }
+  c1 = wave_sum(c1) / D;
+  c2 = wave_sum(c2) / D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const float4 xh = R.xv[i], gy = gyv[i];
+      float4 o = make_float4(R.rs * (gy.x - c1 - xh.x * c2), R.rs * (gy.y - c1 - xh.y * c2),
+                             R.rs * (gy.z - c1 - xh.z * c2), R.rs * (gy.w - c1 - xh.w * c2));
+      const float4 rr = R.rv[i];
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      *reinterpret_cast<float4*>(dx + row * D + c) = o;
+    }
+  }
+}
+
+// dx = dres + LN'(dy);  dw/db column sums.  Persistent waves (grid <= 512 blocks) stream rows with a two-deep software
+// pipeline: the loads of the NEXT row are issued before the current row is reduced and stored, so a wave always has a row
+// (7.5 KiB at D = 768) in flight -- without it every iteration paid one full HBM round trip (3.5 TB/s at 512 blocks).
 template <bool DYF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -270,65 +346,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     wv4[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
   }
   const long stride = (long)gridDim.x * 4;
-  for (long row0 = (long)blockIdx.x * 4 + wv; row0 < rows; row0 += 2 * stride) {
-    float4 xv[2][NV], dv[2][NV], rv[2][NV];
-    float mu[2], rs[2];
-    bool ok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const long row = row0 + r * stride;
-      ok[r] = row < rows;
-      mu[r] = ok[r] ? mean[row] : 0.f;
-      rs[r] = ok[r] ? rstd[row] : 0.f;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        xv[r][i] = make_float4(0, 0, 0, 0); dv[r][i] = make_float4(0, 0, 0, 0); rv[r][i] = make_float4(0, 0, 0, 0);
-        if (ok[r] && c < D) {
-          xv[r][i] = *reinterpret_cast<const float4*>(x + row * D + c);
-          if (dres) rv[r][i] = *reinterpret_cast<const float4*>(dres + row * D + c);  // residual gradient prefetched with the row
-          if (DYF32) dv[r][i] = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
-          else {
-            const uint2 u = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
-            dv[r][i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (!ok[r]) continue;
-      const long row = row0 + r * stride;
-      float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) {
-          const float4 d = dv[r][i];
-          const float4 xh = make_float4((xv[r][i].x - mu[r]) * rs[r], (xv[r][i].y - mu[r]) * rs[r], (xv[r][i].z - mu[r]) * rs[r], (xv[r][i].w - mu[r]) * rs[r]);
-          const float4 gy = make_float4(d.x * wv4[i].x, d.y * wv4[i].y, d.z * wv4[i].z, d.w * wv4[i].w);
-          c1 += gy.x + gy.y + gy.z + gy.w;
-          c2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
-          aw[i].x += d.x * xh.x; aw[i].y += d.y * xh.y; aw[i].z += d.z * xh.z; aw[i].w += d.w * xh.w;
-          ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-          xv[r][i] = xh; dv[r][i] = gy;
-        }
-      }
-      c1 = wave_sum(c1) / D;
-      c2 = wave_sum(c2) / D;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) {
-          const float4 xh = xv[r][i], gy = dv[r][i];
-          float4 o = make_float4(rs[r] * (gy.x - c1 - xh.x * c2), rs[r] * (gy.y - c1 - xh.y * c2),
-                                 rs[r] * (gy.z - c1 - xh.z * c2), rs[r] * (gy.w - c1 - xh.w * c2));
-          const float4 rr = rv[r][i];
-          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-          *reinterpret_cast<float4*>(dx + row * D + c) = o;
-        }
-      }
-    }
+  long row = (long)blockIdx.x * 4 + wv;
+  LnbRow<DYF32, NV> A, B;
+  lnb_load<DYF32, NV>(A, row, rows, D, lane, x, mean, rstd, dyv, dres);
+  while (row < rows) {
+    lnb_load<DYF32, NV>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
+    lnb_compute<DYF32, NV>(A, row, D, lane, wv4, aw, ab, dx);
+    row += stride;
+    if (row >= rows) break;
+    lnb_load<DYF32, NV>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
+    lnb_compute<DYF32, NV>(B, row, D, lane, wv4, aw, ab, dx);
+    row += stride;
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -722,11 +750,12 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
                                 int rows, int D, void* stream) {
   LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
   if (rows == 0) return LT_OK;
-  int grid = min(lt_cdiv(rows, 4), 512);
+  static const int grid_cap = [] { const char* e = getenv("LT_LN_BWD_GRID"); return e ? atoi(e) : 256; }();  // one 4-wave block per CU: best measured (115 us vs 133 at 512)
+  int grid = min(lt_cdiv(rows, 4), grid_cap);
   const bool vec_ok = D % 4 == 0;
   float* partial = nullptr;
-  if (vec_ok && ws && ws_floats >= (int64_t)2 * D * 64) {  // workspace given: more blocks, no same-address atomics
-    grid = (int)std::min<int64_t>(std::min<int64_t>(lt_cdiv(rows, 4), 2048), ws_floats / (2 * D));
+  if (vec_ok && ws && ws_floats >= (int64_t)2 * D * 64) {  // workspace given: no same-address atomics
+    grid = (int)std::min<int64_t>(grid, ws_floats / (2 * D));
     partial = ws;
   }
   const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&

@@ -1036,7 +1036,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     if (rc != LT_OK) return rc;
     LT_CHECK_LAUNCH("lt_gemm_bf16");
   }
-  if (d->force_kernel == 2) {
+  if (d->force_kernel == 2 || d->force_kernel == 6) {
     LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
@@ -1064,6 +1064,31 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     const bool slab = accum && sp > 1 && d->workspace && d->workspace_bytes >= (size_t)sp * d->M * d->N * sizeof(float);
     g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, bn);
+    // Tail split: when the last wave of 256x256 tiles would leave most CUs idle (591 tiles = 2.31 waves for the N = 768
+    // GEMMs), the rows of that partial wave go to the 128x128 two-blocks-per-CU kernel instead (4x the tiles, 512 slots).
+    // Opt-in (force_kernel = 6): +5..9 % on those GEMMs alone, but inside the step the other streams' kernels already
+    // fill the idle CUs and the extra launch costs more than it saves (121.4 vs 122.5 ms/step).
+    if (d->force_kernel == 6 && !d->trans_a && !accum && bn == 256) {
+      const int ntiles = g.tiles_m * g.tiles_n, rounds = ntiles / cus, rem = ntiles - rounds * cus;
+      const int main_rows = rounds * cus / g.tiles_n;
+      if (rounds >= 1 && rem > 0 && rem <= 144 && main_rows >= 1 && main_rows < g.tiles_m) {
+        const size_t m0 = (size_t)main_rows * 256;
+        lt_gemm_desc tail = *d;
+        tail.M = d->M - (int)m0;
+        tail.force_kernel = 3;
+        tail.A = (const bf16_t*)d->A + m0 * d->lda;
+        tail.C = f32out ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((bf16_t*)d->C + m0 * d->ldc);
+        if (d->C2) tail.C2 = (bf16_t*)d->C2 + m0 * d->ldc2;
+        if (d->resid) tail.resid = d->resid + m0 * d->ldr;
+        if (d->aux) tail.aux = (const bf16_t*)d->aux + m0 * d->ldaux;
+        if (d->rowscale) tail.rowscale = d->rowscale + m0;
+        g.M = (int)m0; g.tiles_m = main_rows;
+        dim3 gridm(g.tiles_m * g.tiles_n, 1);
+        rc = d->trans_b ? g256::launch<false, true, 256>(g, d->epilogue, false, gridm, st) : g256::launch<false, false, 256>(g, d->epilogue, false, gridm, st);
+        if (rc != LT_OK) return rc;
+        return lt_gemm_bf16(&tail, stream);
+      }
+    }
     const int ktiles2 = d->K / BK;
     g.k_per_split = lt_cdiv(ktiles2, sp) * BK;
     sp = lt_cdiv(d->K, g.k_per_split);

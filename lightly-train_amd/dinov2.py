@@ -12,6 +12,8 @@ Differences that are part of the design (all documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Literal, Mapping, Optional, Tuple
@@ -297,11 +299,13 @@ class DINOv2:
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
+        self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
         self._drop_gen = torch.Generator().manual_seed(seed + 7919)  # host RNG of the stochastic-depth draws
         self._grad_sync: Optional[GradSync] = None
         use_streams = self.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device=self.device) if use_streams else None     # weight-gradient GEMMs
         self.teacher_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # teacher forward
+        self.local_bwd_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # local-crop dgrad chain
 
     # ------------------------------------------------------------------ reference-compatible views
     def state_dict(self) -> Dict[str, Tensor]:
@@ -514,8 +518,26 @@ class DINOv2:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
-            self.s_vit.backward(ws, sl, dxn_l, side=side)
-        self.s_vit.backward(ws, sg, dxn_g, side=side)
+        if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
+            # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
+            # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
+            lstream2 = self.local_bwd_stream
+            lstream2.wait_event(main.record_event())
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
+            live = [True, True]
+            while any(live):
+                for ci, (st, gen) in enumerate(chains):
+                    if live[ci]:
+                        with torch.cuda.stream(st):
+                            live[ci] = next(gen) != "tail"
+            main.wait_stream(lstream2)
+            for _, gen in chains:   # tails: plain accumulations into cls/pos/patch-embedding gradients, one after the other
+                for _ in gen:
+                    pass
+        else:
+            if sl is not None:
+                self.s_vit.backward(ws, sl, dxn_l, side=side)
+            self.s_vit.backward(ws, sg, dxn_g, side=side)
         if side is not None:
             main.wait_stream(side)
 

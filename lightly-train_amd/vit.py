@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Iterator, Any, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -384,7 +384,17 @@ class ViTEngine:
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> None:
+        """Run `backward_iter` to completion on the current stream."""
+        for _ in self.backward_iter(ws, ctx, dxn, side):
+            pass
+
+    def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Iterator[str]:
         """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
+
+        Generator: yields "block" after enqueuing each transformer block and "tail" before the token-assembly /
+        patch-embedding part, so that a caller can interleave the launches of two independent backward passes (global and
+        local crops) on two streams.  Everything before "tail" only uses atomics or side-stream-ordered accumulations into
+        the shared gradient buffer; the tail does plain read-modify-writes and must run after the other pass's tail.
 
         `side`: optional second HIP stream for the weight-gradient GEMMs and bias column sums.  They depend only on
         tensors the main (dgrad) chain has already produced and feed nothing but the optimizer, so running them beside
@@ -502,7 +512,10 @@ class ViTEngine:
                 ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, dx, other,
                                   self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D)
                 dx, other = other, dx
+            yield "block"
 
+        yield "tail"
+        main = torch.cuda.current_stream()   # the tail may be resumed on another stream than the block loop
         # ---- token assembly + patch embedding
         dpatch = ws.get(tag + ".dpatch", (B * n_p, D), torch.bfloat16)
         mp = self._pos_map(ctx["gh"], ctx["gw"])

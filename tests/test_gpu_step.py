@@ -281,7 +281,7 @@ def test_loss_trajectory_100_steps_matches_oracle():
     import trajectory
 
     worst, rows = trajectory.run("step_d64_softmax", 100, 0.0, quiet=True)
-    assert rows[-1][1] < rows[0][1] - 1.0          # it trains: 12.5 -> 9.8
+    assert rows[-1][1] < rows[0][1] - 0.3          # it trains: 10.21 -> 9.79 (KoLeo off)
     assert worst["loss"] < 2e-3 and worst["dino_global_loss"] < 4e-3 and worst["dino_local_loss"] < 4e-3 and worst["ibot_loss"] < 2e-3, worst
 
 
