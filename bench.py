@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--out-dim", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: every launch on one stream (clean per-kernel durations)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +112,8 @@ def main() -> None:
     margs = DINOv2Args(output_dim=args.out_dim)
     B = args.batch
     method = DINOv2(cfg, margs, global_batch_size=B * world, total_steps=125_000, device=dev, seed=0)
+    if args.single_stream:
+        method.overlap_streams = False
     g = torch.Generator().manual_seed(1234 + rank)
     views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [
         torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
@@ -165,7 +168,7 @@ def main() -> None:
             torch.cuda.synchronize()
         finally:
             ops.gemm = orig
-            method.overlap_streams = True
+            method.overlap_streams = not args.single_stream
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
         fl = sum(f for _, _, f in recs)
         achieved = fl / (t_ms * 1e-3) / 1e12

@@ -113,6 +113,13 @@ int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
 int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
                      int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
                      int rows, int D, void* stream);
+/* same, plus the fused producer of the NEXT branch's upstream gradient (block.py:90-115 backward, the branch whose output
+ * was added to this residual stream): dnext bf16 [rows,D] = dx * gamma_next * scale_next * rowscale_next[row] and
+ * dbias_next[D] += column sums of dnext (bias gradient of the Linear that feeds that LayerScale).  dnext NULL = plain. */
+int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, const float* rstd, const void* dy, int dy_is_f32,
+                           const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats, void* dnext_bf16,
+                           const float* gamma_next, const float* rowscale_next, float scale_next, float* dbias_next, int rows,
+                           int D, void* stream);
 
 /* LayerScale (+ stochastic depth) backward (layer_scale.py:27-28, block.py:118-141, drop_path.py:16-28):
  *   m_r = scale * (rowscale ? rowscale[r] : 1);  dy(bf16) = dout*gamma*m_r;  dgamma += sum_r dout*y*m_r;
@@ -120,6 +127,11 @@ int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const fl
  * gamma == NULL: dy = bf16(dout*m_r). */
 int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
                       float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
+/* LayerScale gradient from the weight gradient instead of the saved branch output (layer_scale.py:27-28 backward):
+ * dgamma[c] += (sum_k W[c,k] dW[c,k] + bias[c] dbias[c]) / gamma[c], W bf16 [N,K] = the Linear feeding the LayerScale,
+ * dW/dbias = its accumulated gradients (computed from dD = dx*gamma).  Call once per step after all weight gradients. */
+int lt_layerscale_dgamma(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
+                         float* dgamma, int N, int K, void* stream);
 /* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */
 int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream);
 /* out[N] (+)= column sums of an f32 [rows,N] matrix (teacher center, dinov2_loss.py:139-145,274-282) */

@@ -41,6 +41,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_assemble_tokens_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "lt_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lt_layernorm_bwd": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "lt_layernorm_bwd_fused": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, vp, i32, i32, vp],
+    "lt_layerscale_dgamma": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],
     "lt_colsum_bf16": [vp, vp, i32, i32, vp],
     "lt_colsum_f32": [vp, vp, i32, i32, i32, vp],

@@ -285,9 +285,15 @@ __device__ __forceinline__ void lnb_load(LnbRow<DYF32, NV>& R, long row, int row
   }
 }
 
+// optional fused producer of the NEXT branch's upstream gradient: dnext(bf16) = dx * gamma_next * rowscale_next, column sums -> abn
+struct LnbNext {
+  bf16_t* dnext; const float* rowscale; float scale;
+};
+
 template <bool DYF32, int NV>
 __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int D, int lane, const float4 (&wv4)[NV], float4 (&aw)[NV],
-                                            float4 (&ab)[NV], float* __restrict__ dx) {
+                                            float4 (&ab)[NV], float* __restrict__ dx, const LnbNext& nx, const float4 (&gn4)[NV],
+                                            float4 (&abn)[NV]) {
   if (!R.ok) return;
   float c1 = 0.f, c2 = 0.f;
   float4 gyv[NV];
@@ -323,6 +329,12 @@ __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int 
       const float4 rr = R.rv[i];
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      if (nx.dnext) {
+        const float m_r = nx.scale * (nx.rowscale ? nx.rowscale[row] : 1.f);
+        const float4 dn = make_float4(o.x * m_r * gn4[i].x, o.y * m_r * gn4[i].y, o.z * m_r * gn4[i].z, o.w * m_r * gn4[i].w);
+        *reinterpret_cast<uint2*>(nx.dnext + row * D + c) = make_uint2(pack_bf2(dn.x, dn.y), pack_bf2(dn.z, dn.w));
+        abn[i].x += dn.x; abn[i].y += dn.y; abn[i].z += dn.z; abn[i].w += dn.w;
+      }
     }
   }
 }
@@ -335,15 +347,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const void* __restrict__ dyv, const float* __restrict__ dres,
                                                                 float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-                                                                float* __restrict__ partial, int rows, int D) {
+                                                                float* __restrict__ partial, int rows, int D, LnbNext nx,
+                                                                const float* __restrict__ gamma_next, float* __restrict__ dbias_next) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float4 aw[NV], ab[NV], wv4[NV];
+  float4 aw[NV], ab[NV], wv4[NV], gn4[NV], abn[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); abn[i] = make_float4(0, 0, 0, 0);
     const int c = (i * 64 + lane) * 4;
     wv4[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
+    gn4[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (nx.dnext && gamma_next && c < D) gn4[i] = *reinterpret_cast<const float4*>(gamma_next + c);
   }
   const long stride = (long)gridDim.x * 4;
   long row = (long)blockIdx.x * 4 + wv;
@@ -351,11 +366,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   lnb_load<DYF32, NV>(A, row, rows, D, lane, x, mean, rstd, dyv, dres);
   while (row < rows) {
     lnb_load<DYF32, NV>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
-    lnb_compute<DYF32, NV>(A, row, D, lane, wv4, aw, ab, dx);
+    lnb_compute<DYF32, NV>(A, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
     if (row >= rows) break;
     lnb_load<DYF32, NV>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
-    lnb_compute<DYF32, NV>(B, row, D, lane, wv4, aw, ab, dx);
+    lnb_compute<DYF32, NV>(B, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
   }
 #pragma unroll
@@ -378,6 +393,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         } else {
           atomicAdd(&dw[c], sa.x); atomicAdd(&dw[c + 1], sa.y); atomicAdd(&dw[c + 2], sa.z); atomicAdd(&dw[c + 3], sa.w);
           atomicAdd(&db[c], sb.x); atomicAdd(&db[c + 1], sb.y); atomicAdd(&db[c + 2], sb.z); atomicAdd(&db[c + 3], sb.w);
+        }
+      }
+    }
+    if (nx.dnext && dbias_next) {  // column sums of the fused next-branch gradient (bias of the Linear feeding that LayerScale)
+      __syncthreads();
+      red[0][wv][lane] = abn[i];
+      __syncthreads();
+      if (wv == 0) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+          const float4 a0 = red[0][0][lane], a1 = red[0][1][lane], a2 = red[0][2][lane], a3 = red[0][3][lane];
+          atomicAdd(&dbias_next[c], a0.x + a1.x + a2.x + a3.x); atomicAdd(&dbias_next[c + 1], a0.y + a1.y + a2.y + a3.y);
+          atomicAdd(&dbias_next[c + 2], a0.z + a1.z + a2.z + a3.z); atomicAdd(&dbias_next[c + 3], a0.w + a1.w + a2.w + a3.w);
         }
       }
     }
@@ -484,7 +512,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
       const float4 o = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
       *reinterpret_cast<uint2*>(dy + r * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
       abias.x += o.x; abias.y += o.y; abias.z += o.z; abias.w += o.w;
-      if (gamma) {
+      if (gamma && y) {
         const uint2 u = *reinterpret_cast<const uint2*>(y + r * D + c);
         ag.x += g.x * bf2f((bf16_t)(u.x & 0xffff)); ag.y += g.y * bf2f((bf16_t)(u.x >> 16));
         ag.z += g.z * bf2f((bf16_t)(u.y & 0xffff)); ag.w += g.w * bf2f((bf16_t)(u.y >> 16));
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
       a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
     }
-    if (gamma) { atomicAdd(&dgamma[c], a.x); atomicAdd(&dgamma[c + 1], a.y); atomicAdd(&dgamma[c + 2], a.z); atomicAdd(&dgamma[c + 3], a.w); }
+    if (gamma && y) { atomicAdd(&dgamma[c], a.x); atomicAdd(&dgamma[c + 1], a.y); atomicAdd(&dgamma[c + 2], a.z); atomicAdd(&dgamma[c + 3], a.w); }
     if (dbias) { atomicAdd(&dbias[c], b.x); atomicAdd(&dbias[c + 1], b.y); atomicAdd(&dbias[c + 2], b.z); atomicAdd(&dbias[c + 3], b.w); }
   }
 }
@@ -521,13 +549,13 @@ __global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float*
       const float g = dout[r * D + c] * scale * (rowscale ? rowscale[r] : 1.f);
       dy[r * D + c] = f2bf(g * gm);
       accb += g * gm;
-      if (gamma) acc += g * bf2f(y[r * D + c]);
+      if (gamma && y) acc += g * bf2f(y[r * D + c]);
     }
   }
   red[0][rl][cl] = acc; red[1][rl][cl] = accb;
   __syncthreads();
   if (rl == 0 && c < D) {
-    if (gamma) atomicAdd(&dgamma[c], red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    if (gamma && y) atomicAdd(&dgamma[c], red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
     if (dbias) atomicAdd(&dbias[c], red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
   }
 }
@@ -745,10 +773,22 @@ extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, 
                        mean, rstd, rows, D, eps);
   LT_CHECK_LAUNCH("lt_layernorm_fwd");
 }
+extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                                      int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                                      void* dnext_bf16, const float* gamma_next, const float* rowscale_next, float scale_next,
+                                      float* dbias_next, int rows, int D, void* stream);
 extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
                                 int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
                                 int rows, int D, void* stream) {
+  return lt_layernorm_bwd_fused(x, w, mean, rstd, dy, dy_is_f32, dres, dx, dw, db, ws, ws_floats, nullptr, nullptr, nullptr, 1.f,
+                                nullptr, rows, D, stream);
+}
+extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                                      int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                                      void* dnext_bf16, const float* gamma_next, const float* rowscale_next, float scale_next,
+                                      float* dbias_next, int rows, int D, void* stream) {
   LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
+  LnbNext nx{(bf16_t*)dnext_bf16, rowscale_next, scale_next};
   if (rows == 0) return LT_OK;
   static const int grid_cap = [] { const char* e = getenv("LT_LN_BWD_GRID"); return e ? atoi(e) : 256; }();  // one 4-wave block per CU: best measured (115 us vs 133 at 512)
   int grid = min(lt_cdiv(rows, 4), grid_cap);
@@ -760,7 +800,9 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
   }
   const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
                    (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)w % 16 == 0);
-#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, rows, D)
+  LT_CHECK_ARG(!dnext_bf16 || (vec && (uintptr_t)dnext_bf16 % 8 == 0 && (!gamma_next || (uintptr_t)gamma_next % 16 == 0)),
+               "lt_layernorm_bwd_fused: the fused next-branch output needs D %% 4 == 0 and 16-byte aligned rows");
+#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, rows, D, nx, gamma_next, dbias_next)
   if (vec) {
     const int nv = (D + 255) / 256;
     if (dy_is_f32) { if (nv <= 2) LT_LNB(true, 2); else if (nv <= 3) LT_LNB(true, 3); else if (nv <= 4) LT_LNB(true, 4); else LT_LNB(true, 8); }
@@ -778,7 +820,7 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
 }
 extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
                                  float* dbias, const float* rowscale, float scale, int rows, int D, void* stream) {
-  LT_CHECK_ARG(dout && dy_bf16 && (!gamma || (y_bf16 && dgamma)), "lt_layerscale_bwd: null pointer");
+  LT_CHECK_ARG(dout && dy_bf16 && (!y_bf16 || (gamma && dgamma)), "lt_layerscale_bwd: null pointer");
   if (rows == 0) return LT_OK;
   if (D % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dy_bf16 % 8 == 0 && (!y_bf16 || (uintptr_t)y_bf16 % 8 == 0) &&
       (!gamma || (uintptr_t)gamma % 16 == 0)) {
@@ -791,6 +833,30 @@ extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const fl
                        dgamma, dbias, rowscale, scale, rows, D);
   }
   LT_CHECK_LAUNCH("lt_layerscale_bwd");
+}
+// LayerScale gradient without the saved branch output y:  sum_r dD[r,c] * y[r,c]  with y = A W^T + b and dW = dD^T A is
+// sum_k W[c,k] dW[c,k] + b[c] db[c];  dD = dx * gamma  =>  dgamma[c] += (rowdot(W, dW)[c] + b[c] db[c]) / gamma[c].
+// One wave per output channel c.
+__global__ __launch_bounds__(256) void layerscale_dgamma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ dW,
+                                                                const float* __restrict__ bias, const float* __restrict__ dbias,
+                                                                const float* __restrict__ gamma, float* __restrict__ dgamma, int N, int K) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += bf2f(W[(size_t)c * K + k]) * dW[(size_t)c * K + k];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float g = gamma[c];
+    if (bias && dbias) acc += bias[c] * dbias[c];
+    if (fabsf(g) > 1e-30f) dgamma[c] += acc / g;
+  }
+}
+extern "C" int lt_layerscale_dgamma(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
+                                    float* dgamma, int N, int K, void* stream) {
+  LT_CHECK_ARG(W_bf16 && dW && gamma && dgamma && N > 0 && K > 0, "lt_layerscale_dgamma: bad arguments");
+  hipLaunchKernelGGL(layerscale_dgamma_kernel, dim3(lt_cdiv(N, 4)), dim3(256), 0, ST, (const bf16_t*)W_bf16, dW, bias, dbias, gamma,
+                     dgamma, N, K);
+  LT_CHECK_LAUNCH("lt_layerscale_dgamma");
 }
 extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream) {
   LT_CHECK_ARG(x && out, "lt_colsum_bf16: null pointer");

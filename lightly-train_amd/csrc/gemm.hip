@@ -387,18 +387,22 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
   constexpr int WN = BN / 64, WM = 8 / WN, MI = BM2 / (WM * 32);
   constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   const int ntiles = g.tiles_m * g.tiles_n;
-  int id = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-  const int m0 = tm * BM2, n0 = tn * BN;
   const int kbeg = blockIdx.y * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nk = (kend - kbeg) / BK;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
+  // gridDim.x == ntiles: one tile per block.  gridDim.x < ntiles (a multiple of 8): persistent blocks walk the tiles, so the
+  // stores of tile i drain while tile i+1 runs its main loop.
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+  int id;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, j = v >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    if (j >= q + (xcd < r ? 1 : 0)) continue;  // persistent grids are rounded up to a multiple of 8
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * BM2, n0 = tn * BN;
 
   f32x16 acc[MI][2];
 #pragma unroll
@@ -467,6 +471,8 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
     else emit_subtile<EPI>(ge, wl, m0 + wm * (MI * 32) + h * 64, n0 + wn * 64, l, gridDim.y > 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();  // every wave is done with its epilogue scratch before the next tile's DMA overwrites it
   }
 }
 
@@ -1036,7 +1042,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     if (rc != LT_OK) return rc;
     LT_CHECK_LAUNCH("lt_gemm_bf16");
   }
-  if (d->force_kernel == 2 || d->force_kernel == 6) {
+  if (d->force_kernel == 2 || d->force_kernel == 6 || d->force_kernel == 7) {
     LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
@@ -1094,6 +1100,8 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     sp = lt_cdiv(d->K, g.k_per_split);
     if (slab) g.C2 = d->workspace;
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
+    static const int persist = [] { const char* e = getenv("LT_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+    if ((d->force_kernel == 7 || (persist && d->force_kernel == 0)) && !accum && (int)grid2.x > cus) grid2.x = cus;
     if (!d->trans_a && !d->trans_b) rc = bn == 256 ? g256::launch<false, false, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, false, 128>(g, d->epilogue, slab, grid2, st);
     else if (!d->trans_a) rc = bn == 256 ? g256::launch<false, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, true, 128>(g, d->epilogue, slab, grid2, st);
     else rc = bn == 256 ? g256::launch<true, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<true, true, 128>(g, d->epilogue, slab, grid2, st);

@@ -540,6 +540,7 @@ class DINOv2:
             self.s_vit.backward(ws, sg, dxn_g, side=side)
         if side is not None:
             main.wait_stream(side)
+        self.s_vit.finish_layerscale_grads()
 
         ls = self._loss_slots
         # slots hold weighted terms; report the unweighted terms like the reference's log_dict

@@ -148,10 +148,24 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, rows: int, D: int, y_bf16: Op
 
 
 def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, dres: Optional[Tensor], dx: Tensor, dw: Tensor,
-                  db: Tensor, rows: int, D: int, ws: Optional[Tensor] = None) -> None:
-    check(_lib.load().lt_layernorm_bwd(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx),
-                                       _p(dw), _p(db), _p(ws), ws.numel() if ws is not None else 0, rows, D, _stream()),
-          "lt_layernorm_bwd")
+                  db: Tensor, rows: int, D: int, ws: Optional[Tensor] = None, dnext: Optional[Tensor] = None,
+                  gamma_next: Optional[Tensor] = None, rowscale_next: Optional[Tensor] = None, scale_next: float = 1.0,
+                  dbias_next: Optional[Tensor] = None) -> None:
+    """dx = dres + LN'(dy).  With `dnext` (bf16 [rows, D]) the kernel also emits the next branch's upstream gradient
+    dx * gamma_next * scale_next * rowscale_next and adds its column sums to `dbias_next`."""
+    if dnext is not None:
+        _chk(dnext, torch.bfloat16, "layernorm_bwd.dnext")
+    check(_lib.load().lt_layernorm_bwd_fused(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx),
+                                             _p(dw), _p(db), _p(ws), ws.numel() if ws is not None else 0, _p(dnext), _p(gamma_next),
+                                             _p(rowscale_next), scale_next, _p(dbias_next), rows, D, _stream()), "lt_layernorm_bwd")
+
+
+def layerscale_dgamma(w_bf16: Tensor, dw: Tensor, bias: Optional[Tensor], dbias: Optional[Tensor], gamma: Tensor, dgamma: Tensor,
+                      N: int, K: int) -> None:
+    """dgamma += (rowdot(W, dW) + bias * dbias) / gamma  -- the LayerScale gradient from the weight gradient."""
+    _chk(w_bf16, torch.bfloat16, "layerscale_dgamma.w")
+    check(_lib.load().lt_layerscale_dgamma(_p(w_bf16), _p(dw), _p(bias), _p(dbias), _p(gamma), _p(dgamma), N, K, _stream()),
+          "lt_layerscale_dgamma")
 
 
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,

@@ -334,7 +334,7 @@ class ViTEngine:
             att = ws.get(s + "att", (T, D), torch.bfloat16)
             lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
             ops.attention_fwd(qkv, att, lse, nb, N, Hh, dh, scale)
-            y1 = ws.get(s + "y1", (T, D), torch.bfloat16) if (save and g1 is not None) else None
+            y1 = None   # the LayerScale gradient comes from the weight gradient (ops.layerscale_dgamma): no saved branch output
             if a["mode"] == "subset":
                 delta = ws.get(tag + ".delta", (T, D), torch.float32)
                 ops.gemm(att, self.wb(pre + "attn.proj.weight"), delta, M=R, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
@@ -359,7 +359,7 @@ class ViTEngine:
             else:
                 hpre = ws.get(s + "hpre", (T, hid), torch.bfloat16) if save else None
                 ops.gemm(ln2, self.wb(pre + "mlp.fc1.weight"), act, M=R2, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(pre + "mlp.fc1.bias"), out2=hpre)
-            y2 = ws.get(s + "y2", (T, D), torch.bfloat16) if (save and g2 is not None) else None
+            y2 = None
             if m["mode"] == "subset":
                 delta = ws.get(tag + ".delta", (T, D), torch.float32)
                 ops.gemm(act, self.wb(pre + fc2 + ".weight"), delta, M=R2, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + fc2 + ".bias"),
@@ -384,9 +384,24 @@ class ViTEngine:
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> None:
-        """Run `backward_iter` to completion on the current stream."""
+        """Run `backward_iter` to completion on the current stream (the LayerScale gradients still need
+        `finish_layerscale_grads` once all passes of the step are done)."""
         for _ in self.backward_iter(ws, ctx, dxn, side):
             pass
+
+    def finish_layerscale_grads(self) -> None:
+        """LayerScale gradients from the accumulated weight gradients: dgamma = (rowdot(W, dW) + b * db) / gamma
+        (layer_scale.py:27-28 backward without saving the branch outputs).  Call once per step, after every backward pass
+        (global and local crops) and its weight-gradient GEMMs have been enqueued / joined, before the optimizer."""
+        cfg = self.cfg
+        D, hid = cfg.embed_dim, cfg.hidden
+        fc2 = "mlp.w3" if cfg.swiglu else "mlp.fc2"
+        for i in range(cfg.depth):
+            pre = f"blocks.{i}."
+            for gname, lin, k_in in ((pre + "ls1.gamma", pre + "attn.proj", D), (pre + "ls2.gamma", pre + fc2, hid)):
+                if self.has(gname):
+                    ops.layerscale_dgamma(self.wb(lin + ".weight"), self.gw(lin + ".weight"), self.w(lin + ".bias"), self.gw(lin + ".bias"),
+                                          self.w(gname), self.gw(gname), D, k_in)
 
     def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Iterator[str]:
         """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
@@ -406,7 +421,8 @@ class ViTEngine:
         scale = dh ** -0.5
         dxa = ws.get(tag + ".dxa", (T, D), torch.float32)
         dxb = ws.get(tag + ".dxb", (T, D), torch.float32)
-        dD = ws.get(tag + ".dD", (T, D), torch.bfloat16)        # bf16 [T,D] gradient scratch
+        dDs = [ws.get(tag + ".dD", (T, D), torch.bfloat16), ws.get(tag + ".dDb", (T, D), torch.bfloat16)]  # upstream grads of
+        # consecutive branches alternate between two buffers: the LayerNorm backward of one branch writes the next one's
         dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16)
         dH = ws.get(tag + ".dH", (T, 2 * hid if cfg.swiglu else hid), torch.bfloat16)
         dAct = ws.get(tag + ".dAct", (T, hid), torch.bfloat16) if cfg.swiglu else None
@@ -415,8 +431,22 @@ class ViTEngine:
         dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
+        blocks_ctx = ctx["blocks"]
+
+        def fuse_args(br: Dict[str, Any], gname: str, bname: str, buf: Tensor) -> Dict[str, Any]:
+            """LayerNorm-backward arguments that also produce the upstream gradient of branch `br` (not in subset mode)."""
+            if br["mode"] == "subset":
+                return {}
+            return dict(dnext=buf, gamma_next=self.w(gname) if self.has(gname) else None, rowscale_next=br["rowscale"],
+                        scale_next=float(br["scale"]), dbias_next=self.gw(bname))
+
+        fc2n = "mlp.w3" if cfg.swiglu else "mlp.fc2"
+        cur = 0   # index into dDs of the branch about to be processed
+        last = f"blocks.{cfg.depth - 1}."
+        nxt = fuse_args(blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
         ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
-                          self.gw("norm.weight"), self.gw("norm.bias"), T, D)
+                          self.gw("norm.weight"), self.gw("norm.bias"), T, D, **nxt)
+        have = bool(nxt)   # dDs[cur] already holds the upstream gradient of the branch about to be processed
         dx = dxa
         other = dxb
 
@@ -468,10 +498,11 @@ class ViTEngine:
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
             # ---- MLP branch: xo = xm + scale * g2 * (fc2(gelu(fc1(ln2(rows)))))
             R2 = m["rows"]
-            din = branch_grad_in(m, ".dxs")
-            before_write(dD)
-            ops.layerscale_bwd(din, m["y"], g2, dD, self.gw(pre + "ls2.gamma") if g2 is not None else None, R2, D,
-                               dbias=self.gw(pre + fc2 + ".bias"), rowscale=m["rowscale"], scale=m["scale"])
+            dD = dDs[cur]
+            if not have:   # subset rows (gathered), or the producing LayerNorm backward ran on a subset
+                din = branch_grad_in(m, ".dxs")
+                before_write(dD)
+                ops.layerscale_bwd(din, None, g2, dD, None, R2, D, dbias=self.gw(pre + fc2 + ".bias"), rowscale=m["rowscale"], scale=m["scale"])
             wgrad(dD, m["act"], pre + fc2 + ".weight", D, hid, R2)
             before_write(dH)
             if cfg.swiglu:
@@ -486,16 +517,22 @@ class ViTEngine:
                 ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, None, lng,
                                   self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), R2, D)
                 ops.scatter_add_rows(lng, m["idx"], dx, D, R2, D)   # dx += LN'(.) on the subset rows; identity path untouched
+                have = False
             else:
+                before_write(dDs[cur ^ 1])
+                nxt = fuse_args(a, pre + "ls1.gamma", pre + "attn.proj.bias", dDs[cur ^ 1])
                 ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, dx, other,
-                                  self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D)
+                                  self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D, **nxt)
                 dx, other = other, dx
+                have = bool(nxt)
+            cur ^= 1
             # ---- attention branch: xm = x + scale * g1 * proj(attn(qkv(ln1(rows))))
             R1, nb = a["rows"], a["nb"]
-            din = branch_grad_in(a, ".dxs")
-            before_write(dD)
-            ops.layerscale_bwd(din, a["y"], g1, dD, self.gw(pre + "ls1.gamma") if g1 is not None else None, R1, D,
-                               dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
+            dD = dDs[cur]
+            if not have:
+                din = branch_grad_in(a, ".dxs")
+                before_write(dD)
+                ops.layerscale_bwd(din, None, g1, dD, None, R1, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
             wgrad(dD, a["att"], pre + "attn.proj.weight", D, D, R1)
             ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             before_write(dQ)
@@ -508,10 +545,18 @@ class ViTEngine:
                 ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, None, lng,
                                   self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), R1, D)
                 ops.scatter_add_rows(lng, a["idx"], dx, D, R1, D)
+                have = False
             else:
+                nxt = {}
+                if i > 0:
+                    pp = f"blocks.{i - 1}."
+                    before_write(dDs[cur ^ 1])
+                    nxt = fuse_args(blocks_ctx[i - 1]["mlp"], pp + "ls2.gamma", pp + fc2n + ".bias", dDs[cur ^ 1])
                 ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, dx, other,
-                                  self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D)
+                                  self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, **nxt)
                 dx, other = other, dx
+                have = bool(nxt)
+            cur ^= 1
             yield "block"
 
         yield "tail"

@@ -241,6 +241,37 @@ def test_layernorm(rows, D):
         assert rel_err(db, br.grad) < 2e-5
 
 
+def test_layernorm_bwd_fused_next_branch_and_layerscale_dgamma():
+    """(1) LayerNorm backward that also emits the next branch's upstream gradient dx*gamma*rowscale (+ its column sums);
+    (2) the LayerScale gradient from the weight gradient: (rowdot(W, dW) + b*db)/gamma == sum_r dx * y."""
+    o = ops()
+    g = torch.Generator().manual_seed(21)
+    rows, D, K = 1000, 768, 256
+    x = torch.randn(rows, D, generator=g).to(DEV); w = torch.randn(D, generator=g).to(DEV)
+    dy = bf(torch.randn(rows, D, generator=g)).to(DEV); dres = torch.randn(rows, D, generator=g).to(DEV)
+    mean = x.mean(1); rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt()
+    gam = (torch.randn(D, generator=g) * 1e-3).to(DEV); rsc = (torch.rand(rows, generator=g) < 0.8).float().to(DEV) / 0.8
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    dw0, db0, dw1, db1 = (torch.zeros(D, device=DEV) for _ in range(4))
+    o.layernorm_bwd(x, w, mean, rstd, dy, dres, dx0, dw0, db0, rows, D)
+    dn = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16); dbn = torch.zeros(D, device=DEV)
+    o.layernorm_bwd(x, w, mean, rstd, dy, dres, dx1, dw1, db1, rows, D, dnext=dn, gamma_next=gam, rowscale_next=rsc, scale_next=1.25, dbias_next=dbn)
+    assert torch.equal(dx0, dx1) and rel_err(dw1, dw0) < 1e-5 and rel_err(db1, db0) < 1e-5
+    ref_dn = dx0 * gam * rsc[:, None] * 1.25
+    assert rel_err(dn, ref_dn) < 6e-3 and rel_err(dbn, ref_dn.sum(0)) < 1e-4
+
+    # LayerScale gradient identity on a Linear y = A W^T + b with upstream dD = bf16(dx * gamma)
+    A = bf(torch.randn(rows, K, generator=g)).to(DEV); W = bf(torch.randn(D, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(D, generator=g).to(DEV)
+    dxu = torch.randn(rows, D, generator=g).to(DEV)
+    dD = bf(dxu * gam)
+    y = A.float() @ W.float().t() + b
+    dW = dD.float().t() @ A.float(); dbias = dD.float().sum(0)
+    dgam = torch.zeros(D, device=DEV)
+    o.layerscale_dgamma(W, dW.contiguous(), b, dbias, gam, dgam, D, K)
+    assert rel_err(dgam, (dxu * y).sum(0)) < 1e-2   # bf16 rounding of dD only
+
+
 def test_im2col_and_tokens():
     o = ops()
     B, C, H, W, p, D = 3, 3, 32, 48, 16, 24

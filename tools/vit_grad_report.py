@@ -26,6 +26,7 @@ def run(D, depth, heads, mlp_ratio, img, B, masked, ls=1e-5, seed=0):
     ctx = eng.forward(ws, "s", x.cuda(), masks.to(torch.uint8).cuda() if masked else None, save=True)
     dxn = torch.randn(B, n_p + 1, D, generator=g)
     eng.backward(ws, ctx, dxn.cuda().contiguous())
+    eng.finish_layerscale_grads()
     torch.cuda.synchronize()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = O.vit_forward(p, x, dict(patch_size=16, num_heads=heads, depth=depth), masks=masks)
