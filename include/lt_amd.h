@@ -65,7 +65,8 @@ typedef struct lt_gemm_desc {
   float alpha;
   int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
   int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged, 2 = 256-row LDS-DMA, 3 = 128x128 LDS-DMA (2 blocks/CU),
-                                     4 = 256x256 BK=32 4-stage, 5 = persistent 256x128 (2 blocks/CU), 6 = 2 with tail split */
+                                     4 = 256x256 BK=32 4-stage, 5 = persistent 256x128 (2 blocks/CU), 6 = 2 with tail split,
+                                     7 = 2 with a persistent 256-block grid, 8 = 256x256 four-phase ping-pong K-loop (the default for large shapes) */
   const float* rowscale;          /* [M] per-row multiplier of the LayerScale branch (LT_EPI_RESID; per-sample DropPath) or NULL */
   float branch_scale;             /* scalar multiplier of the branch (LT_EPI_RESID; batch-subset stochastic depth b/s); 0 = 1 */
   void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */

@@ -476,6 +476,185 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
   }
 }
 
+// ---- 4-phase ping-pong K-loop ("q" kernel) ------------------------------------------------------------------------------
+// Same 256 x 256 x 64 tile, wave layout (2 x 4, wave tile 128 x 64), LDS images and epilogue as gemm256_kernel; only the K-loop
+// schedule differs.  Each operand stage is four 16-KiB half-tiles [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols
+// 128-255]; a K-tile is computed in four phases, one 64 x 32 output quadrant (8 MFMAs over the whole BK = 64) per phase:
+//   P1: read B-sub0 + A-sub0 | DMA half-tile 1 of tile t+1 | quadrant (0,0)
+//   P2: read B-sub1          | DMA half-tile 2 of tile t+1 | quadrant (0,1)
+//   P3: read A-sub1          | DMA half-tile 3 of tile t+1 | quadrant (1,1)
+//   P4: -                    | DMA half-tile 0 of tile t+2 | quadrant (1,0)      + the only vmcnt wait: vmcnt(2), never 0
+// Phase = [load segment; lgkmcnt(0); s_barrier; MFMA segment at raised priority; s_barrier].  The second wave of every SIMD
+// (wm = 1: waves 4-7) runs one barrier behind the first, so on each SIMD one wave's MFMA segment always overlaps its
+// partner's LDS-read / DMA-issue segment.  Hazards: a half-tile is re-filled >= 1 phase after its last ds_read, whose
+// lgkmcnt(0) precedes the reader's first barrier of that phase (WAR); every wave's vmcnt wait precedes its first barrier of
+// P4 and the data is first read in the next phase (RAW, one barrier more for the staggered group).
+template <bool TA, bool TB, int EPI, bool SLAB>
+__global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HB = 128 * 128, BUF = 4 * HB;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id;
+  {
+    const int v = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, j = v >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int kbeg = blockIdx.y * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg) / BK;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define LT_DMA_HALF(TILE, H)                                                                                     \
+  do {                                                                                                           \
+    char* dst_ = smem + ((TILE) & 1) * BUF + (H) * HB;                                                           \
+    const int k0_ = kbeg + (TILE) * BK;                                                                          \
+    if ((H) < 2) stage_dma<TA, 128>(dst_, g.A, g.lda, g.M, m0 + (H) * 128, k0_);                                 \
+    else stage_dma<TB, 128>(dst_, g.B, g.ldb, g.N, n0 + ((H) - 2) * 128, k0_);                                   \
+  } while (0)
+#define LT_PHASE_SYNC_IN()                      \
+  do {                                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);         \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_setprio(1);              \
+  } while (0)
+#define LT_PHASE_SYNC_OUT()                     \
+  do {                                          \
+    __builtin_amdgcn_s_setprio(0);              \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+  if (nk > 0) {
+    LT_DMA_HALF(0, 0); LT_DMA_HALF(0, 1); LT_DMA_HALF(0, 2); LT_DMA_HALF(0, 3);
+  }
+  if (nk > 1) { LT_DMA_HALF(1, 0); __builtin_amdgcn_s_waitcnt(0xF72); }  // vmcnt(2)
+  else __builtin_amdgcn_s_waitcnt(0xF70);                                  // vmcnt(0)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of each SIMD by one barrier
+
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+  const int bcol = (wn & 1) * 2;
+  for (int t = 0; t < nk; ++t) {
+    const char* buf = smem + (t & 1) * BUF;
+    const char* la = buf + wm * HB;
+    const char* lb = buf + (2 + (wn >> 1)) * HB;
+    // ---- P1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_frag2<TB, 128>(lb, bcol, ks);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128>(la, i, ks);
+    if (t + 1 < nk) LT_DMA_HALF(t + 1, 1);
+    LT_PHASE_SYNC_IN();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[i][0], 0, 0, 0);
+    LT_PHASE_SYNC_OUT();
+    // ---- P2
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_frag2<TB, 128>(lb, bcol + 1, ks);
+    if (t + 1 < nk) LT_DMA_HALF(t + 1, 2);
+    LT_PHASE_SYNC_IN();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[i][1], 0, 0, 0);
+    LT_PHASE_SYNC_OUT();
+    // ---- P3
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128>(la, 2 + i, ks);
+    if (t + 1 < nk) LT_DMA_HALF(t + 1, 3);
+    LT_PHASE_SYNC_IN();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[2 + i][1], 0, 0, 0);
+    LT_PHASE_SYNC_OUT();
+    // ---- P4
+    if (t + 2 < nk) { LT_DMA_HALF(t + 2, 0); __builtin_amdgcn_s_waitcnt(0xF72); }  // everything but these two has landed
+    else __builtin_amdgcn_s_waitcnt(0xF70);
+    LT_PHASE_SYNC_IN();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[2 + i][0], 0, 0, 0);
+    LT_PHASE_SYNC_OUT();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+#undef LT_DMA_HALF
+#undef LT_PHASE_SYNC_IN
+#undef LT_PHASE_SYNC_OUT
+  __syncthreads();
+  GemmArgs ge = g;
+  if (SLAB) {
+    ge.C = (float*)g.C2 + (size_t)blockIdx.y * g.M * g.N;
+    ge.ldc = g.N; ge.alpha = 1.f; ge.bias = nullptr;
+  }
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (SLAB) emit_subtile<EPI_F32>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
+    else emit_subtile<EPI>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, gridDim.y > 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool TA, bool TB, int EPI, bool SLAB>
+int launch_q_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<TA, TB, EPI, SLAB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm256q_kernel<TA, TB, EPI, SLAB>), grid, dim3(NT2), LDS_BYTES, st, g);
+  return LT_OK;
+}
+template <bool TA, bool TB>
+int launch_q(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_q_one<TA, TB, EPI_BF16, false>(g, grid, st);
+    case EPI_BF16_GELU: return launch_q_one<TA, TB, EPI_BF16_GELU, false>(g, grid, st);
+    case EPI_RESID: return launch_q_one<TA, TB, EPI_RESID, false>(g, grid, st);
+    case EPI_F32: return launch_q_one<TA, TB, EPI_F32, false>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_q_one<TA, TB, EPI_BF16_GELUGRAD, false>(g, grid, st);
+    case EPI_F32_ACCUM:
+      return slab ? launch_q_one<TA, TB, EPI_F32_ACCUM, true>(g, grid, st) : launch_q_one<TA, TB, EPI_F32_ACCUM, false>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: unknown epilogue %d", epi); return LT_ERR_INVALID;
+  }
+}
+
 // out[i] (+)= alpha * sum_s slab[s][i]   (deterministic split-K reduction)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int S, float alpha) {
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1042,7 +1221,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     if (rc != LT_OK) return rc;
     LT_CHECK_LAUNCH("lt_gemm_bf16");
   }
-  if (d->force_kernel == 2 || d->force_kernel == 6 || d->force_kernel == 7) {
+  if (d->force_kernel == 2 || d->force_kernel == 6 || d->force_kernel == 7 || d->force_kernel == 8) {
     LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
@@ -1102,6 +1281,12 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
     static const int persist = [] { const char* e = getenv("LT_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
     if ((d->force_kernel == 7 || (persist && d->force_kernel == 0)) && !accum && (int)grid2.x > cus) grid2.x = cus;
+    static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // 4-phase ping-pong K-loop by default
+    if (bn == 256 && (d->force_kernel == 8 || (use_q && d->force_kernel == 0))) {
+      if (!d->trans_a && !d->trans_b) rc = g256::launch_q<false, false>(g, d->epilogue, slab, grid2, st);
+      else if (!d->trans_a) rc = g256::launch_q<false, true>(g, d->epilogue, slab, grid2, st);
+      else rc = g256::launch_q<true, true>(g, d->epilogue, slab, grid2, st);
+    } else
     if (!d->trans_a && !d->trans_b) rc = bn == 256 ? g256::launch<false, false, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, false, 128>(g, d->epilogue, slab, grid2, st);
     else if (!d->trans_a) rc = bn == 256 ? g256::launch<false, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<false, true, 128>(g, d->epilogue, slab, grid2, st);
     else rc = bn == 256 ? g256::launch<true, true, 256>(g, d->epilogue, slab, grid2, st) : g256::launch<true, true, 128>(g, d->epilogue, slab, grid2, st);

@@ -52,7 +52,7 @@ def test_gemm_layouts(M, N, K, ta, tb):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("fk", [2, 3, 4, 5])
+@pytest.mark.parametrize("fk", [2, 3, 4, 5, 8])
 def test_gemm_256_kernel(M, N, K, tb, fk):
     """the 256x256 LDS-DMA kernel (forced) against the fp32 reference, incl. M/N tails and every epilogue it serves."""
     o = ops()
@@ -127,8 +127,9 @@ def test_gemm_persistent_scheduler_reuse():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("fk", [2, 8])
 @pytest.mark.parametrize("M,N,K", [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)])
-def test_gemm_256_wgrad_slab_and_atomic(M, N, K):
+def test_gemm_256_wgrad_slab_and_atomic(M, N, K, fk):
     """dW[M,N] += dY[K,M]^T X[K,N] on the 256-row kernel: deterministic slab split-K and the atomic variant."""
     o = ops()
     g = torch.Generator().manual_seed(K)
@@ -140,7 +141,7 @@ def test_gemm_256_wgrad_slab_and_atomic(M, N, K):
     for ws in (slab, None, slab):
         dW = torch.ones(M, N, device=DEV)
         o.gemm(dY, X, dW, M=M, N=N, K=K, trans_a=True, trans_b=True, epilogue=o.EPI_F32_ACCUM, split_k=2, alpha=0.5, lda=M, ldb=N,
-               force_kernel=2, workspace=ws)
+               force_kernel=fk, workspace=ws)
         assert rel_err(dW, ref) < 2e-5
         outs.append(dW)
     assert torch.equal(outs[0], outs[2]), "slab split-K must be bit-reproducible"

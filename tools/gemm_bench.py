@@ -33,7 +33,7 @@ def bench(name, M, N, K, ta, tb, epi, split=1, iters=10, fk=0, ws=None):
 T = 256 * 197
 D = 768
 FKS = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (2, 5)
-for fk in (FKS if not (len(sys.argv) > 2 and sys.argv[2] == 'tok-only') else ()):
+for fk in (FKS if not (len(sys.argv) > 2 and sys.argv[2] in ('tok-only', 'all')) else ()):
     bench("square 4096 NN bf16", 4096, 4096, 4096, False, False, ops.EPI_BF16, fk=fk)
     bench("square 8192 NN bf16", 8192, 8192, 8192, False, False, ops.EPI_BF16, fk=fk)
     bench("square 4096 NT(tb) bf16", 4096, 4096, 4096, False, True, ops.EPI_BF16, fk=fk)
@@ -54,6 +54,23 @@ if len(sys.argv) > 2 and sys.argv[2] == "tok-only":
         bench("fc2 fwd resid", T, D, 4 * D, False, False, ops.EPI_RESID, fk=fk)
         bench("fc2 dgrad gelugrad", T, 4 * D, D, False, True, ops.EPI_BF16_GELUGRAD, fk=fk)
         bench("fc1 dgrad", T, D, 4 * D, False, True, ops.EPI_BF16, fk=fk)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "all":
+    WS = torch.empty(64 * 1024 * 1024, device="cuda")
+    for fk in FKS:
+        bench("square 4096 NN bf16", 4096, 4096, 4096, False, False, ops.EPI_BF16, fk=fk)
+        bench("square 8192 NN bf16", 8192, 8192, 8192, False, False, ops.EPI_BF16, fk=fk)
+        bench("square 4096 NT(tb) bf16", 4096, 4096, 4096, False, True, ops.EPI_BF16, fk=fk)
+        bench("square 4096 TT f32acc", 4096, 4096, 4096, True, True, ops.EPI_F32_ACCUM, fk=fk)
+        bench("qkv fwd", T, 3 * D, D, False, False, ops.EPI_BF16, fk=fk)
+        bench("proj fwd resid", T, D, D, False, False, ops.EPI_RESID, fk=fk)
+        bench("fc1 fwd gelu", T, 4 * D, D, False, False, ops.EPI_BF16_GELU, fk=fk)
+        bench("fc2 fwd resid", T, D, 4 * D, False, False, ops.EPI_RESID, fk=fk)
+        bench("fc2 dgrad gelugrad", T, 4 * D, D, False, True, ops.EPI_BF16_GELUGRAD, fk=fk)
+        bench("fc1 dgrad", T, D, 4 * D, False, True, ops.EPI_BF16, fk=fk)
+        bench("qkv dgrad", T, D, 3 * D, False, True, ops.EPI_BF16, fk=fk)
+        for nm, mm, nn in (("fc1 wgrad", 4 * D, D), ("fc2 wgrad", D, 4 * D), ("qkv wgrad", 3 * D, D), ("proj wgrad", D, D)):
+            bench(nm + " slab", mm, nn, T, True, True, ops.EPI_F32_ACCUM, split=0, fk=fk, ws=WS)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "fwd-only":
     sys.exit(0)
