@@ -15,6 +15,7 @@
 //   is applied to both operands of every such MFMA.
 // Other head dims (toy models of the reference's tests, head_dim 4) run plain one-block-per-row kernels.
 #include "lt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,6 +179,160 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
   }
   if (!active) return;
+  const int q = q0 + (l & 31);
+  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
+  store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
+}
+
+// ---- forward, 8 waves per block (N > 128): one block covers 256 queries of one (b, h); every K/V chunk is staged once for
+// all eight query tiles, and the NEXT chunk's global loads are issued into registers before the current chunk is computed
+// (the 4-wave kernel above stages K/V once per 128 queries and waits for each chunk's loads with nothing else in flight).
+__device__ __forceinline__ void chunk_load8(uint4 (&kr)[2], uint4 (&vr)[2], const bf16_t* kb, const bf16_t* vb, long ts, int tok0, int N) {
+  const int t = threadIdx.x, c = t & 7, rr = t >> 3;   // 512 threads: 64 rows x 8 sixteen-byte chunks per pass, two passes
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = rr + 64 * i;
+    kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0);
+    if (tok0 + r < N) {
+      kr[i] = *reinterpret_cast<const uint4*>(kb + (long)(tok0 + r) * ts + c * 8);
+      vr[i] = *reinterpret_cast<const uint4*>(vb + (long)(tok0 + r) * ts + c * 8);
+    }
+  }
+}
+__device__ __forceinline__ void chunk_store8(char* ldsK, char* ldsV, const uint4 (&kr)[2], const uint4 (&vr)[2]) {
+  const int t = threadIdx.x, c = t & 7, rr = t >> 3;
+  const int b = c >> 1, half = c & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = rr + 64 * i;
+    *reinterpret_cast<uint4*>(ldsK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kr[i];
+    *reinterpret_cast<uint4*>(ldsV + ((r >> 2) * 4 + b) * 128 + ((((r & 3) + b) & 3) << 5) + (half << 4)) = vr[i];
+  }
+}
+
+// one 32-query x 32-key tile step of the online softmax (shared by the forward kernels)
+__device__ __forceinline__ void fwd_tile(const char* ldsK, const char* ldsV, int tt, int key0, int N, float scale, const bf16x8 (&qf)[4],
+                                         float& m, float& lsum, f32x16 (&o)[2], int hi) {
+  f32x16 s;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, tt, ks), qf[ks], s, 0, 0, 0);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = key0 + crow(e, hi);
+    s[e] = key < N ? s[e] * scale : -INFINITY;
+    mx = fmaxf(mx, s[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mnew = fmaxf(m, mx);
+  const float alpha = __expf(m - mnew);
+  float rs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { s[e] = __expf(s[e] - mnew); rs += s[e]; }
+  rs += __shfl_xor(rs, 32, 64);
+  lsum = lsum * alpha + rs;
+  m = mnew;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+  const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, tt * 32), p0, o[db], 0, 0, 0);
+    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, tt * 32 + 16), p1, o[db], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                        float* __restrict__ lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + IMG;
+  char* scratch = smem + 2 * IMG + (threadIdx.x >> 6) * (32 * 144);
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const long ts = 3L * H * DH;
+  const bf16_t* qb = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* kb = qb + (long)H * DH;
+  const bf16_t* vb = qb + 2L * H * DH;
+  const int q0 = (blockIdx.x * 8 + wave) * 32;
+  const bool active = q0 < N;
+
+  uint4 kr[2], vr[2];
+  chunk_load8(kr, vr, kb, vb, ts, 0, N);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ts, q0, N, ks);
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+  chunk_store8(ldsK, ldsV, kr, vr);
+  __syncthreads();
+  for (int c0 = 0; c0 < N; c0 += CH) {
+    const bool more = c0 + CH < N;
+    if (more) chunk_load8(kr, vr, kb, vb, ts, c0 + CH, N);   // in flight while this chunk is computed
+    if (active) {
+      const int ntile = min(4, (N - c0 + 31) / 32);
+      for (int t = 0; t < ntile; ++t) fwd_tile(ldsK, ldsV, t, c0 + t * 32, N, scale, qf, m, lsum, o, hi);
+    }
+    if (more) {
+      __syncthreads();
+      chunk_store8(ldsK, ldsV, kr, vr);
+      __syncthreads();
+    }
+  }
+  if (!active) return;
+  const int q = q0 + (l & 31);
+  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
+  store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
+}
+
+// ---- forward, short sequences (N <= 64: local crops): two heads per 4-wave block, wave -> (head, query tile); the K / V
+// images hold [head][64 tokens], staged once, no chunk loop.
+__global__ __launch_bounds__(256) void attn_fwd2h_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                         float* __restrict__ lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + IMG;
+  char* scratch = smem + 2 * IMG + (threadIdx.x >> 6) * (32 * 144);
+  const int hp = H >> 1;
+  const int b = blockIdx.x / hp, h0 = (blockIdx.x % hp) * 2;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int hh = wave >> 1, qt = wave & 1;
+  const long ts = 3L * H * DH;
+  const bf16_t* base = qkv + (long)b * N * ts;
+  {  // stage K (row image) and V (transposable image) of both heads: image row r = head (r >> 6), token (r & 63)
+    const int t = threadIdx.x, c = t & 7, rr = t >> 3;
+    const int bb = c >> 1, half = c & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 32 * i, tok = r & 63, hd = h0 + (r >> 6);
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (tok < N) {
+        const bf16_t* p = base + (long)tok * ts + hd * DH + c * 8;
+        kv = *reinterpret_cast<const uint4*>(p + (long)H * DH);
+        vv = *reinterpret_cast<const uint4*>(p + 2L * H * DH);
+      }
+      *reinterpret_cast<uint4*>(ldsK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
+      *reinterpret_cast<uint4*>(ldsV + ((r >> 2) * 4 + bb) * 128 + ((((r & 3) + bb) & 3) << 5) + (half << 4)) = vv;
+    }
+  }
+  const int h = h0 + hh, q0 = qt * 32;
+  const bool active = q0 < N;
+  const bf16_t* qb = base + h * DH;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qb, ts, q0, N, ks);
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+  __syncthreads();
+  if (!active) return;
+  const int ntile = (N + 31) / 32;   // 1 or 2
+  for (int t = 0; t < ntile; ++t) fwd_tile(ldsK, ldsV, hh * 2 + t, t * 32, N, scale, qf, m, lsum, o, hi);
   const int q = q0 + (l & 31);
   if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
   store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
@@ -372,6 +527,257 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   store_qd_tile(scratch, dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, q0, N);
 }
 
+// ================================================================================================ backward, v2
+// Same math and LDS images as the two kernels above, restructured like the v2 forward kernels:
+//   <8 waves, one head>  : a block covers 256 query rows (dQ) / 8 key tiles (dK,dV) of one (b, h); every chunk of the streamed
+//                          side is staged once per block, the next chunk's global loads are in flight (registers) while the
+//                          current one is computed;
+//   <4 waves, two heads> : short sequences (N <= 64, the local crops): wave -> (head, tile), images hold [head][64 tokens].
+// dK / dV leave through a wave-private LDS transpose (the accumulators are [key][d] with lane -> d) as 16-byte row stores.
+template <int NT, bool TWOHEAD>
+struct Stager {
+  static constexpr int PER = 1024 / NT;   // (row, 16-byte chunk) items per thread for a 128-row x 128-byte image
+  // `base`: tensor pointer of batch b at head h (one head) or h0 (two heads); row r of the image = token tok0 + r (one head)
+  // or head r >> 6, token r & 63 (two heads)
+  static __device__ __forceinline__ void load(uint4 (&reg)[PER], const bf16_t* base, long stride, int tok0, int N) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + NT * i, r = idx >> 3, c = idx & 7;
+      const int tok = TWOHEAD ? (r & 63) : tok0 + r;
+      const int hoff = TWOHEAD ? (r >> 6) * DH : 0;
+      reg[i] = make_uint4(0, 0, 0, 0);
+      if (tok < N) reg[i] = *reinterpret_cast<const uint4*>(base + (long)tok * stride + hoff + c * 8);
+    }
+  }
+  static __device__ __forceinline__ void store_rows(char* lds, const uint4 (&reg)[PER]) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + NT * i, r = idx >> 3, c = idx & 7;
+      *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = reg[i];
+    }
+  }
+  static __device__ __forceinline__ void store_tr(char* lds, const uint4 (&reg)[PER]) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + NT * i, r = idx >> 3, c = idx & 7, b = c >> 1, half = c & 1;
+      *reinterpret_cast<uint4*>(lds + ((r >> 2) * 4 + b) * 128 + ((((r & 3) + b) & 3) << 5) + (half << 4)) = reg[i];
+    }
+  }
+};
+
+// write a [32 tok][64 d] accumulator pair held as D[tok][d] (lane -> d column, regs -> token rows) as bf16 rows dst[tok][0..63]
+__device__ __forceinline__ void store_td_tile(char* scratch, const f32x16 (&a)[2], bf16_t* dst, long tok_stride, int tok0, int ntok_valid) {
+  const int l = threadIdx.x & 63, hi = l >> 5;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      *reinterpret_cast<bf16_t*>(scratch + crow(e, hi) * 144 + (db * 32 + (l & 31)) * 2) = f2bf(a[db][e]);
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private scratch
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + (l >> 3), c = l & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(scratch + r * 144 + c * 16);
+    if (tok0 + r < ntok_valid) *reinterpret_cast<uint4*>(dst + (long)(tok0 + r) * tok_stride + c * 8) = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+template <int NW, bool TWOHEAD>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_v2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
+                                                                 float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using St = Stager<NW * 64, TWOHEAD>;
+  char* ldsK = smem;
+  char* ldsKt = smem + IMG;
+  char* ldsV = smem + 2 * IMG;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  int b, h0, h, q0, tb;
+  if (TWOHEAD) {
+    const int hp = H >> 1;
+    b = blockIdx.x / hp; h0 = (blockIdx.x % hp) * 2; h = h0 + (wave >> 1); q0 = (wave & 1) * 32; tb = (wave >> 1) * 2;
+  } else {
+    b = blockIdx.y / H; h0 = h = blockIdx.y % H; q0 = (blockIdx.x * NW + wave) * 32; tb = 0;
+  }
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qb = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* kst = qkv + (long)b * N * ts + (long)H * DH + h0 * DH;   // staging bases (head h0)
+  const bf16_t* vst = qkv + (long)b * N * ts + 2L * H * DH + h0 * DH;
+  const bf16_t* dob = dout + (long)b * N * tso + h * DH;
+  const bf16_t* ob = out + (long)b * N * tso + h * DH;
+  const bool active = q0 < N;
+  const int q = q0 + (l & 31);
+
+  uint4 kr[St::PER], vr[St::PER];
+  St::load(kr, kst, ts, 0, N);
+  St::load(vr, vst, ts, 0, N);
+  const float lse_q = (q < N) ? lse[((long)b * H + h) * N + q] : INFINITY;
+  bf16x8 qf[4], dof[4];
+  float del_q = 0.f;   // delta[q] = sum_d dO[q,d] * O[q,d]
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = frag_global(qb, ts, q0, N, ks);
+    dof[ks] = frag_global(dob, tso, q0, N, ks);
+    const bf16x8 of = frag_global(ob, tso, q0, N, ks);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) del_q += (float)dof[ks][j] * (float)of[j];
+  }
+  del_q += __shfl_xor(del_q, 32, 64);
+  if (active && hi == 0 && q < N) delta[((long)b * H + h) * N + q] = del_q;
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+  St::store_rows(ldsK, kr); St::store_tr(ldsKt, kr); St::store_rows(ldsV, vr);
+  __syncthreads();
+  const int nloop = TWOHEAD ? CH : N;   // two heads: a single chunk of [2][64] tokens
+  for (int c0 = 0; c0 < nloop; c0 += CH) {
+    const bool more = !TWOHEAD && c0 + CH < N;
+    if (more) { St::load(kr, kst, ts, c0 + CH, N); St::load(vr, vst, ts, c0 + CH, N); }
+    if (active) {
+      const int ntile = TWOHEAD ? (N + 31) / 32 : min(4, (N - c0 + 31) / 32);
+      for (int t = 0; t < ntile; ++t) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, tb + t, ks), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsV, tb + t, ks), dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = c0 + t * 32 + crow(e, hi);
+          const float p = key < N ? __expf(s[e] * scale - lse_q) : 0.f;
+          dp[e] = p * (dp[e] - del_q) * scale;
+        }
+        const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, (tb + t) * 32), d0, dq[db], 0, 0, 0);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, (tb + t) * 32 + 16), d1, dq[db], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();
+      St::store_rows(ldsK, kr); St::store_tr(ldsKt, kr); St::store_rows(ldsV, vr);
+      __syncthreads();
+    }
+  }
+  __syncthreads();   // the images become the store scratch
+  if (!active) return;
+  store_qd_tile(smem + wave * (32 * 144), dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, q0, N);
+}
+
+template <int NW, bool TWOHEAD>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using St = Stager<NW * 64, TWOHEAD>;
+  char* ldsQ = smem;            // row image of Q
+  char* ldsQt = smem + IMG;     // T image of Q
+  char* ldsD = smem + 2 * IMG;  // row image of dO
+  char* ldsDt = smem + 3 * IMG; // T image of dO
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * IMG);  // lse [CH], delta [CH]  (image-row indexed)
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  int b, h0, h, k0, tb;
+  if (TWOHEAD) {
+    const int hp = H >> 1;
+    b = blockIdx.x / hp; h0 = (blockIdx.x % hp) * 2; h = h0 + (wave >> 1); k0 = (wave & 1) * 32; tb = (wave >> 1) * 2;
+  } else {
+    b = blockIdx.y / H; h0 = h = blockIdx.y % H; k0 = (blockIdx.x * NW + wave) * 32; tb = 0;
+  }
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qst = qkv + (long)b * N * ts + h0 * DH;
+  const bf16_t* dst = dout + (long)b * N * tso + h0 * DH;
+  const bf16_t* kb = qkv + (long)b * N * ts + (long)H * DH + h * DH;
+  const bf16_t* vb = qkv + (long)b * N * ts + 2L * H * DH + h * DH;
+  const bool active = k0 < N;
+  const bool key_ok = k0 + (l & 31) < N;
+
+  uint4 qr[St::PER], dr[St::PER];
+  St::load(qr, qst, ts, 0, N);
+  St::load(dr, dst, tso, 0, N);
+  float l_reg = INFINITY, d_reg = 0.f;
+  auto load_stats = [&](int tok0) {
+    if (threadIdx.x < CH) {
+      const int r = threadIdx.x;
+      const int tok = TWOHEAD ? (r & 63) : tok0 + r;
+      const long row = ((long)b * H + (TWOHEAD ? h0 + (r >> 6) : h)) * N + tok;
+      l_reg = tok < N ? lse[row] : INFINITY;
+      d_reg = tok < N ? delta[row] : 0.f;
+    }
+  };
+  auto store_all = [&]() {
+    St::store_rows(ldsQ, qr); St::store_tr(ldsQt, qr); St::store_rows(ldsD, dr); St::store_tr(ldsDt, dr);
+    if (threadIdx.x < CH) { ldsL[threadIdx.x] = l_reg; ldsL[CH + threadIdx.x] = d_reg; }
+  };
+  load_stats(0);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global(kb, ts, k0, N, ks); vf[ks] = frag_global(vb, ts, k0, N, ks); }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+  store_all();
+  __syncthreads();
+  const int nloop = TWOHEAD ? CH : N;
+  for (int c0 = 0; c0 < nloop; c0 += CH) {
+    const bool more = !TWOHEAD && c0 + CH < N;
+    if (more) { St::load(qr, qst, ts, c0 + CH, N); St::load(dr, dst, tso, c0 + CH, N); load_stats(c0 + CH); }
+    if (active) {
+      const int ntile = TWOHEAD ? (N + 31) / 32 : min(4, (N - c0 + 31) / 32);
+      for (int t = 0; t < ntile; ++t) {
+        const int it = tb + t;
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
+        }
+        // rows = queries crow(e,hi), col = key lane
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[CH + it * 32 + 8 * g + 4 * hi]);
+          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g + j;
+            const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - dlv[j]) * scale;
+          }
+        }
+        const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8), d0 = pack8(dp, 0), d1 = pack8(dp, 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();
+      store_all();
+      __syncthreads();
+    }
+  }
+  __syncthreads();   // images -> store scratch
+  if (!active) return;
+  char* scratch = smem + wave * (32 * 144);
+  store_td_tile(scratch, dk, dqkv + (long)b * N * ts + (long)H * DH + h * DH, ts, k0, N);
+  store_td_tile(scratch, dv, dqkv + (long)b * N * ts + 2L * H * DH + h * DH, ts, k0, N);
+}
+
 // ================================================================================================ generic head dims
 // one block (64 threads) per (b, h, q); scores in LDS (N <= 4096)
 __global__ void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N,
@@ -459,9 +865,25 @@ extern "C" int lt_attention_fwd(const void* qkv, void* out_bf16, float* lse, int
   LT_CHECK_ARG(qkv && out_bf16 && B > 0 && N > 0 && H > 0 && dh > 0, "lt_attention_fwd: bad arguments");
   if (dh == DH) {
     LT_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out_bf16 & 15) == 0, "lt_attention_fwd: 16-byte alignment required");
-    dim3 grid(lt_cdiv(N, 128), B * H);
-    const size_t smem = 2 * IMG + 4 * 32 * 144;
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), smem, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse, N, H, scale);
+    static const int variant = [] { const char* e = getenv("LT_ATTN_FWD"); return e ? atoi(e) : 1; }();
+    if (variant && N <= 64 && H % 2 == 0) {          // two heads per block
+      hipLaunchKernelGGL(attn_fwd2h_kernel, dim3(B * (H / 2)), dim3(256), 2 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
+                         (bf16_t*)out_bf16, lse, N, H, scale);
+    } else if (variant && N > 128) {                 // eight query tiles per block, K/V chunks prefetched through registers
+      static bool configured = false;
+      const size_t smem8 = 2 * IMG + 8 * 32 * 144;
+      if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+        if (e != hipSuccess) { lt_set_error("lt_attention_fwd: cannot enable %zu B of LDS: %s", smem8, hipGetErrorString(e)); return LT_ERR_HIP; }
+        configured = true;
+      }
+      hipLaunchKernelGGL(attn_fwd8_kernel, dim3(lt_cdiv(N, 256), B * H), dim3(512), smem8, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse,
+                         N, H, scale);
+    } else {
+      dim3 grid(lt_cdiv(N, 128), B * H);
+      const size_t smem = 2 * IMG + 4 * 32 * 144;
+      hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), smem, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse, N, H, scale);
+    }
   } else {
     LT_CHECK_ARG(N <= 8192, "lt_attention_fwd: generic path supports N <= 8192 (N=%d)", N);
     hipLaunchKernelGGL(attn_fwd_generic_kernel, dim3(N, B * H), dim3(64), N * sizeof(float), ST, (const bf16_t*)qkv,
@@ -477,6 +899,32 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
   const long total = (long)B * N * H;
   if (dh == DH) {
     const int nkt = lt_cdiv(N, 32);
+    static const int variant = [] { const char* e = getenv("LT_ATTN_BWD"); return e ? atoi(e) : 1; }();
+    if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels
+      static bool configured = false;
+      const int lds_dq = 3 * IMG, lds_kv = 4 * IMG + 2 * CH * (int)sizeof(float);
+      if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v2_kernel<8, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v2_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", lds_kv, hipGetErrorString(e)); return LT_ERR_HIP; }
+        configured = true;
+      }
+      // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+      if (N <= 64 && H % 2 == 0) {
+        hipLaunchKernelGGL((attn_bwd_dq_v2_kernel<4, true>), dim3(B * (H / 2)), dim3(256), lds_dq, ST, (const bf16_t*)qkv,
+                           (const bf16_t*)out_bf16, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<4, true>), dim3(B * (H / 2)), dim3(256), lds_kv, ST, (const bf16_t*)qkv,
+                           (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+      } else {
+        hipLaunchKernelGGL((attn_bwd_dq_v2_kernel<8, false>), dim3(lt_cdiv(N, 256), B * H), dim3(512), lds_dq, ST, (const bf16_t*)qkv,
+                           (const bf16_t*)out_bf16, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<8, false>), dim3(lt_cdiv(nkt, 8), B * H), dim3(512), lds_kv, ST, (const bf16_t*)qkv,
+                           (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);
+      }
+      LT_CHECK_LAUNCH("lt_attention_bwd");
+    }
     // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(lt_cdiv(N, 128), B * H), dim3(256), 3 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
                        (const bf16_t*)out_bf16, (const bf16_t*)dout_bf16, lse, ws, (bf16_t*)dqkv, N, H, scale);

@@ -1,0 +1,29 @@
+"""Attention forward / backward timings on the step's shapes (ViT-B/16, per-GPU batch 128)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lightly_train_amd
+from lightly_train_amd import ops
+
+def bench(name, B, N, H=12, dh=64, iters=10):
+    qkv = torch.randn(B, N, 3 * H * dh, device="cuda").to(torch.bfloat16)
+    out = torch.empty(B, N, H * dh, device="cuda", dtype=torch.bfloat16); lse = torch.empty(B, H, N, device="cuda")
+    dout = torch.randn(B, N, H * dh, device="cuda").to(torch.bfloat16)
+    ws = torch.empty(ops.attention_bwd_ws_floats(B, N, H, dh), device="cuda"); dqkv = torch.empty_like(qkv)
+    res = {}
+    for tag, fn in (("fwd", lambda: ops.attention_fwd(qkv, out, lse, B, N, H, dh, dh ** -0.5)),
+                    ("bwd", lambda: ops.attention_bwd(qkv, out, dout, lse, ws, dqkv, B, N, H, dh, dh ** -0.5))):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        res[tag] = e0.elapsed_time(e1) / iters * 1e3
+    fl = 4.0 * B * H * N * N * dh
+    print(f"{name:28s} B={B:5d} N={N:4d}: fwd {res['fwd']:7.1f} us ({fl / res['fwd'] / 1e6:6.1f} TF/s)   bwd {res['bwd']:7.1f} us ({2.5 * fl / res['bwd'] / 1e6:6.1f} TF/s)")
+
+bench("global 224/16", 256, 197)
+bench("local 96/16", 1024, 37)
+bench("local 98->112/16", 1024, 50)
+bench("global 224/14", 256, 257)
+bench("518/14 (ViT-L shape, H=16)", 8, 1370, H=16)
