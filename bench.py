@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--out-dim", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every launch on one stream (clean per-kernel durations)")
     args = ap.parse_args()
 
@@ -117,6 +118,8 @@ def main() -> None:
     g = torch.Generator().manual_seed(1234 + rank)
     views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [
         torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
+    if args.host_inputs:
+        views = [v.cpu().pin_memory() for v in views]
     random.seed(100 + rank)
 
     def barrier() -> None:
@@ -190,7 +193,8 @@ def main() -> None:
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "
                                    f"K={args.out_dim} prototypes, softmax centering, drop-path 0",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
+                       "inputs": "pinned host memory (H2D inside the timed region)" if args.host_inputs else "resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

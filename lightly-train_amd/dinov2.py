@@ -363,7 +363,8 @@ class DINOv2:
         n_global = 2
         n_local = len(views) - n_global
         terms = (n_global - 1) * n_global + max(n_local * n_global, 1)
-        gv = torch.cat(views[:n_global]).to(dev, torch.float32)
+        views = [v.to(dev, torch.float32, non_blocking=True) for v in views]   # pinned host views: async H2D per view, cat on the GPU
+        gv = torch.cat(views[:n_global])
         n_crops = gv.shape[0]
         B = n_crops // n_global
         p = cfg.patch_size
