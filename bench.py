@@ -96,12 +96,17 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP kernels)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("LT_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only to smoke-test the N>1 code path on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import lightly_train_amd  # noqa: F401
     from lightly_train_amd import ops
@@ -150,7 +155,7 @@ def main() -> None:
                                   2048, 256, m_tokens) / 1e9
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:   # every rank runs the instrumented step (it contains the step's collectives); rank 0 reports
         # one instrumented step: HIP events (torch.cuda.Event on the launch stream = torch's current stream)
         # around every MFMA GEMM launch; achieved = algorithmic GEMM FLOPs / summed GEMM time.
         recs = []
@@ -212,6 +217,7 @@ def main() -> None:
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

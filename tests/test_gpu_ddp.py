@@ -1,0 +1,92 @@
+"""-m gpu: the N > 1 data-parallel step end to end on real kernels.  The GPU boxes have one device, so two ranks share
+cuda:0 and talk over gloo (RCCL refuses two ranks on one GPU); every collective of the step is exercised: async center
+all-reduces (softmax centering), synchronous Sinkhorn row sums, the bucketed gradient mean.
+
+Both ranks are fed the SAME views and masks.  Then every all-reduce averages identical values and the result must equal
+the single-process run with the same per-rank batch and the same `global_batch_size` (LR scale) -- which pins the
+scaling factors (1/world on gradients, /(2B*world) on the DINO center, per-rank mean/world on the iBOT center, the
+Sinkhorn totals) and the ordering of async handles across streams."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_steps(center_method: str, n_steps: int = 3):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_step as T
+
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_softmax.pt"), weights_only=False)
+    m = T.build(fx, koleo_loss_weight=0.0, center_method=center_method)
+    losses = []
+    for s in range(n_steps):
+        rec = fx["steps"][min(s, len(fx["steps"]) - 1)]
+        views = T.synth_views(rec["view_seed"] + 10 * s, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        res = m.train_step(views, masks=rec["masks"])
+        losses.append(float(res.loss))
+    torch.cuda.synchronize()
+    return losses, m.student.data.detach().cpu().clone(), m.teacher.data.detach().cpu().clone(), m.dino_center.cpu().clone()
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str, center_method: str) -> None:
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        out = _run_steps(center_method)
+        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("center_method", ["softmax", "sinkhorn_knopp"])
+def test_two_ranks_match_single_process(tmp_path, center_method):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), center_method), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    single = _run_steps(center_method)
+    for a, b in ((r0, r1), (r0, single)):
+        assert a[0] == pytest.approx(b[0], rel=2e-4), "loss per step"
+        for i, nm in ((1, "student"), (2, "teacher"), (3, "dino center")):
+            d = (a[i] - b[i]).abs().max().item()
+            assert d <= 2e-4 * max(1.0, b[i].abs().max().item()), (nm, d)
+
+
+def test_bench_contract_two_ranks():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), with the two ranks
+    folded onto cuda:0 over gloo (LT_BENCH_BACKEND): every rank has to take part in every step that contains collectives
+    (incl. the instrumented roofline step), rank 0 prints ONE JSON line with whole-job throughput."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, LT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--model", "vit_small", "--batch", "8", "--out-dim", "4096", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    assert out["value"] == pytest.approx(16 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1e3), rel=1e-2)
+    assert out["roofline"]["launches_per_step"] > 0 and out["cpu_baseline"] is None

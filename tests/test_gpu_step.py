@@ -47,8 +47,10 @@ def build(fx, **over):
     vc = ViTConfig(embed_dim=D, depth=cfgd["depth"], num_heads=cfgd["num_heads"], patch_size=cfgd["patch_size"], img_size=fx["g_size"],
                    num_register_tokens=cfgd.get("num_register_tokens", 0), interpolate_offset=cfgd.get("interpolate_offset", 0.1),
                    interpolate_antialias=cfgd.get("interpolate_antialias", False), **extra)
-    args = DINOv2Args(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"],
-                      center_method=mk.get("center_method", "softmax"), ibot_separate_head=mk.get("ibot_separate_head", False), **over)
+    kw = dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"],
+              center_method=mk.get("center_method", "softmax"), ibot_separate_head=mk.get("ibot_separate_head", False))
+    kw.update(over)
+    args = DINOv2Args(**kw)
     return DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=sb,
                   student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"],
                   student_ibot_head_state=fx["init"].get("student_ibot_head"), teacher_ibot_head_state=fx["init"].get("teacher_ibot_head"))
