@@ -91,6 +91,12 @@ int lt_resize_4tap(const float* in, float* out, const int32_t* iy, const float* 
                    int planes, int H, int W, int Ho, int Wo, void* stream);
 /* img f32 [B,C,H,W] -> cols bf16 [B*gh*gw, kpad], k = (c*p + py)*p + px, zero padded to kpad */
 int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H, int W, int p, int kpad, void* stream);
+/* Rotary position embedding of DINOv3 (reference _models/dinov3/dinov3_src/layers/attention.py:23-34,79-103): in place on
+ * the packed qkv [B,N,3,H,dh] bf16, q and k of tokens >= prefix become x*cos + rotate_half(x)*sin; sin/cos f32 [N-prefix, dh]
+ * (layers/rope_position_encoding.py:62-117, computed by the caller); inverse = 1 applies the transposed rotation (backward) */
+int lt_rope_apply(void* qkv_bf16, const float* sin_t, const float* cos_t, int B, int N, int H, int dh, int prefix, int inverse,
+                  void* stream);
+
 /* SwiGLU FFN gate (reference layers/swiglu_ffn.py:31-35): x12 bf16 [rows, 2H] = [x1 | x2], out bf16 [rows, H] =
  * silu(x1) * x2.  Backward: d12 bf16 [rows, 2H] = [dh * x2 * silu'(x1) | dh * silu(x1)].  H % 8 == 0. */
 int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream);

@@ -35,6 +35,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_debug_gemm_log": [vp, i32],
+    "lt_rope_apply": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
     "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
     "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -105,6 +105,51 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------ RoPE (DINOv3)
+// In place on the packed qkv activation [B, N, 3, H, dh] (bf16): q and k of the tokens >= prefix (cls / storage tokens are not
+// rotated) become x*cos + rotate_half(x)*sin with rotate_half([x1 | x2]) = [-x2 | x1]  (dinov3 layers/attention.py:23-34,79-103).
+// sin / cos: f32 [N - prefix, dh].  inverse = 1 applies the transposed rotation (backward of the same op).
+// One thread per (token, q|k, head, 4-wide group of the first half).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ sin_t, const float* __restrict__ cos_t,
+                                                   long total, int N, int H, int dh, int prefix, int inverse) {
+  const int hq = dh >> 3;                 // groups of 4 in the first half
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % hq);
+  long r = idx / hq;
+  const int h = (int)(r % H); r /= H;
+  const int which = (int)(r % 2); r /= 2;   // 0 = q, 1 = k
+  const int n = (int)(r % N);
+  const long b = r / N;
+  if (n < prefix) return;
+  const int half = dh >> 1, d = g * 4;
+  bf16_t* p = qkv + (((b * N + n) * 3 + which) * H + h) * (long)dh;
+  const float* sn = sin_t + (long)(n - prefix) * dh;
+  const float* cs = cos_t + (long)(n - prefix) * dh;
+  const uint2 u1 = *reinterpret_cast<const uint2*>(p + d);
+  const uint2 u2 = *reinterpret_cast<const uint2*>(p + half + d);
+  const float x1[4] = {bf2f((bf16_t)(u1.x & 0xffff)), bf2f((bf16_t)(u1.x >> 16)), bf2f((bf16_t)(u1.y & 0xffff)), bf2f((bf16_t)(u1.y >> 16))};
+  const float x2[4] = {bf2f((bf16_t)(u2.x & 0xffff)), bf2f((bf16_t)(u2.x >> 16)), bf2f((bf16_t)(u2.y & 0xffff)), bf2f((bf16_t)(u2.y >> 16))};
+  float y1[4], y2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float c1 = cs[d + j], s1 = sn[d + j], c2 = cs[half + d + j], s2 = sn[half + d + j];
+    if (!inverse) { y1[j] = x1[j] * c1 - x2[j] * s1; y2[j] = x2[j] * c2 + x1[j] * s2; }
+    else { y1[j] = x1[j] * c1 + x2[j] * s2; y2[j] = x2[j] * c2 - x1[j] * s1; }
+  }
+  *reinterpret_cast<uint2*>(p + d) = make_uint2(pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3]));
+  *reinterpret_cast<uint2*>(p + half + d) = make_uint2(pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3]));
+}
+extern "C" int lt_rope_apply(void* qkv_bf16, const float* sin_t, const float* cos_t, int B, int N, int H, int dh, int prefix,
+                             int inverse, void* stream) {
+  LT_CHECK_ARG(qkv_bf16 && sin_t && cos_t && B > 0 && N > 0 && H > 0 && dh > 0 && dh % 8 == 0 && prefix >= 0 && prefix <= N,
+               "lt_rope_apply: bad arguments (head_dim must be a multiple of 8)");
+  const long total = (long)B * N * 2 * H * (dh >> 3);
+  hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv_bf16, sin_t, cos_t,
+                     total, N, H, dh, prefix, inverse);
+  LT_CHECK_LAUNCH("lt_rope_apply");
+}
+
 // ------------------------------------------------------------------------------------ SwiGLU
 // x12 [rows, 2H] bf16 = [x1 | x2];  hidden = silu(x1) * x2   (swiglu_ffn.py:31-35).  8 columns per thread.
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }

@@ -1,0 +1,57 @@
+"""DINOv3 ViT (frozen distillation teacher) on the same HIP engine as the DINOv2 ViT.
+
+Reference: LT/_models/dinov3/dinov3_src/models/vision_transformer.py:75-320 (DinoVisionTransformer),
+layers/attention.py:23-133 (SelfAttention + RoPE), layers/rope_position_encoding.py:62-127, dinov3_vit.py:40-90 (wrapper).
+Differences from the DINOv2 ViT that matter for the forward pass: no learned position embedding -- rotary embedding on q / k
+of the patch tokens in every block; `storage_tokens` instead of `register_tokens`; LayerNorm eps 1e-5 ("layernormbf16");
+the K third of the qkv bias is masked to zero (`LinearKMaskedBias`).  The engine state keeps the DINOv2 key names, so a DINOv3
+state dict is converted once at load time.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+from torch import Tensor
+
+from .vit import ViTConfig
+
+
+def dinov3_vit_config(embed_dim: int, depth: int, num_heads: int, patch_size: int = 16, img_size: int = 224, ffn_ratio: float = 4.0,
+                      n_storage_tokens: int = 4, layerscale_init: float | None = 1e-5, rope_base: float = 100.0,
+                      ln_eps: float = 1e-5, ffn_layer: str = "mlp") -> ViTConfig:
+    """`dinov3_vitl16` = (1024, 24, 16) with the defaults (hub/backbones.py:467-512)."""
+    return ViTConfig(embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=ffn_ratio, patch_size=patch_size, img_size=img_size,
+                     init_values=layerscale_init, num_register_tokens=n_storage_tokens, ffn_layer=ffn_layer, ln_eps=ln_eps,
+                     rope_base=rope_base)
+
+
+def convert_dinov3_state(state: Dict[str, Tensor], cfg: ViTConfig) -> Dict[str, Tensor]:
+    """Reference DINOv3 `state_dict()` -> the engine's (DINOv2-named) backbone state: storage_tokens -> register_tokens, the
+    qkv bias multiplied by its mask (layers/attention.py:37-57), a zero pos_embed, `rope_embed.periods` dropped (the sin / cos
+    tables are rebuilt from `cfg.rope_base`, checked here against the stored periods)."""
+    out: Dict[str, Tensor] = {}
+    D = cfg.embed_dim
+    for k, v in state.items():
+        if k == "storage_tokens":
+            out["register_tokens"] = v.detach().clone().float()
+        elif k == "rope_embed.periods":
+            dh = cfg.head_dim
+            expect = float(cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
+            if not torch.allclose(v.float().cpu(), expect, rtol=1e-2):
+                raise ValueError("rope_embed.periods of the checkpoint do not match base ** (2 i / (head_dim / 2)) for cfg.rope_base")
+        elif k.endswith("attn.qkv.bias_mask"):
+            continue
+        elif k.endswith("attn.qkv.bias"):
+            mask = state.get(k + "_mask")
+            b = v.detach().clone().float()
+            if mask is not None:
+                b = b * mask.to(b.dtype).nan_to_num(nan=0.0)
+            out[k] = b
+        elif k.startswith(("cls_norm.", "local_cls_norm.", "head.")):
+            raise NotImplementedError(f"untied cls norms / heads are not supported by the engine ({k})")
+        else:
+            out[k] = v.detach().clone().float()
+    n_p = (cfg.img_size // cfg.patch_size) ** 2
+    out["pos_embed"] = torch.zeros(1, n_p + 1, D)
+    return out

@@ -197,6 +197,12 @@ def cast_bf16(src: Tensor, dst: Tensor) -> None:
     check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
 
 
+def rope_apply(qkv: Tensor, sin_t: Tensor, cos_t: Tensor, B: int, N: int, H: int, dh: int, prefix: int, inverse: bool = False) -> None:
+    """DINOv3 rotary embedding, in place on q and k of the packed bf16 qkv activation (tokens >= prefix)."""
+    _chk(qkv, torch.bfloat16, "rope.qkv"); _chk(sin_t, torch.float32, "rope.sin"); _chk(cos_t, torch.float32, "rope.cos")
+    check(_lib.load().lt_rope_apply(_p(qkv), _p(sin_t), _p(cos_t), B, N, H, dh, prefix, int(inverse), _stream()), "lt_rope_apply")
+
+
 def swiglu_fwd(x12: Tensor, out: Tensor, rows: int, H: int) -> None:
     """out[rows, H] = silu(x12[:, :H]) * x12[:, H:]  (bf16, reference swiglu_ffn.py:31-35)."""
     _chk(x12, torch.bfloat16, "swiglu.x12"); _chk(out, torch.bfloat16, "swiglu.out")

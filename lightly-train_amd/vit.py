@@ -36,6 +36,9 @@ class ViTConfig:
     drop_path_uniform: bool = False
     num_register_tokens: int = 0
     ffn_layer: str = "mlp"   # "mlp" | "swiglu" | "swiglufused" (vision_transformer.py:179-185)
+    ln_eps: float = 1e-6     # DINOv3 "layernormbf16" uses 1e-5
+    rope_base: Optional[float] = None   # DINOv3: rotary embedding on q/k of the patch tokens instead of a learned pos_embed
+                                        # (zero pos_embed in the state); eval-mode coordinates (no shift / jitter / rescale)
 
     @property
     def swiglu(self) -> bool:
@@ -189,6 +192,7 @@ class ViTEngine:
         self.prefix = prefix
         self.dev = params.device
         self._pos_maps: Dict[Tuple[int, int], Optional[Tensor]] = {}
+        self._rope: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
         self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
         D = cfg.embed_dim
         kreal = cfg.in_chans * cfg.patch_size ** 2
@@ -246,6 +250,22 @@ class ViTEngine:
         self._pos_maps[key] = mp
         return mp
 
+    def _rope_tables(self, gh: int, gw: int) -> Tuple[Tensor, Tensor]:
+        """(sin, cos) f32 [gh*gw, head_dim] of DINOv3's RopePositionEmbedding in eval mode (layers/rope_position_encoding.py:
+        62-117, normalize_coords="separate", periods = base ** (2 i / (head_dim/2)), i < head_dim/4; :118-127)."""
+        key = (gh, gw)
+        if key not in self._rope:
+            dh = self.cfg.head_dim
+            periods = float(self.cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
+            ch = torch.arange(0.5, gh, dtype=torch.float32) / gh
+            cw = torch.arange(0.5, gw, dtype=torch.float32) / gw
+            coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
+            coords = 2.0 * coords - 1.0
+            angles = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2)
+            angles = torch.cat((angles, angles), dim=-1)
+            self._rope[key] = (torch.sin(angles).contiguous().to(self.dev), torch.cos(angles).contiguous().to(self.dev))
+        return self._rope[key]
+
     def _pos_for_grid(self, ws: Workspace, tag: str, gh: int, gw: int) -> Tensor:
         D = self.cfg.embed_dim
         pe = self.w("pos_embed").view(-1, D)
@@ -281,10 +301,11 @@ class ViTEngine:
             H, W = nh, nw
         gh, gw = H // p, W // p
         n_reg = cfg.num_register_tokens
+        rope = self._rope_tables(gh, gw) if cfg.rope_base is not None else None
         n_p, N = gh * gw, gh * gw + 1 + n_reg
         T = B * N
         scale = dh ** -0.5
-        ctx: Dict[str, Any] = dict(B=B, N=N, n_p=n_p, gh=gh, gw=gw, T=T, masks=masks, tag=tag)
+        ctx: Dict[str, Any] = dict(B=B, N=N, n_p=n_p, gh=gh, gw=gw, T=T, masks=masks, tag=tag, rope=rope)
 
         cols = ops.im2col(img.contiguous(), p, self.kpad)
         patch = ws.get(tag + ".patch", (B * n_p, D), torch.float32)
@@ -328,11 +349,13 @@ class ViTEngine:
             R, nb = a["rows"], a["nb"]
             ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16)
             a["mean"], a["rstd"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
-            ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"])
+            ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"], eps=cfg.ln_eps)
             qkv = ws.get(s + "qkv", (T, 3 * D), torch.bfloat16)
             ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=R, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
             att = ws.get(s + "att", (T, D), torch.bfloat16)
             lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
+            if rope is not None:
+                ops.rope_apply(qkv, rope[0], rope[1], nb, N, Hh, dh, 1 + n_reg)
             ops.attention_fwd(qkv, att, lse, nb, N, Hh, dh, scale)
             y1 = None   # the LayerScale gradient comes from the weight gradient (ops.layerscale_dgamma): no saved branch output
             if a["mode"] == "subset":
@@ -350,7 +373,7 @@ class ViTEngine:
             R2 = m["rows"]
             ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16)
             m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
-            ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"])
+            ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"], eps=cfg.ln_eps)
             act = ws.get(s + "act", (T, hid), torch.bfloat16)
             if cfg.swiglu:   # w12 -> silu(x1) * x2 -> w3
                 hpre = ws.get(s + "hpre", (T, 2 * hid), torch.bfloat16)
@@ -378,7 +401,7 @@ class ViTEngine:
         xn = ws.get(tag + ".xn", (B, N, D), torch.float32)
         mean = ws.get(tag + ".meanf", (T,), torch.float32)
         rstd = ws.get(tag + ".rstdf", (T,), torch.float32)
-        ops.layernorm_fwd(x, self.w("norm.weight"), self.w("norm.bias"), T, D, y_f32=xn, mean=mean, rstd=rstd)
+        ops.layernorm_fwd(x, self.w("norm.weight"), self.w("norm.bias"), T, D, y_f32=xn, mean=mean, rstd=rstd, eps=cfg.ln_eps)
         ctx.update(blocks=blocks, x_last=x, meanf=mean, rstdf=rstd, xn=xn)
         return ctx
 
@@ -537,6 +560,8 @@ class ViTEngine:
             ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             before_write(dQ)
             ops.attention_bwd(a["qkv"], a["att"], dD2, a["lse"], aws, dQ, nb, N, Hh, dh, scale)
+            if ctx.get("rope") is not None:   # gradients w.r.t. the un-rotated q / k: transposed rotation
+                ops.rope_apply(dQ, ctx["rope"][0], ctx["rope"][1], nb, N, Hh, dh, 1 + cfg.num_register_tokens, inverse=True)
             wgrad(dQ, a["ln"], pre + "attn.qkv.weight", 3 * D, D, R1, bias=pre + "attn.qkv.bias")
             before_write(dD)
             ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)

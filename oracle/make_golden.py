@@ -173,6 +173,9 @@ def main() -> None:
     if "--reg4-only" in sys.argv:
         make_reg4_swiglu()
         return
+    if "--dinov3-only" in sys.argv:
+        make_dinov3_vit()
+        return
     make_loss_kats()
     small_head = dict(output_dim=512, hidden_dim=64, dino_bottleneck_dim=32)
     # (a) the reference tests' own toy model: D=8, depth 3, 2 heads (head_dim 4)
@@ -192,6 +195,39 @@ def main() -> None:
                       dict(patch_size=16, num_heads=1, depth=2), b=8, g_size=96, l_size=48, n_local=2,
                       n_steps=2, total_steps=50, keep_params_every_step=False)
     make_reg4_swiglu()
+    make_dinov3_vit()
+
+
+def make_dinov3_vit() -> None:
+    """(d) DINOv3 ViT forward (the distillation teacher, eval mode): the dinov3_vitl16 recipe (hub/backbones.py:467-512: RoPE
+    base 100 in fp32, 4 storage tokens, LayerScale, eps 1e-5, K-masked qkv bias) at D=64, head_dim 64, 64^2 and 64x96 inputs."""
+    H.install()
+    from lightly_train._models.dinov3.dinov3_src.models import vision_transformer as v3
+    from oracle import dinov3_oracle as O3
+
+    torch.manual_seed(77)
+    m = v3.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
+                                 layerscale_init=0.5, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True,
+                                 pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
+    m.init_weights()
+    for n_, prm in m.named_parameters():   # biases / LayerNorm affine are initialised to constants: randomise for a real test
+        if n_.endswith(".bias") or "norm" in n_:
+            prm.data.add_(0.1 * torch.randn_like(prm))
+    m.eval()
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cfg = dict(patch_size=16, num_heads=1, depth=2, rope_base=100.0, ln_eps=1e-5, embed_dim=64, n_storage_tokens=4, img_size=64)
+    cases = []
+    for seed, (hh, ww) in ((5, (64, 64)), (6, (64, 96))):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(3, 3, hh, ww, generator=g)
+        with torch.no_grad():
+            ref = m.forward_features(x)
+            mine = O3.dinov3_vit_forward(state, x, cfg)
+        for k in ("x_norm_clstoken", "x_storage_tokens", "x_norm_patchtokens"):
+            assert (ref[k] - mine[k]).abs().max().item() <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, (ref[k] - mine[k]).abs().max())
+        cases.append({"seed": seed, "shape": (3, 3, hh, ww), "out": {k: ref[k].clone() for k in ("x_norm_clstoken", "x_storage_tokens", "x_norm_patchtokens")}})
+    torch.save({"cfg": cfg, "state": state, "cases": cases}, os.path.join(OUT, "dinov3_vit_fwd.pt"))
+    print("wrote dinov3_vit_fwd.pt", os.path.getsize(os.path.join(OUT, "dinov3_vit_fwd.pt")) // 1024, "KiB")
 
 
 def make_reg4_swiglu() -> None:

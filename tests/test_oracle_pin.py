@@ -168,3 +168,16 @@ def test_oracle_stochastic_depth_vs_live_reference(rate, uniform):
     b = o.train_step(views)
     for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
         assert a[k] == pytest.approx(b[k], rel=2e-5, abs=2e-5), k
+
+
+def test_dinov3_vit_oracle_matches_reference_fixture():
+    """DINOv3 ViT forward (distillation teacher, eval): oracle/dinov3_oracle.py against outputs of the reference's own
+    DinoVisionTransformer (tests/golden/dinov3_vit_fwd.pt, written by oracle/make_golden.py)."""
+    from oracle import dinov3_oracle as O3
+
+    fx = torch.load(os.path.join(GOLD, "dinov3_vit_fwd.pt"), weights_only=False)
+    for case in fx["cases"]:
+        x = torch.randn(*case["shape"], generator=torch.Generator().manual_seed(case["seed"]))
+        out = O3.dinov3_vit_forward(fx["state"], x, fx["cfg"])
+        for k, ref in case["out"].items():
+            assert (out[k] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
