@@ -70,6 +70,9 @@ typedef struct lt_gemm_desc {
   const float* rowscale;          /* [M] per-row multiplier of the LayerScale branch (LT_EPI_RESID; per-sample DropPath) or NULL */
   float branch_scale;             /* scalar multiplier of the branch (LT_EPI_RESID; batch-subset stochastic depth b/s); 0 = 1 */
   void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */
+  int batch;                      /* > 1: `batch` independent problems of this shape, operands `stride_*` elements apart (plain
+                                     epilogues only; 0 / 1 = single problem) */
+  int64_t stride_a, stride_b, stride_c;
 } lt_gemm_desc;
 
 int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);
@@ -193,6 +196,15 @@ int lt_center_ema(float* center, const float* colsum, float scale, float momentu
 int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
                   const int32_t* slot, float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K,
                   void* stream);
+/* Distillation v3 (reference _methods/distillationv3/distillationv3_loss.py:60-115): per row KL(softmax(t/T) || softmax(s/T));
+ * loss[0] += coef * KL, dlogits bf16 = coef/T * (softmax(s/T) - softmax(t/T)); rows `ld` (dlogits: `ldd`) elements apart */
+int lt_kl_fwd_bwd(const float* s_logits, const float* t_logits, int ld, float inv_temp, float coef, float* loss,
+                  void* dlogits_bf16, int ldd, int rows, int K, void* stream);
+/* g[b] = d[b] + d[b]^T for `batch` square bf16 matrices (n x n, row stride ld): upstream gradient of X X^T */
+int lt_symmetrize_bf16(const void* d, void* g, int batch, int n, int ld, void* stream);
+/* DistillationV3._mixup_data (distillationv3.py:356-368): out[b] = lam * x[b] + (1 - lam) * x[index[b]], index int64 [B] */
+int lt_mixup(const float* x, const int64_t* index, float lam, float* out, int B, int64_t per_image, void* stream);
+
 /* Sinkhorn-Knopp pieces (:84-115, :188-224); Q f32 [rows,K] holds exp(logits*inv_temp) */
 int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream);
 /* Q[r,k] *= 1/(colsum[k]*K); then row-normalise: Q[r,:] /= (rowsum(r) * n_total); final: Q *= final_mul */

@@ -20,6 +20,7 @@ class GemmDesc(C.Structure):
         ("trans_a", i32), ("trans_b", i32), ("epilogue", i32), ("C", vp), ("ldc", i32), ("C2", vp), ("ldc2", i32),
         ("bias", vp), ("gamma", vp), ("resid", vp), ("ldr", i32), ("aux", vp), ("ldaux", i32),
         ("alpha", f32), ("split_k", i32), ("force_kernel", i32), ("rowscale", vp), ("branch_scale", f32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
+        ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64),
     ]
 
 
@@ -35,6 +36,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_debug_gemm_log": [vp, i32],
+    "lt_kl_fwd_bwd": [vp, vp, i32, f32, f32, vp, vp, i32, i32, i32, vp],
+    "lt_symmetrize_bf16": [vp, vp, i32, i32, i32, vp],
+    "lt_mixup": [vp, vp, f32, vp, i32, i64, vp],
     "lt_rope_apply": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
     "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],

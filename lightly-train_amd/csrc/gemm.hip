@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* rowscale; float branch_scale;
   float alpha;
   int tiles_m, tiles_n, k_per_split;
+  long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
   int dbg;     // profiling aid for the persistent kernel: 1 = skip main loop, 2 = skip epilogue, 4 = no priorities
   int* sched;  // persistent kernel: 8 per-XCD tile counters + 1 exit counter (self-resetting)
 };
@@ -191,8 +192,15 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
 }
 
 template <bool TA, bool TB, int EPI, bool VEC>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GemmArgs g = g0;
+  if (gridDim.z > 1) {  // batched: independent problems of one shape (per-image token-similarity matrices of the distillation loss)
+    constexpr bool F32OUT = EPI == EPI_RESID || EPI == EPI_F32 || EPI == EPI_F32_ACCUM;
+    g.A = g0.A + (size_t)blockIdx.z * g0.sa;
+    g.B = g0.B + (size_t)blockIdx.z * g0.sb;
+    g.C = F32OUT ? (void*)((float*)g0.C + (size_t)blockIdx.z * g0.sc) : (void*)((bf16_t*)g0.C + (size_t)blockIdx.z * g0.sc);
+  }
   // stage s: A image at smem + 2*s*TILE_BYTES, B image right behind it
 #define LDS_A(s) (smem + (2 * (s)) * TILE_BYTES)
 #define LDS_B(s) (smem + (2 * (s) + 1) * TILE_BYTES)
@@ -1173,6 +1181,10 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux;
   g.rowscale = d->rowscale; g.branch_scale = d->branch_scale == 0.f ? 1.f : d->branch_scale;
   g.alpha = d->alpha;
+  g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
+  const int batch = d->batch > 1 ? d->batch : 1;
+  LT_CHECK_ARG(batch == 1 || (!d->C2 && !d->resid && !d->aux && !d->rowscale && d->split_k <= 1 && d->force_kernel <= 1),
+               "lt_gemm_bf16: batched launches support the plain epilogues of the 128x128 kernel only");
   g.tiles_m = lt_cdiv(d->M, BM); g.tiles_n = lt_cdiv(d->N, BN);
   int split = d->split_k > 0 ? d->split_k : 1;
   if (d->epilogue != LT_EPI_F32_ACCUM) split = 1;
@@ -1180,7 +1192,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   if (split > ktiles) split = ktiles;
   g.k_per_split = lt_cdiv(ktiles, split) * BK;
   split = lt_cdiv(d->K, g.k_per_split);
-  dim3 grid(g.tiles_m * g.tiles_n, split);
+  dim3 grid(g.tiles_m * g.tiles_n, split, batch);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   // vector epilogue needs 4-element alignment of every row it touches
@@ -1191,7 +1203,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   // ---- 256-row LDS-DMA kernel for the large GEMMs (forward / dgrad over tokens; wgrad with slab split-K)
   const bool same_t = d->trans_a == d->trans_b || !d->trans_a;  // (N,N), (N,T), (T,T)
   const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
-  bool big = eligible && d->force_kernel != 1 && d->N >= 128 &&
+  bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= 128 &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
   g.sched = nullptr; g.dbg = 0;
   static const int token_kernel = [] { const char* e = getenv("LT_GEMM_TOKEN_KERNEL"); return e ? atoi(e) : 2; }();

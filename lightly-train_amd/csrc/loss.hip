@@ -89,6 +89,77 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, co
   }
 }
 
+// ------------------------------------------------------------------------------------ distillation (KL on similarity logits)
+// One block per row: KL(softmax(t/T) || softmax(s/T)) = sum_k t_k (log t_k - log p_k), d(s_logit) = coef/T * (p_k - t_k)
+// (DistillationV3Loss, LT/_methods/distillationv3/distillationv3_loss.py:60-115: KLDivLoss(batchmean) of a log_softmax
+// student against a softmax teacher).  Rows are `ld` floats apart (>= K; the similarity matrices are padded to 8 columns).
+__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ s, const float* __restrict__ t, int ld, float inv_temp,
+                                                 float coef, float* __restrict__ loss, bf16_t* __restrict__ dlogits, int ldd, int K) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* zs = s + row * ld;
+  const float* zt = t + row * ld;
+  MaxSum a, b; a.m = b.m = -INFINITY; a.s = b.s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) { ms_push(a, zs[k] * inv_temp); ms_push(b, zt[k] * inv_temp); }
+  a = block_ms(a, red);
+  b = block_ms(b, red);
+  const float lse_s = a.m + __logf(a.s), lse_t = b.m + __logf(b.s);
+  float kl = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float ls = zs[k] * inv_temp - lse_s, lt = zt[k] * inv_temp - lse_t;
+    const float tk = __expf(lt);
+    kl += tk * (lt - ls);
+    if (dlogits) dlogits[row * ldd + k] = f2bf(coef * inv_temp * (__expf(ls) - tk));
+  }
+  kl = block_sum(kl, red);
+  if (threadIdx.x == 0) atomicAdd(loss, coef * kl);
+}
+extern "C" int lt_kl_fwd_bwd(const float* s_logits, const float* t_logits, int ld, float inv_temp, float coef, float* loss,
+                             void* dlogits_bf16, int ldd, int rows, int K, void* stream) {
+  LT_CHECK_ARG(s_logits && t_logits && loss && K > 0 && ld >= K && (!dlogits_bf16 || ldd >= K), "lt_kl_fwd_bwd: bad arguments");
+  if (rows == 0) return LT_OK;
+  hipLaunchKernelGGL(kl_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s_logits, t_logits, ld, inv_temp, coef, loss, (bf16_t*)dlogits_bf16, ldd, K);
+  LT_CHECK_LAUNCH("lt_kl_fwd_bwd");
+}
+
+// g[b][i][j] = d[b][i][j] + d[b][j][i]  (gradient of X X^T w.r.t. X is (dS + dS^T) X); square n x n matrices, row stride ld
+__global__ __launch_bounds__(256) void symmetrize_kernel(const bf16_t* __restrict__ d, bf16_t* __restrict__ g, int n, int ld, long per) {
+  const long base = (long)blockIdx.y * per;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n * n; idx += gridDim.x * 256) {
+    const int i = idx / n, j = idx - i * n;
+    g[base + (long)i * ld + j] = f2bf(bf2f(d[base + (long)i * ld + j]) + bf2f(d[base + (long)j * ld + i]));
+  }
+}
+extern "C" int lt_symmetrize_bf16(const void* d, void* g, int batch, int n, int ld, void* stream) {
+  LT_CHECK_ARG(d && g && d != g && batch > 0 && n > 0 && ld >= n, "lt_symmetrize_bf16: bad arguments (in-place is not supported)");
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(min(lt_cdiv(n * n, 256), 64), batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d, (bf16_t*)g, n, ld,
+                     (long)n * ld);
+  LT_CHECK_LAUNCH("lt_symmetrize_bf16");
+}
+
+// mixup (DistillationV3._mixup_data, distillationv3.py:356-368): out[b] = lam * x[b] + (1 - lam) * x[index[b]]
+__global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x, const int64_t* __restrict__ index, float lam,
+                                                    float* __restrict__ out, long per) {
+  const long b = blockIdx.y;
+  const float* a = x + b * per;
+  const float* c = x + index[b] * per;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long)gridDim.x * 1024) {
+    if (i + 3 < per) {
+      const float4 u = *reinterpret_cast<const float4*>(a + i), v = *reinterpret_cast<const float4*>(c + i);
+      *reinterpret_cast<float4*>(out + b * per + i) = make_float4(lam * u.x + (1.f - lam) * v.x, lam * u.y + (1.f - lam) * v.y,
+                                                                  lam * u.z + (1.f - lam) * v.z, lam * u.w + (1.f - lam) * v.w);
+    } else {
+      for (long j = i; j < per; ++j) out[b * per + j] = lam * a[j] + (1.f - lam) * c[j];
+    }
+  }
+}
+extern "C" int lt_mixup(const float* x, const int64_t* index, float lam, float* out, int B, int64_t per_image, void* stream) {
+  LT_CHECK_ARG(x && index && out && x != out && B > 0 && per_image > 0 && per_image % 4 == 0, "lt_mixup: bad arguments (per-image size must be a multiple of 4)");
+  hipLaunchKernelGGL(mixup_kernel, dim3((unsigned)min((long)256, (long)lt_cdiv(per_image, 1024)), B), dim3(256), 0, (hipStream_t)stream, x, index, lam, out,
+                     (long)per_image);
+  LT_CHECK_LAUNCH("lt_mixup");
+}
+
 __global__ void sk_exp_kernel(const float* __restrict__ x, float* __restrict__ q, long n, float inv_temp) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;

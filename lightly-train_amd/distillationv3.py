@@ -1,0 +1,312 @@
+"""DistillationV3 on MI355X: frozen ViT teacher -> ViT student, the whole step in HIP.
+
+Mirrors LT/_methods/distillationv3/distillationv3.py: `DistillationV3Args` (:109-169), `DistillationV3.training_step_impl`
+(:235-273), `_mixup_data` (:356-368), `_forward_teacher` (:293-322), `_forward_student` (:324-354), `_update_queue` (:275-291),
+`DistillationV3Loss.forward` (distillationv3_loss.py:35-117), `configure_gradient_clipping` (:400-410, norm 1.0) and the generic
+`Method.configure_optimizers` (LT/_methods/method.py:89-121: AdamW, sqrt LR scaling, CosineWarmupScheduler).
+
+Teacher: DINOv3 ViT (RoPE, storage tokens; `dinov3.py`) or a DINOv2 ViT; student: DINOv2 ViT -- both on `vit.ViTEngine`.
+State-dict names follow the reference: `student_embedding_model.wrapped_model._model.*`, `student_projection_head_global.*`,
+`student_projection_head_local.*`, `teacher_queue`.
+
+Not implemented (raise): student / teacher token grids of different size (the bilinear resize of :338-345), convolutional
+students (torchvision/resnet50 of BASELINE config 4), LARS.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Mapping, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops
+from .parallel import GradSync
+from .params import FlatParams
+from .schedules import warmup_cosine_lr_factor
+from .vit import ViTConfig, ViTEngine, Workspace, vit_param_shapes
+
+NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "pos_embed")
+
+
+@dataclass
+class DistillationV3Args:
+    """Method + AdamW arguments (distillationv3.py:109-193; weight_decay "auto" resolves to 0.04 for transformer students)."""
+    queue_size: int = 8192
+    temperature_global: float = 0.07
+    temperature_local: float = 0.07
+    lr_scale_method: str = "sqrt"
+    reference_batch_size: int = 1536
+    loss_local_weight: float = 1.0
+    lr: float = 0.0005
+    betas: Tuple[float, float] = (0.9, 0.999)
+    eps: float = 1e-8
+    weight_decay: float = 0.04
+    gradient_clip_val: float = 1.0
+
+
+@dataclass
+class TrainingStepResult:
+    loss: Tensor
+    log_dict: Mapping[str, Any]
+
+
+def weight_decays(name: str, shape: torch.Size) -> bool:
+    """LT/_optim/optimizer_helpers.py:83-175 restricted to the modules on this path: no decay for norm layers, biases,
+    <= 1-D parameters (LayerScale), tokens and positional embeddings."""
+    if len(shape) <= 1 or "norm" in name or name.endswith("bias") or any(k in name for k in NO_DECAY_KEYS):
+        return False
+    return True
+
+
+class _Trainer:
+    def __init__(self, total_steps: int, max_epochs: int) -> None:
+        self.global_step = 0
+        self.max_epochs = max_epochs
+        self.estimated_stepping_batches = total_steps
+
+
+class DistillationV3:
+    def __init__(self, student_cfg: ViTConfig, teacher_cfg: ViTConfig, method_args: Optional[DistillationV3Args] = None,
+                 global_batch_size: int = 128, total_steps: int = 100_000, max_epochs: int = 100, device: str | torch.device = "cuda",
+                 student_state: Optional[Dict[str, Tensor]] = None, teacher_state: Optional[Dict[str, Tensor]] = None,
+                 proj_global_state: Optional[Dict[str, Tensor]] = None, proj_local_state: Optional[Dict[str, Tensor]] = None,
+                 seed: int = 0) -> None:
+        from .vit import init_vit_state
+
+        self.method_args = a = method_args or DistillationV3Args()
+        self.scfg, self.tcfg = student_cfg, teacher_cfg
+        self.device = dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("DistillationV3 runs on an MI355X only (no CPU fallback for the HIP kernels)")
+        g = torch.Generator().manual_seed(seed)
+        Ds, Dt = student_cfg.embed_dim, teacher_cfg.embed_dim
+        sb = student_state if student_state is not None else init_vit_state(student_cfg, g)
+        tb = teacher_state if teacher_state is not None else init_vit_state(teacher_cfg, g)
+
+        def lin(state: Optional[Dict[str, Tensor]]) -> Dict[str, Tensor]:
+            if state is not None:
+                return {k: v.detach().clone().float() for k, v in state.items()}
+            w = torch.nn.init.trunc_normal_(torch.empty(Dt, Ds), std=0.02, generator=g)   # distillationv3.py:212-213
+            bound = 1.0 / math.sqrt(Ds)
+            return {"weight": w, "bias": torch.empty(Dt).uniform_(-bound, bound, generator=g)}
+
+        pg, pl = lin(proj_global_state), lin(proj_local_state)
+        named: List[Tuple[str, Tensor]] = [("backbone." + n, sb[n]) for n, _ in vit_param_shapes(student_cfg)]
+        named += [("proj_global.weight", pg["weight"]), ("proj_global.bias", pg["bias"]),
+                  ("proj_local.weight", pl["weight"]), ("proj_local.bias", pl["bias"])]
+        self.student = FlatParams(named, dev, True)
+        self.teacher = FlatParams([(n, tb[n]) for n, _ in vit_param_shapes(teacher_cfg)], dev, False)
+        self.s_vit = ViTEngine(student_cfg, self.student, "backbone.")
+        self.t_vit = ViTEngine(teacher_cfg, self.teacher, "")
+        self.ws = Workspace(dev)
+        self.teacher_queue = torch.zeros(a.queue_size, Dt, device=dev)
+        self.global_batch_size = global_batch_size
+        self.trainer = _Trainer(total_steps, max_epochs)
+        # ---- optimizer (method.py:89-121)
+        scale = global_batch_size / a.reference_batch_size
+        if a.lr_scale_method == "sqrt":
+            scale = math.sqrt(scale)
+        self.base_lr = a.lr * scale
+        warm_epochs = min(10, max_epochs / 10)
+        self.warmup_steps = min(int(total_steps), int(total_steps / max(1, max_epochs) * warm_epochs))
+        self.exp_avg = torch.zeros_like(self.student.data)
+        self.exp_avg_sq = torch.zeros_like(self.student.data)
+        self.seg_lr = torch.full((len(self.student.names),), self.base_lr, dtype=torch.float32, device=dev)
+        self.seg_wd_on = torch.tensor([1 if weight_decays(n, self.student.shapes[n]) else 0 for n in self.student.names],
+                                      dtype=torch.uint8, device=dev)
+        self.seg_frozen = torch.zeros(len(self.student.names), dtype=torch.uint8, device=dev)
+        self._sumsq = torch.zeros(1, device=dev)
+        self._loss_slots = torch.zeros(2, device=dev)
+        self.opt_step = 0
+        self.last_grad_norm: Optional[Tensor] = None
+        self._grad_sync: Optional[GradSync] = None
+        self.teacher_stream = torch.cuda.Stream(device=dev)
+        self.side_stream = torch.cuda.Stream(device=dev)
+        self._idx: Dict[Tuple[int, int, int], Tuple[Tensor, Tensor]] = {}
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def world(self) -> int:
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _rows(self, B: int, N: int, prefix: int) -> Tuple[Tensor, Tensor]:
+        """Row indices of the cls tokens and of the patch tokens in a [B*N, D] token matrix."""
+        key = (B, N, prefix)
+        if key not in self._idx:
+            r = torch.arange(B, dtype=torch.int64)
+            cls = r * N
+            patch = (r[:, None] * N + torch.arange(prefix, N, dtype=torch.int64)[None, :]).reshape(-1)
+            self._idx[key] = (cls.to(self.device), patch.to(self.device))
+        return self._idx[key]
+
+    def _normalize(self, tag: str, x: Tensor, rows: int, D: int) -> Tuple[Tensor, Tensor]:
+        """F.normalize(x, dim=-1): returns (bf16 normalised rows, 1/||x||)."""
+        y = self.ws.get(tag + ".n", (rows, D), torch.bfloat16)
+        inv = self.ws.get(tag + ".inv", (rows,), torch.float32)
+        ops.l2norm_fwd(x, y, inv, rows, D, 1e-12)
+        return y, inv
+
+    # ------------------------------------------------------------------ the step
+    def training_step_impl(self, batch: Dict[str, Any], batch_idx: int, mix: Optional[Tuple[float, Tensor]] = None) -> TrainingStepResult:
+        a, ws, dev = self.method_args, self.ws, self.device
+        Ds, Dt = self.scfg.embed_dim, self.tcfg.embed_dim
+        views = batch["views"][0].to(dev, torch.float32, non_blocking=True).contiguous()
+        B = views.shape[0]
+        # ---- mixup (:356-368): lambda ~ U(0,1), random permutation -- same host RNG draws, same order, as the reference
+        if mix is None:
+            lam = torch.empty(1).uniform_(0.0, 1.0).item()
+            index = torch.randperm(B)
+        else:
+            lam, index = mix
+        x = ws.get("mix.x", tuple(views.shape), torch.float32)
+        ops.mixup(views, index.to(dev, torch.int64), float(lam), x)
+
+        main = torch.cuda.current_stream()
+        self.student.grad.zero_()
+        self._loss_slots.zero_()
+        # ---- teacher (no grad) on its own stream
+        ts = self.teacher_stream
+        ts.wait_event(main.record_event())
+        with torch.cuda.stream(ts):
+            tc = self.t_vit.forward(ws, "t", x, None, save=False)
+            Nt, pre_t = tc["N"], 1 + self.tcfg.num_register_tokens
+            n_pt = Nt - pre_t
+            t_cls_rows, t_patch_rows = self._rows(B, Nt, pre_t)
+            txn = tc["xn"].view(-1, Dt)
+            tg_raw = ws.get("t.g", (B, Dt), torch.float32)
+            tl_raw = ws.get("t.l", (B * n_pt + 8, Dt), torch.float32, zero=True)   # (+8 zero rows: padded-K reads of the batched GEMMs)
+            ops.gather_rows(txn, Dt, t_cls_rows, B, Dt, out_f32=tg_raw)
+            ops.gather_rows(txn, Dt, t_patch_rows, B * n_pt, Dt, out_f32=tl_raw)
+            tg, tg_inv = self._normalize("t.g", tg_raw, B, Dt)
+            tl, _ = self._normalize("t.l", tl_raw, B * n_pt + 8, Dt)
+            # queue update (:275-291) with the fp32 normalised global features
+            tgn = ws.get("t.gn", (B, Dt), torch.float32)
+            torch.mul(tg_raw, tg_inv[:, None], out=tgn)          # plumbing: B x Dt scale for the fp32 queue rows
+            Q = self.teacher_queue.shape[0]
+            if B >= Q:
+                self.teacher_queue.copy_(tgn[:Q])
+            else:
+                self.teacher_queue[B:] = self.teacher_queue[:-B].clone()
+                self.teacher_queue[:B] = tgn
+            qb = ws.get("queue.bf16", (Q, Dt), torch.bfloat16)
+            ops.cast_bf16(self.teacher_queue, qb)
+            t_logits = ws.get("g.t_logits", (B, Q), torch.float32)
+            ops.gemm(tg, qb, t_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
+            n_pad = (n_pt + 7) // 8 * 8
+            St = ws.get("l.St", (B * n_pt, n_pad), torch.float32)
+            ops.gemm(tl, tl, St, M=n_pt, N=n_pt, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_pt * Dt, stride_b=n_pt * Dt,
+                     stride_c=n_pt * n_pad)
+            teacher_done = ts.record_event()
+
+        # ---- student forward
+        sc = self.s_vit.forward(ws, "s", x, None, save=True)
+        Ns, pre_s = sc["N"], 1 + self.scfg.num_register_tokens
+        n_ps = Ns - pre_s
+        if (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"]):
+            raise NotImplementedError("student and teacher token grids differ: the bilinear resize of distillationv3.py:338-345 is not implemented")
+        s_cls_rows, s_patch_rows = self._rows(B, Ns, pre_s)
+        sxn = sc["xn"].view(-1, Ds)
+        sg_in = ws.get("s.g_in", (B, Ds), torch.bfloat16)
+        sl_in = ws.get("s.l_in", (B * n_ps, Ds), torch.bfloat16)
+        ops.gather_rows(sxn, Ds, s_cls_rows, B, Ds, out_bf16=sg_in)
+        ops.gather_rows(sxn, Ds, s_patch_rows, B * n_ps, Ds, out_bf16=sl_in)
+        P = self.student
+        sg_raw = ws.get("s.g", (B, Dt), torch.float32)
+        sl_raw = ws.get("s.l", (B * n_ps + 8, Dt), torch.float32, zero=True)
+        ops.gemm(sg_in, P.b["proj_global.weight"], sg_raw, M=B, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_global.bias"])
+        ops.gemm(sl_in, P.b["proj_local.weight"], sl_raw, M=B * n_ps, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_local.bias"])
+        sg, sg_inv = self._normalize("s.g", sg_raw, B, Dt)
+        sl, sl_inv = self._normalize("s.l", sl_raw, B * n_ps + 8, Dt)
+
+        # ---- losses (distillationv3_loss.py:60-115) and their gradients w.r.t. the similarity logits
+        main.wait_event(teacher_done)
+        Q = self.teacher_queue.shape[0]
+        s_logits = ws.get("g.s_logits", (B, Q), torch.float32)
+        ops.gemm(sg, qb, s_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
+        Qp = (Q + 7) // 8 * 8
+        dlg = ws.get("g.dlogits", (B, Qp), torch.bfloat16)
+        ops.kl_fwd_bwd(s_logits, t_logits, Q, 1.0 / a.temperature_global, 1.0 / B, self._loss_slots[0:], dlg, Qp, B, Q)
+        Ss = ws.get("l.Ss", (B * n_ps, n_pad), torch.float32)
+        ops.gemm(sl, sl, Ss, M=n_ps, N=n_ps, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_ps * Dt, stride_b=n_ps * Dt,
+                 stride_c=n_ps * n_pad)
+        dS = ws.get("l.dS", (B * n_ps, n_pad), torch.bfloat16, zero=True)     # pad columns stay zero
+        ops.kl_fwd_bwd(Ss, St, n_pad, 1.0 / a.temperature_local, a.loss_local_weight / (B * n_ps), self._loss_slots[1:], dS, n_pad,
+                       B * n_ps, n_ps)
+
+        # ---- backward: similarity logits -> normalised features -> projection heads -> student tokens
+        dsg_n = ws.get("g.dsg_n", (B, Dt), torch.float32)
+        if Qp != Q:
+            raise NotImplementedError("queue sizes must be multiples of 8")
+        ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Q, trans_b=True, epilogue=ops.EPI_F32)
+        G = ws.get("l.G", (B * n_ps, n_pad), torch.bfloat16, zero=True)
+        ops.symmetrize_bf16(dS, G, B, n_ps, n_pad)
+        dsl_n = ws.get("l.dsl_n", (B * n_ps, Dt), torch.float32)
+        ops.gemm(G, sl, dsl_n, M=n_ps, N=Dt, K=n_pad, trans_b=True, epilogue=ops.EPI_F32, lda=n_pad, batch=B, stride_a=n_ps * n_pad,
+                 stride_b=n_ps * Dt, stride_c=n_ps * Dt)
+        dsg = ws.get("g.dsg", (B, Dt), torch.bfloat16)
+        dsl = ws.get("l.dsl", (B * n_ps, Dt), torch.bfloat16)
+        ops.l2norm_bwd(dsg_n, sg_raw, sg_inv, dsg, B, Dt)
+        ops.l2norm_bwd(dsl_n, sl_raw, sl_inv, dsl, B * n_ps, Dt)
+        for tagp, dy, xin, rows in (("proj_global", dsg, sg_in, B), ("proj_local", dsl, sl_in, B * n_ps)):
+            ops.colsum_bf16(dy, P.g[tagp + ".bias"], rows, Dt)
+            ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds)
+        dxn = ws.get("s.dxn", (B * Ns, Ds), torch.float32)
+        dxn.zero_()
+        dcls = ws.get("s.dcls", (B, Ds), torch.float32)
+        dpat = ws.get("s.dpat", (B * n_ps, Ds), torch.float32)
+        ops.gemm(dsg, P.b["proj_global.weight"], dcls, M=B, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
+        ops.gemm(dsl, P.b["proj_local.weight"], dpat, M=B * n_ps, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
+        ops.scatter_add_rows(dcls, s_cls_rows, dxn, Ds, B, Ds)
+        ops.scatter_add_rows(dpat, s_patch_rows, dxn, Ds, B * n_ps, Ds)
+        self.s_vit.backward(ws, sc, dxn.view(B, Ns, Ds), side=self.side_stream)
+        main.wait_stream(self.side_stream)
+        self.s_vit.finish_layerscale_grads()
+
+        ls = self._loss_slots
+        w = a.loss_local_weight
+        logs = {"train_loss/global_loss": ls[0], "train_loss/local_loss": ls[1] / w if w else ls[1]}
+        self._last = dict(B=B, lam=lam, index=index, t_logits=t_logits, s_logits=s_logits, tg=tg, tl=tl, sg=sg, sl=sl)
+        return TrainingStepResult(loss=ls[0] + ls[1], log_dict=logs)
+
+    # ------------------------------------------------------------------ optimizer hooks
+    def optimizer_step(self) -> None:
+        a = self.method_args
+        k = self.trainer.global_step
+        total = int(self.trainer.estimated_stepping_batches)
+        lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, 0.001)   # CosineWarmupScheduler default end_value
+        if self.world > 1:
+            if self._grad_sync is None:
+                self._grad_sync = GradSync(self.student.grad)
+            self._grad_sync.start()
+            self._grad_sync.finish()
+        self._sumsq.zero_()
+        ops.sumsq(self.student.grad, self._sumsq)
+        self.opt_step += 1
+        ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
+                       self.seg_lr, self.seg_wd_on, self.seg_frozen, False, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
+                       self.opt_step, self._sumsq, a.gradient_clip_val)
+        self.s_vit.refresh_padded_weights()
+        self.last_grad_norm = self._sumsq
+        self.trainer.global_step += 1
+
+    def train_step(self, views: Tensor, mix: Optional[Tuple[float, Tensor]] = None) -> TrainingStepResult:
+        res = self.training_step_impl({"views": [views]}, 0, mix=mix)
+        self.optimizer_step()
+        return res
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        """Reference key names; the teacher is left out like `on_save_checkpoint` does (:415-423)."""
+        out: Dict[str, Tensor] = {}
+        for n in self.student.names:
+            v = self.student.p[n].detach().clone()
+            if n.startswith("backbone."):
+                out["student_embedding_model.wrapped_model._model." + n[9:]] = v
+            elif n.startswith("proj_global."):
+                out["student_projection_head_global." + n[12:]] = v
+            else:
+                out["student_projection_head_local." + n[11:]] = v
+        out["teacher_queue"] = self.teacher_queue.detach().clone()
+        return out

@@ -44,8 +44,10 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
          resid: Optional[Tensor] = None, out2: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
          ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None,
-         rowscale: Optional[Tensor] = None, branch_scale: float = 1.0) -> Tensor:
-    """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h."""
+         rowscale: Optional[Tensor] = None, branch_scale: float = 1.0, batch: int = 1, stride_a: int = 0, stride_b: int = 0,
+         stride_c: int = 0) -> Tensor:
+    """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h.  batch > 1: that many independent
+    problems, operands `stride_*` elements apart (plain epilogues of the 128x128 kernel)."""
     _chk(a, torch.bfloat16, "gemm.a")
     _chk(b, torch.bfloat16, "gemm.b")
     d = GemmDesc()
@@ -70,6 +72,7 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
     d.rowscale, d.branch_scale = _p(rowscale), branch_scale
     d.workspace = _p(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    d.batch, d.stride_a, d.stride_b, d.stride_c = batch, stride_a, stride_b, stride_c
     check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
     return out
 
@@ -195,6 +198,23 @@ def scatter_add_rows(src: Tensor, idx: Tensor, dst: Tensor, ld: int, M: int, D: 
 
 def cast_bf16(src: Tensor, dst: Tensor) -> None:
     check(_lib.load().lt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "lt_cast_f32_to_bf16")
+
+
+def kl_fwd_bwd(s_logits: Tensor, t_logits: Tensor, ld: int, inv_temp: float, coef: float, loss: Tensor, dlogits: Optional[Tensor], ldd: int,
+               rows: int, K: int) -> None:
+    """loss[0] += coef * sum_rows KL(softmax(t/T) || softmax(s/T)); dlogits (bf16) = its gradient w.r.t. the student logits."""
+    _chk(s_logits, torch.float32, "kl.s"); _chk(t_logits, torch.float32, "kl.t"); _chk(loss, torch.float32, "kl.loss")
+    check(_lib.load().lt_kl_fwd_bwd(_p(s_logits), _p(t_logits), ld, inv_temp, coef, _p(loss), _p(dlogits), ldd, rows, K, _stream()), "lt_kl_fwd_bwd")
+
+
+def symmetrize_bf16(d: Tensor, g: Tensor, batch: int, n: int, ld: int) -> None:
+    _chk(d, torch.bfloat16, "symmetrize.d"); _chk(g, torch.bfloat16, "symmetrize.g")
+    check(_lib.load().lt_symmetrize_bf16(_p(d), _p(g), batch, n, ld, _stream()), "lt_symmetrize_bf16")
+
+
+def mixup(x: Tensor, index: Tensor, lam: float, out: Tensor) -> None:
+    _chk(x, torch.float32, "mixup.x"); _chk(index, torch.int64, "mixup.index"); _chk(out, torch.float32, "mixup.out")
+    check(_lib.load().lt_mixup(_p(x), _p(index), lam, _p(out), x.shape[0], x[0].numel(), _stream()), "lt_mixup")
 
 
 def rope_apply(qkv: Tensor, sin_t: Tensor, cos_t: Tensor, B: int, N: int, H: int, dh: int, prefix: int, inverse: bool = False) -> None:

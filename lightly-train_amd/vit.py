@@ -157,10 +157,11 @@ class Workspace:
         self.device = device
         self.bufs: Dict[str, Tensor] = {}
 
-    def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype) -> Tensor:
+    def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype, zero: bool = False) -> Tensor:
+        """`zero`: zero-fill when the buffer is (re)allocated (padding that kernels never write must stay finite)."""
         t = self.bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.bufs[name] = t
         return t
 

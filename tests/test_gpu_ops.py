@@ -342,6 +342,41 @@ def test_tokens_with_registers_and_swiglu():
     assert (d12.float() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
 
 
+def test_distillation_ops_kl_symmetrize_mixup_batched_gemm():
+    """Kernels of the DistillationV3 step: row KL with gradient, dS + dS^T, mixup, batched GEMM (per-image X X^T)."""
+    o = ops()
+    g = torch.Generator().manual_seed(31)
+    rows, K, ld, T = 50, 196, 200, 0.07
+    s = torch.zeros(rows, ld); t = torch.zeros(rows, ld)
+    s[:, :K] = torch.randn(rows, K, generator=g) * 0.3; t[:, :K] = torch.randn(rows, K, generator=g) * 0.3
+    sd, td = s.to(DEV), t.to(DEV)
+    loss = torch.zeros(1, device=DEV); dl = torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16)
+    o.kl_fwd_bwd(sd, td, ld, 1.0 / T, 1.0 / rows, loss, dl, ld, rows, K)
+    sr = s[:, :K].clone().requires_grad_(True)
+    ref = torch.nn.KLDivLoss(reduction="batchmean")(F.log_softmax(sr / T, -1), F.softmax(t[:, :K] / T, -1))
+    ref.backward()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-4)
+    assert rel_err(dl[:, :K], sr.grad) < 6e-3 and dl[:, K:].abs().max().item() == 0
+
+    B, n = 3, 20
+    d = bf(torch.randn(B, n, 24, generator=g)).to(DEV)
+    gsym = torch.zeros_like(d)
+    o.symmetrize_bf16(d, gsym, B, n, 24)
+    assert rel_err(gsym[:, :, :n], d[:, :, :n].float() + d[:, :, :n].float().transpose(1, 2)) < 6e-3
+
+    x = torch.randn(5, 3, 8, 8, generator=g).to(DEV); idx = torch.randperm(5, generator=g)
+    out = torch.empty_like(x)
+    o.mixup(x, idx.to(DEV), 0.3, out)
+    assert torch.allclose(out, 0.3 * x + 0.7 * x[idx.to(DEV)], atol=1e-6)
+
+    Bq, m, Kd = 4, 196, 64                                  # per-image token similarity S_b = X_b X_b^T into a padded [m, 200] tile
+    X = bf(torch.randn(Bq * m, Kd, generator=g) * 0.2).to(DEV)
+    S = torch.zeros(Bq * m, 200, device=DEV)
+    o.gemm(X, X, S, M=m, N=m, K=Kd, epilogue=o.EPI_F32, ldc=200, batch=Bq, stride_a=m * Kd, stride_b=m * Kd, stride_c=m * 200)
+    Xf = X.float().view(Bq, m, Kd)
+    assert rel_err(S.view(Bq, m, 200)[:, :, :m], Xf @ Xf.transpose(1, 2)) < 1e-5 and S.view(Bq, m, 200)[:, :, m:].abs().max().item() == 0
+
+
 def test_bicubic_pad_resize():
     """98x98 -> 112x112 (the literal 8 x 98^2 local crops with patch 16): taps read off F.interpolate, applied in HIP."""
     o = ops()

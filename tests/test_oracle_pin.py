@@ -181,3 +181,23 @@ def test_dinov3_vit_oracle_matches_reference_fixture():
         out = O3.dinov3_vit_forward(fx["state"], x, fx["cfg"])
         for k, ref in case["out"].items():
             assert (out[k] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_distillation_oracle_matches_reference_fixture():
+    """oracle/distill_oracle.py (DistillationV3: DINOv3 ViT teacher -> DINOv2 ViT student) against 3 optimizer steps of the
+    reference's own DistillationV3 class (tests/golden/distill_v3_d64.pt): losses, grad-norm, LR, final parameters, queue."""
+    from oracle import distill_oracle as OD
+
+    fx = torch.load(os.path.join(GOLD, "distill_v3_d64.pt"), weights_only=False)
+    o = OD.OracleDistillationV3(fx["init"]["student_backbone"], fx["student_cfg"], fx["teacher_state"], fx["teacher_cfg"],
+                                fx["init"]["proj_global"], fx["init"]["proj_local"], fx["queue_size"], fx["b"], fx["total_steps"],
+                                weight_decay=fx["weight_decay"])
+    for rec in fx["steps"]:
+        x = torch.randn(fx["b"], 3, 64, 64, generator=torch.Generator().manual_seed(rec["x_seed"]))
+        assert o.opt.param_groups[0]["lr"] == pytest.approx(rec["logs"]["lr"], rel=1e-6)
+        logs = o.train_step(x, rec["lam"], rec["index"])
+        for k in ("loss", "global_loss", "local_loss", "grad_norm"):
+            assert logs[k] == pytest.approx(rec["logs"][k], rel=2e-5, abs=2e-7), k
+    for k, v in fx["final"]["student_backbone"].items():
+        assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+    assert (o.queue - fx["final"]["queue"]).abs().max().item() < 1e-6
