@@ -85,6 +85,8 @@ def main() -> None:
     ap.add_argument("--local-size", type=int, default=98, help="98 = BASELINE config (pad-resized to 112 by PatchEmbed); 96 = upstream DINOv2 default")
     ap.add_argument("--n-local", type=int, default=8)
     ap.add_argument("--out-dim", type=int, default=65536)
+    ap.add_argument("--method", default="dinov2", choices=["dinov2", "distillationv3"],
+                    help="dinov2 = the BASELINE metric; distillationv3 = SURVEY 8(a) a22: frozen DINOv3 ViT-L/16 teacher -> ViT student, one 224^2 view")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
@@ -115,17 +117,28 @@ def main() -> None:
 
     arch = MODELS[args.model]
     cfg = ViTConfig(patch_size=16, img_size=args.global_size, init_values=1e-5, **arch)
-    margs = DINOv2Args(output_dim=args.out_dim)
     B = args.batch
-    method = DINOv2(cfg, margs, global_batch_size=B * world, total_steps=125_000, device=dev, seed=0)
-    if args.single_stream:
-        method.overlap_streams = False
     g = torch.Generator().manual_seed(1234 + rank)
-    views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [
-        torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
-    if args.host_inputs:
-        views = [v.cpu().pin_memory() for v in views]
+    if args.method == "distillationv3":
+        from lightly_train_amd.dinov3 import dinov3_vit_config
+        from lightly_train_amd.distillationv3 import DistillationV3, DistillationV3Args
+
+        tcfg = dinov3_vit_config(1024, 24, 16, patch_size=16, img_size=args.global_size)     # dinov3_vitl16
+        method = DistillationV3(cfg, tcfg, DistillationV3Args(), global_batch_size=B * world, total_steps=125_000, max_epochs=100, device=dev, seed=0)
+        views = torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev)
+        if args.host_inputs:
+            views = views.cpu().pin_memory()
+    else:
+        margs = DINOv2Args(output_dim=args.out_dim)
+        method = DINOv2(cfg, margs, global_batch_size=B * world, total_steps=125_000, device=dev, seed=0)
+        if args.single_stream:
+            method.overlap_streams = False
+        views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [
+            torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
+        if args.host_inputs:
+            views = [v.cpu().pin_memory() for v in views]
     random.seed(100 + rank)
+    torch.manual_seed(100 + rank)
 
     def barrier() -> None:
         if world > 1:
@@ -150,9 +163,15 @@ def main() -> None:
 
     n_g = (-(-args.global_size // 16)) ** 2 + 1
     n_l = (-(-args.local_size // 16)) ** 2 + 1  # 98 -> 112 (bicubic pad-resize of patch_embed.py:90-99) -> 7x7 patches
-    m_tokens = method._last["M"] / B
-    gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
-                                  2048, 256, m_tokens) / 1e9
+    if args.method == "distillationv3":
+        def vit_fwd(D: int, depth: int, T: int) -> float:
+            return depth * (2 * T * 12 * D * D + 4 * T * T * D) + 2 * (n_g - 1) * D * 3 * 256
+        # teacher forward (ViT-L/16, 1 + 4 + 196 tokens) + 3 x student forward; projection heads / similarity GEMMs are < 1 %
+        gf_img = (vit_fwd(1024, 24, n_g + 4) + 3 * vit_fwd(arch["embed_dim"], arch["depth"], n_g)) / 1e9
+    else:
+        m_tokens = method._last["M"] / B
+        gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
+                                      2048, 256, m_tokens) / 1e9
 
     roofline = None
     if not args.no_roofline:   # every rank runs the instrumented step (it contains the step's collectives); rank 0 reports
@@ -170,7 +189,7 @@ def main() -> None:
             return r
 
         ops.gemm = timed_gemm
-        method.overlap_streams = False  # kernels must run alone for their HIP-event durations to mean anything
+        method.overlap_streams = False  # kernels must run alone for their HIP-event durations to mean anything (DINOv2 method)
         try:
             method.train_step(views)
             torch.cuda.synchronize()
@@ -185,7 +204,7 @@ def main() -> None:
         # applied by tools/pmc_step_traffic.py).  Only quoted for the configuration it was measured on.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01h_gemm_traffic.json")
-        default_cfg = (args.model == "vit_base" and B == 128 and args.global_size == 224 and args.local_size == 98 and args.n_local == 8
+        default_cfg = (args.method == "dinov2" and args.model == "vit_base" and B == 128 and args.global_size == 224 and args.local_size == 98 and args.n_local == 8
                        and args.out_dim == 65536)
         if default_cfg and os.path.exists(tpath):
             with open(tpath) as f:
@@ -200,17 +219,24 @@ def main() -> None:
                     "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.method == "dinov2":
         cpu = cpu_baseline(arch, args.out_dim, args.global_size, args.local_size, args.n_local)
 
     if rank == 0:
+        if args.method == "distillationv3":
+            metric = f"images/sec DistillationV3 DINOv3 ViT-L/16 teacher -> {args.model}/16 student"
+            workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> DINOv2 {args.model}/16 student, per-GPU batch {B}, "
+                        f"one {args.global_size}^2 view, queue 8192 (BASELINE config 4 names a torchvision/resnet50 student: not built)")
+        else:
+            metric = "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops"
+            workload = (f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "
+                        f"K={args.out_dim} prototypes, softmax centering, drop-path 0")
         out = {
-            "metric": "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops",
+            "metric": metric,
             "value": round(img_per_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "
-                                   f"K={args.out_dim} prototypes, softmax centering, drop-path 0",
+            "config": {"workload": workload,
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
                        "inputs": "pinned host memory (H2D inside the timed region)" if args.host_inputs else "resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -356,13 +356,13 @@ def test_distillation_ops_kl_symmetrize_mixup_batched_gemm():
     ref = torch.nn.KLDivLoss(reduction="batchmean")(F.log_softmax(sr / T, -1), F.softmax(t[:, :K] / T, -1))
     ref.backward()
     assert float(loss) == pytest.approx(float(ref), rel=1e-4)
-    assert rel_err(dl[:, :K], sr.grad) < 6e-3 and dl[:, K:].abs().max().item() == 0
+    assert rel_err(dl[:, :K].cpu(), sr.grad) < 6e-3 and dl[:, K:].abs().max().item() == 0
 
     B, n = 3, 20
     d = bf(torch.randn(B, n, 24, generator=g)).to(DEV)
     gsym = torch.zeros_like(d)
     o.symmetrize_bf16(d, gsym, B, n, 24)
-    assert rel_err(gsym[:, :, :n], d[:, :, :n].float() + d[:, :, :n].float().transpose(1, 2)) < 6e-3
+    assert rel_err(gsym[:, :, :n].cpu(), (d[:, :, :n].float() + d[:, :, :n].float().transpose(1, 2)).cpu()) < 6e-3
 
     x = torch.randn(5, 3, 8, 8, generator=g).to(DEV); idx = torch.randperm(5, generator=g)
     out = torch.empty_like(x)
@@ -374,7 +374,7 @@ def test_distillation_ops_kl_symmetrize_mixup_batched_gemm():
     S = torch.zeros(Bq * m, 200, device=DEV)
     o.gemm(X, X, S, M=m, N=m, K=Kd, epilogue=o.EPI_F32, ldc=200, batch=Bq, stride_a=m * Kd, stride_b=m * Kd, stride_c=m * 200)
     Xf = X.float().view(Bq, m, Kd)
-    assert rel_err(S.view(Bq, m, 200)[:, :, :m], Xf @ Xf.transpose(1, 2)) < 1e-5 and S.view(Bq, m, 200)[:, :, m:].abs().max().item() == 0
+    assert rel_err(S.view(Bq, m, 200)[:, :, :m].cpu(), (Xf @ Xf.transpose(1, 2)).cpu()) < 1e-5 and S.view(Bq, m, 200)[:, :, m:].abs().max().item() == 0
 
 
 def test_bicubic_pad_resize():
