@@ -2,6 +2,7 @@
 // One 256-thread block per logits row; rows are streamed as float4 with an online (max, sum-exp) so each
 // row is read twice (second pass from L2: one row = 256 KiB) instead of three times.
 #include "lt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -46,6 +47,89 @@ __global__ __launch_bounds__(256) void softmax_center_kernel(const float* __rest
   const float inv = 1.f / a.s;
   for (int k = threadIdx.x; k < K; k += 256)
     probs[row * K + k] = __expf((x[k] - (center ? center[k] : 0.f)) * inv_temp - a.m) * inv;
+}
+
+// Register-resident variants for K <= 65 536 (K % 4 == 0): 1024 threads hold the whole row (16 float4 each), so the logits
+// are read from HBM once instead of twice (the 256-thread kernels re-read the 256-KiB row for their second pass; 32 rows in
+// flight per XCD do not fit its 4-MiB L2).
+constexpr int ROW_NV = 16;
+__global__ __launch_bounds__(1024) void softmax_center_reg_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+                                                                  float* __restrict__ probs, int K, float inv_temp) {
+  __shared__ float red[32];
+  const long row = blockIdx.x;
+  const float* x = logits + row * K;
+  float4 v[ROW_NV];
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K) {
+      float4 u = *reinterpret_cast<const float4*>(x + k);
+      if (center) { const float4 c = *reinterpret_cast<const float4*>(center + k); u.x -= c.x; u.y -= c.y; u.z -= c.z; u.w -= c.w; }
+      u.x *= inv_temp; u.y *= inv_temp; u.z *= inv_temp; u.w *= inv_temp;
+      v[i] = u;
+      ms_push(a, u.x); ms_push(a, u.y); ms_push(a, u.z); ms_push(a, u.w);
+    }
+  }
+  a = block_ms(a, red);
+  const float inv = 1.f / a.s;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K)
+      *reinterpret_cast<float4*>(probs + row * K + k) = make_float4(__expf(v[i].x - a.m) * inv, __expf(v[i].y - a.m) * inv,
+                                                                    __expf(v[i].z - a.m) * inv, __expf(v[i].w - a.m) * inv);
+  }
+}
+
+__global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ s, const float* __restrict__ teacher,
+                                                      const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
+                                                      const float* __restrict__ row_weight, const int32_t* __restrict__ slot,
+                                                      float scale, float inv_temp, float* __restrict__ loss,
+                                                      bf16_t* __restrict__ dlogits, int K) {
+  __shared__ float red[32];
+  const long row = blockIdx.x;
+  const float* z = s + row * K;
+  const float* t0 = teacher + (long)ta[row] * K;
+  const float* t1 = (tb && tb[row] >= 0) ? teacher + (long)tb[row] * K : nullptr;
+  float4 v[ROW_NV];
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  float dot = 0.f, tsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K) {
+      float4 u = *reinterpret_cast<const float4*>(z + k);
+      u.x *= inv_temp; u.y *= inv_temp; u.z *= inv_temp; u.w *= inv_temp;
+      v[i] = u;
+      float4 t = *reinterpret_cast<const float4*>(t0 + k);
+      if (t1) { const float4 t2 = *reinterpret_cast<const float4*>(t1 + k); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
+      ms_push(a, u.x); ms_push(a, u.y); ms_push(a, u.z); ms_push(a, u.w);
+      dot += t.x * u.x + t.y * u.y + t.z * u.z + t.w * u.w;
+      tsum += t.x + t.y + t.z + t.w;
+    }
+  }
+  a = block_ms(a, red);
+  dot = block_sum(dot, red);
+  tsum = block_sum(tsum, red);
+  const float lse = a.m + __logf(a.s);
+  const float coef = scale * (row_weight ? row_weight[row] : 1.f);
+  if (threadIdx.x == 0) atomicAdd(loss + (slot ? slot[row] : 0), -coef * (dot - lse * tsum));
+  if (dlogits) {
+    const float c2 = coef * inv_temp;
+#pragma unroll
+    for (int i = 0; i < ROW_NV; ++i) {
+      const int k = (i * 1024 + threadIdx.x) * 4;
+      if (k < K) {
+        float4 t = *reinterpret_cast<const float4*>(t0 + k);   // second read of the teacher row(s): L2 / Infinity Cache
+        if (t1) { const float4 t2 = *reinterpret_cast<const float4*>(t1 + k); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
+        const float4 u = v[i];
+        *reinterpret_cast<uint2*>(dlogits + row * K + k) =
+            make_uint2(pack_bf2(c2 * (__expf(u.x - lse) * tsum - t.x), c2 * (__expf(u.y - lse) * tsum - t.y)),
+                       pack_bf2(c2 * (__expf(u.z - lse) * tsum - t.z), c2 * (__expf(u.w - lse) * tsum - t.w)));
+      }
+    }
+  }
 }
 
 __global__ void center_ema_kernel(float* center, const float* colsum, float scale, float momentum, int K) {
@@ -257,7 +341,12 @@ __global__ __launch_bounds__(256) void koleo_dx_kernel(const float* __restrict__
 extern "C" int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream) {
   LT_CHECK_ARG(logits && probs && K > 0, "lt_softmax_center: bad arguments");
   if (rows == 0) return LT_OK;
-  hipLaunchKernelGGL(softmax_center_kernel, dim3(rows), dim3(256), 0, ST, logits, center, probs, K, inv_temp);
+  static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
+  if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)probs % 16 == 0) &&
+      (!center || (uintptr_t)center % 16 == 0))
+    hipLaunchKernelGGL(softmax_center_reg_kernel, dim3(rows), dim3(1024), 0, ST, logits, center, probs, K, inv_temp);
+  else
+    hipLaunchKernelGGL(softmax_center_kernel, dim3(rows), dim3(256), 0, ST, logits, center, probs, K, inv_temp);
   LT_CHECK_LAUNCH("lt_softmax_center");
 }
 extern "C" int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream) {
@@ -270,8 +359,14 @@ extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t
                              void* stream) {
   LT_CHECK_ARG(s && teacher && ta && loss && K > 0, "lt_ce_fwd_bwd: bad arguments");
   if (rows == 0) return LT_OK;
-  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
-                     (bf16_t*)dlogits_bf16, K);
+  static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
+  if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)s % 16 == 0) && ((uintptr_t)teacher % 16 == 0) &&
+      (!dlogits_bf16 || (uintptr_t)dlogits_bf16 % 8 == 0))
+    hipLaunchKernelGGL(ce_reg_kernel, dim3(rows), dim3(1024), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
+                       (bf16_t*)dlogits_bf16, K);
+  else
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
+                       (bf16_t*)dlogits_bf16, K);
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
 }
 extern "C" int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream) {
