@@ -295,3 +295,26 @@ def test_loss_trajectory_with_koleo_40_steps():
 
     worst, _ = trajectory.run("step_d64_softmax", 40, 0.1, quiet=True)
     assert worst["loss"] < 8e-3 and worst["dino_global_loss"] < 6e-3 and worst["dino_local_loss"] < 6e-3 and worst["ibot_loss"] < 6e-3, worst
+
+
+def test_model_wrapper_forward_features_matches_oracle():
+    """ModelWrapper surface (dinov2_vit.py:67-103): features [B,D,h,w] / cls_token / pooled_features, with iBOT masks."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.model_wrapper import DINOv2ViTModelWrapper
+    from lightly_train_amd.vit import ViTConfig
+    from oracle import dinov2_oracle as O
+
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    sb = fx["init"]["student_backbone"]
+    cfg = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"])
+    w = DINOv2ViTModelWrapper(cfg, state=sb)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3, 96, 96, generator=g)
+    masks = torch.rand(3, 36, generator=g) < 0.3
+    out = w.forward_features(x, masks)
+    ref = O.vit_forward(sb, x, dict(patch_size=16, num_heads=1, depth=2), masks=masks)
+    assert out["features"].shape == (3, 64, 6, 6) and w.feature_dim() == 64 and w.patch_size() == 16
+    assert rel(out["cls_token"], ref["cls"]) < 2e-2
+    assert rel(out["features"].flatten(2).transpose(1, 2), ref["patch"]) < 2e-2
+    assert w.forward_pool(out)["pooled_features"].shape == (3, 64, 1, 1)
+    assert set(w.get_model().state_dict()) == set(sb)
