@@ -318,3 +318,39 @@ def test_model_wrapper_forward_features_matches_oracle():
     assert rel(out["features"].flatten(2).transpose(1, 2), ref["patch"]) < 2e-2
     assert w.forward_pool(out)["pooled_features"].shape == (3, 64, 1, 1)
     assert set(w.get_model().state_dict()) == set(sb)
+
+
+def test_vit_small_full_depth_step_matches_oracle():
+    """Production shapes in one piece: ViT-S/16 (D=384, 6 heads, 12 blocks), 224^2 global + 98^2 local crops (197 / 50 tokens,
+    the 98 -> 112 pad-resize), K = 8192, batch 4: loss terms and well-conditioned gradients against the fp32 oracle."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(21)
+    vc = ViTConfig(embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-2)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(384, 512, 256, 8192, g), init_head_state(384, 512, 256, 8192, g)
+    args = DINOv2Args(output_dim=8192, hidden_dim=512, dino_bottleneck_dim=256, koleo_loss_weight=0.0)
+    b = 4
+    m = DINOv2(vc, args, global_batch_size=b, total_steps=100, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    o = O.OracleDINOv2(bsd, shs, dict(patch_size=16, num_heads=6, depth=12), args=dict(output_dim=8192, hidden_dim=512, bottleneck_dim=256, koleo_loss_weight=0.0),
+                       global_batch_size=b, total_steps=100, teacher_head=ths)
+    views = [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(4)]
+    random.seed(3)
+    res = m.training_step_impl({"views": views}, 0)
+    loss, ologs = o.forward_loss(views, m._last_masks)
+    loss.backward()
+    logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(float(ologs[k]), rel=5e-3), k
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=5e-3)
+    sq_o = sq_r = 0.0
+    for n in m.student.names:
+        ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+        ours = m.student.g[n].cpu()
+        sq_o += float((ours.double() ** 2).sum()); sq_r += float((ref.double() ** 2).sum())
+        if n.startswith(("head.", "backbone.norm.", "backbone.blocks.11.", "backbone.blocks.0.attn.qkv.weight", "backbone.patch_embed")):
+            assert rel(ours, ref) < 6e-2, n
+    assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2)
