@@ -26,17 +26,17 @@ def warmup_cosine_lr_factor(step: int, warmup_steps: int, max_steps: int, end_va
 
 
 def linear_warmup_schedule(step: int, warmup_steps: int, start_value: float, end_value: float) -> float:
-    """LT/_methods/dinov2/scheduler.py:13-34 (same argument validation / errors)."""
-    if warmup_steps < 0:
-        raise ValueError(f"Warmup steps {warmup_steps} can't be negative.")
-    if step < 0:
-        raise ValueError(f"Current step number {step} can't be negative.")
-    if start_value < 0:
-        raise ValueError(f"Start value {start_value} can't be negative.")
-    if end_value <= 0:
-        raise ValueError(f"End value {end_value} can't be non-positive.")
-    if start_value > end_value:
-        raise ValueError(f"Start value {start_value} must be less than or equal to end value {end_value}.")
-    if step < warmup_steps:
-        return start_value + step / warmup_steps * (end_value - start_value)
-    return end_value
+    """Teacher-temperature ramp (reference LT/_methods/dinov2/scheduler.py:13-34): linear from `start_value` to `end_value`
+    over `warmup_steps`, constant afterwards; the same argument domain is enforced (ValueError outside it)."""
+    domain = (
+        (warmup_steps >= 0, f"warmup_steps must be >= 0, got {warmup_steps}"),
+        (step >= 0, f"step must be >= 0, got {step}"),
+        (start_value >= 0, f"start_value must be >= 0, got {start_value}"),
+        (end_value > 0, f"end_value must be > 0, got {end_value}"),
+        (start_value <= end_value, f"start_value {start_value} exceeds end_value {end_value}"),
+    )
+    for ok, msg in domain:
+        if not ok:
+            raise ValueError(msg)
+    frac = min(step / warmup_steps, 1.0) if warmup_steps > 0 else 1.0
+    return start_value + frac * (end_value - start_value) if frac < 1.0 else end_value
