@@ -70,6 +70,48 @@ def test_two_ranks_match_single_process(tmp_path, center_method):
             assert d <= 2e-4 * max(1.0, b[i].abs().max().item()), (nm, d)
 
 
+def _run_distill(n_steps: int = 3):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_distill as TD
+
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "distill_v3_d64.pt"), weights_only=False)
+    m = TD.build(fx)
+    losses = []
+    for rec in fx["steps"][:n_steps]:
+        x = torch.randn(fx["b"], 3, 64, 64, generator=torch.Generator().manual_seed(rec["x_seed"]))
+        losses.append(float(m.train_step(x, mix=(rec["lam"], rec["index"])).loss))
+    torch.cuda.synchronize()
+    return losses, m.student.data.detach().cpu().clone(), m.teacher_queue.cpu().clone()
+
+
+def _distill_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.save(_run_distill(), os.path.join(out_dir, f"d{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distillation_two_ranks_match_single_process(tmp_path):
+    """DistillationV3 under data parallelism: per-GPU queues, gradient mean -- same data on both ranks == single process."""
+    mp.spawn(_distill_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "d0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "d1.pt", weights_only=False)
+    single = _run_distill()
+    for a, b in ((r0, r1), (r0, single)):
+        assert a[0] == pytest.approx(b[0], rel=2e-4)
+        for i in (1, 2):
+            assert (a[i] - b[i]).abs().max().item() <= 2e-4 * max(1.0, b[i].abs().max().item())
+
+
 def test_bench_contract_two_ranks():
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), with the two ranks
     folded onto cuda:0 over gloo (LT_BENCH_BACKEND): every rank has to take part in every step that contains collectives
