@@ -64,9 +64,8 @@ typedef struct lt_gemm_desc {
   const void* aux; int ldaux;     /* [M][N] bf16 pre-activation (LT_EPI_BF16_GELUGRAD) */
   float alpha;
   int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
-  int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged, 2 = 256-row LDS-DMA, 3 = 128x128 LDS-DMA (2 blocks/CU),
-                                     4 = 256x256 BK=32 4-stage, 5 = persistent 256x128 (2 blocks/CU), 6 = 2 with tail split,
-                                     7 = 2 with a persistent 256-block grid, 8 = 256x256 four-phase ping-pong K-loop (the default for large shapes) */
+  int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel with the 2-stage K-loop,
+                                     8 = 256x256 LDS-DMA kernel with the four-phase ping-pong K-loop (the default for large shapes) */
   const float* rowscale;          /* [M] per-row multiplier of the LayerScale branch (LT_EPI_RESID; per-sample DropPath) or NULL */
   float branch_scale;             /* scalar multiplier of the branch (LT_EPI_RESID; batch-subset stochastic depth b/s); 0 = 1 */
   void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */
@@ -79,9 +78,6 @@ int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);
 /* one-thread-per-output fp32-accumulate GEMM on the same bf16 operands (cross-check only) */
 int lt_gemm_bf16_naive(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int trans_a, int trans_b, void* stream);
-/* diagnostics: per-block records [hw_id, xcc_id, priority ticket, start tick, end tick, tiles, -, -] (8 x u64 per block,
- * 100 MHz ticks) of the last persistent two-blocks-per-CU GEMM launched with force_kernel = 58; synchronises the device */
-int lt_debug_gemm_log(unsigned long long* host_dst, int n_blocks);
 /* tiny fp32 matmul C[M,N] (+)= op(A)[M,K] . B[K,N]  (pos-embed bicubic map, vision_transformer.py:251-305) */
 int lt_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate, void* stream);
 

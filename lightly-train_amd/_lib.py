@@ -35,7 +35,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_matmul_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_resize_4tap": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_im2col_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "lt_debug_gemm_log": [vp, i32],
     "lt_kl_fwd_bwd": [vp, vp, i32, f32, f32, vp, vp, i32, i32, i32, vp],
     "lt_symmetrize_bf16": [vp, vp, i32, i32, i32, vp],
     "lt_mixup": [vp, vp, f32, vp, i32, i64, vp],

@@ -23,9 +23,7 @@
 #include <algorithm>
 
 #include "lt_common.h"
-#include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 namespace {
 
@@ -53,8 +51,6 @@ struct GemmArgs {
   float alpha;
   int tiles_m, tiles_n, k_per_split;
   long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
-  int dbg;     // profiling aid for the persistent kernel: 1 = skip main loop, 2 = skip epilogue, 4 = no priorities
-  int* sched;  // persistent kernel: 8 per-XCD tile counters + 1 exit counter (self-resetting)
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p, bool ok) {
@@ -400,8 +396,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
   const int nk = (kend - kbeg) / BK;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
-  // gridDim.x == ntiles: one tile per block.  gridDim.x < ntiles (a multiple of 8): persistent blocks walk the tiles, so the
-  // stores of tile i drain while tile i+1 runs its main loop.
+  // one tile per block (gridDim.x == ntiles); a smaller grid (multiple of 8) would walk the tiles persistently
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
   int id;
   {
@@ -708,418 +703,6 @@ int launch(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
 
 // 128 x 128 x 64 tile, 4 waves, LDS-DMA staged, 64 KiB LDS -> TWO workgroups per CU: one workgroup's epilogue (GELU / residual
 // traffic) overlaps the other's MFMA main loop.  Used where the epilogue is heavy relative to a short K loop.
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm128dma_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int OP = 128 * 128, STAGE = 2 * OP;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int id = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 128;
-  const int nk = g.K / BK;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  stage_dma<TA, 128, 4>(smem, g.A, g.lda, g.M, m0, 0);
-  stage_dma<TB, 128, 4>(smem + OP, g.B, g.ldb, g.N, n0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* la = smem + (kt & 1) * STAGE;
-    const char* lb = la + OP;
-    if (kt + 1 < nk) {
-      char* na = smem + ((kt + 1) & 1) * STAGE;
-      stage_dma<TA, 128, 4>(na, g.A, g.lda, g.M, m0, (kt + 1) * BK);
-      stage_dma<TB, 128, 4>(na + OP, g.B, g.ldb, g.N, n0, (kt + 1) * BK);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = read_frag2<TA, 128>(la, wm * 2 + i, ks);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = read_frag2<TB, 128>(lb, wn * 2 + j, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        wl[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[i][j][e];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  emit_subtile<EPI>(g, wl, m0 + wm * 64, n0 + wn * 64, l, false);
-}
-
-template <bool TA, bool TB>
-int launch128(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
-#define LT_C(E) case E: hipLaunchKernelGGL((gemm128dma_kernel<TA, TB, E>), grid, dim3(256), 65536, st, g); return LT_OK;
-  switch (epi) {
-    LT_C(EPI_BF16) LT_C(EPI_BF16_GELU) LT_C(EPI_RESID) LT_C(EPI_F32) LT_C(EPI_BF16_GELUGRAD)
-    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the 128x128 LDS-DMA kernel", epi); return LT_ERR_INVALID;
-  }
-#undef LT_C
-}
-// ---- deeper pipeline variant: BK = 32, FOUR 32-KiB LDS stages, DMA issued three k-tiles ahead, counted vmcnt + raw s_barrier
-// (never vmcnt(0) in the steady state): ~96 KiB of operand bytes in flight per CU instead of 64 KiB.
-template <bool TR, int ROWS>
-__device__ __forceinline__ void stage_dma32(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  constexpr int PER_WAVE = ROWS / 16 / 8, NB = ROWS / 16;
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int blk = w * PER_WAVE + j;
-    const bf16_t* src;
-    if (!TR) {
-      const int row = blk * 16 + (l >> 2), slot = l & 3;
-      const int c = slot ^ ((row >> 2) & 3);
-      const int gr = min(row0 + row, rows - 1);
-      src = P + (size_t)gr * ld + k0 + c * 8;
-    } else {
-      const int p = blk * 8 + (l >> 3), slot = l & 7;
-      const int q = p / NB, b = p % NB;
-      const int kr = ((slot >> 1) - b) & 3;
-      int col = row0 + b * 16 + (slot & 1) * 8;
-      if (col >= rows) col = 0;
-      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
-    }
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
-  }
-}
-template <bool TR, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag32(const char* lds, int rb, int ks) {
-  const int l = threadIdx.x & 63;
-  if (!TR) {
-    const int row = rb * 32 + (l & 31);
-    const int c = ks * 2 + (l >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-  } else {
-    return read_frag2<true, ROWS>(lds, rb, ks);
-  }
-}
-
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(NT2) void gemm256p_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BKP = 32, OPB = 256 * BKP * 2, STAGE = 2 * OPB, NS = 4;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int id = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, j = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = g.K / BKP;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int wm = wave >> 2, wn = wave & 3;
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#pragma unroll
-  for (int s2 = 0; s2 < NS - 1; ++s2)
-    if (s2 < nk) {
-      stage_dma32<TA, 256>(smem + s2 * STAGE, g.A, g.lda, g.M, m0, s2 * BKP);
-      stage_dma32<TB, 256>(smem + s2 * STAGE + OPB, g.B, g.ldb, g.N, n0, s2 * BKP);
-    }
-  for (int kt = 0; kt < nk; ++kt) {
-    // each wave issues 4 DMA instructions per k-tile; tiles kt+1, kt+2 (8 instructions) may stay in flight
-    const int ahead = nk - 1 - kt;
-    if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0xF78);       // vmcnt(8)
-    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0xF74);  // vmcnt(4)
-    else __builtin_amdgcn_s_waitcnt(0xF70);                  // vmcnt(0)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) {
-      char* na = smem + ((kt + NS - 1) % NS) * STAGE;
-      stage_dma32<TA, 256>(na, g.A, g.lda, g.M, m0, (kt + NS - 1) * BKP);
-      stage_dma32<TB, 256>(na + OPB, g.B, g.ldb, g.N, n0, (kt + NS - 1) * BKP);
-    }
-    const char* la = smem + (kt % NS) * STAGE;
-    const char* lb = la + OPB;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag32<TA, 256>(la, wm * 4 + i, ks);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = read_frag32<TB, 256>(lb, wn * 2 + j, ks);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  __syncthreads();
-  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    emit_subtile<EPI>(g, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-template <bool TA, bool TB, int EPI>
-int launch_p_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<TA, TB, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm256p_kernel<TA, TB, EPI>), grid, dim3(NT2), LDS_BYTES, st, g);
-  return LT_OK;
-}
-template <bool TA, bool TB>
-int launch_p(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
-  switch (epi) {
-    case EPI_BF16: return launch_p_one<TA, TB, EPI_BF16>(g, grid, st);
-    case EPI_BF16_GELU: return launch_p_one<TA, TB, EPI_BF16_GELU>(g, grid, st);
-    case EPI_RESID: return launch_p_one<TA, TB, EPI_RESID>(g, grid, st);
-    case EPI_F32: return launch_p_one<TA, TB, EPI_F32>(g, grid, st);
-    case EPI_BF16_GELUGRAD: return launch_p_one<TA, TB, EPI_BF16_GELUGRAD>(g, grid, st);
-    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the pipelined kernel", epi); return LT_ERR_INVALID;
-  }
-}
-
-// ---- persistent two-blocks-per-CU kernel -----------------------------------------------------------------------------------
-// 256 x 128 tile, 4 waves (2 x 2, wave tile 128 x 64 like the 256x256 kernel), BK = 32, three 24-KiB LDS stages (72 KiB) so
-// that TWO blocks are resident per CU.  The epilogue of the token-shaped GEMMs moves as many bytes as the main loop reads
-// (fp32 residual in + out, bf16 copies) and is HBM-bound while the main loop is MFMA-bound; with one block per CU -- or two
-// blocks running in lock-step -- the phases of all CUs coincide and add up (measured: time = rounds x (main + epilogue)).
-// Here the two co-resident blocks get DIFFERENT wave priorities (ticket parity per CU), so the high-priority block owns the
-// matrix pipe during its main loop and the other one advances while it stores: MFMA and HBM phases of a CU overlap.
-// Tiles are handed out dynamically from per-XCD counters (each XCD walks a contiguous range of tile ids, A rows shared in
-// its L2), which also softens the 591-tile / 256-CU wave quantisation of the N = 768 GEMMs.
-__device__ unsigned g_cu_ticket[4096];
-__device__ unsigned long long g_blk_log[512 * 8];  // diagnostics of the last persistent launch (lt_debug_gemm_log)
-
-template <bool TR, int ROWS>
-__device__ __forceinline__ void stage_dma32w4(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  constexpr int PER_WAVE = ROWS / 16 / 4, NB = ROWS / 16;
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int blk = w * PER_WAVE + j;
-    const bf16_t* src;
-    if (!TR) {
-      const int row = blk * 16 + (l >> 2), slot = l & 3;
-      const int c = slot ^ ((row >> 2) & 3);
-      const int gr = min(row0 + row, rows - 1);
-      src = P + (size_t)gr * ld + k0 + c * 8;
-    } else {
-      const int p = blk * 8 + (l >> 3), slot = l & 7;
-      const int q = p / NB, b = p % NB;
-      const int kr = ((slot >> 1) - b) & 3;
-      int col = row0 + b * 16 + (slot & 1) * 8;
-      if (col >= rows) col = 0;
-      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
-    }
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
-  }
-}
-
-constexpr int P2_LDS = 73728;
-
-template <bool TB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm2x_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_ctl[2];
-  constexpr int BKP = 32, A_B = 256 * BKP * 2, B_B = 128 * BKP * 2, STAGE = A_B + B_B, NS = 3;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  if (threadIdx.x == 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);    // HW_ID[15:0]: .. CU_ID[11:8] SH_ID[12] SE_ID[15:13]
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID[3:0]
-    s_ctl[0] = atomicAdd(&g_cu_ticket[((xcc & 15) << 8) | ((hw >> 8) & 255)], 1u) & 1;
-    if (g.dbg & 8) {
-      unsigned long long* lg = g_blk_log + (size_t)blockIdx.x * 8;
-      lg[0] = hw; lg[1] = xcc; lg[2] = s_ctl[0]; lg[3] = wall_clock64(); lg[5] = 0;
-    }
-  }
-  __syncthreads();
-  if (s_ctl[0] && !(g.dbg & 4)) __builtin_amdgcn_s_setprio(3);
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int xcd = blockIdx.x & 7;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int t_count = q8 + (xcd < r8 ? 1 : 0);
-  const int nk = (g.dbg & 1) ? 0 : g.K / BKP;
-  const bool one_shot = g.sched == nullptr;  // plain grid: one tile per block, XCD-contiguous like the 256x256 kernel
-  for (int iter = 0;; ++iter) {
-    int t;
-    if (one_shot) {
-      t = iter == 0 ? (int)(blockIdx.x >> 3) : t_count;
-    } else {
-      if (threadIdx.x == 0) s_ctl[1] = atomicAdd(&g.sched[xcd], 1);
-      __syncthreads();
-      t = s_ctl[1];
-    }
-    if (t >= t_count) break;
-    const int id = t_begin + t;
-    const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 128;
-    if ((g.dbg & 8) && threadIdx.x == 0) g_blk_log[(size_t)blockIdx.x * 8 + 5] += 1;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < NS - 1; ++s2)
-      if (s2 < nk) {
-        stage_dma32w4<false, 256>(smem + s2 * STAGE, g.A, g.lda, g.M, m0, s2 * BKP);
-        stage_dma32w4<TB, 128>(smem + s2 * STAGE + A_B, g.B, g.ldb, g.N, n0, s2 * BKP);
-      }
-    for (int kt = 0; kt < nk; ++kt) {
-      // 6 DMA instructions per wave per k-tile; tile kt+1 may stay in flight
-      if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
-      else __builtin_amdgcn_s_waitcnt(0xF70);              // vmcnt(0)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + NS - 1 < nk) {
-        char* na = smem + ((kt + NS - 1) % NS) * STAGE;
-        stage_dma32w4<false, 256>(na, g.A, g.lda, g.M, m0, (kt + NS - 1) * BKP);
-        stage_dma32w4<TB, 128>(na + A_B, g.B, g.ldb, g.N, n0, (kt + NS - 1) * BKP);
-      }
-      const char* la = smem + (kt % NS) * STAGE;
-      const char* lb = la + A_B;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 fa[4], fb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = read_frag32<false, 256>(la, wm * 4 + i, ks);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = read_frag32<TB, 128>(lb, wn * 2 + j, ks);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();  // every wave is done with the operand stages: they become the epilogue scratch
-    if (g.dbg & 2) continue;
-    float* wl = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      emit_subtile<EPI>(g, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();  // scratch reads done before the next tile's DMA lands; s_ctl[1] may be rewritten
-  }
-  if (threadIdx.x == 0 && !one_shot) {
-    if (g.dbg & 8) g_blk_log[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
-    const int done = atomicAdd(&g.sched[8], 1);
-    if (done == (int)gridDim.x - 1) {  // last block out: every other block has fetched its final ticket -> reset for the next user
-#pragma unroll
-      for (int i = 0; i < 9; ++i) g.sched[i] = 0;
-    }
-  }
-}
-
-// ring of self-resetting scheduler slots (16 ints each); one small device allocation per device, made on first use
-inline int* sched_slot() {
-  constexpr int SLOTS = 1024;
-  static int* base[16] = {nullptr};
-  static std::atomic<unsigned> next{0};
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!base[dev]) {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!base[dev]) {
-      int* p = nullptr;
-      if (hipMalloc(&p, SLOTS * 16 * sizeof(int)) != hipSuccess) return nullptr;
-      if (hipMemset(p, 0, SLOTS * 16 * sizeof(int)) != hipSuccess) return nullptr;
-      if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-      base[dev] = p;
-    }
-  }
-  return base[dev] + (next.fetch_add(1) % SLOTS) * 16;
-}
-
-template <bool TB, int EPI>
-int launch2x_one(GemmArgs& g, hipStream_t st) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2x_kernel<TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
-    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 72 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
-    configured = true;
-  }
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int grid;
-  if (g.dbg & 16) {  // one tile per block
-    g.sched = nullptr;
-    grid = (ntiles + 7) / 8 * 8;
-  } else {
-    g.sched = sched_slot();
-    if (!g.sched) { lt_set_error("lt_gemm_bf16: cannot allocate the tile-scheduler counters"); return LT_ERR_HIP; }
-    grid = std::min(512, (ntiles + 7) / 8 * 8);
-  }
-  hipLaunchKernelGGL((gemm2x_kernel<TB, EPI>), dim3(grid), dim3(256), P2_LDS, st, g);
-  return LT_OK;
-}
-template <bool TB>
-int launch2x(GemmArgs& g, int epi, hipStream_t st) {
-  switch (epi) {
-    case EPI_BF16: return launch2x_one<TB, EPI_BF16>(g, st);
-    case EPI_BF16_GELU: return launch2x_one<TB, EPI_BF16_GELU>(g, st);
-    case EPI_RESID: return launch2x_one<TB, EPI_RESID>(g, st);
-    case EPI_F32: return launch2x_one<TB, EPI_F32>(g, st);
-    case EPI_BF16_GELUGRAD: return launch2x_one<TB, EPI_BF16_GELUGRAD>(g, st);
-    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the two-blocks-per-CU kernel", epi); return LT_ERR_INVALID;
-  }
-}
 }  // namespace g256
 
 // ---- plain reference-grade GEMM (one thread per output; cross-check for the MFMA kernel) -------
@@ -1205,35 +788,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= 128 &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
-  g.sched = nullptr; g.dbg = 0;
-  static const int token_kernel = [] { const char* e = getenv("LT_GEMM_TOKEN_KERNEL"); return e ? atoi(e) : 2; }();
-  const bool auto5 = (token_kernel == 5 || token_kernel == 6) && d->force_kernel == 0 && big && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM;
-  if (auto5 && token_kernel == 6) g.dbg = 16;
-  if (auto5 || d->force_kernel == 5 || (d->force_kernel >= 50 && d->force_kernel < 82)) {
-    if (d->force_kernel >= 50) g.dbg = d->force_kernel - 50;
-    LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM && d->N >= 128, "lt_gemm_bf16: not eligible for the two-blocks-per-CU kernel");
-    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 128);
-    rc = d->trans_b ? g256::launch2x<true>(g, d->epilogue, st) : g256::launch2x<false>(g, d->epilogue, st);
-    if (rc != LT_OK) return rc;
-    LT_CHECK_LAUNCH("lt_gemm_bf16");
-  }
-  if (d->force_kernel == 4) {
-    LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM && d->N >= 256, "lt_gemm_bf16: not eligible for the pipelined 256x256 kernel");
-    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 256);
-    dim3 grid4(g.tiles_m * g.tiles_n);
-    rc = d->trans_b ? g256::launch_p<false, true>(g, d->epilogue, grid4, st) : g256::launch_p<false, false>(g, d->epilogue, grid4, st);
-    if (rc != LT_OK) return rc;
-    LT_CHECK_LAUNCH("lt_gemm_bf16");
-  }
-  if (d->force_kernel == 3) {
-    LT_CHECK_ARG(eligible && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM, "lt_gemm_bf16: not eligible for the 128x128 LDS-DMA kernel");
-    g.tiles_m = lt_cdiv(d->M, 128); g.tiles_n = lt_cdiv(d->N, 128);
-    dim3 grid3(g.tiles_m * g.tiles_n);
-    rc = d->trans_b ? g256::launch128<false, true>(g, d->epilogue, grid3, st) : g256::launch128<false, false>(g, d->epilogue, grid3, st);
-    if (rc != LT_OK) return rc;
-    LT_CHECK_LAUNCH("lt_gemm_bf16");
-  }
-  if (d->force_kernel == 2 || d->force_kernel == 6 || d->force_kernel == 7 || d->force_kernel == 8) {
+  if (d->force_kernel == 2 || d->force_kernel == 8) {
     LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
@@ -1261,40 +816,13 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     const bool slab = accum && sp > 1 && d->workspace && d->workspace_bytes >= (size_t)sp * d->M * d->N * sizeof(float);
     g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, bn);
-    // Tail split: when the last wave of 256x256 tiles would leave most CUs idle (591 tiles = 2.31 waves for the N = 768
-    // GEMMs), the rows of that partial wave go to the 128x128 two-blocks-per-CU kernel instead (4x the tiles, 512 slots).
-    // Opt-in (force_kernel = 6): +5..9 % on those GEMMs alone, but inside the step the other streams' kernels already
-    // fill the idle CUs and the extra launch costs more than it saves (121.4 vs 122.5 ms/step).
-    if (d->force_kernel == 6 && !d->trans_a && !accum && bn == 256) {
-      const int ntiles = g.tiles_m * g.tiles_n, rounds = ntiles / cus, rem = ntiles - rounds * cus;
-      const int main_rows = rounds * cus / g.tiles_n;
-      if (rounds >= 1 && rem > 0 && rem <= 144 && main_rows >= 1 && main_rows < g.tiles_m) {
-        const size_t m0 = (size_t)main_rows * 256;
-        lt_gemm_desc tail = *d;
-        tail.M = d->M - (int)m0;
-        tail.force_kernel = 3;
-        tail.A = (const bf16_t*)d->A + m0 * d->lda;
-        tail.C = f32out ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((bf16_t*)d->C + m0 * d->ldc);
-        if (d->C2) tail.C2 = (bf16_t*)d->C2 + m0 * d->ldc2;
-        if (d->resid) tail.resid = d->resid + m0 * d->ldr;
-        if (d->aux) tail.aux = (const bf16_t*)d->aux + m0 * d->ldaux;
-        if (d->rowscale) tail.rowscale = d->rowscale + m0;
-        g.M = (int)m0; g.tiles_m = main_rows;
-        dim3 gridm(g.tiles_m * g.tiles_n, 1);
-        rc = d->trans_b ? g256::launch<false, true, 256>(g, d->epilogue, false, gridm, st) : g256::launch<false, false, 256>(g, d->epilogue, false, gridm, st);
-        if (rc != LT_OK) return rc;
-        return lt_gemm_bf16(&tail, stream);
-      }
-    }
     const int ktiles2 = d->K / BK;
     g.k_per_split = lt_cdiv(ktiles2, sp) * BK;
     sp = lt_cdiv(d->K, g.k_per_split);
     if (slab) g.C2 = d->workspace;
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
-    static const int persist = [] { const char* e = getenv("LT_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-    if ((d->force_kernel == 7 || (persist && d->force_kernel == 0)) && !accum && (int)grid2.x > cus) grid2.x = cus;
-    static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // 4-phase ping-pong K-loop by default
-    if (bn == 256 && (d->force_kernel == 8 || (use_q && d->force_kernel == 0))) {
+    static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
+    if (bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || use_q)) {
       if (!d->trans_a && !d->trans_b) rc = g256::launch_q<false, false>(g, d->epilogue, slab, grid2, st);
       else if (!d->trans_a) rc = g256::launch_q<false, true>(g, d->epilogue, slab, grid2, st);
       else rc = g256::launch_q<true, true>(g, d->epilogue, slab, grid2, st);
@@ -1325,13 +853,4 @@ extern "C" int lt_gemm_bf16_naive(const void* A, const void* B, float* C, int M,
   hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(128), 0, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N,
                      K, lda, ldb, ldc, trans_a, trans_b);
   LT_CHECK_LAUNCH("lt_gemm_bf16_naive");
-}
-
-// diagnostics: per-block records of the last persistent GEMM launched with dbg bit 8 (force_kernel = 58):
-// [hw_id, xcc_id, priority ticket, start (100 MHz ticks), end, tiles processed, -, -] x 512 blocks
-extern "C" int lt_debug_gemm_log(unsigned long long* host_dst, int n_blocks) {
-  LT_CHECK_ARG(host_dst && n_blocks > 0 && n_blocks <= 512, "lt_debug_gemm_log: bad arguments");
-  hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g256::g_blk_log), (size_t)n_blocks * 8 * sizeof(unsigned long long));
-  if (e != hipSuccess) { lt_set_error("lt_debug_gemm_log: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
-  return LT_OK;
 }

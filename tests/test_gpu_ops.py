@@ -52,7 +52,7 @@ def test_gemm_layouts(M, N, K, ta, tb):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("fk", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("fk", [2, 8])
 def test_gemm_256_kernel(M, N, K, tb, fk):
     """the 256x256 LDS-DMA kernel (forced) against the fp32 reference, incl. M/N tails and every epilogue it serves."""
     o = ops()
@@ -77,54 +77,6 @@ def test_gemm_256_kernel(M, N, K, tb, fk):
     x = aux.float().requires_grad_(True)
     F.gelu(x).sum().backward()
     assert rel_err(ob, ref * x.grad) < 6e-3
-
-
-@pytest.mark.parametrize("tb", [False, True])
-def test_gemm_tail_split(tb):
-    """force_kernel = 6: 118 x 3 = 354 tiles = 1 full wave + 98 -> rows of the partial wave run on the 128x128 kernel."""
-    o = ops()
-    g = torch.Generator(device="cpu").manual_seed(77)
-    M, N, K = 30000, 768, 128
-    A = bf(torch.randn(M, K, generator=g)).to(DEV)
-    B = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
-    ref = A.float() @ B.float().t()
-    b_in = B.t().contiguous() if tb else B
-    bias, gamma = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
-    resid = torch.randn(M, N, generator=g).to(DEV)
-    rowscale = torch.rand(M, generator=g).to(DEV)
-    out = torch.empty(M, N, device=DEV, dtype=torch.float32); y2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, out2=y2, rowscale=rowscale, force_kernel=6)
-    y = ref + bias
-    assert rel_err(out, resid + rowscale[:, None] * gamma * y) < 1e-5 and rel_err(y2, y) < 6e-3
-    aux = bf(torch.randn(M, N, generator=g)).to(DEV)
-    ob = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    o.gemm(A, b_in, ob, M=M, N=N, K=K, trans_b=tb, epilogue=o.EPI_BF16_GELUGRAD, aux=aux, force_kernel=6)
-    x = aux.float().requires_grad_(True)
-    F.gelu(x).sum().backward()
-    assert rel_err(ob, ref * x.grad) < 6e-3
-
-
-def test_gemm_persistent_scheduler_reuse():
-    """The two-blocks-per-CU kernel takes its tiles from self-resetting per-XCD counters in a ring of 1024 slots: run it more
-    often than there are slots, on two streams at once, and require identical results every time."""
-    o = ops()
-    g = torch.Generator(device="cpu").manual_seed(5)
-    M, N, K = 3000, 384, 128
-    A = bf(torch.randn(M, K, generator=g)).to(DEV)
-    B = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
-    ref = torch.empty(M, N, device=DEV, dtype=torch.float32)
-    o.gemm(A, B, ref, M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=2)
-    outs = [torch.zeros(M, N, device=DEV, dtype=torch.float32) for _ in range(2)]
-    side = torch.cuda.Stream()
-    for it in range(600):
-        o.gemm(A, B, outs[0], M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=5)
-        with torch.cuda.stream(side):
-            o.gemm(A, B, outs[1], M=M, N=N, K=K, epilogue=o.EPI_F32, force_kernel=5)
-        if it % 150 == 149:
-            torch.cuda.synchronize()
-            assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref), it
-            outs[0].zero_(); outs[1].zero_()
-    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("fk", [2, 8])
