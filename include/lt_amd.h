@@ -101,6 +101,11 @@ int lt_rope_apply(void* qkv_bf16, const float* sin_t, const float* cos_t, int B,
 int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream);
 int lt_swiglu_bwd(const void* x12_bf16, const void* dh_bf16, void* d12_bf16, int64_t rows, int H, void* stream);
 
+/* out f32 [B, n_out, D] = sparse linear map of in f32 [B, n_in, D]: out[b,o,:] = sum_{a<taps} w[o,a] * in[b, idx[o,a], :]
+ * (bilinear resize of the student's spatial features onto the teacher grid, distillationv3.py:338-345; backward = the
+ * transposed table).  Tables int32 / f32 [n_out, taps], built by the caller from F.interpolate. */
+int lt_resample_tokens(const float* in, const int32_t* idx, const float* w, float* out, int B, int n_in, int n_out, int D, int taps,
+                       void* stream);
 /* tokens [cls | n_reg registers | n_p patches]: x[b,0]=cls+pos[0]; x[b,1+r]=reg[r] (no pos-embed);
  * x[b,1+n_reg+i]=(mask[b,i]?mask_token:patch[b*n_p+i])+pos[1+i]; masks / reg may be NULL */
 int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,

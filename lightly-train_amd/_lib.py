@@ -38,6 +38,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_kl_fwd_bwd": [vp, vp, i32, f32, f32, vp, vp, i32, i32, i32, vp],
     "lt_symmetrize_bf16": [vp, vp, i32, i32, i32, vp],
     "lt_mixup": [vp, vp, f32, vp, i32, i64, vp],
+    "lt_resample_tokens": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_rope_apply": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
     "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],

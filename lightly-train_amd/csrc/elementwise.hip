@@ -49,6 +49,35 @@ __global__ __launch_bounds__(256) void resize4tap_kernel(const float* __restrict
   }
 }
 
+// Linear resampling of token grids with a sparse tap table: out[b, o, :] = sum_a w[o, a] * in[b, idx[o, a], :]
+// (the bilinear F.interpolate of the student's spatial features onto the teacher's grid, distillationv3.py:338-345; its
+// backward is the same kernel with the transposed table).  grid (n_out, B).
+__global__ __launch_bounds__(256) void resample_tokens_kernel(const float* __restrict__ in, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ w, float* __restrict__ out, int n_in, int n_out,
+                                                              int D, int taps) {
+  const int o = blockIdx.x;
+  const long b = blockIdx.y;
+  const float* src = in + b * n_in * D;
+  float* dst = out + (b * n_out + o) * D;
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < taps; ++a) {
+      const float wa = w[o * taps + a];
+      if (wa == 0.f) continue;
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)idx[o * taps + a] * D + d);
+      acc.x = fmaf(wa, v.x, acc.x); acc.y = fmaf(wa, v.y, acc.y); acc.z = fmaf(wa, v.z, acc.z); acc.w = fmaf(wa, v.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(dst + d) = acc;
+  }
+}
+extern "C" int lt_resample_tokens(const float* in, const int32_t* idx, const float* w, float* out, int B, int n_in, int n_out, int D,
+                                  int taps, void* stream) {
+  LT_CHECK_ARG(in && idx && w && out && in != out && B > 0 && n_in > 0 && n_out > 0 && D > 0 && D % 4 == 0 && taps > 0,
+               "lt_resample_tokens: bad arguments (D must be a multiple of 4)");
+  hipLaunchKernelGGL(resample_tokens_kernel, dim3(n_out, B), dim3(256), 0, (hipStream_t)stream, in, idx, w, out, n_in, n_out, D, taps);
+  LT_CHECK_LAUNCH("lt_resample_tokens");
+}
+
 // ------------------------------------------------------------------------------------ tokens
 __global__ void assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
                                 const float* __restrict__ mask_token, const uint8_t* __restrict__ masks, const float* __restrict__ reg,

@@ -9,8 +9,7 @@ Teacher: DINOv3 ViT (RoPE, storage tokens; `dinov3.py`) or a DINOv2 ViT; student
 State-dict names follow the reference: `student_embedding_model.wrapped_model._model.*`, `student_projection_head_global.*`,
 `student_projection_head_local.*`, `teacher_queue`.
 
-Not implemented (raise): student / teacher token grids of different size (the bilinear resize of :338-345), convolutional
-students (torchvision/resnet50 of BASELINE config 4), LARS.
+Not implemented (raise): convolutional students (torchvision/resnet50 of BASELINE config 4), LARS.
 """
 from __future__ import annotations
 
@@ -126,6 +125,7 @@ class DistillationV3:
         self.teacher_stream = torch.cuda.Stream(device=dev)
         self.side_stream = torch.cuda.Stream(device=dev)
         self._idx: Dict[Tuple[int, int, int], Tuple[Tensor, Tensor]] = {}
+        self._resample_tabs: Dict[Tuple[int, int, int, int], Any] = {}
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -141,6 +141,14 @@ class DistillationV3:
             patch = (r[:, None] * N + torch.arange(prefix, N, dtype=torch.int64)[None, :]).reshape(-1)
             self._idx[key] = (cls.to(self.device), patch.to(self.device))
         return self._idx[key]
+
+    def _resample(self, hs: int, ws_: int, ht: int, wt: int):
+        key = (hs, ws_, ht, wt)
+        if key not in self._resample_tabs:
+            (fi, fw, ft), (bi, bw, bt) = ops.resample_tables(hs, ws_, ht, wt, "bilinear")
+            dev = self.device
+            self._resample_tabs[key] = ((fi.to(dev), fw.to(dev), ft), (bi.to(dev), bw.to(dev), bt))
+        return self._resample_tabs[key]
 
     def _normalize(self, tag: str, x: Tensor, rows: int, D: int) -> Tuple[Tensor, Tensor]:
         """F.normalize(x, dim=-1): returns (bf16 normalised rows, 1/||x||)."""
@@ -205,8 +213,7 @@ class DistillationV3:
         sc = self.s_vit.forward(ws, "s", x, None, save=True)
         Ns, pre_s = sc["N"], 1 + self.scfg.num_register_tokens
         n_ps = Ns - pre_s
-        if (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"]):
-            raise NotImplementedError("student and teacher token grids differ: the bilinear resize of distillationv3.py:338-345 is not implemented")
+        resize = (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"])   # bilinear resize of the student map onto the teacher grid (:338-345)
         s_cls_rows, s_patch_rows = self._rows(B, Ns, pre_s)
         sxn = sc["xn"].view(-1, Ds)
         sg_in = ws.get("s.g_in", (B, Ds), torch.bfloat16)
@@ -214,12 +221,20 @@ class DistillationV3:
         ops.gather_rows(sxn, Ds, s_cls_rows, B, Ds, out_bf16=sg_in)
         ops.gather_rows(sxn, Ds, s_patch_rows, B * n_ps, Ds, out_bf16=sl_in)
         P = self.student
+        n_pl = n_pt if resize else n_ps            # tokens per image of the (resized) student local features
         sg_raw = ws.get("s.g", (B, Dt), torch.float32)
-        sl_raw = ws.get("s.l", (B * n_ps + 8, Dt), torch.float32, zero=True)
+        sl_raw = ws.get("s.l", (B * n_pl + 8, Dt), torch.float32, zero=True)
         ops.gemm(sg_in, P.b["proj_global.weight"], sg_raw, M=B, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_global.bias"])
-        ops.gemm(sl_in, P.b["proj_local.weight"], sl_raw, M=B * n_ps, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_local.bias"])
+        if resize:
+            tabs = self._resample(sc["gh"], sc["gw"], tc["gh"], tc["gw"])
+            sl_proj = ws.get("s.l_proj", (B * n_ps, Dt), torch.float32)
+            ops.gemm(sl_in, P.b["proj_local.weight"], sl_proj, M=B * n_ps, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_local.bias"])
+            (fi, fw, ft), _ = tabs
+            ops.resample_tokens(sl_proj, fi, fw, sl_raw, B, n_ps, n_pt, Dt, ft)
+        else:
+            ops.gemm(sl_in, P.b["proj_local.weight"], sl_raw, M=B * n_ps, N=Dt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["proj_local.bias"])
         sg, sg_inv = self._normalize("s.g", sg_raw, B, Dt)
-        sl, sl_inv = self._normalize("s.l", sl_raw, B * n_ps + 8, Dt)
+        sl, sl_inv = self._normalize("s.l", sl_raw, B * n_pl + 8, Dt)
 
         # ---- losses (distillationv3_loss.py:60-115) and their gradients w.r.t. the similarity logits
         main.wait_event(teacher_done)
@@ -229,27 +244,37 @@ class DistillationV3:
         Qp = (Q + 7) // 8 * 8
         dlg = ws.get("g.dlogits", (B, Qp), torch.bfloat16)
         ops.kl_fwd_bwd(s_logits, t_logits, Q, 1.0 / a.temperature_global, 1.0 / B, self._loss_slots[0:], dlg, Qp, B, Q)
-        Ss = ws.get("l.Ss", (B * n_ps, n_pad), torch.float32)
-        ops.gemm(sl, sl, Ss, M=n_ps, N=n_ps, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_ps * Dt, stride_b=n_ps * Dt,
-                 stride_c=n_ps * n_pad)
-        dS = ws.get("l.dS", (B * n_ps, n_pad), torch.bfloat16, zero=True)     # pad columns stay zero
-        ops.kl_fwd_bwd(Ss, St, n_pad, 1.0 / a.temperature_local, a.loss_local_weight / (B * n_ps), self._loss_slots[1:], dS, n_pad,
-                       B * n_ps, n_ps)
+        Ss = ws.get("l.Ss", (B * n_pl, n_pad), torch.float32)
+        ops.gemm(sl, sl, Ss, M=n_pl, N=n_pl, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_pl * Dt, stride_b=n_pl * Dt,
+                 stride_c=n_pl * n_pad)
+        dS = ws.get("l.dS", (B * n_pl, n_pad), torch.bfloat16, zero=True)     # pad columns stay zero
+        ops.kl_fwd_bwd(Ss, St, n_pad, 1.0 / a.temperature_local, a.loss_local_weight / (B * n_pl), self._loss_slots[1:], dS, n_pad,
+                       B * n_pl, n_pl)
 
         # ---- backward: similarity logits -> normalised features -> projection heads -> student tokens
         dsg_n = ws.get("g.dsg_n", (B, Dt), torch.float32)
         if Qp != Q:
             raise NotImplementedError("queue sizes must be multiples of 8")
         ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Q, trans_b=True, epilogue=ops.EPI_F32)
-        G = ws.get("l.G", (B * n_ps, n_pad), torch.bfloat16, zero=True)
-        ops.symmetrize_bf16(dS, G, B, n_ps, n_pad)
-        dsl_n = ws.get("l.dsl_n", (B * n_ps, Dt), torch.float32)
-        ops.gemm(G, sl, dsl_n, M=n_ps, N=Dt, K=n_pad, trans_b=True, epilogue=ops.EPI_F32, lda=n_pad, batch=B, stride_a=n_ps * n_pad,
-                 stride_b=n_ps * Dt, stride_c=n_ps * Dt)
+        G = ws.get("l.G", (B * n_pl, n_pad), torch.bfloat16, zero=True)
+        ops.symmetrize_bf16(dS, G, B, n_pl, n_pad)
+        dsl_n = ws.get("l.dsl_n", (B * n_pl, Dt), torch.float32)
+        ops.gemm(G, sl, dsl_n, M=n_pl, N=Dt, K=n_pad, trans_b=True, epilogue=ops.EPI_F32, lda=n_pad, batch=B, stride_a=n_pl * n_pad,
+                 stride_b=n_pl * Dt, stride_c=n_pl * Dt)
         dsg = ws.get("g.dsg", (B, Dt), torch.bfloat16)
         dsl = ws.get("l.dsl", (B * n_ps, Dt), torch.bfloat16)
         ops.l2norm_bwd(dsg_n, sg_raw, sg_inv, dsg, B, Dt)
-        ops.l2norm_bwd(dsl_n, sl_raw, sl_inv, dsl, B * n_ps, Dt)
+        if resize:   # gradient of the resized features -> transposed bilinear map -> projection output
+            dsl_r = ws.get("l.dsl_r", (B * n_pl, Dt), torch.bfloat16)
+            ops.l2norm_bwd(dsl_n, sl_raw, sl_inv, dsl_r, B * n_pl, Dt)
+            dsl_rf = ws.get("l.dsl_rf", (B * n_pl, Dt), torch.float32)
+            dsl_rf.copy_(dsl_r)                                   # plumbing: dtype of the resampling kernel's input
+            dsl_pf = ws.get("l.dsl_pf", (B * n_ps, Dt), torch.float32)
+            _, (bi, bw, bt) = tabs
+            ops.resample_tokens(dsl_rf, bi, bw, dsl_pf, B, n_pl, n_ps, Dt, bt)
+            ops.cast_bf16(dsl_pf, dsl)
+        else:
+            ops.l2norm_bwd(dsl_n, sl_raw, sl_inv, dsl, B * n_ps, Dt)
         for tagp, dy, xin, rows in (("proj_global", dsg, sg_in, B), ("proj_local", dsl, sl_in, B * n_ps)):
             ops.colsum_bf16(dy, P.g[tagp + ".bias"], rows, Dt)
             ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds)

@@ -217,6 +217,33 @@ def mixup(x: Tensor, index: Tensor, lam: float, out: Tensor) -> None:
     check(_lib.load().lt_mixup(_p(x), _p(index), lam, _p(out), x.shape[0], x[0].numel(), _stream()), "lt_mixup")
 
 
+def resample_tables(hs: int, ws_: int, ht: int, wt: int, mode: str = "bilinear"):
+    """Sparse tap tables (forward and transposed) of F.interpolate((hs, ws) -> (ht, wt), mode, align_corners=False), read off
+    F.interpolate itself on an identity basis (host, once per size pair)."""
+    import torch.nn.functional as F
+
+    n_s, n_t = hs * ws_, ht * wt
+    basis = torch.eye(n_s).view(1, n_s, hs, ws_)
+    R = F.interpolate(basis, size=(ht, wt), mode=mode, align_corners=False)[0].reshape(n_s, n_t).t().contiguous()   # [n_t, n_s]
+
+    def sparse(M: Tensor):
+        taps = max(int((M != 0).sum(1).max()), 1)
+        idx = torch.zeros(M.shape[0], taps, dtype=torch.int32)
+        wts = torch.zeros(M.shape[0], taps, dtype=torch.float32)
+        for r in range(M.shape[0]):
+            nz = M[r].nonzero().flatten()
+            idx[r, : nz.numel()] = nz.to(torch.int32)
+            wts[r, : nz.numel()] = M[r, nz]
+        return idx, wts, taps
+
+    return sparse(R), sparse(R.t().contiguous())
+
+
+def resample_tokens(x: Tensor, idx: Tensor, w: Tensor, out: Tensor, B: int, n_in: int, n_out: int, D: int, taps: int) -> None:
+    _chk(x, torch.float32, "resample.x"); _chk(idx, torch.int32, "resample.idx"); _chk(w, torch.float32, "resample.w")
+    check(_lib.load().lt_resample_tokens(_p(x), _p(idx), _p(w), _p(out), B, n_in, n_out, D, taps, _stream()), "lt_resample_tokens")
+
+
 def rope_apply(qkv: Tensor, sin_t: Tensor, cos_t: Tensor, B: int, N: int, H: int, dh: int, prefix: int, inverse: bool = False) -> None:
     """DINOv3 rotary embedding, in place on q and k of the packed bf16 qkv activation (tokens >= prefix)."""
     _chk(qkv, torch.bfloat16, "rope.qkv"); _chk(sin_t, torch.float32, "rope.sin"); _chk(cos_t, torch.float32, "rope.cos")

@@ -79,8 +79,13 @@ class OracleDistillationV3:
         s = O2.vit_forward(self.sb, x, self.scfg, masks=None)
         sg = F.linear(s["cls"], self.pg["weight"], self.pg["bias"])
         sl = F.linear(s["patch"], self.pl["weight"], self.pl["bias"])
-        if sl.shape[1] != tl.shape[1]:
-            raise NotImplementedError("student / teacher token grids differ (bilinear resize of distillationv3.py:338-345)")
+        if sl.shape[1] != tl.shape[1]:      # bilinear resize onto the teacher grid (distillationv3.py:338-345)
+            ps_s, ps_t = self.scfg["patch_size"], self.tcfg["patch_size"]
+            hs, ws_ = x.shape[2] // ps_s, x.shape[3] // ps_s
+            ht, wt = x.shape[2] // ps_t, x.shape[3] // ps_t
+            sl = sl.reshape(sl.shape[0], hs, ws_, -1).permute(0, 3, 1, 2)
+            sl = F.interpolate(sl, size=(ht, wt), mode="bilinear", align_corners=False)
+            sl = sl.permute(0, 2, 3, 1).flatten(1, 2)
         sg, sl = F.normalize(sg, dim=-1, p=2), F.normalize(sl, dim=-1, p=2)
         B, Q = tg.shape[0], self.queue.shape[0]
         with torch.no_grad():                                   # _update_queue, distillationv3.py:275-291

@@ -204,7 +204,13 @@ def main() -> None:
 
 def make_distill() -> None:
     """(e) DistillationV3 (config 4 path): the reference's own DistillationV3 class with a frozen DINOv3 ViT teacher (the
-    dinov3_vitl16 recipe at D=64) and a DINOv2-ViT student (D=64, depth 2), 64^2 images, queue 32, AdamW, 3 steps."""
+    dinov3_vitl16 recipe at D=64) and a DINOv2-ViT student (D=64, depth 2), queue 32, AdamW, 3 steps: 64^2 images with a /16
+    student (equal grids), and 112^2 images with a /14 student (8x8 student grid resized bilinearly onto the 7x7 teacher grid)."""
+    make_distill_case("distill_v3_d64", img=64, s_patch=16, b=8)
+    make_distill_case("distill_v3_d64_p14", img=112, s_patch=14, b=4)
+
+
+def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
     H.install()
     from lightly_train._methods.distillationv3.distillationv3 import DistillationV3, DistillationV3AdamWArgs, DistillationV3Args
     from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
@@ -215,14 +221,14 @@ def make_distill() -> None:
     from oracle import distill_oracle as OD
 
     torch.manual_seed(4321)
-    t = v3.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
+    t = v3.DinoVisionTransformer(img_size=img, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
                                  layerscale_init=0.5, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True,
                                  pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
     t.init_weights()
-    s_model = v2.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
+    s_model = v2.DinoVisionTransformer(img_size=img, patch_size=s_patch, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
                                        drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
     sw = DINOv2ViTModelWrapper(s_model)
-    b, total, qsz = 8, 20, 32
+    total, qsz = 20, 32
     margs = DistillationV3Args(queue_size=qsz, teacher=DINOv3ViTModelWrapper(t))
     oargs = DistillationV3AdamWArgs()
     oargs.resolve_auto(wrapped_model=sw)
@@ -235,14 +241,14 @@ def make_distill() -> None:
     init = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
             "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},
             "proj_local": {k: v.detach().clone() for k, v in m.student_projection_head_local.state_dict().items()}}
-    scfg = dict(patch_size=16, num_heads=1, depth=2, img_size=64, embed_dim=64, init_values=0.1)
-    tcfg = dict(patch_size=16, num_heads=1, depth=2, rope_base=100.0, ln_eps=1e-5, embed_dim=64, n_storage_tokens=4, img_size=64)
+    scfg = dict(patch_size=s_patch, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
+    tcfg = dict(patch_size=16, num_heads=1, depth=2, rope_base=100.0, ln_eps=1e-5, embed_dim=64, n_storage_tokens=4, img_size=img)
     o = OD.OracleDistillationV3(init["student_backbone"], scfg, teacher_state, tcfg, init["proj_global"], init["proj_local"], qsz, b, total,
                                 weight_decay=float(oargs.weight_decay))
     assert (o.n_decay, o.n_no_decay) == tuple(len(g["params"]) for g in opt.param_groups), (o.n_decay, o.n_no_decay)
     steps = []
     for step in range(3):
-        x = torch.randn(b, 3, 64, 64, generator=torch.Generator().manual_seed(2000 + step))
+        x = torch.randn(b, 3, img, img, generator=torch.Generator().manual_seed(2000 + step))
         torch.manual_seed(300 + step)
         lam = torch.empty(1).uniform_(0.0, 1.0).item()      # the draws of DistillationV3._mixup_data, in its order
         index = torch.randperm(b)
@@ -261,7 +267,7 @@ def make_distill() -> None:
         for k in ("loss", "global_loss", "local_loss", "grad_norm"):
             assert abs(ol[k] - logs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (step, k, ol[k], logs[k])
         steps.append({"x_seed": 2000 + step, "lam": lam, "index": index.clone(), "logs": logs})
-        print("distill", step, {k: round(v, 6) for k, v in logs.items()})
+        print(name, step, {k: round(v, 6) for k, v in logs.items()})
     final = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
              "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},
              "proj_local": {k: v.detach().clone() for k, v in m.student_projection_head_local.state_dict().items()},
@@ -269,10 +275,10 @@ def make_distill() -> None:
     for k, v in final["student_backbone"].items():
         assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
     assert (o.queue - final["queue"]).abs().max().item() < 1e-6
-    torch.save({"b": b, "total_steps": total, "queue_size": qsz, "weight_decay": float(oargs.weight_decay), "student_cfg": scfg,
+    torch.save({"b": b, "img": img, "total_steps": total, "queue_size": qsz, "weight_decay": float(oargs.weight_decay), "student_cfg": scfg,
                 "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final},
-               os.path.join(OUT, "distill_v3_d64.pt"))
-    print("wrote distill_v3_d64.pt", os.path.getsize(os.path.join(OUT, "distill_v3_d64.pt")) // 1024, "KiB")
+               os.path.join(OUT, name + ".pt"))
+    print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")
 
 
 def make_dinov3_vit() -> None:

@@ -183,17 +183,19 @@ def test_dinov3_vit_oracle_matches_reference_fixture():
             assert (out[k] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
 
 
-def test_distillation_oracle_matches_reference_fixture():
+@pytest.mark.parametrize("name", ["distill_v3_d64", "distill_v3_d64_p14"])
+def test_distillation_oracle_matches_reference_fixture(name):
     """oracle/distill_oracle.py (DistillationV3: DINOv3 ViT teacher -> DINOv2 ViT student) against 3 optimizer steps of the
     reference's own DistillationV3 class (tests/golden/distill_v3_d64.pt): losses, grad-norm, LR, final parameters, queue."""
     from oracle import distill_oracle as OD
 
-    fx = torch.load(os.path.join(GOLD, "distill_v3_d64.pt"), weights_only=False)
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    img = fx.get("img", 64)
     o = OD.OracleDistillationV3(fx["init"]["student_backbone"], fx["student_cfg"], fx["teacher_state"], fx["teacher_cfg"],
                                 fx["init"]["proj_global"], fx["init"]["proj_local"], fx["queue_size"], fx["b"], fx["total_steps"],
                                 weight_decay=fx["weight_decay"])
     for rec in fx["steps"]:
-        x = torch.randn(fx["b"], 3, 64, 64, generator=torch.Generator().manual_seed(rec["x_seed"]))
+        x = torch.randn(fx["b"], 3, img, img, generator=torch.Generator().manual_seed(rec["x_seed"]))
         assert o.opt.param_groups[0]["lr"] == pytest.approx(rec["logs"]["lr"], rel=1e-6)
         logs = o.train_step(x, rec["lam"], rec["index"])
         for k in ("loss", "global_loss", "local_loss", "grad_norm"):
