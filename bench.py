@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--out-dim", type=int, default=65536)
     ap.add_argument("--method", default="dinov2", choices=["dinov2", "distillationv3"],
                     help="dinov2 = the BASELINE metric; distillationv3 = SURVEY 8(a) a22: frozen DINOv3 ViT-L/16 teacher -> ViT student, one 224^2 view")
+    ap.add_argument("--student", default="dinov2", choices=["dinov2", "dinov3"], help="distillationv3 only: student ViT family (dinov3 = RoPE, storage tokens)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
@@ -124,6 +125,8 @@ def main() -> None:
         from lightly_train_amd.distillationv3 import DistillationV3, DistillationV3Args
 
         tcfg = dinov3_vit_config(1024, 24, 16, patch_size=16, img_size=args.global_size)     # dinov3_vitl16
+        if args.student == "dinov3":
+            cfg = dinov3_vit_config(arch["embed_dim"], arch["depth"], arch["num_heads"], patch_size=16, img_size=args.global_size, rope_rescale=2.0)
         method = DistillationV3(cfg, tcfg, DistillationV3Args(), global_batch_size=B * world, total_steps=125_000, max_epochs=100, device=dev, seed=0)
         views = torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev)
         if args.host_inputs:
@@ -238,8 +241,8 @@ def main() -> None:
 
     if rank == 0:
         if args.method == "distillationv3":
-            metric = f"images/sec DistillationV3 DINOv3 ViT-L/16 teacher -> {args.model}/16 student"
-            workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> DINOv2 {args.model}/16 student, per-GPU batch {B}, "
+            metric = f"images/sec DistillationV3 DINOv3 ViT-L/16 teacher -> {args.student} {args.model}/16 student"
+            workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> {args.student} {args.model}/16 student, per-GPU batch {B}, "
                         f"one {args.global_size}^2 view, queue 8192 (BASELINE config 4 names a torchvision/resnet50 student: not built)")
         else:
             metric = "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops"

@@ -19,11 +19,33 @@ from .vit import ViTConfig
 
 def dinov3_vit_config(embed_dim: int, depth: int, num_heads: int, patch_size: int = 16, img_size: int = 224, ffn_ratio: float = 4.0,
                       n_storage_tokens: int = 4, layerscale_init: float | None = 1e-5, rope_base: float = 100.0,
-                      ln_eps: float = 1e-5, ffn_layer: str = "mlp") -> ViTConfig:
-    """`dinov3_vitl16` = (1024, 24, 16) with the defaults (hub/backbones.py:467-512)."""
+                      ln_eps: float = 1e-5, ffn_layer: str = "mlp", rope_rescale: float | None = None,
+                      mask_k_bias: bool = True) -> ViTConfig:
+    """`dinov3_vitl16` = (1024, 24, 16) with the defaults (hub/backbones.py:467-512).  `rope_rescale` (2 in those recipes)
+    only matters for a *student* (training-mode coordinate augmentation); a frozen teacher runs in eval mode."""
     return ViTConfig(embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=ffn_ratio, patch_size=patch_size, img_size=img_size,
                      init_values=layerscale_init, num_register_tokens=n_storage_tokens, ffn_layer=ffn_layer, ln_eps=ln_eps,
-                     rope_base=rope_base)
+                     rope_base=rope_base, rope_rescale=rope_rescale, mask_k_bias=mask_k_bias)
+
+
+def export_dinov3_state(engine_state: Dict[str, Tensor], cfg: ViTConfig) -> Dict[str, Tensor]:
+    """Inverse of `convert_dinov3_state` for checkpoints: register_tokens -> storage_tokens, pos_embed dropped, the bias mask
+    and the RoPE periods re-created."""
+    out: Dict[str, Tensor] = {}
+    D, dh = cfg.embed_dim, cfg.head_dim
+    for k, v in engine_state.items():
+        if k == "pos_embed":
+            continue
+        if k == "register_tokens":
+            out["storage_tokens"] = v
+        else:
+            out[k] = v
+        if k.endswith("attn.qkv.bias") and cfg.mask_k_bias:
+            m = torch.ones(3 * D)
+            m[D:2 * D] = 0
+            out[k + "_mask"] = m
+    out["rope_embed.periods"] = float(cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
+    return out
 
 
 def convert_dinov3_state(state: Dict[str, Tensor], cfg: ViTConfig) -> Dict[str, Tensor]:

@@ -82,8 +82,18 @@ class DistillationV3:
             raise RuntimeError("DistillationV3 runs on an MI355X only (no CPU fallback for the HIP kernels)")
         g = torch.Generator().manual_seed(seed)
         Ds, Dt = student_cfg.embed_dim, teacher_cfg.embed_dim
-        sb = student_state if student_state is not None else init_vit_state(student_cfg, g)
-        tb = teacher_state if teacher_state is not None else init_vit_state(teacher_cfg, g)
+        def random_init(c: ViTConfig) -> Dict[str, Tensor]:
+            sd = init_vit_state(c, g)
+            if c.rope_base is not None:          # RoPE models have no positional table: the engine's slot stays zero
+                sd["pos_embed"] = torch.zeros_like(sd["pos_embed"])
+            if c.mask_k_bias:
+                for k in sd:
+                    if k.endswith("attn.qkv.bias"):
+                        sd[k][c.embed_dim:2 * c.embed_dim] = 0
+            return sd
+
+        sb = student_state if student_state is not None else random_init(student_cfg)
+        tb = teacher_state if teacher_state is not None else random_init(teacher_cfg)
 
         def lin(state: Optional[Dict[str, Tensor]]) -> Dict[str, Tensor]:
             if state is not None:
@@ -210,7 +220,11 @@ class DistillationV3:
             teacher_done = ts.record_event()
 
         # ---- student forward
-        sc = self.s_vit.forward(ws, "s", x, None, save=True)
+        s_rope = None
+        if self.scfg.rope_base is not None:   # DINOv3 student in training mode: per-block RoPE tables, drawn after the mixup draws
+            p_ = self.scfg.patch_size
+            s_rope = self.s_vit.rope_tables_train(-(-x.shape[2] // p_), -(-x.shape[3] // p_))
+        sc = self.s_vit.forward(ws, "s", x, None, save=True, rope_tables=s_rope)
         Ns, pre_s = sc["N"], 1 + self.scfg.num_register_tokens
         n_ps = Ns - pre_s
         resize = (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"])   # bilinear resize of the student map onto the teacher grid (:338-345)
@@ -325,10 +339,17 @@ class DistillationV3:
     def state_dict(self) -> Dict[str, Tensor]:
         """Reference key names; the teacher is left out like `on_save_checkpoint` does (:415-423)."""
         out: Dict[str, Tensor] = {}
+        bb = {n[9:]: self.student.p[n].detach().clone() for n in self.student.names if n.startswith("backbone.")}
+        if self.scfg.rope_base is not None:
+            from .dinov3 import export_dinov3_state
+
+            bb = export_dinov3_state(bb, self.scfg)
+        for k, v in bb.items():
+            out["student_embedding_model.wrapped_model._model." + k] = v
         for n in self.student.names:
             v = self.student.p[n].detach().clone()
             if n.startswith("backbone."):
-                out["student_embedding_model.wrapped_model._model." + n[9:]] = v
+                continue
             elif n.startswith("proj_global."):
                 out["student_projection_head_global." + n[12:]] = v
             else:

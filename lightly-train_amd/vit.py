@@ -38,7 +38,10 @@ class ViTConfig:
     ffn_layer: str = "mlp"   # "mlp" | "swiglu" | "swiglufused" (vision_transformer.py:179-185)
     ln_eps: float = 1e-6     # DINOv3 "layernormbf16" uses 1e-5
     rope_base: Optional[float] = None   # DINOv3: rotary embedding on q/k of the patch tokens instead of a learned pos_embed
-                                        # (zero pos_embed in the state); eval-mode coordinates (no shift / jitter / rescale)
+                                        # (zero, frozen pos_embed in the state)
+    rope_rescale: Optional[float] = None  # training-mode coordinate augmentation of a DINOv3 *student*: log-uniform rescale
+                                          # in [1/r, r], drawn per block (rope_position_encoding.py:104-109; 2 for vits16..vitl16)
+    mask_k_bias: bool = False           # DINOv3 LinearKMaskedBias: the K third of the qkv bias is held at zero (no gradient)
 
     @property
     def swiglu(self) -> bool:
@@ -251,9 +254,34 @@ class ViTEngine:
         self._pos_maps[key] = mp
         return mp
 
-    def _rope_tables(self, gh: int, gw: int) -> Tuple[Tensor, Tensor]:
-        """(sin, cos) f32 [gh*gw, head_dim] of DINOv3's RopePositionEmbedding in eval mode (layers/rope_position_encoding.py:
-        62-117, normalize_coords="separate", periods = base ** (2 i / (head_dim/2)), i < head_dim/4; :118-127)."""
+    def rope_tables_train(self, gh: int, gw: int) -> List[Tuple[Tensor, Tensor]]:
+        """Per-block (sin, cos) tables of a DINOv3 student in training mode: the reference calls `rope_embed(H, W)` once per
+        block (vision_transformer.py:269-271) and every call draws its own log-uniform rescale factor from torch's default
+        generator (rope_position_encoding.py:104-109) -- same draws, same order here."""
+        cfg = self.cfg
+        out = []
+        for _ in range(cfg.depth):
+            mul = 1.0
+            if cfg.rope_rescale is not None:
+                rmax = math.log(cfg.rope_rescale)
+                mul = float(torch.empty(1, dtype=torch.float32).uniform_(-rmax, rmax).exp())
+            out.append(self._rope_tables(gh, gw, mul))
+        return out
+
+    def _rope_tables(self, gh: int, gw: int, coord_mul: float = 1.0) -> Tuple[Tensor, Tensor]:
+        """(sin, cos) f32 [gh*gw, head_dim] of DINOv3's RopePositionEmbedding (layers/rope_position_encoding.py:62-117,
+        normalize_coords="separate", periods = base ** (2 i / (head_dim/2)), i < head_dim/4; :118-127); `coord_mul` = the
+        training-mode rescale factor (1 = eval mode, cached)."""
+        if coord_mul != 1.0:
+            dh = self.cfg.head_dim
+            periods = float(self.cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
+            ch = torch.arange(0.5, gh, dtype=torch.float32) / gh
+            cw = torch.arange(0.5, gw, dtype=torch.float32) / gw
+            coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
+            coords = (2.0 * coords - 1.0) * torch.tensor(coord_mul, dtype=torch.float32)
+            angles = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2)
+            angles = torch.cat((angles, angles), dim=-1)
+            return torch.sin(angles).contiguous().to(self.dev, non_blocking=True), torch.cos(angles).contiguous().to(self.dev, non_blocking=True)
         key = (gh, gw)
         if key not in self._rope:
             dh = self.cfg.head_dim
@@ -280,7 +308,7 @@ class ViTEngine:
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
-                drop_plan: Optional[List[Any]] = None) -> Dict[str, Any]:
+                drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None) -> Dict[str, Any]:
         """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
 
         drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
@@ -302,7 +330,9 @@ class ViTEngine:
             H, W = nh, nw
         gh, gw = H // p, W // p
         n_reg = cfg.num_register_tokens
-        rope = self._rope_tables(gh, gw) if cfg.rope_base is not None else None
+        rope = None
+        if cfg.rope_base is not None:   # one table per block: eval mode repeats the cached one
+            rope = rope_tables if rope_tables is not None else [self._rope_tables(gh, gw)] * cfg.depth
         n_p, N = gh * gw, gh * gw + 1 + n_reg
         T = B * N
         scale = dh ** -0.5
@@ -356,7 +386,7 @@ class ViTEngine:
             att = ws.get(s + "att", (T, D), torch.bfloat16)
             lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
             if rope is not None:
-                ops.rope_apply(qkv, rope[0], rope[1], nb, N, Hh, dh, 1 + n_reg)
+                ops.rope_apply(qkv, rope[i][0], rope[i][1], nb, N, Hh, dh, 1 + n_reg)
             ops.attention_fwd(qkv, att, lse, nb, N, Hh, dh, scale)
             y1 = None   # the LayerScale gradient comes from the weight gradient (ops.layerscale_dgamma): no saved branch output
             if a["mode"] == "subset":
@@ -420,8 +450,12 @@ class ViTEngine:
         cfg = self.cfg
         D, hid = cfg.embed_dim, cfg.hidden
         fc2 = "mlp.w3" if cfg.swiglu else "mlp.fc2"
+        if cfg.rope_base is not None:
+            self.gw("pos_embed").zero_()            # no positional embedding in a RoPE model: the zero table stays zero
         for i in range(cfg.depth):
             pre = f"blocks.{i}."
+            if cfg.mask_k_bias:
+                self.gw(pre + "attn.qkv.bias")[D:2 * D].zero_()   # LinearKMaskedBias: bias * mask => no gradient for the K third
             for gname, lin, k_in in ((pre + "ls1.gamma", pre + "attn.proj", D), (pre + "ls2.gamma", pre + fc2, hid)):
                 if self.has(gname):
                     ops.layerscale_dgamma(self.wb(lin + ".weight"), self.gw(lin + ".weight"), self.w(lin + ".bias"), self.gw(lin + ".bias"),
@@ -562,7 +596,7 @@ class ViTEngine:
             before_write(dQ)
             ops.attention_bwd(a["qkv"], a["att"], dD2, a["lse"], aws, dQ, nb, N, Hh, dh, scale)
             if ctx.get("rope") is not None:   # gradients w.r.t. the un-rotated q / k: transposed rotation
-                ops.rope_apply(dQ, ctx["rope"][0], ctx["rope"][1], nb, N, Hh, dh, 1 + cfg.num_register_tokens, inverse=True)
+                ops.rope_apply(dQ, ctx["rope"][i][0], ctx["rope"][i][1], nb, N, Hh, dh, 1 + cfg.num_register_tokens, inverse=True)
             wgrad(dQ, a["ln"], pre + "attn.qkv.weight", 3 * D, D, R1, bias=pre + "attn.qkv.bias")
             before_write(dD)
             ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)

@@ -13,12 +13,15 @@ import torch.nn.functional as F
 from torch import Tensor
 
 
-def rope_sincos(H: int, W: int, head_dim: int, base: float = 100.0):
+def rope_sincos(H: int, W: int, head_dim: int, base: float = 100.0, rescale: Tensor | None = None):
+    """`rescale`: the training-mode log-uniform factor of rope_position_encoding.py:104-109 (a [1] tensor) or None (eval)."""
     periods = base ** (2 * torch.arange(head_dim // 4, dtype=torch.float32) / (head_dim // 2))
     ch = torch.arange(0.5, H, dtype=torch.float32) / H        # normalize_coords = "separate"
     cw = torch.arange(0.5, W, dtype=torch.float32) / W
     coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
     coords = 2.0 * coords - 1.0
+    if rescale is not None:
+        coords = coords * rescale
     angles = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2)
     angles = torch.cat((angles, angles), dim=-1)
     return torch.sin(angles), torch.cos(angles)
@@ -29,8 +32,9 @@ def rope_apply(x: Tensor, sin: Tensor, cos: Tensor) -> Tensor:
     return x * cos + torch.cat([-x2, x1], dim=-1) * sin
 
 
-def dinov3_vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any]) -> Dict[str, Tensor]:
-    """p: the reference state_dict (DINOv3 key names).  cfg: patch_size, num_heads, depth, rope_base, ln_eps."""
+def dinov3_vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], rescales: Any = None) -> Dict[str, Tensor]:
+    """p: the reference state_dict (DINOv3 key names).  cfg: patch_size, num_heads, depth, rope_base, ln_eps.
+    `rescales`: per-block RoPE rescale factors of a training-mode forward (list of [1] tensors) or None (eval mode)."""
     ps, heads, depth, eps = cfg["patch_size"], cfg["num_heads"], cfg["depth"], cfg.get("ln_eps", 1e-5)
     B = x.shape[0]
     t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=ps)
@@ -43,10 +47,10 @@ def dinov3_vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any]) -> 
     t = torch.cat(toks + [t], dim=1)
     D = t.shape[-1]
     dh = D // heads
-    sin, cos = rope_sincos(gh, gw, dh, cfg.get("rope_base", 100.0))
     prefix = 1 + n_st
     for i in range(depth):
         pre = f"blocks.{i}."
+        sin, cos = rope_sincos(gh, gw, dh, cfg.get("rope_base", 100.0), None if rescales is None else rescales[i])
         y = F.layer_norm(t, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
         bias = p[pre + "attn.qkv.bias"]
         if pre + "attn.qkv.bias_mask" in p:

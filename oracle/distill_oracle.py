@@ -42,7 +42,8 @@ class OracleDistillationV3:
                  global_batch_size: int, total_steps: int, max_epochs: int = 1, temperature_global: float = 0.07,
                  temperature_local: float = 0.07, loss_local_weight: float = 1.0, lr: float = 0.0005, weight_decay: float = 0.04,
                  reference_batch_size: int = 1536) -> None:
-        self.sb = {k: v.detach().clone().requires_grad_(True) for k, v in student_backbone.items()}
+        self.sb = {k: (v.detach().clone().requires_grad_(True) if not k.endswith(("bias_mask", "periods")) else v.detach().clone())
+                   for k, v in student_backbone.items()}
         self.pg = {k: v.detach().clone().requires_grad_(True) for k, v in proj_global.items()}
         self.pl = {k: v.detach().clone().requires_grad_(True) for k, v in proj_local.items()}
         self.teacher = {k: v.detach().clone() for k, v in teacher_state.items()}
@@ -50,7 +51,7 @@ class OracleDistillationV3:
         self.tg_t, self.tl_t, self.w_local = temperature_global, temperature_local, loss_local_weight
         d_t = teacher_state["cls_token"].shape[-1]
         self.queue = torch.zeros(queue_size, d_t)
-        named = [("backbone." + k, v) for k, v in self.sb.items()] + [("proj_global." + k, v) for k, v in self.pg.items()] + \
+        named = [("backbone." + k, v) for k, v in self.sb.items() if v.requires_grad] + [("proj_global." + k, v) for k, v in self.pg.items()] + \
                 [("proj_local." + k, v) for k, v in self.pl.items()]
         dec = [p for n, p in named if decays(n, p)]
         nod = [p for n, p in named if not decays(n, p)]
@@ -70,13 +71,19 @@ class OracleDistillationV3:
         for g in self.opt.param_groups:
             g["lr"] = self.base_lr * f
 
-    def forward_loss(self, x: Tensor, lam: float, index: Tensor) -> Tuple[Tensor, Dict[str, float]]:
+    def forward_loss(self, x: Tensor, lam: float, index: Tensor, rescales: Any = None) -> Tuple[Tensor, Dict[str, float]]:
         x = lam * x + (1.0 - lam) * x[index]
         with torch.no_grad():
             t = O3.dinov3_vit_forward(self.teacher, x, self.tcfg)
             tg = F.normalize(t["x_norm_clstoken"], dim=-1, p=2)
             tl = F.normalize(t["x_norm_patchtokens"], dim=-1, p=2)
-        s = O2.vit_forward(self.sb, x, self.scfg, masks=None)
+        if "rope_base" in self.scfg:     # DINOv3 student in training mode: one log-uniform RoPE rescale draw per block, after the
+            rmax = math.log(self.scfg["rope_rescale"]) if self.scfg.get("rope_rescale") else None   # mixup draws (same RNG order)
+            rs = [torch.empty(1).uniform_(-rmax, rmax).exp() for _ in range(self.scfg["depth"])] if rmax is not None and rescales is None else rescales
+            s3 = O3.dinov3_vit_forward(self.sb, x, self.scfg, rescales=rs)
+            s = {"cls": s3["x_norm_clstoken"], "patch": s3["x_norm_patchtokens"]}
+        else:
+            s = O2.vit_forward(self.sb, x, self.scfg, masks=None)
         sg = F.linear(s["cls"], self.pg["weight"], self.pg["bias"])
         sl = F.linear(s["patch"], self.pl["weight"], self.pl["bias"])
         if sl.shape[1] != tl.shape[1]:      # bilinear resize onto the teacher grid (distillationv3.py:338-345)
@@ -98,8 +105,8 @@ class OracleDistillationV3:
         loss = g + self.w_local * l
         return loss, {"global_loss": float(g.detach()), "local_loss": float(l.detach())}
 
-    def train_step(self, x: Tensor, lam: float, index: Tensor) -> Dict[str, float]:
-        loss, logs = self.forward_loss(x, lam, index)
+    def train_step(self, x: Tensor, lam: float, index: Tensor, rescales: Any = None) -> Dict[str, float]:
+        loss, logs = self.forward_loss(x, lam, index, rescales)
         loss.backward()
         params = [p for g in self.opt.param_groups for p in g["params"]]
         gnorm = torch.nn.utils.clip_grad_norm_(params, 1.0)

@@ -12,6 +12,7 @@ each optimizer step (Lightning hook order, see ReferenceRunner).
 """
 from __future__ import annotations
 
+import math
 import os
 import random
 import sys
@@ -208,9 +209,10 @@ def make_distill() -> None:
     student (equal grids), and 112^2 images with a /14 student (8x8 student grid resized bilinearly onto the 7x7 teacher grid)."""
     make_distill_case("distill_v3_d64", img=64, s_patch=16, b=8)
     make_distill_case("distill_v3_d64_p14", img=112, s_patch=14, b=4)
+    make_distill_case("distill_v3_d64_v3s", img=64, s_patch=16, b=8, s_kind="dinov3")   # DINOv3 student (train-mode RoPE rescale)
 
 
-def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
+def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "dinov2") -> None:
     H.install()
     from lightly_train._methods.distillationv3.distillationv3 import DistillationV3, DistillationV3AdamWArgs, DistillationV3Args
     from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
@@ -225,9 +227,17 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
                                  layerscale_init=0.5, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True,
                                  pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
     t.init_weights()
-    s_model = v2.DinoVisionTransformer(img_size=img, patch_size=s_patch, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
-                                       drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
-    sw = DINOv2ViTModelWrapper(s_model)
+    if s_kind == "dinov3":
+        s_model = v3.DinoVisionTransformer(img_size=img, patch_size=s_patch, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
+                                           layerscale_init=0.1, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4,
+                                           mask_k_bias=True, pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32",
+                                           pos_embed_rope_rescale_coords=2)
+        s_model.init_weights()
+        sw = DINOv3ViTModelWrapper(s_model)
+    else:
+        s_model = v2.DinoVisionTransformer(img_size=img, patch_size=s_patch, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
+                                           drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+        sw = DINOv2ViTModelWrapper(s_model)
     total, qsz = 20, 32
     margs = DistillationV3Args(queue_size=qsz, teacher=DINOv3ViTModelWrapper(t))
     oargs = DistillationV3AdamWArgs()
@@ -242,6 +252,8 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
             "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},
             "proj_local": {k: v.detach().clone() for k, v in m.student_projection_head_local.state_dict().items()}}
     scfg = dict(patch_size=s_patch, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
+    if s_kind == "dinov3":
+        scfg.update(rope_base=100.0, rope_rescale=2.0, ln_eps=1e-5, n_storage_tokens=4, kind="dinov3")
     tcfg = dict(patch_size=16, num_heads=1, depth=2, rope_base=100.0, ln_eps=1e-5, embed_dim=64, n_storage_tokens=4, img_size=img)
     o = OD.OracleDistillationV3(init["student_backbone"], scfg, teacher_state, tcfg, init["proj_global"], init["proj_local"], qsz, b, total,
                                 weight_decay=float(oargs.weight_decay))
@@ -252,6 +264,9 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
         torch.manual_seed(300 + step)
         lam = torch.empty(1).uniform_(0.0, 1.0).item()      # the draws of DistillationV3._mixup_data, in its order
         index = torch.randperm(b)
+        rescales = None
+        if s_kind == "dinov3":                              # then one RoPE rescale draw per student block (training mode)
+            rescales = [torch.empty(1).uniform_(-math.log(2.0), math.log(2.0)).exp() for _ in range(2)]
         torch.manual_seed(300 + step)
         lr_now = opt.param_groups[0]["lr"]
         res = m.training_step_impl({"views": [x], "filename": []}, 0)
@@ -263,10 +278,10 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int) -> None:
         logs = {"loss": float(res.loss.detach()), "global_loss": res.log_dict["train_loss/global_loss"],
                 "local_loss": res.log_dict["train_loss/local_loss"], "grad_norm": float(gnorm), "lr": lr_now}
         assert abs(o.opt.param_groups[0]["lr"] - lr_now) <= 1e-12 + 1e-6 * lr_now, (o.opt.param_groups[0]["lr"], lr_now)
-        ol = o.train_step(x, lam, index)
+        ol = o.train_step(x, lam, index, rescales)
         for k in ("loss", "global_loss", "local_loss", "grad_norm"):
             assert abs(ol[k] - logs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (step, k, ol[k], logs[k])
-        steps.append({"x_seed": 2000 + step, "lam": lam, "index": index.clone(), "logs": logs})
+        steps.append({"x_seed": 2000 + step, "lam": lam, "index": index.clone(), "logs": logs, "rescales": rescales})
         print(name, step, {k: round(v, 6) for k, v in logs.items()})
     final = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
              "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},

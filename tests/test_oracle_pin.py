@@ -183,7 +183,7 @@ def test_dinov3_vit_oracle_matches_reference_fixture():
             assert (out[k] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
 
 
-@pytest.mark.parametrize("name", ["distill_v3_d64", "distill_v3_d64_p14"])
+@pytest.mark.parametrize("name", ["distill_v3_d64", "distill_v3_d64_p14", "distill_v3_d64_v3s"])
 def test_distillation_oracle_matches_reference_fixture(name):
     """oracle/distill_oracle.py (DistillationV3: DINOv3 ViT teacher -> DINOv2 ViT student) against 3 optimizer steps of the
     reference's own DistillationV3 class (tests/golden/distill_v3_d64.pt): losses, grad-norm, LR, final parameters, queue."""
@@ -197,7 +197,7 @@ def test_distillation_oracle_matches_reference_fixture(name):
     for rec in fx["steps"]:
         x = torch.randn(fx["b"], 3, img, img, generator=torch.Generator().manual_seed(rec["x_seed"]))
         assert o.opt.param_groups[0]["lr"] == pytest.approx(rec["logs"]["lr"], rel=1e-6)
-        logs = o.train_step(x, rec["lam"], rec["index"])
+        logs = o.train_step(x, rec["lam"], rec["index"], rec.get("rescales"))
         for k in ("loss", "global_loss", "local_loss", "grad_norm"):
             assert logs[k] == pytest.approx(rec["logs"][k], rel=2e-5, abs=2e-7), k
     for k, v in fx["final"]["student_backbone"].items():
