@@ -279,7 +279,7 @@ def test_loss_trajectory_100_steps_matches_oracle():
     the module docstring): total loss within 2e-3 relative at EVERY step (observed max 9.8e-4), DINO terms 4e-3 (1.5e-3),
     iBOT 2e-3 (2.8e-4) -- bf16 MFMA operands against fp32, through 100 AdamW + EMA updates."""
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
 
     worst, rows = trajectory.run("step_d64_softmax", 100, 0.0, quiet=True)
@@ -290,7 +290,7 @@ def test_loss_trajectory_100_steps_matches_oracle():
 def test_loss_trajectory_with_koleo_40_steps():
     """Same with the default KoLeo weight 0.1: 40 steps, total loss within 8e-3 (observed 2.2e-3), DINO / iBOT terms 6e-3."""
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
 
     worst, _ = trajectory.run("step_d64_softmax", 40, 0.1, quiet=True)

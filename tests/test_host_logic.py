@@ -134,6 +134,14 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("# oracle", ""), f"{fn} references the oracle"
+    # tools/ (benchmarks, profile summaries) stay oracle-free as well; checkers that need it live under tests/tools/
+    tools = os.path.join(ROOT, "tools")
+    for fn in os.listdir(tools):
+        if fn.endswith(".py"):
+            assert "import oracle" not in open(os.path.join(tools, fn)).read() and "from oracle" not in open(os.path.join(tools, fn)).read(), fn
+    # bench.py: only inside cpu_baseline()
+    bsrc = open(os.path.join(ROOT, "bench.py")).read()
+    assert bsrc.count("from oracle") == 1 and bsrc.index("from oracle") > bsrc.index("def cpu_baseline") and bsrc.index("from oracle") < bsrc.index("def main")
 
 
 def test_ops_fail_loudly_without_gpu():

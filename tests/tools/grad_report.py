@@ -1,7 +1,7 @@
 """Diagnostic: per-tensor gradient comparison HIP step vs the CPU oracle (fp32 autograd) on a golden fixture."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools.parity_report import build_from_fixture, synth_views
 from oracle import dinov2_oracle as O

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import lightly_train_amd  # noqa: E402
 from lightly_train_amd.dinov2 import DINOv2, DINOv2Args  # noqa: E402

@@ -1,7 +1,7 @@
 """Diagnostic: ViTEngine forward/backward vs CPU autograd of the oracle ViT with a dense random upstream gradient."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import lightly_train_amd
 from lightly_train_amd.vit import ViTConfig, ViTEngine, Workspace, init_vit_state, vit_param_shapes
