@@ -151,3 +151,42 @@ def test_ops_fail_loudly_without_gpu():
 
     with pytest.raises((AssertionError, ValueError, RuntimeError)):
         ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 4, 8, y_f32=torch.zeros(4, 8))
+
+
+def test_distillation_host_logic_matches_oracle_and_reference_fixture():
+    """DistillationV3 host side without a GPU: the weight-decay partition (optimizer_helpers.py:83-175) agrees with the oracle's
+    (which make_golden.py asserted equal to the reference optimizer's param groups), the LR schedule reproduces the LRs the
+    reference scheduler produced, and the DINOv3 state conversion round-trips."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov3 import convert_dinov3_state, dinov3_vit_config, export_dinov3_state
+    from lightly_train_amd.distillationv3 import weight_decays
+    from lightly_train_amd.schedules import warmup_cosine_lr_factor
+    from oracle import distill_oracle as OD
+    import math
+
+    for name in ("distill_v3_d64", "distill_v3_d64_v3s"):
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", name + ".pt"), weights_only=False)
+        for k, v in fx["init"]["student_backbone"].items():
+            if k.endswith(("bias_mask", "periods")):
+                continue
+            assert weight_decays("backbone." + k, v.shape) == OD.decays("backbone." + k, v), k
+        for head in ("proj_global", "proj_local"):
+            for k, v in fx["init"][head].items():
+                assert weight_decays(f"{head}.{k}", v.shape) == OD.decays(f"{head}.{k}", v)
+        base = 0.0005 * math.sqrt(fx["b"] / 1536)
+        warm = min(fx["total_steps"], int(fx["total_steps"] / 1 * min(10, 1 / 10)))
+        for i, rec in enumerate(fx["steps"]):
+            assert base * warmup_cosine_lr_factor(i, warm, fx["total_steps"], 0.001) == pytest.approx(rec["logs"]["lr"], rel=1e-6)
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "dinov3_vit_fwd.pt"), weights_only=False)
+    c = fx["cfg"]
+    cfg = dinov3_vit_config(c["embed_dim"], c["depth"], c["num_heads"], patch_size=16, img_size=c["img_size"], n_storage_tokens=4, layerscale_init=0.5)
+    eng = convert_dinov3_state(fx["state"], cfg)
+    assert "register_tokens" in eng and eng["pos_embed"].abs().max().item() == 0
+    assert eng["blocks.0.attn.qkv.bias"][64:128].abs().max().item() == 0            # K third masked
+    back = export_dinov3_state(eng, cfg)
+    assert set(back) == set(fx["state"])
+    for k, v in fx["state"].items():
+        if k.endswith("attn.qkv.bias"):
+            assert torch.equal(back[k], v * fx["state"][k + "_mask"].nan_to_num(nan=0.0))
+        else:
+            assert torch.allclose(back[k].float(), v.float(), rtol=1e-6), k
