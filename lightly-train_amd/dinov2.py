@@ -558,6 +558,15 @@ class DINOv2:
                           B=B, M=M, Rl=Rl)
         return TrainingStepResult(loss=ls.sum(), log_dict=logs)
 
+    def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:
+        """`train_loss` + `log_dict` averaged over ranks in one coalesced all-reduce (what `Method.training_step` logs with
+        `sync_dist=True`, method.py:131-144)."""
+        from .parallel import coalesced_mean
+
+        keys = ["train_loss"] + list(res.log_dict)
+        vals = coalesced_mean([res.loss] + [torch.as_tensor(res.log_dict[k], device=res.loss.device) for k in res.log_dict])
+        return dict(zip(keys, vals))
+
     def _sinkhorn(self, logits: Tensor, out: Tensor, rows: int, K: int, temp: float, n_total: Any, tag: str) -> None:
         """dinov2_loss.py:84-115 / :188-224.  The initial Q /= sum(Q) is a global scalar that cancels in the first
         row normalisation, so it is skipped (same value up to fp32 rounding)."""

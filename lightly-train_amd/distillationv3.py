@@ -310,6 +310,15 @@ class DistillationV3:
         self._last = dict(B=B, lam=lam, index=index, t_logits=t_logits, s_logits=s_logits, tg=tg, tl=tl, sg=sg, sl=sl)
         return TrainingStepResult(loss=ls[0] + ls[1], log_dict=logs)
 
+    def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:
+        """`train_loss` + `log_dict` averaged over ranks in one coalesced all-reduce (what `Method.training_step` logs with
+        `sync_dist=True`, method.py:131-144)."""
+        from .parallel import coalesced_mean
+
+        keys = ["train_loss"] + list(res.log_dict)
+        vals = coalesced_mean([res.loss] + [torch.as_tensor(res.log_dict[k], device=res.loss.device) for k in res.log_dict])
+        return dict(zip(keys, vals))
+
     # ------------------------------------------------------------------ optimizer hooks
     def optimizer_step(self) -> None:
         a = self.method_args

@@ -68,3 +68,15 @@ class GradSync:
             ops.scale_f32(self.g, 1.0 / w)
         else:
             self.g.mul_(1.0 / w)
+
+
+def coalesced_mean(values: "List[Tensor]") -> "List[Tensor]":
+    """Mean over ranks of several scalars with ONE all-reduce (the reference logs `train_loss` and each entry of `log_dict`
+    with `sync_dist=True`, i.e. one tiny all-reduce per scalar per step, LT/_methods/method.py:131-144 -- SURVEY.md 8(f).1)."""
+    w = world_size()
+    if w == 1 or not values:
+        return list(values)
+    buf = torch.stack([v.detach().reshape(()).float() for v in values])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    buf /= w
+    return list(buf.unbind(0))

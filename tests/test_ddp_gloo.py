@@ -43,6 +43,10 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         h = dist.all_reduce(cs, async_op=True)
         h.wait()
         assert torch.equal(cs, torch.full((8,), 3.0))
+        # logging scalars: one coalesced all-reduce instead of one per scalar (method.py:131-144, sync_dist=True)
+        from lightly_train_amd.parallel import coalesced_mean
+        vals = coalesced_mean([torch.tensor(float(rank)), torch.tensor(10.0 + rank), torch.tensor(2.0)])
+        assert [round(float(v), 6) for v in vals] == [0.5, 10.5, 2.0]
         torch.save(grad, os.path.join(out_dir, f"grad{rank}.pt"))
     finally:
         dist.destroy_process_group()
