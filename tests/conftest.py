@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the shared library is built in-tree and git-ignored: build it when a fresh checkout runs the tests before build()
+    lib = os.path.join(ROOT, "lightly-train_amd", "lib", "liblt_amd.so")
+    if not os.path.exists(lib):
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("lt_build", os.path.join(ROOT, "lightly-train_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
 
 
 def pytest_collection_modifyitems(config, items):
