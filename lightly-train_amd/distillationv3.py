@@ -25,7 +25,7 @@ from . import ops
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, vit_param_shapes
 
 NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "pos_embed")
 
@@ -289,9 +289,12 @@ class DistillationV3:
             ops.cast_bf16(dsl_pf, dsl)
         else:
             ops.l2norm_bwd(dsl_n, sl_raw, sl_inv, dsl, B * n_ps, Dt)
+        slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
         for tagp, dy, xin, rows in (("proj_global", dsg, sg_in, B), ("proj_local", dsl, sl_in, B * n_ps)):
             ops.colsum_bf16(dy, P.g[tagp + ".bias"], rows, Dt)
-            ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds)
+            tiles = ((Dt + 127) // 128) * ((Ds + 127) // 128)   # few output tiles, long contraction: split-K into slabs
+            ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds,
+                     split_k=_split_k(tiles, rows), workspace=slab)
         dxn = ws.get("s.dxn", (B * Ns, Ds), torch.float32)
         dxn.zero_()
         dcls = ws.get("s.dcls", (B, Ds), torch.float32)
