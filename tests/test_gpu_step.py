@@ -354,3 +354,31 @@ def test_vit_small_full_depth_step_matches_oracle():
         if n.startswith(("head.", "backbone.norm.", "backbone.blocks.11.", "backbone.blocks.0.attn.qkv.weight", "backbone.patch_embed")):
             assert rel(ours, ref) < 6e-2, n
     assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2)
+
+
+@pytest.mark.parametrize("n_local,b", [(0, 4), (3, 2), (8, 1)])
+def test_edge_crop_and_batch_configurations_match_oracle(n_local, b):
+    """No local crops (terms = 2), odd crop counts, batch 1 (KoLeo needs a neighbour: weight 0): loss terms vs the oracle."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(100 + n_local)
+    vc = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=96, init_values=0.3)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(64, 128, 64, 512, g), init_head_state(64, 128, 64, 512, g)
+    args = DINOv2Args(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, koleo_loss_weight=0.0)
+    m = DINOv2(vc, args, global_batch_size=b, total_steps=50, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    o = O.OracleDINOv2(bsd, shs, dict(patch_size=16, num_heads=1, depth=2), args=dict(output_dim=512, hidden_dim=128, bottleneck_dim=64, koleo_loss_weight=0.0),
+                       global_batch_size=b, total_steps=50, teacher_head=ths)
+    views = [torch.randn(b, 3, 96, 96, generator=g) for _ in range(2)] + [torch.randn(b, 3, 48, 48, generator=g) for _ in range(n_local)]
+    random.seed(5)
+    res = m.training_step_impl({"views": views}, 0)
+    loss, ologs = o.forward_loss(views, m._last_masks)
+    logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(float(ologs[k]), rel=5e-3, abs=1e-6), k
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=5e-3)
+    m.optimizer_step(); m.on_train_batch_end()
+    assert torch.isfinite(m.student.data).all()
