@@ -202,7 +202,12 @@ def main() -> None:
             e0.record()
             r = orig(a, b, out, M=M, N=N, K=K, **kw)
             e1.record()
-            recs.append((e0, e1, 2.0 * M * N * K))
+            epi = kw.get("epilogue", ops.EPI_BF16)
+            f32out = epi in (ops.EPI_RESID, ops.EPI_F32, ops.EPI_F32_ACCUM)
+            nb = 2.0 * M * K + 2.0 * N * K + (4.0 if f32out else 2.0) * M * N        # operands in, result out
+            nb += 4.0 * M * N * (kw.get("resid") is not None) + 2.0 * M * N * (kw.get("aux") is not None) + 2.0 * M * N * (kw.get("out2") is not None)
+            nb += 4.0 * M * N * (epi == ops.EPI_F32_ACCUM)                           # read-modify-write of the accumulated gradient
+            recs.append((e0, e1, 2.0 * M * N * K, nb))
             return r
 
         ops.gemm = timed_gemm
@@ -213,8 +218,9 @@ def main() -> None:
         finally:
             ops.gemm = orig
             method.overlap_streams = not args.single_stream
-        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-        fl = sum(f for _, _, f in recs)
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+        fl = sum(f for _, _, f, _ in recs)
+        alg_bytes = sum(b_ for _, _, _, b_ in recs) / max(1, len(recs))
         achieved = fl / (t_ms * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process; the committed value comes from
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01h_gemm_traffic.md, gfx950 corrections
@@ -231,7 +237,7 @@ def main() -> None:
         roofline = {"bound": "mfma", "kernel": "gemm256q_kernel<TA,TB,EPI,SLAB> (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per GEMM launch, L2 memory-side (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r01h_gemm_traffic.md",
-                    "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
+                    "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
                     "gemm_flops_per_step": fl, "step_algorithmic_gflop_per_image": round(gf_img, 1),
                     "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
