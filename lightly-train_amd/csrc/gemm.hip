@@ -497,14 +497,19 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HB = 128 * 128, BUF = 4 * HB;
   const int ntiles = g.tiles_m * g.tiles_n;
-  int id;
+  // XCD-contiguous work order over (k-slice, tile): workgroups go round-robin to the 8 XCDs in launch order (x fastest), so
+  // workgroup L runs on XCD L % 8; giving XCD c the c-th contiguous range of the work list (tile fastest, tn fastest inside)
+  // makes the ~32 tiles an XCD holds at a time share their A panels (same tm) and all B panels of one k-slice in its L2.
+  int id, slice;
   {
-    const int v = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, j = v >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int W = ntiles * (int)gridDim.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const int q = W >> 3, r = W & 7, xcd = L & 7, j = L >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    slice = w / ntiles; id = w - slice * ntiles;
   }
   const int tm = id / g.tiles_n, tn = id % g.tiles_n;
   const int m0 = tm * 256, n0 = tn * 256;
-  const int kbeg = blockIdx.y * g.k_per_split;
+  const int kbeg = slice * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nk = (kend - kbeg) / BK;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   __syncthreads();
   GemmArgs ge = g;
   if (SLAB) {
-    ge.C = (float*)g.C2 + (size_t)blockIdx.y * g.M * g.N;
+    ge.C = (float*)g.C2 + (size_t)slice * g.M * g.N;
     ge.ldc = g.N; ge.alpha = 1.f; ge.bias = nullptr;
   }
   float* wl = reinterpret_cast<float*>(smem + wave * 16384);
