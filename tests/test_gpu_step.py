@@ -382,3 +382,20 @@ def test_edge_crop_and_batch_configurations_match_oracle(n_local, b):
     assert float(res.loss) == pytest.approx(float(loss.detach()), rel=5e-3)
     m.optimizer_step(); m.on_train_batch_end()
     assert torch.isfinite(m.student.data).all()
+
+
+def test_view_prefetcher_stages_batches_in_order():
+    """prefetch.ViewPrefetcher: pinned host views arrive on the device unchanged, in order, one batch ahead."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.prefetch import ViewPrefetcher
+
+    g = torch.Generator().manual_seed(1)
+    batches = [{"views": [torch.randn(2, 3, 32, 32, generator=g).pin_memory(), torch.randn(2, 3, 16, 16, generator=g)], "filename": [str(i)]}
+               for i in range(4)]
+    seen = 0
+    for i, b in enumerate(ViewPrefetcher(iter(batches), "cuda")):
+        assert b["filename"] == [str(i)] and all(v.is_cuda for v in b["views"])
+        for v, ref in zip(b["views"], batches[i]["views"]):
+            assert torch.equal(v.cpu(), ref)
+        seen += 1
+    assert seen == 4
