@@ -300,6 +300,9 @@ class DINOv2:
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
+        # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
+        # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
+        self.activation_checkpointing = False
         self._drop_gen = torch.Generator().manual_seed(seed + 7919)  # host RNG of the stochastic-depth draws
         self._grad_sync: Optional[GradSync] = None
         use_streams = self.device.type == "cuda"
@@ -453,13 +456,13 @@ class DINOv2:
         if lstream is not None:
             lstream.wait_event(main.record_event())
             with torch.cuda.stream(lstream):
-                sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l)
+                sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing)
                 local_done = lstream.record_event()
-        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g)
+        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g, checkpoint=self.activation_checkpointing)
         if lstream is not None:
             main.wait_event(local_done)
         elif lv is not None:
-            sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l)
+            sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing)
         Rl = n_local * B
         Rd = 2 * B + Rl                      # rows of the DINO head: global cls + local cls
         Rs, cap_s = Rd + M, Rd + cap_M       # student row layout [2B cls | Rl local cls | M masked patches]

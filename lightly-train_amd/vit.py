@@ -308,7 +308,8 @@ class ViTEngine:
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
-                drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None) -> Dict[str, Any]:
+                drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None,
+                checkpoint: bool = False) -> Dict[str, Any]:
         """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
 
         drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
@@ -367,9 +368,10 @@ class ViTEngine:
             br.update(mode="subset", rows=Ts, nb=sb, x=xs, idx=idx, scale=B / sb)
             return br
 
-        blocks: List[Dict[str, Any]] = []
-        for i in range(cfg.depth):
-            s = f"{tag}.b{i}." if save else f"{tag}.tmp."
+        def run_block(i: int, x: Tensor, prefix: str, save: bool, keep_out: bool):
+            """One transformer block.  `prefix`: workspace names of its saved activations; `keep_out`: give the block output its
+            own per-block buffer (it is the next block's input: the only activation kept under activation checkpointing)."""
+            s = prefix
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
@@ -421,14 +423,32 @@ class ViTEngine:
                 ops.scatter_add_rows(delta, m["idx"], xm, D, R2, D)
                 xo = xm
             else:
-                xo = ws.get(f"{tag}.b{i}.xo" if save else (tag + ".xa"), (T, D), torch.float32)
+                xo = ws.get(f"{tag}.b{i}.xo" if keep_out else (tag + ".xa"), (T, D), torch.float32)
                 ops.gemm(act, self.wb(pre + fc2 + ".weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + fc2 + ".bias"),
                          gamma=g2, resid=xm, out2=y2, rowscale=m["rowscale"])
-            if save:
-                a.update(ln=ln1, qkv=qkv, att=att, lse=lse, y=y1)
-                m.update(ln=ln2, act=act, hpre=hpre, y=y2)
-                blocks.append({"attn": a, "mlp": m})
-            x = xo
+            a.update(ln=ln1, qkv=qkv, att=att, lse=lse, y=y1)
+            m.update(ln=ln2, act=act, hpre=hpre, y=y2)
+            return xo, a, m
+        ctx["run_block"] = run_block
+        blocks: List[Dict[str, Any]] = []
+        block_in: List[Tensor] = []
+        for i in range(cfg.depth):
+            if save and checkpoint:
+                # activation checkpointing (reference _activation_checkpointing.py): keep only the block input, recompute the
+                # block in backward.  Subset stochastic depth updates x in place, so the input is copied aside first.
+                e1 = drop_plan[2 * i] if drop_plan is not None else None
+                if e1 is not None and e1[0] != "persample":
+                    xin = ws.get(f"{tag}.b{i}.xin", (T, D), torch.float32)
+                    xin.copy_(x)
+                    block_in.append(xin)
+                else:
+                    block_in.append(x)
+                x, _, _ = run_block(i, x, f"{tag}.ck.", False, True)
+            else:
+                x, a_, m_ = run_block(i, x, f"{tag}.b{i}." if save else f"{tag}.tmp.", save, save)
+                if save:
+                    blocks.append({"attn": a_, "mlp": m_})
+        ctx["block_in"] = block_in if (save and checkpoint) else None
         xn = ws.get(tag + ".xn", (B, N, D), torch.float32)
         mean = ws.get(tag + ".meanf", (T,), torch.float32)
         rstd = ws.get(tag + ".rstdf", (T,), torch.float32)
@@ -490,10 +510,12 @@ class ViTEngine:
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
         blocks_ctx = ctx["blocks"]
+        ckpt = ctx.get("block_in") is not None   # activation checkpointing: blocks are recomputed one at a time below
 
-        def fuse_args(br: Dict[str, Any], gname: str, bname: str, buf: Tensor) -> Dict[str, Any]:
-            """LayerNorm-backward arguments that also produce the upstream gradient of branch `br` (not in subset mode)."""
-            if br["mode"] == "subset":
+        def fuse_args(br: Optional[Dict[str, Any]], gname: str, bname: str, buf: Tensor) -> Dict[str, Any]:
+            """LayerNorm-backward arguments that also produce the upstream gradient of branch `br` (not in subset mode, and
+            not under checkpointing, where the next branch's bookkeeping does not exist yet)."""
+            if br is None or br["mode"] == "subset":
                 return {}
             return dict(dnext=buf, gamma_next=self.w(gname) if self.has(gname) else None, rowscale_next=br["rowscale"],
                         scale_next=float(br["scale"]), dbias_next=self.gw(bname))
@@ -501,7 +523,7 @@ class ViTEngine:
         fc2n = "mlp.w3" if cfg.swiglu else "mlp.fc2"
         cur = 0   # index into dDs of the branch about to be processed
         last = f"blocks.{cfg.depth - 1}."
-        nxt = fuse_args(blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
+        nxt = fuse_args(None if ckpt else blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
         ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
                           self.gw("norm.weight"), self.gw("norm.bias"), T, D, **nxt)
         have = bool(nxt)   # dDs[cur] already holds the upstream gradient of the branch about to be processed
@@ -549,8 +571,13 @@ class ViTEngine:
             return dxs
 
         for i in reversed(range(cfg.depth)):
-            blk = ctx["blocks"][i]
-            a, m = blk["attn"], blk["mlp"]
+            if ckpt:
+                if side is not None:
+                    main.wait_stream(side)   # the previous block's weight-gradient GEMMs still read the shared activation buffers
+                _, a, m = ctx["run_block"](i, ctx["block_in"][i], f"{tag}.ck.", True, False)
+            else:
+                blk = ctx["blocks"][i]
+                a, m = blk["attn"], blk["mlp"]
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
@@ -611,7 +638,7 @@ class ViTEngine:
                 if i > 0:
                     pp = f"blocks.{i - 1}."
                     before_write(dDs[cur ^ 1])
-                    nxt = fuse_args(blocks_ctx[i - 1]["mlp"], pp + "ls2.gamma", pp + fc2n + ".bias", dDs[cur ^ 1])
+                    nxt = fuse_args(None if ckpt else blocks_ctx[i - 1]["mlp"], pp + "ls2.gamma", pp + fc2n + ".bias", dDs[cur ^ 1])
                 ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, dx, other,
                                   self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, **nxt)
                 dx, other = other, dx

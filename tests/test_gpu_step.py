@@ -399,3 +399,34 @@ def test_view_prefetcher_stages_batches_in_order():
             assert torch.equal(v.cpu(), ref)
         seen += 1
     assert seen == 4
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.1, 0.3])
+def test_activation_checkpointing_gives_the_same_gradients(rate):
+    """Activation checkpointing (reference _activation_checkpointing.py: recompute every block in backward) must not change
+    the step: same loss, same gradients (same kernels on the same inputs; atomics may reorder), for plain blocks, per-sample
+    DropPath and batch-subset stochastic depth."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig, make_drop_plan
+
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    outs = []
+    for ck in (False, True):
+        cfgd, mk = fx["cfg"], fx["method_kwargs"]
+        vc = ViTConfig(embed_dim=64, depth=cfgd["depth"], num_heads=cfgd["num_heads"], mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"],
+                       drop_path_rate=rate, drop_path_uniform=True)
+        args = DINOv2Args(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"], koleo_loss_weight=0.0)
+        m = DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=fx["init"]["student_backbone"],
+                   student_head_state=fx["init"]["student_head"], teacher_head_state=fx["init"]["teacher_head"])
+        m.activation_checkpointing = ck
+        gen = torch.Generator().manual_seed(7)
+        batch = {"views": views, "drop_plan_global": make_drop_plan(vc, 2 * fx["b"], gen), "drop_plan_local": make_drop_plan(vc, fx["n_local"] * fx["b"], gen)}
+        res = m.training_step_impl(batch, 0, masks=rec["masks"])
+        torch.cuda.synchronize()
+        outs.append((float(res.loss), m.student.grad.detach().cpu().clone()))
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
+    d = (outs[0][1] - outs[1][1]).abs().max().item()
+    assert d <= 2e-5 * outs[0][1].abs().max().item(), d

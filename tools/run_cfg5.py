@@ -8,8 +8,10 @@ from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
 from lightly_train_amd.vit import ViTConfig
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+CKPT = len(sys.argv) > 2 and sys.argv[2] == "ckpt"
 cfg = ViTConfig(embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.0, patch_size=14, img_size=518, init_values=1e-5, ffn_layer="swiglufused")
 m = DINOv2(cfg, DINOv2Args(), global_batch_size=B, total_steps=1000, device="cuda", seed=0)
+m.activation_checkpointing = CKPT
 g = torch.Generator().manual_seed(0)
 views = [torch.randn(B, 3, 518, 518, generator=g).cuda() for _ in range(2)] + [torch.randn(B, 3, 98, 98, generator=g).cuda() for _ in range(8)]
 random.seed(0)
