@@ -220,7 +220,8 @@ int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, int ld_dx, 
  * dinov2.py:588-660 clip / WD schedule / EMA; LT/_torch_helpers.py:75-96)
  * The flat f32 buffer is split into segments; seg_of_chunk[i] gives the segment of 1024-element chunk i.
  * ------------------------------------------------------------------------------------------ */
-/* out[0] += sum(g^2) */
+/* out[0] += sum(g^2); deterministic (fixed summation order: identical gradients give identical bits on every rank).
+ * At most 16 calls may be in flight on different streams at once. */
 int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
 /* AdamW (torch.optim.AdamW semantics, decoupled wd). clip_coef = min(1, max_norm/(||g||+1e-6)) is computed on
  * device from *sumsq.  lr = seg_lr[seg]*lr_factor (0 if seg_frozen[seg] && freeze); wd = seg_wd_on[seg] ? wd : 0.

@@ -3,11 +3,20 @@
 // Replaces torch.optim.AdamW(foreach) + clip_grad_norm_ + _foreach_mul_/_foreach_add_
 // (LT/_methods/dinov2/utils.py:191-250, dinov2.py:588-660, LT/_torch_helpers.py:75-96).
 #include "lt_common.h"
+#include <atomic>
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n) {
+// Deterministic global sum of squares: every block leaves its partial in a scratch slot, the last block to arrive adds
+// the partials in a fixed order.  The clip coefficient derived from it multiplies every gradient, so an atomic (order-
+// dependent) sum would let data-parallel replicas drift apart by an ulp per step although their gradients are identical.
+constexpr int SUMSQ_SLOTS = 16, SUMSQ_MAX_GRID = 1024;
+__device__ float sumsq_partials[SUMSQ_SLOTS][SUMSQ_MAX_GRID];
+__device__ unsigned sumsq_tickets[SUMSQ_SLOTS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n, int slot) {
   __shared__ float red[16];
+  __shared__ bool last;
   float s = 0.f;
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
@@ -17,7 +26,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   }
   if (i < n) for (long j = i; j < n; ++j) s += g[j] * g[j];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) {
+    sumsq_partials[slot][blockIdx.x] = s;
+    __threadfence();
+    last = atomicAdd(&sumsq_tickets[slot], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __builtin_nontemporal_load(&sumsq_partials[slot][b]);
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) {
+    *out += t;
+    sumsq_tickets[slot] = 0;
+  }
 }
 
 // one block per 1024-element chunk (a chunk never straddles two parameter tensors)
@@ -77,8 +100,10 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const f
 extern "C" int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream) {
   LT_CHECK_ARG(g && out && ((uintptr_t)g & 15) == 0, "lt_sumsq_f32: bad pointer/alignment");
   if (n == 0) return LT_OK;
-  const int grid = (int)min((long)1024, (long)lt_cdiv(n, 1024));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, out, (long)n);
+  static std::atomic<unsigned> next_slot{0};   // launches in flight on different streams use different scratch slots
+  const int slot = (int)(next_slot.fetch_add(1) % SUMSQ_SLOTS);
+  const int grid = (int)min((long)SUMSQ_MAX_GRID, (long)lt_cdiv(n, 1024));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, ST, g, out, (long)n, slot);
   LT_CHECK_LAUNCH("lt_sumsq_f32");
 }
 

@@ -305,10 +305,16 @@ class DINOv2:
         self.activation_checkpointing = False
         self._drop_gen = torch.Generator().manual_seed(seed + 7919)  # host RNG of the stochastic-depth draws
         self._grad_sync: Optional[GradSync] = None
+        # data parallel: all-reduce the head gradients and each transformer block's gradients as soon as they are final,
+        # underneath the rest of backward (what DDP's bucket hooks do in the reference); LT_GRAD_OVERLAP=0 reduces after it
+        self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
+        self._head_span = self.student.span(("head.", "ihead."))
+        self._block_spans = [self.student.span((f"backbone.blocks.{i}.",)) for i in range(vit_cfg.depth)]
         use_streams = self.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device=self.device) if use_streams else None     # weight-gradient GEMMs
         self.teacher_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # teacher forward
         self.local_bwd_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # local-crop dgrad chain
+        self.reduce_stream = torch.cuda.Stream(device=self.device) if use_streams else None    # orders the early all-reduces
 
     # ------------------------------------------------------------------ reference-compatible views
     def state_dict(self) -> Dict[str, Tensor]:
@@ -393,6 +399,8 @@ class DINOv2:
         n_p_l = (-(-lv.shape[2] // p)) * (-(-lv.shape[3] // p)) if lv is not None else 0
         Nl = n_p_l + 1 + n_reg
         ix = self._indices(B, n_p + n_reg, n_local, n_p_l + n_reg)
+        if self._grad_sync is not None:
+            self._grad_sync.reset()   # a step whose optimizer_step was skipped must not leak its ranges into this one
         self.student.grad.zero_()
         self._loss_slots.zero_()
 
@@ -509,6 +517,23 @@ class DINOv2:
 
         # ---------------- backward
         side = self.side_stream if self.overlap_streams else None
+        sync = self._gradient_sync() if self.overlap_grad_reduce and self.reduce_stream is not None else None
+        done_blocks: List[int] = []
+
+        def reduce_block(i: int, after: Tuple[Any, ...]) -> None:
+            """Block i is through every backward pass: finish its LayerScale gradients and start its all-reduce, ordered
+            after the streams that wrote its gradients, on a stream of its own (nothing of backward waits for it)."""
+            if sync is None:
+                return
+            rs = self.reduce_stream
+            for st in after:
+                if st is not None:
+                    rs.wait_event(st.record_event())
+            with torch.cuda.stream(rs):
+                self.s_vit.finish_layerscale_grads(blocks=[i], last_call=False)
+                sync.start(*self._block_spans[i])
+            done_blocks.append(i)
+
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
@@ -518,6 +543,8 @@ class DINOv2:
             dx_ihead = self.s_ihead.backward(ws, shi, dlogits_i)
             self.s_ihead.finish_weightnorm_grad()
             ops.scatter_add_rows(dx_ihead[:M], patch_rows, dxn_g, D, M, D)
+        if sync is not None:
+            sync.start(*self._head_span)   # the prototype heads are final: their all-reduce runs under the whole ViT backward
         if sl is not None:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
@@ -529,11 +556,15 @@ class DINOv2:
             lstream2.wait_event(main.record_event())
             chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
             live = [True, True]
+            blk = self.cfg.depth
             while any(live):
                 for ci, (st, gen) in enumerate(chains):
                     if live[ci]:
                         with torch.cuda.stream(st):
                             live[ci] = next(gen) != "tail"
+                blk -= 1
+                if blk >= 0:
+                    reduce_block(blk, (lstream2, main, side))
             main.wait_stream(lstream2)
             for _, gen in chains:   # tails: plain accumulations into cls/pos/patch-embedding gradients, one after the other
                 for _ in gen:
@@ -541,10 +572,16 @@ class DINOv2:
         else:
             if sl is not None:
                 self.s_vit.backward(ws, sl, dxn_l, side=side)
-            self.s_vit.backward(ws, sg, dxn_g, side=side)
+            blk = self.cfg.depth
+            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side):
+                if ev == "block":
+                    blk -= 1
+                    reduce_block(blk, (main, side))
         if side is not None:
             main.wait_stream(side)
-        self.s_vit.finish_layerscale_grads()
+        if sync is not None:
+            main.wait_stream(self.reduce_stream)
+        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
 
         ls = self._loss_slots
         # slots hold weighted terms; report the unweighted terms like the reference's log_dict
@@ -583,14 +620,20 @@ class DINOv2:
             ops.sk_iter(out, cs, rows, K, nt, nt if it == 2 else 1.0)
 
     # ------------------------------------------------------------------ optimizer / EMA hooks
-    def allreduce_gradients(self) -> None:
-        """DDP gradient mean over ranks (C1 in SURVEY.md 2c) on the flat grad buffer (parallel.GradSync)."""
+    def _gradient_sync(self) -> Optional[GradSync]:
         if self.world == 1:
-            return
+            return None
         if self._grad_sync is None:
             self._grad_sync = GradSync(self.student.grad)
-        self._grad_sync.start()
-        self._grad_sync.finish()
+        return self._grad_sync
+
+    def allreduce_gradients(self) -> None:
+        """DDP gradient mean over ranks (C1 in SURVEY.md 2c) on the flat grad buffer (parallel.GradSync): reduces what the
+        backward pass has not already started (the small embedding / final-norm tensors, or everything with
+        LT_GRAD_OVERLAP=0), waits for all of it on the current stream and scales by 1/world."""
+        sync = self._gradient_sync()
+        if sync is not None:
+            sync.finish()
 
     def optimizer_step(self) -> Dict[str, float]:
         """on_before_optimizer_step + configure_gradient_clipping + AdamW + CosineWarmupScheduler (dinov2.py:576-639)."""

@@ -37,31 +37,60 @@ def bucket_ranges(numel: int, bucket_elems: int) -> List[Tuple[int, int]]:
 
 
 class GradSync:
-    """Mean-all-reduce of a flat gradient buffer in fixed-size buckets.  xGMI is point-to-point (7 links/GPU), so
-    large buckets (64 MiB fp32) keep RCCL on its bandwidth-optimal direct algorithms; buckets are issued async and
-    back-to-back so RCCL pipelines them on its own stream while the caller continues."""
+    """Mean-all-reduce of a flat gradient buffer.  xGMI is point-to-point (7 links/GPU), so large messages (up to 64 MiB
+    fp32 per call) keep RCCL on its bandwidth-optimal algorithms; calls are issued async and back-to-back so RCCL
+    pipelines them on its own stream while the caller continues.
+
+    `start(lo, hi)` may be called during backward for a range whose gradients are final (enqueued on the CURRENT stream:
+    the collective is ordered after it); `finish()` reduces whatever no `start` has covered, waits for everything on the
+    current stream and applies the 1/world scale.  Every rank must issue the same ranges in the same order."""
 
     def __init__(self, flat_grad: Tensor, bucket_bytes: int = 64 << 20) -> None:
         self.g = flat_grad
-        self.ranges = bucket_ranges(flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size()))
+        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.ranges = bucket_ranges(flat_grad.numel(), self.bucket_elems)
         self.handles: List = []
+        self.covered: List[Tuple[int, int]] = []
+
+    def uncovered(self, lo: int, hi: int) -> List[Tuple[int, int]]:
+        """Sub-ranges of [lo, hi) no earlier `start` of this step has reduced."""
+        gaps, at = [], lo
+        for a, b in sorted(self.covered):
+            if b <= at or a >= hi:
+                continue
+            if a > at:
+                gaps.append((at, a))
+            at = max(at, b)
+        if at < hi:
+            gaps.append((at, hi))
+        return gaps
 
     def start(self, lo: int = 0, hi: Optional[int] = None) -> None:
-        """Launch the all-reduce of every bucket that lies inside [lo, hi) (call as gradients become final)."""
+        """Launch the all-reduce of the not-yet-reduced part of [lo, hi) (call as gradients become final)."""
         if world_size() == 1:
             return
         hi = self.g.numel() if hi is None else hi
-        for a, b in self.ranges:
-            if a >= lo and b <= hi:
-                self.handles.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        for a, b in self.uncovered(lo, hi):
+            for c, d in bucket_ranges(b - a, self.bucket_elems):
+                self.handles.append(dist.all_reduce(self.g[a + c:a + d], op=dist.ReduceOp.SUM, async_op=True))
+            self.covered.append((a, b))
+
+    def reset(self) -> None:
+        """Drop the bookkeeping of an unfinished step (waits for its collectives first)."""
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self.covered.clear()
 
     def finish(self) -> None:
         w = world_size()
         if w == 1:
             return
+        self.start()
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        self.covered.clear()
         if self.g.is_cuda:
             from . import ops
 

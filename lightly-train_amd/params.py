@@ -44,6 +44,15 @@ class FlatParams:
             self.p[n].copy_(t.to(device=self.device, dtype=torch.float32))
         self.bf16.copy_(self.data)  # one-time init cast (torch plumbing); steady-state casts are fused into AdamW/EMA
 
+    def span(self, prefixes: Tuple[str, ...]) -> Tuple[int, int]:
+        """[lo, hi) of the flat buffers that holds exactly the tensors whose names start with one of `prefixes`
+        (ValueError when those tensors are not contiguous in the flat order)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefixes)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError(f"parameters {prefixes} are not one contiguous run of the flat buffer")
+        hi = self.offsets[self.names[idx[-1] + 1]] if idx[-1] + 1 < len(self.names) else self.numel
+        return self.offsets[self.names[idx[0]]], hi
+
     def state_dict(self, prefix: str = "") -> Dict[str, Tensor]:
         return {prefix + n: self.p[n].detach().clone() for n in self.names}
 

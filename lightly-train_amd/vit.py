@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Iterator, Any, Dict, List, Optional, Tuple
+from typing import Any, Dict, Iterable, Iterator, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -463,16 +463,18 @@ class ViTEngine:
         for _ in self.backward_iter(ws, ctx, dxn, side):
             pass
 
-    def finish_layerscale_grads(self) -> None:
+    def finish_layerscale_grads(self, blocks: Optional[Iterable[int]] = None, last_call: bool = True) -> None:
         """LayerScale gradients from the accumulated weight gradients: dgamma = (rowdot(W, dW) + b * db) / gamma
         (layer_scale.py:27-28 backward without saving the branch outputs).  Call once per step, after every backward pass
-        (global and local crops) and its weight-gradient GEMMs have been enqueued / joined, before the optimizer."""
+        (global and local crops) and its weight-gradient GEMMs have been enqueued / joined, before the optimizer.
+        `blocks`: only these blocks (a data-parallel caller finishes a block as soon as both passes are through it, so that
+        its gradient all-reduce can start during backward, `last_call=False`) -- every block exactly once per step."""
         cfg = self.cfg
         D, hid = cfg.embed_dim, cfg.hidden
         fc2 = "mlp.w3" if cfg.swiglu else "mlp.fc2"
-        if cfg.rope_base is not None:
+        if cfg.rope_base is not None and last_call:
             self.gw("pos_embed").zero_()            # no positional embedding in a RoPE model: the zero table stays zero
-        for i in range(cfg.depth):
+        for i in (range(cfg.depth) if blocks is None else blocks):
             pre = f"blocks.{i}."
             if cfg.mask_k_bias:
                 self.gw(pre + "attn.qkv.bias")[D:2 * D].zero_()   # LinearKMaskedBias: bias * mask => no gradient for the K third

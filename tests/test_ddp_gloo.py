@@ -31,9 +31,13 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         mine = grad.clone()
         sync = GradSync(grad, bucket_bytes=4096 * 4)  # 3 buckets: 4096 + 4096 + 1808
         assert len(sync.ranges) == 3 and sync.ranges[-1] == (8192, 10_000)
-        sync.start(0, 8192)      # buckets that are already final
-        sync.start(8192, 10_000)  # the tail
-        sync.finish()
+        sync.start(5000, 9200)   # a range that became final during backward (split at the bucket size: 4096 + 104)
+        sync.start(100, 200)
+        assert sync.uncovered(0, 10_000) == [(0, 100), (200, 5000), (9200, 10_000)] and len(sync.handles) == 3
+        sync.start(4000, 6000)   # overlapping request: only the part not reduced yet
+        assert sync.uncovered(0, 10_000) == [(0, 100), (200, 4000), (9200, 10_000)]
+        sync.finish()            # the rest, then wait + 1/world
+        assert sync.covered == [] and sync.handles == []
         others = [torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
         expect = sum(others) / world
         assert torch.allclose(grad, expect, atol=1e-6)

@@ -70,6 +70,58 @@ def test_two_ranks_match_single_process(tmp_path, center_method):
             assert d <= 2e-4 * max(1.0, b[i].abs().max().item()), (nm, d)
 
 
+def _overlap_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import test_gpu_step as T
+
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_softmax.pt"), weights_only=False)
+        out = {}
+        for key, overlap, streams in (("overlap", True, True), ("overlap_one_stream", True, False), ("after", False, True)):
+            m = T.build(fx, koleo_loss_weight=0.0)
+            m.overlap_grad_reduce = overlap
+            m.overlap_streams = streams
+            early = []
+            for s in range(3):
+                rec = fx["steps"][min(s, len(fx["steps"]) - 1)]
+                views = T.synth_views(rec["view_seed"] + 10 * s + 1000 * rank, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])  # per-rank data
+                m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+                early.append(sum(b - a for a, b in m._grad_sync.covered) if m._grad_sync is not None else 0)
+                m.optimizer_step()
+                m.on_train_batch_end()
+            torch.cuda.synchronize()
+            out[key] = (m.student.data.cpu().clone(), early, m.student.numel)
+        torch.save(out, os.path.join(out_dir, f"o{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_overlapped_with_backward(tmp_path):
+    """Different images on the two ranks: after three steps the parameters are bit-identical across ranks only if every
+    element of the gradient went through the all-reduce exactly once; starting the head / per-block all-reduces during
+    backward (the default) gives the same parameters as one all-reduce after it, and covers nearly all of the buffer early."""
+    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "o0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "o1.pt", weights_only=False)
+    for key in ("overlap", "overlap_one_stream", "after"):
+        bad = (r0[key][0] != r1[key][0]).nonzero().flatten()
+        assert bad.numel() == 0, f"ranks diverged ({key}): {bad.numel()} elements, first at {bad[:4].tolist()}, last {bad[-1].item()}, max diff {(r0[key][0] - r1[key][0]).abs().max().item()}"
+    b = r0["after"][0]
+    for key in ("overlap", "overlap_one_stream"):
+        assert (r0[key][0] - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), key
+        early, numel = r0[key][1], r0[key][2]
+        assert all(e > 0.5 * numel for e in early), (key, early, numel)   # heads + every block were in flight before backward ended
+    assert all(e == 0 for e in r0["after"][1])
+
+
 def _run_distill(n_steps: int = 3):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
