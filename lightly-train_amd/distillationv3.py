@@ -14,6 +14,7 @@ Not implemented (raise): convolutional students (torchvision/resnet50 of BASELIN
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Mapping, Optional, Tuple
 
@@ -134,6 +135,11 @@ class DistillationV3:
         self._grad_sync: Optional[GradSync] = None
         self.teacher_stream = torch.cuda.Stream(device=dev)
         self.side_stream = torch.cuda.Stream(device=dev)
+        self.reduce_stream = torch.cuda.Stream(device=dev)
+        # data parallel: per-block gradient all-reduces issued during backward (see dinov2.py); LT_GRAD_OVERLAP=0 = after it
+        self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
+        self._proj_span = self.student.span(("proj_global.", "proj_local."))
+        self._block_spans = [self.student.span((f"backbone.blocks.{i}.",)) for i in range(student_cfg.depth)]
         self._idx: Dict[Tuple[int, int, int], Tuple[Tensor, Tensor]] = {}
         self._resample_tabs: Dict[Tuple[int, int, int, int], Any] = {}
 
@@ -183,6 +189,8 @@ class DistillationV3:
         ops.mixup(views, index.to(dev, torch.int64), float(lam), x)
 
         main = torch.cuda.current_stream()
+        if self._grad_sync is not None:
+            self._grad_sync.reset()
         self.student.grad.zero_()
         self._loss_slots.zero_()
         # ---- teacher (no grad) on its own stream
@@ -303,9 +311,26 @@ class DistillationV3:
         ops.gemm(dsl, P.b["proj_local.weight"], dpat, M=B * n_ps, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
         ops.scatter_add_rows(dcls, s_cls_rows, dxn, Ds, B, Ds)
         ops.scatter_add_rows(dpat, s_patch_rows, dxn, Ds, B * n_ps, Ds)
-        self.s_vit.backward(ws, sc, dxn.view(B, Ns, Ds), side=self.side_stream)
+        sync = self._gradient_sync() if self.overlap_grad_reduce else None
+        done_blocks: List[int] = []
+        if sync is not None:
+            sync.start(*self._proj_span)   # projection heads are final: reduce them under the ViT backward
+        blk = self.scfg.depth
+        for ev in self.s_vit.backward_iter(ws, sc, dxn.view(B, Ns, Ds), side=self.side_stream):
+            if ev == "block":
+                blk -= 1
+                if sync is not None:   # block `blk` is final: LayerScale gradients, then its all-reduce, beside the rest of backward
+                    rs = self.reduce_stream
+                    rs.wait_event(main.record_event())
+                    rs.wait_event(self.side_stream.record_event())
+                    with torch.cuda.stream(rs):
+                        self.s_vit.finish_layerscale_grads(blocks=[blk], last_call=False)
+                        sync.start(*self._block_spans[blk])
+                    done_blocks.append(blk)
         main.wait_stream(self.side_stream)
-        self.s_vit.finish_layerscale_grads()
+        if sync is not None:
+            main.wait_stream(self.reduce_stream)
+        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.scfg.depth) if i not in done_blocks])
 
         ls = self._loss_slots
         w = a.loss_local_weight
@@ -323,16 +348,21 @@ class DistillationV3:
         return dict(zip(keys, vals))
 
     # ------------------------------------------------------------------ optimizer hooks
+    def _gradient_sync(self) -> Optional[GradSync]:
+        if self.world == 1:
+            return None
+        if self._grad_sync is None:
+            self._grad_sync = GradSync(self.student.grad)
+        return self._grad_sync
+
     def optimizer_step(self) -> None:
         a = self.method_args
         k = self.trainer.global_step
         total = int(self.trainer.estimated_stepping_batches)
         lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, 0.001)   # CosineWarmupScheduler default end_value
-        if self.world > 1:
-            if self._grad_sync is None:
-                self._grad_sync = GradSync(self.student.grad)
-            self._grad_sync.start()
-            self._grad_sync.finish()
+        sync = self._gradient_sync()
+        if sync is not None:
+            sync.finish()   # what backward has not started yet (embeddings, final norm), wait, 1/world
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1

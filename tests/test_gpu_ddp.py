@@ -152,6 +152,44 @@ def _distill_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.destroy_process_group()
 
 
+def _distill_overlap_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import test_gpu_distill as TD
+
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", "distill_v3_d64.pt"), weights_only=False)
+        out = {}
+        for overlap in (True, False):
+            m = TD.build(fx)
+            m.overlap_grad_reduce = overlap
+            for rec in fx["steps"][:3]:
+                x = torch.randn(fx["b"], 3, 64, 64, generator=torch.Generator().manual_seed(rec["x_seed"] + 1000 * rank))  # per-rank images
+                m.train_step(x, mix=(rec["lam"], rec["index"]))
+            torch.cuda.synchronize()
+            out[overlap] = m.student.data.cpu().clone()
+        torch.save(out, os.path.join(out_dir, f"do{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distillation_gradient_allreduce_overlapped(tmp_path):
+    """DistillationV3 with different images per rank: replicas stay bit-identical, overlapped == after-backward reduction."""
+    mp.spawn(_distill_overlap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "do0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "do1.pt", weights_only=False)
+    for overlap in (True, False):
+        assert torch.equal(r0[overlap], r1[overlap]), f"ranks diverged (overlap={overlap})"
+    assert (r0[True] - r0[False]).abs().max().item() <= 1e-5 * max(1.0, r0[False].abs().max().item())
+
+
 def test_distillation_two_ranks_match_single_process(tmp_path):
     """DistillationV3 under data parallelism: per-GPU queues, gradient mean -- same data on both ranks == single process."""
     mp.spawn(_distill_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
