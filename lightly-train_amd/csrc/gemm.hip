@@ -130,35 +130,42 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rb, int ks) {
 }
 
 // ---- vector epilogue: emit a [64 x 64] fp32 sub-tile staged in wave-private LDS `wl` (row-major, 64 floats/row) --------
-template <int EPI>
-__device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl, int row_base, int col_base, int l, bool atomic) {
-  const int cc = (l & 15) * 4, rs = l >> 4;
-  const int col = col_base + cc;
-  if (col >= g.N) return;
+// FULL: all 64 rows are inside the matrix.  That path has no per-row branch on purpose: with one basic block per row the
+// waitcnt pass has to assume the bias / residual loads may still be pending at every join and puts `s_waitcnt vmcnt(0)` in
+// front of every row -- and since stores count in vmcnt too, each row then waits for the previous row's store to complete
+// (measured: 3.6-4.5 TB/s epilogues).  Straight-line code gets counted waits and keeps all 16 stores of a lane in flight.
+template <int EPI, bool FULL>
+__device__ __forceinline__ void emit_rows(const GemmArgs& g, const float* wl, int row_base, int col, int cc, int rs, bool atomic) {
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
   if (EPI != EPI_F32_ACCUM && EPI != EPI_BF16_GELUGRAD && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + col);
   if (EPI == EPI_RESID && g.gamma) gam4 = *reinterpret_cast<const float4*>(g.gamma + col);
-  // operands the epilogue has to fetch from HBM (residual rows / GELU pre-activations): issue all 16 loads up front so
-  // their latency overlaps instead of being paid once per row group
+  // operands the epilogue has to fetch from HBM (residual rows / GELU pre-activations / stochastic-depth row scales): issue
+  // all loads up front so their latency overlaps instead of being paid once per row group
   float4 r4[16];
   uint2 a2[16];
+  float rsc[16];
   if (EPI == EPI_RESID || EPI == EPI_BF16_GELUGRAD) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int row = row_base + it * 4 + rs;
       r4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       a2[it] = make_uint2(0, 0);
-      if (row < g.M) {
+      rsc[it] = 1.f;
+      if (FULL || row < g.M) {
         if (EPI == EPI_RESID && g.resid) r4[it] = *reinterpret_cast<const float4*>(g.resid + (size_t)row * g.ldr + col);
         if (EPI == EPI_BF16_GELUGRAD) a2[it] = *reinterpret_cast<const uint2*>(g.aux + (size_t)row * g.ldaux + col);
       }
+    }
+    if (EPI == EPI_RESID && g.rowscale) {   // stochastic depth: subset b/s or per-sample mask/keep
+#pragma unroll
+      for (int it = 0; it < 16; ++it) rsc[it] = g.rowscale[min(row_base + it * 4 + rs, g.M - 1)];
     }
   }
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int rl = it * 4 + rs;
     const int row = row_base + rl;
-    if (row >= g.M) continue;
+    if (!FULL && row >= g.M) continue;
     float4 v = *reinterpret_cast<const float4*>(wl + rl * 64 + cc);
     v.x = v.x * g.alpha + bias4.x; v.y = v.y * g.alpha + bias4.y; v.z = v.z * g.alpha + bias4.z; v.w = v.w * g.alpha + bias4.w;
     const size_t o = (size_t)row * g.ldc + col;
@@ -169,9 +176,9 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
       *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(gelu_f(v.x), gelu_f(v.y)), pack_bf2(gelu_f(v.z), gelu_f(v.w)));
     } else if (EPI == EPI_RESID) {
       if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      const float rsc = g.branch_scale * (g.rowscale ? g.rowscale[row] : 1.f);  // stochastic depth: subset b/s or per-sample mask/keep
-      *reinterpret_cast<float4*>((float*)g.C + o) = make_float4(r4[it].x + rsc * gam4.x * v.x, r4[it].y + rsc * gam4.y * v.y,
-                                                                r4[it].z + rsc * gam4.z * v.z, r4[it].w + rsc * gam4.w * v.w);
+      const float sc = g.branch_scale * rsc[it];
+      *reinterpret_cast<float4*>((float*)g.C + o) = make_float4(r4[it].x + sc * gam4.x * v.x, r4[it].y + sc * gam4.y * v.y,
+                                                                r4[it].z + sc * gam4.z * v.z, r4[it].w + sc * gam4.w * v.w);
     } else if (EPI == EPI_F32) {
       *reinterpret_cast<float4*>((float*)g.C + o) = v;
     } else if (EPI == EPI_BF16_GELUGRAD) {
@@ -185,6 +192,15 @@ __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl,
       else { float4 old = *reinterpret_cast<float4*>(c); *reinterpret_cast<float4*>(c) = make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w); }
     }
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl, int row_base, int col_base, int l, bool atomic) {
+  const int cc = (l & 15) * 4, rs = l >> 4;
+  const int col = col_base + cc;
+  if (col >= g.N) return;
+  if (row_base + 64 <= g.M) emit_rows<EPI, true>(g, wl, row_base, col, cc, rs, atomic);
+  else emit_rows<EPI, false>(g, wl, row_base, col, cc, rs, atomic);
 }
 
 template <bool TA, bool TB, int EPI, bool VEC>
@@ -361,7 +377,11 @@ __device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ 
   }
 }
 
-template <bool TR, int ROWS>
+// RAW_TR: issue the transposing LDS reads as inline asm.  The waitcnt pass cannot see which LDS bytes ds_read_b64_tr_b16
+// touches, so after any LDS-DMA it puts `s_waitcnt vmcnt(0)` in front of the builtin form -- which in a K-loop that keeps
+// DMAs in flight across phases serialises every phase behind the DMA issued just before it.  Callers of the RAW_TR form
+// order DMA and reads themselves (explicit vmcnt / lgkmcnt waits + barriers) and must wait lgkmcnt(0) before using the result.
+template <bool TR, int ROWS, bool RAW_TR = false>
 __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int rb, int ks) {
   const int l = threadIdx.x & 63;
   if (!TR) {
@@ -375,8 +395,15 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int rb, int ks) {
     const int inner = ((((i >> 2) + b) & 3) << 5) + ((i & 3) << 3);
     const int q0 = ks * 4 + kh * 2;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (q0 * NB + b) * 128 + inner));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((q0 + 1) * NB + b) * 128 + inner));
+    s16x4 lo, hi;
+    if (RAW_TR) {
+      const unsigned a0 = (unsigned)(uintptr_t)(lptr_t*)(lds + (q0 * NB + b) * 128 + inner);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(NB * 128));
+    } else {
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (q0 * NB + b) * 128 + inner));
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((q0 + 1) * NB + b) * 128 + inner));
+    }
     union { struct { s16x4 a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
@@ -564,11 +591,11 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     const char* lb = buf + (2 + (wn >> 1)) * HB;
     // ---- P1
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_frag2<TB, 128>(lb, bcol, ks);
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = read_frag2<TB, 128, true>(lb, bcol, ks);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128>(la, i, ks);
+      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128, true>(la, i, ks);
     if (t + 1 < nk) LT_DMA_HALF(t + 1, 1);
     LT_PHASE_SYNC_IN();
 #pragma unroll
@@ -578,7 +605,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     LT_PHASE_SYNC_OUT();
     // ---- P2
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_frag2<TB, 128>(lb, bcol + 1, ks);
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = read_frag2<TB, 128, true>(lb, bcol + 1, ks);
     if (t + 1 < nk) LT_DMA_HALF(t + 1, 2);
     LT_PHASE_SYNC_IN();
 #pragma unroll
@@ -590,7 +617,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128>(la, 2 + i, ks);
+      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = read_frag2<TA, 128, true>(la, 2 + i, ks);
     if (t + 1 < nk) LT_DMA_HALF(t + 1, 3);
     LT_PHASE_SYNC_IN();
 #pragma unroll
