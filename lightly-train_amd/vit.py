@@ -196,6 +196,7 @@ class ViTEngine:
         self.prefix = prefix
         self.dev = params.device
         self._pos_maps: Dict[Tuple[int, int], Optional[Tensor]] = {}
+        self._rope_ang: Dict[Tuple[int, int], Tensor] = {}
         self._rope: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
         self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
         D = cfg.embed_dim
@@ -257,33 +258,23 @@ class ViTEngine:
     def rope_tables_train(self, gh: int, gw: int) -> List[Tuple[Tensor, Tensor]]:
         """Per-block (sin, cos) tables of a DINOv3 student in training mode: the reference calls `rope_embed(H, W)` once per
         block (vision_transformer.py:269-271) and every call draws its own log-uniform rescale factor from torch's default
-        generator (rope_position_encoding.py:104-109) -- same draws, same order here."""
+        generator (rope_position_encoding.py:104-109) -- same draws, same order here.  The tables of all blocks are built on
+        the device in one go (angles are linear in the factor), so a step costs one small H2D copy instead of 2 per block."""
         cfg = self.cfg
-        out = []
-        for _ in range(cfg.depth):
-            mul = 1.0
-            if cfg.rope_rescale is not None:
-                rmax = math.log(cfg.rope_rescale)
-                mul = float(torch.empty(1, dtype=torch.float32).uniform_(-rmax, rmax).exp())
-            out.append(self._rope_tables(gh, gw, mul))
-        return out
+        if cfg.rope_rescale is None:
+            return [self._rope_tables(gh, gw)] * cfg.depth
+        rmax = math.log(cfg.rope_rescale)
+        muls = [float(torch.empty(1, dtype=torch.float32).uniform_(-rmax, rmax).exp()) for _ in range(cfg.depth)]
+        base = self._rope_angles(gh, gw)                                                     # [P, head_dim] at factor 1
+        ang = base.unsqueeze(0) * torch.tensor(muls, dtype=torch.float32).to(self.dev, non_blocking=True).view(-1, 1, 1)
+        sin, cos = torch.sin(ang), torch.cos(ang)
+        return [(sin[i], cos[i]) for i in range(cfg.depth)]
 
-    def _rope_tables(self, gh: int, gw: int, coord_mul: float = 1.0) -> Tuple[Tensor, Tensor]:
-        """(sin, cos) f32 [gh*gw, head_dim] of DINOv3's RopePositionEmbedding (layers/rope_position_encoding.py:62-117,
-        normalize_coords="separate", periods = base ** (2 i / (head_dim/2)), i < head_dim/4; :118-127); `coord_mul` = the
-        training-mode rescale factor (1 = eval mode, cached)."""
-        if coord_mul != 1.0:
-            dh = self.cfg.head_dim
-            periods = float(self.cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
-            ch = torch.arange(0.5, gh, dtype=torch.float32) / gh
-            cw = torch.arange(0.5, gw, dtype=torch.float32) / gw
-            coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
-            coords = (2.0 * coords - 1.0) * torch.tensor(coord_mul, dtype=torch.float32)
-            angles = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2)
-            angles = torch.cat((angles, angles), dim=-1)
-            return torch.sin(angles).contiguous().to(self.dev, non_blocking=True), torch.cos(angles).contiguous().to(self.dev, non_blocking=True)
+    def _rope_angles(self, gh: int, gw: int) -> Tensor:
+        """Rotation angles f32 [gh*gw, head_dim] of DINOv3's RopePositionEmbedding (layers/rope_position_encoding.py:62-127,
+        normalize_coords="separate", periods = base ** (2 i / (head_dim/2)), i < head_dim/4), on the device, cached per grid."""
         key = (gh, gw)
-        if key not in self._rope:
+        if key not in self._rope_ang:
             dh = self.cfg.head_dim
             periods = float(self.cfg.rope_base) ** (2 * torch.arange(dh // 4, dtype=torch.float32) / (dh // 2))
             ch = torch.arange(0.5, gh, dtype=torch.float32) / gh
@@ -291,8 +282,15 @@ class ViTEngine:
             coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
             coords = 2.0 * coords - 1.0
             angles = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2)
-            angles = torch.cat((angles, angles), dim=-1)
-            self._rope[key] = (torch.sin(angles).contiguous().to(self.dev), torch.cos(angles).contiguous().to(self.dev))
+            self._rope_ang[key] = torch.cat((angles, angles), dim=-1).contiguous().to(self.dev)
+        return self._rope_ang[key]
+
+    def _rope_tables(self, gh: int, gw: int) -> Tuple[Tensor, Tensor]:
+        """(sin, cos) f32 [gh*gw, head_dim] at rescale factor 1 (eval mode / frozen teacher), cached per grid."""
+        key = (gh, gw)
+        if key not in self._rope:
+            ang = self._rope_angles(gh, gw)
+            self._rope[key] = (torch.sin(ang), torch.cos(ang))
         return self._rope[key]
 
     def _pos_for_grid(self, ws: Workspace, tag: str, gh: int, gw: int) -> Tensor:
