@@ -77,8 +77,8 @@ def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int) -> 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="vit_base", choices=sorted(MODELS))
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (images)")
     ap.add_argument("--global-size", type=int, default=224)

@@ -377,17 +377,25 @@ __device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ 
   }
 }
 
-// RAW_TR: issue the transposing LDS reads as inline asm.  The waitcnt pass cannot see which LDS bytes ds_read_b64_tr_b16
-// touches, so after any LDS-DMA it puts `s_waitcnt vmcnt(0)` in front of the builtin form -- which in a K-loop that keeps
-// DMAs in flight across phases serialises every phase behind the DMA issued just before it.  Callers of the RAW_TR form
-// order DMA and reads themselves (explicit vmcnt / lgkmcnt waits + barriers) and must wait lgkmcnt(0) before using the result.
+// RAW_TR: issue the LDS reads as inline asm.  The waitcnt pass cannot see which LDS bytes ds_read_b64_tr_b16 touches, so
+// after any LDS-DMA it puts `s_waitcnt vmcnt(0)` in front of the builtin form -- which in a K-loop that keeps DMAs in flight
+// across phases serialises every phase behind the DMA issued just before it; and before every LDS-DMA it waits lgkmcnt(0)
+// for the tracked ds_reads issued just before (possible WAR through LDS), so the DMA issue cannot overlap their latency.
+// Callers of the RAW_TR form order DMA and reads themselves (explicit vmcnt / lgkmcnt waits + barriers) and must wait
+// lgkmcnt(0) before using the result.
 template <bool TR, int ROWS, bool RAW_TR = false>
 __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int rb, int ks) {
   const int l = threadIdx.x & 63;
   if (!TR) {
     const int row = rb * 32 + (l & 31);
     const int c = ks * 2 + (l >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    const char* p = lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    if (RAW_TR) {   // same reason, mirrored: a tracked ds_read makes the pass wait lgkmcnt(0) before the next LDS-DMA is issued
+      bf16x8 v;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lptr_t*)p));
+      return v;
+    }
+    return *reinterpret_cast<const bf16x8*>(p);
   } else {
     constexpr int NB = ROWS / 16;
     const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
@@ -583,6 +591,10 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   }
   if (nk > 1) { LT_DMA_HALF(1, 2); LT_DMA_HALF(1, 3); LT_DMA_HALF(1, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6): tile 0 landed
   else __builtin_amdgcn_s_waitcnt(0xF70);                                                                      // vmcnt(0)
+  // lgkmcnt(0) on every path into the loop: otherwise the waitcnt pass has to assume the kernel-argument loads may still be
+  // pending at the loop header and waits lgkmcnt(0) before the first DMA address computation of every iteration -- which,
+  // the counter being shared, also waits for the LDS reads just issued
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
