@@ -551,3 +551,29 @@ def test_adamw_ema_match_torch():
     t = torch.randn(n, generator=g).to(DEV); t0 = t.clone(); tb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
     o.ema_flat(t, p, tb, 0.992)
     assert torch.allclose(t, t0 * 0.992 + p * (1 - 0.992), atol=1e-6)
+
+
+def test_sumsq_is_deterministic_and_accumulates():
+    """The global gradient norm feeds the clip coefficient of every parameter: identical gradients must give identical bits
+    (data-parallel replicas would otherwise drift apart), on any stream, and `out` accumulates across calls."""
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    for n in (1000, 1024 * 1024 + 4, 37 * 1024 * 1024):   # one block, ragged tail, more chunks than the 1024-block grid
+        x = (torch.randn(n, generator=g) * 3).to(DEV)
+        outs = []
+        for rep in range(6):
+            ss = torch.zeros(1, device=DEV)
+            torch.cuda.synchronize()
+            if rep % 2:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    o.sumsq(x, ss)
+            else:
+                o.sumsq(x, ss)
+            torch.cuda.synchronize()
+            outs.append(ss.clone())
+        assert all(torch.equal(outs[0], t) for t in outs[1:]), [t.item() for t in outs]
+        ref = (x.double() ** 2).sum().item()
+        assert abs(outs[0].item() - ref) < 2e-6 * ref
+        ss = torch.full((1,), 5.0, device=DEV)
+        o.sumsq(x, ss)
+        assert abs(ss.item() - 5.0 - ref) < 2e-6 * ref + 1e-3

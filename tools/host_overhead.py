@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import lightly_train_amd
 from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
 from lightly_train_amd.vit import ViTConfig
-cfg = ViTConfig(embed_dim=768, depth=12, num_heads=12, patch_size=16, img_size=224)
+ARCH = {"vit_small": (384, 6), "vit_base": (768, 12)}[sys.argv[1] if len(sys.argv) > 1 else "vit_base"]
+cfg = ViTConfig(embed_dim=ARCH[0], depth=12, num_heads=ARCH[1], patch_size=16, img_size=224, init_values=1e-5)
 m = DINOv2(cfg, DINOv2Args(), global_batch_size=128, total_steps=125000, device="cuda")
 g = torch.Generator().manual_seed(0)
 B = 128
