@@ -334,28 +334,30 @@ struct LnbRow {
   float4 xv[NV], rv[NV];
   float4 dvf[DYF32 ? NV : 1];
   uint2 dvh[DYF32 ? 1 : NV];
-  float mu, rs;
+  float mu, rs, rsn;   // rsn: row scale of the fused next-branch output (loaded with the row, not at its use)
   bool ok;
 };
 
 template <bool DYF32, int NV>
 __device__ __forceinline__ void lnb_load(LnbRow<DYF32, NV>& R, long row, int rows, int D, int lane, const float* __restrict__ x,
                                          const float* __restrict__ mean, const float* __restrict__ rstd, const void* __restrict__ dyv,
-                                         const float* __restrict__ dres) {
+                                         const float* __restrict__ dres, const float* __restrict__ rowscale_next) {
+  // branch-free on purpose: rows / columns out of range load from a clamped (valid) address and are ignored by lnb_compute.
+  // With one basic block per guarded load the waitcnt pass cannot count, and the wait for THIS row's operands became
+  // vmcnt(0) -- i.e. it also waited for the next row's loads issued just before, which is the whole point of the pipeline.
   R.ok = row < rows;
-  R.mu = R.ok ? mean[row] : 0.f;
-  R.rs = R.ok ? rstd[row] : 0.f;
+  const long r = R.ok ? row : (long)rows - 1;
+  R.mu = mean[r];
+  R.rs = rstd[r];
+  R.rsn = rowscale_next ? rowscale_next[r] : 1.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    R.xv[i] = make_float4(0, 0, 0, 0); R.rv[i] = make_float4(0, 0, 0, 0);
-    if (DYF32) R.dvf[i] = make_float4(0, 0, 0, 0); else R.dvh[i] = make_uint2(0, 0);
-    if (R.ok && c < D) {
-      R.xv[i] = *reinterpret_cast<const float4*>(x + row * D + c);
-      if (dres) R.rv[i] = *reinterpret_cast<const float4*>(dres + row * D + c);  // residual gradient travels with the row
-      if (DYF32) R.dvf[i] = *reinterpret_cast<const float4*>((const float*)dyv + row * D + c);
-      else R.dvh[i] = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + row * D + c);
-    }
+    const int c0 = (i * 64 + lane) * 4;
+    const int c = c0 < D ? c0 : 0;
+    R.xv[i] = *reinterpret_cast<const float4*>(x + r * D + c);
+    R.rv[i] = dres ? *reinterpret_cast<const float4*>(dres + r * D + c) : make_float4(0, 0, 0, 0);
+    if (DYF32) R.dvf[i] = *reinterpret_cast<const float4*>((const float*)dyv + r * D + c);
+    else R.dvh[i] = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + r * D + c);
   }
 }
 
@@ -404,7 +406,7 @@ __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int 
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       *reinterpret_cast<float4*>(dx + row * D + c) = o;
       if (nx.dnext) {
-        const float m_r = nx.scale * (nx.rowscale ? nx.rowscale[row] : 1.f);
+        const float m_r = nx.scale * R.rsn;
         const float4 dn = make_float4(o.x * m_r * gn4[i].x, o.y * m_r * gn4[i].y, o.z * m_r * gn4[i].z, o.w * m_r * gn4[i].w);
         *reinterpret_cast<uint2*>(nx.dnext + row * D + c) = make_uint2(pack_bf2(dn.x, dn.y), pack_bf2(dn.z, dn.w));
         abn[i].x += dn.x; abn[i].y += dn.y; abn[i].z += dn.z; abn[i].w += dn.w;
@@ -437,13 +439,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   const long stride = (long)gridDim.x * 4;
   long row = (long)blockIdx.x * 4 + wv;
   LnbRow<DYF32, NV> A, B;
-  lnb_load<DYF32, NV>(A, row, rows, D, lane, x, mean, rstd, dyv, dres);
+  lnb_load<DYF32, NV>(A, row, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
   while (row < rows) {
-    lnb_load<DYF32, NV>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
+    lnb_load<DYF32, NV>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
     lnb_compute<DYF32, NV>(A, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
     if (row >= rows) break;
-    lnb_load<DYF32, NV>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres);
+    lnb_load<DYF32, NV>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
     lnb_compute<DYF32, NV>(B, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
   }
