@@ -356,6 +356,46 @@ def test_vit_small_full_depth_step_matches_oracle():
     assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2)
 
 
+def test_baseline_config_shapes_step_matches_oracle():
+    """BASELINE.json configs[1] at its real shapes except the batch: ViT-B/16 (D=768, 12 heads, 12 blocks, LayerScale 1e-5),
+    2 x 224^2 + 8 x 98^2 crops, DINO/iBOT head 768-2048-2048-256 with K = 65536 prototypes, default loss weights (KoLeo off: it
+    is ill-conditioned at initialisation), batch 2 so that the fp32 CPU oracle finishes in seconds.  Exercises exactly
+    the kernels and tile shapes of the benchmark: the 256x256 GEMM on N = 768 / 2304 / 3072 / 65536, the register-resident
+    65536-wide softmax / CE rows, 197- and 50-token attention."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(33)
+    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    args = DINOv2Args(koleo_loss_weight=0.0)
+    assert (args.output_dim, args.hidden_dim, args.dino_bottleneck_dim) == (65536, 2048, 256)
+    b = 2
+    m = DINOv2(vc, args, global_batch_size=b, total_steps=100, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    o = O.OracleDINOv2(bsd, shs, dict(patch_size=16, num_heads=12, depth=12), args=dict(koleo_loss_weight=0.0), global_batch_size=b, total_steps=100,
+                       teacher_head=ths)
+    views = [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(8)]
+    random.seed(5)
+    res = m.training_step_impl({"views": views}, 0)
+    loss, ologs = o.forward_loss(views, m._last_masks)
+    loss.backward()
+    logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(float(ologs[k]), rel=2e-3), k
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+    sq_o = sq_r = 0.0
+    for n in m.student.names:
+        ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+        ours = m.student.g[n].cpu()
+        sq_o += float((ours.double() ** 2).sum()); sq_r += float((ref.double() ** 2).sum())
+        if n.startswith(("head.", "backbone.norm.")):   # the well-conditioned tensors (LayerScale 1e-5 damps every in-branch gradient)
+            assert rel(ours, ref) < 6e-2, n
+    assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2)
+
+
 @pytest.mark.parametrize("n_local,b", [(0, 4), (3, 2), (8, 1)])
 def test_edge_crop_and_batch_configurations_match_oracle(n_local, b):
     """No local crops (terms = 2), odd crop counts, batch 1 (KoLeo needs a neighbour: weight 0): loss terms vs the oracle."""
