@@ -9,7 +9,7 @@ import os
 from typing import Any
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "liblt_amd.so")
+LIB_PATH = os.environ.get("LT_AMD_LIB") or os.path.join(HERE, "lib", "liblt_amd.so")   # LT_AMD_LIB: another build of the same ABI (A/B runs)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

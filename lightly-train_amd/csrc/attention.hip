@@ -75,12 +75,21 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int db, int tok16) {
   return u.v;
 }
 // 16-B global fragment: token (tok0 + lane&31), d = ks*16 + (lane>>5)*8 .. +8
+// FLAT: branch-free (clamped address + select).  A guarded load is its own basic block, and a run of them makes the waitcnt
+// pass drain vmcnt(0) between groups of loads instead of keeping them all in flight: the backward prologues (12 fragments +
+// staged K / V) gain 7 % on the two-heads-per-block shapes, while the forward kernels (4 fragments) are 5 % faster guarded.
+template <bool FLAT = false>
 __device__ __forceinline__ bf16x8 frag_global(const bf16_t* src, long tok_stride, int tok0, int ntok_valid, int ks) {
   const int l = threadIdx.x & 63;
   const int tok = tok0 + (l & 31);
   union { uint4 u; bf16x8 v; } x;
-  x.u = make_uint4(0, 0, 0, 0);
-  if (tok < ntok_valid) x.u = *reinterpret_cast<const uint4*>(src + (long)tok * tok_stride + ks * 16 + (l >> 5) * 8);
+  if (FLAT) {
+    x.u = *reinterpret_cast<const uint4*>(src + (long)min(tok, ntok_valid - 1) * tok_stride + ks * 16 + (l >> 5) * 8);
+    if (tok >= ntok_valid) x.u = make_uint4(0, 0, 0, 0);
+  } else {
+    x.u = make_uint4(0, 0, 0, 0);
+    if (tok < ntok_valid) x.u = *reinterpret_cast<const uint4*>(src + (long)tok * tok_stride + ks * 16 + (l >> 5) * 8);
+  }
   return x.v;
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int off) {
@@ -546,7 +555,8 @@ struct Stager {
       const int tok = TWOHEAD ? (r & 63) : tok0 + r;
       const int hoff = TWOHEAD ? (r >> 6) * DH : 0;
       reg[i] = make_uint4(0, 0, 0, 0);
-      if (tok < N) reg[i] = *reinterpret_cast<const uint4*>(base + (long)tok * stride + hoff + c * 8);
+      if (tok < N) reg[i] = *reinterpret_cast<const uint4*>(base + (long)tok * stride + hoff + c * 8);   // guarded on purpose: a
+      // select AFTER the load would make the in-loop prefetch wait for its own data right away
     }
   }
   static __device__ __forceinline__ void store_rows(char* lds, const uint4 (&reg)[PER]) {
@@ -618,9 +628,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_v2_kernel(const bf16_t* _
   float del_q = 0.f;   // delta[q] = sum_d dO[q,d] * O[q,d]
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = frag_global(qb, ts, q0, N, ks);
-    dof[ks] = frag_global(dob, tso, q0, N, ks);
-    const bf16x8 of = frag_global(ob, tso, q0, N, ks);
+    qf[ks] = frag_global<true>(qb, ts, q0, N, ks);
+    dof[ks] = frag_global<true>(dob, tso, q0, N, ks);
+    const bf16x8 of = frag_global<true>(ob, tso, q0, N, ks);
 #pragma unroll
     for (int j = 0; j < 8; ++j) del_q += (float)dof[ks][j] * (float)of[j];
   }
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
   load_stats(0);
   bf16x8 kf[4], vf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global(kb, ts, k0, N, ks); vf[ks] = frag_global(vb, ts, k0, N, ks); }
+  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global<true>(kb, ts, k0, N, ks); vf[ks] = frag_global<true>(vb, ts, k0, N, ks); }
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }

@@ -713,12 +713,21 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
   for (; i < n; i += stride) {
+    float4 o = *reinterpret_cast<float4*>(out + i);
     float4 a = *reinterpret_cast<const float4*>(slabs + i);
-    for (int s2 = 1; s2 < S; ++s2) {
+    int s2 = 1;
+    for (; s2 + 3 < S; s2 += 4) {   // four slabs in flight per thread (fixed summation order: deterministic)
+      const float4 b0 = *reinterpret_cast<const float4*>(slabs + (long)s2 * n + i);
+      const float4 b1 = *reinterpret_cast<const float4*>(slabs + (long)(s2 + 1) * n + i);
+      const float4 b2 = *reinterpret_cast<const float4*>(slabs + (long)(s2 + 2) * n + i);
+      const float4 b3 = *reinterpret_cast<const float4*>(slabs + (long)(s2 + 3) * n + i);
+      a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+      a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+    }
+    for (; s2 < S; ++s2) {
       const float4 b = *reinterpret_cast<const float4*>(slabs + (long)s2 * n + i);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    float4 o = *reinterpret_cast<float4*>(out + i);
     o.x += alpha * a.x; o.y += alpha * a.y; o.z += alpha * a.z; o.w += alpha * a.w;
     *reinterpret_cast<float4*>(out + i) = o;
   }
