@@ -91,6 +91,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
+    ap.add_argument("--prefetch-masks", action="store_true", help="sample the iBOT masks one step ahead on a background thread (same random stream)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every launch on one stream (clean per-kernel durations)")
     args = ap.parse_args()
 
@@ -134,6 +135,7 @@ def main() -> None:
     else:
         margs = DINOv2Args(output_dim=args.out_dim)
         method = DINOv2(cfg, margs, global_batch_size=B * world, total_steps=125_000, device=dev, seed=0)
+        method.prefetch_masks = args.prefetch_masks
         if args.single_stream:
             method.overlap_streams = False
         views = [torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev) for _ in range(2)] + [

@@ -23,7 +23,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import ops
-from .masking import MaskingGenerator, create_collated_masks
+from .masking import MaskingGenerator, MaskProducer, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
@@ -308,6 +308,10 @@ class DINOv2:
         # data parallel: all-reduce the head gradients and each transformer block's gradients as soon as they are final,
         # underneath the rest of backward (what DDP's bucket hooks do in the reference); LT_GRAD_OVERLAP=0 reduces after it
         self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
+        # iBOT masks of the coming steps sampled on a background thread (same `random` stream as the in-line call); off by
+        # default so that `random.seed()` between steps keeps its in-line meaning -- a training loop switches it on once
+        self.prefetch_masks = False
+        self._mask_producer: Optional[MaskProducer] = None
         self._head_span = self.student.span(("head.", "ihead."))
         self._block_spans = [self.student.span((f"backbone.blocks.{i}.",)) for i in range(vit_cfg.depth)]
         use_streams = self.device.type == "cuda"
@@ -383,7 +387,14 @@ class DINOv2:
         Ng = n_p + 1 + n_reg   # tokens per global crop: [cls | registers | patches]
         D, K = cfg.embed_dim, a.output_dim
 
-        if masks is None:
+        if masks is None and self.prefetch_masks:
+            key = (a.mask_ratio_min, a.mask_ratio_max, int(n_crops * a.mask_probability), n_crops, (gh, gw))
+            if self._mask_producer is None or self._mask_producer.key != key:   # first step, or the batch geometry changed
+                if self._mask_producer is not None:
+                    self._mask_producer.close()
+                self._mask_producer = MaskProducer(*key[:4], grid=(gh, gw))
+            masks = self._mask_producer.get()
+        elif masks is None:
             gen = MaskingGenerator(input_size=(gh, gw), max_num_patches=int(0.5 * gh * gw))
             masks = create_collated_masks(a.mask_ratio_min, a.mask_ratio_max, int(n_crops * a.mask_probability), n_crops, gen)
         cm = masks["collated_masks"]

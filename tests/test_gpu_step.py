@@ -424,6 +424,24 @@ def test_edge_crop_and_batch_configurations_match_oracle(n_local, b):
     assert torch.isfinite(m.student.data).all()
 
 
+def test_background_mask_sampling_gives_the_same_steps():
+    """`prefetch_masks`: masks sampled one step ahead on a thread -- same `random` stream, hence the same losses as in-line."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    losses = {}
+    for mode in (False, True):
+        m = build(fx, koleo_loss_weight=0.0)
+        m.prefetch_masks = mode
+        random.seed(77)
+        out = []
+        for s in range(3):
+            views = synth_views(500 + s, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+            out.append(float(m.train_step(views).loss))
+        losses[mode] = out
+        if m._mask_producer is not None:
+            m._mask_producer.close()
+    assert losses[True] == pytest.approx(losses[False], rel=1e-5)
+
+
 def test_view_prefetcher_stages_batches_in_order():
     """prefetch.ViewPrefetcher: pinned host views arrive on the device unchanged, in order, one batch ahead."""
     import lightly_train_amd  # noqa: F401

@@ -190,3 +190,25 @@ def test_distillation_host_logic_matches_oracle_and_reference_fixture():
             assert torch.equal(back[k], v * fx["state"][k + "_mask"].nan_to_num(nan=0.0))
         else:
             assert torch.allclose(back[k].float(), v.float(), rtol=1e-6), k
+
+
+def test_mask_producer_continues_the_global_random_stream():
+    """Background mask sampling hands out exactly the masks the in-line calls would have drawn from `random`."""
+    import random
+
+    import torch
+
+    from lightly_train_amd.masking import MaskingGenerator, MaskProducer, create_collated_masks
+
+    random.seed(123)
+    gen = MaskingGenerator(input_size=(14, 14), max_num_patches=98)
+    inline = [create_collated_masks(0.1, 0.5, 8, 16, gen) for _ in range(5)]
+    random.seed(123)
+    prod = MaskProducer(0.1, 0.5, 8, 16, grid=(14, 14))
+    try:
+        for ref in inline:
+            got = prod.get()
+            assert all(torch.equal(got[k], ref[k]) for k in ("collated_masks", "mask_indices_list", "masks_weight"))
+    finally:
+        prod.close()
+    assert not prod._thread.is_alive()
