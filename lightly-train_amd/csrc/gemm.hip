@@ -194,8 +194,54 @@ __device__ __forceinline__ void emit_rows(const GemmArgs& g, const float* wl, in
   }
 }
 
+// bf16-output epilogues on a full sub-tile with 16-byte-aligned rows: 8 columns per lane, i.e. 16-byte stores (and 16-byte loads
+// of the saved pre-activations) -- half as many store instructions in the queue as the 8-byte form for the same bytes.
+template <int EPI>
+__device__ __forceinline__ void emit_rows_wide(const GemmArgs& g, const float* wl, int row_base, int col_base, int l) {
+  const int cc = (l & 7) * 8, rs = l >> 3;
+  const int col = col_base + cc;
+  if (col >= g.N) return;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (EPI != EPI_BF16_GELUGRAD && g.bias) { b0 = *reinterpret_cast<const float4*>(g.bias + col); b1 = *reinterpret_cast<const float4*>(g.bias + col + 4); }
+  uint4 a4[8];
+  if (EPI == EPI_BF16_GELUGRAD) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) a4[it] = *reinterpret_cast<const uint4*>(g.aux + (size_t)(row_base + it * 8 + rs) * g.ldaux + col);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int rl = it * 8 + rs;
+    const int row = row_base + rl;
+    const float4 w0 = *reinterpret_cast<const float4*>(wl + rl * 64 + cc), w1 = *reinterpret_cast<const float4*>(wl + rl * 64 + cc + 4);
+    float v[8] = {w0.x * g.alpha + b0.x, w0.y * g.alpha + b0.y, w0.z * g.alpha + b0.z, w0.w * g.alpha + b0.w,
+                  w1.x * g.alpha + b1.x, w1.y * g.alpha + b1.y, w1.z * g.alpha + b1.z, w1.w * g.alpha + b1.w};
+    const size_t o = (size_t)row * g.ldc + col;
+    if (EPI == EPI_BF16_GELU) {
+      if (g.C2) *reinterpret_cast<uint4*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) =
+            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (EPI == EPI_BF16_GELUGRAD) {
+      const unsigned a[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= gelu_grad_f(bf2f((bf16_t)(a[e] & 0xffff)));
+        v[2 * e + 1] *= gelu_grad_f(bf2f((bf16_t)(a[e] >> 16)));
+      }
+    }
+    *reinterpret_cast<uint4*>((bf16_t*)g.C + o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  }
+}
+
 template <int EPI>
 __device__ __forceinline__ void emit_subtile(const GemmArgs& g, const float* wl, int row_base, int col_base, int l, bool atomic) {
+  if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELUGRAD) {
+    const bool wide = row_base + 64 <= g.M && col_base + 64 <= g.N && (g.ldc & 7) == 0 && (((uintptr_t)g.C) & 15) == 0 &&
+                      (EPI != EPI_BF16_GELU || !g.C2 || ((g.ldc2 & 7) == 0 && (((uintptr_t)g.C2) & 15) == 0)) &&
+                      (EPI != EPI_BF16_GELUGRAD || ((g.ldaux & 7) == 0 && (((uintptr_t)g.aux) & 15) == 0)) &&
+                      (EPI == EPI_BF16_GELUGRAD || !g.bias || (((uintptr_t)g.bias) & 15) == 0);
+    if (wide) { emit_rows_wide<EPI>(g, wl, row_base, col_base, l); return; }
+  }
   const int cc = (l & 15) * 4, rs = l >> 4;
   const int col = col_base + cc;
   if (col >= g.N) return;
