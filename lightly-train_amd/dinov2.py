@@ -321,6 +321,12 @@ class DINOv2:
         self.reduce_stream = torch.cuda.Stream(device=self.device) if use_streams else None    # orders the early all-reduces
 
     # ------------------------------------------------------------------ reference-compatible views
+    def close(self) -> None:
+        """Stop background helpers (the mask-sampling thread of `prefetch_masks`)."""
+        if self._mask_producer is not None:
+            self._mask_producer.close()
+            self._mask_producer = None
+
     def state_dict(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
         for role, fp in (("teacher", self.teacher), ("student", self.student)):

@@ -437,8 +437,7 @@ def test_background_mask_sampling_gives_the_same_steps():
             views = synth_views(500 + s, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
             out.append(float(m.train_step(views).loss))
         losses[mode] = out
-        if m._mask_producer is not None:
-            m._mask_producer.close()
+        m.close()
     assert losses[True] == pytest.approx(losses[False], rel=1e-5)
 
 
