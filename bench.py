@@ -225,10 +225,10 @@ def main() -> None:
         alg_bytes = sum(b_ for _, _, _, b_ in recs) / max(1, len(recs))
         achieved = fl / (t_ms * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process; the committed value comes from
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01h_gemm_traffic.md, gfx950 corrections
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01q_pmc_step_report.md, gfx950 corrections
         # applied by tools/pmc_step_traffic.py).  Only quoted for the configuration it was measured on.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01h_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01q_gemm_traffic.json")
         default_cfg = (args.method == "dinov2" and args.model == "vit_base" and B == 128 and args.global_size == 224 and args.local_size == 98 and args.n_local == 8
                        and args.out_dim == 65536)
         if default_cfg and os.path.exists(tpath):
@@ -238,7 +238,7 @@ def main() -> None:
                 traffic = round(tj["traffic_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "gemm256q_kernel<TA,TB,EPI,SLAB> (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per GEMM launch, L2 memory-side (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r01h_gemm_traffic.md",
+                    "traffic_unit": "bytes per GEMM launch, L2 memory-side (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r01q_pmc_step_report.md",
                     "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
                     "gemm_flops_per_step": fl, "step_algorithmic_gflop_per_image": round(gf_img, 1),
                     "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
