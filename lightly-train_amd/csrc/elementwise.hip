@@ -28,24 +28,28 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict_
 
 // ------------------------------------------------------------------------------------ bicubic pad-resize (patch_embed.py:90-99)
 // separable 4-tap resize with host-precomputed taps: out[p,y,x] = sum_a sum_b wy[y,a]*wx[x,b]*in[p, iy[y,a], ix[x,b]]
+// grid (ceil(Ho*Wo / 256), planes): 32-bit index math only, the taps of an output pixel are read once and shared by its 16 gathers
 __global__ __launch_bounds__(256) void resize4tap_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ iy,
                                                          const float* __restrict__ wy, const int32_t* __restrict__ ix,
                                                          const float* __restrict__ wx, int planes, int H, int W, int Ho, int Wo) {
-  const long n = (long)planes * Ho * Wo;
-  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long)gridDim.x * 256) {
-    const int x = o % Wo, y = (o / Wo) % Ho;
-    const long p = o / ((long)Wo * Ho);
-    const float* src = in + p * H * W;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Ho * Wo) return;
+  const int y = o / Wo, x = o - y * Wo;
+  const int4 jx = *reinterpret_cast<const int4*>(ix + x * 4), jy = *reinterpret_cast<const int4*>(iy + y * 4);
+  const float4 cx = *reinterpret_cast<const float4*>(wx + x * 4), cy = *reinterpret_cast<const float4*>(wy + y * 4);
+  const int jya[4] = {jy.x, jy.y, jy.z, jy.w};
+  const float cya[4] = {cy.x, cy.y, cy.z, cy.w};
+  for (int p = blockIdx.y; p < planes; p += gridDim.y) {
+    const float* src = in + (size_t)p * H * W;
     float acc = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const float* row = src + (long)iy[y * 4 + a] * W;
+      const float* row = src + jya[a] * W;
       float r = 0.f;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) r = fmaf(wx[x * 4 + b], row[ix[x * 4 + b]], r);
-      acc = fmaf(wy[y * 4 + a], r, acc);
+      r = fmaf(cx.x, row[jx.x], r); r = fmaf(cx.y, row[jx.y], r); r = fmaf(cx.z, row[jx.z], r); r = fmaf(cx.w, row[jx.w], r);
+      acc = fmaf(cya[a], r, acc);
     }
-    out[o] = acc;
+    out[(size_t)p * Ho * Wo + o] = acc;
   }
 }
 
@@ -818,9 +822,9 @@ extern "C" int lt_im2col_bf16(const float* img, void* cols, int B, int C, int H,
 extern "C" int lt_resize_4tap(const float* in, float* out, const int32_t* iy, const float* wy, const int32_t* ix, const float* wx,
                               int planes, int H, int W, int Ho, int Wo, void* stream) {
   LT_CHECK_ARG(in && out && iy && wy && ix && wx && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "lt_resize_4tap: bad arguments");
-  const long n = (long)planes * Ho * Wo;
-  hipLaunchKernelGGL(resize4tap_kernel, dim3((unsigned)min((long)8192, (n + 255) / 256)), dim3(256), 0, ST, in, out, iy, wy, ix, wx, planes, H, W,
-                     Ho, Wo);
+  LT_CHECK_ARG((((uintptr_t)iy | (uintptr_t)wy | (uintptr_t)ix | (uintptr_t)wx) & 15) == 0, "lt_resize_4tap: tap tables must be 16-byte aligned");
+  hipLaunchKernelGGL(resize4tap_kernel, dim3((unsigned)lt_cdiv(Ho * Wo, 256), (unsigned)min(planes, 2048)), dim3(256), 0, ST, in, out, iy, wy, ix, wx,
+                     planes, H, W, Ho, Wo);
   LT_CHECK_LAUNCH("lt_resize_4tap");
 }
 extern "C" int lt_assemble_tokens(const float* patch, const float* cls, const float* pos, const float* mask_token,
