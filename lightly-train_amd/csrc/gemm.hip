@@ -808,161 +808,6 @@ int launch(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
 
 // 128 x 128 x 64 tile, 4 waves, LDS-DMA staged, 64 KiB LDS -> TWO workgroups per CU: one workgroup's epilogue (GELU / residual
 // traffic) overlaps the other's MFMA main loop.  Used where the epilogue is heavy relative to a short K loop.
-
-// ---- two blocks per CU ("2x" kernel, force_kernel 5) ----------------------------------------------------------------------------
-// 256 x 128 tile, 4 waves (2 x 2, wave tile 128 x 64 as in the 256x256 kernels), BK = 32, three 24-KiB LDS stages (72 KiB) and
-// <= 256 VGPRs, so that TWO blocks are resident per CU and are NOT synchronised with each other: while one block runs its
-// HBM-bound epilogue the other one has the matrix pipe.  One tile per block, XCD-contiguous tile order.  LDS reads are inline
-// asm (see read_frag2) with register double-buffered fragments; A and B operands without transposed A (forward / dgrad).
-template <bool TR, int ROWS>
-__device__ __forceinline__ void stage_dma32w4(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  constexpr int PER_WAVE = ROWS / 16 / 4, NB = ROWS / 16;
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int blk = w * PER_WAVE + j;
-    const bf16_t* src;
-    if (!TR) {   // row image, 64 B per row: 16 rows x 4 chunks per wave-instruction, chunk slot XOR (row >> 2) & 3
-      const int row = blk * 16 + (l >> 2), slot = l & 3;
-      const int c = slot ^ ((row >> 2) & 3);
-      const int gr = min(row0 + row, rows - 1);
-      src = P + (size_t)gr * ld + k0 + c * 8;
-    } else {     // T image as in stage_dma, 32 k-rows
-      const int p = blk * 8 + (l >> 3), slot = l & 7;
-      const int q = p / NB, b = p % NB;
-      const int kr = ((slot >> 1) - b) & 3;
-      int col = row0 + b * 16 + (slot & 1) * 8;
-      if (col >= rows) col = 0;
-      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
-    }
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
-  }
-}
-
-template <bool TR, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag32(const char* lds, int rb, int ks) {
-  if (TR) return read_frag2<true, ROWS, true>(lds, rb, ks);
-  const int l = threadIdx.x & 63;
-  const int row = rb * 32 + (l & 31);
-  const int c = ks * 2 + (l >> 5);
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lptr_t*)(lds + row * 64 + ((c ^ ((row >> 2) & 3)) << 4))));
-  return v;
-}
-
-constexpr int P2_LDS = 73728;
-
-template <bool TB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm2x_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BKP = 32, A_B = 256 * BKP * 2, B_B = 128 * BKP * 2, STAGE = A_B + B_B, NS = 3;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int id;
-  {
-    const int L = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = L & 7, j = L >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-  const int m0 = tm * 256, n0 = tn * 128;
-  const int nk = g.K / BKP;
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-  for (int s2 = 0; s2 < NS - 1; ++s2)
-    if (s2 < nk) {
-      stage_dma32w4<false, 256>(smem + s2 * STAGE, g.A, g.lda, g.M, m0, s2 * BKP);
-      stage_dma32w4<TB, 128>(smem + s2 * STAGE + A_B, g.B, g.ldb, g.N, n0, s2 * BKP);
-    }
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // kernel arguments: no lgkmcnt wait inside the loop (see the four-phase kernel)
-  bf16x8 fa[2][4], fb[2][2];
-  constexpr int NRD = 4 + (TB ? 4 : 2);
-#define LT2_READ(S, LA, LB, KS)                                                                                   \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[S][i] = read_frag32<false, 256>(LA, wm * 4 + i, KS);         \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[S][j] = read_frag32<TB, 128>(LB, wn * 2 + j, KS);            \
-  } while (0)
-#define LT2_WAIT(S, CNT) \
-  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fb[S][0]), "+v"(fb[S][1]))
-#define LT2_MFMA(S)                                                                                               \
-  do {                                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);              \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-  } while (0)
-  for (int kt = 0; kt < nk; ++kt) {
-    // 6 DMA instructions per wave per K-tile; tile kt+1 may stay in flight
-    if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
-    else __builtin_amdgcn_s_waitcnt(0xF70);              // vmcnt(0)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // tile kt visible; every wave is done reading tile kt-1, whose stage is re-filled below
-    asm volatile("" ::: "memory");
-    const char* la = smem + (kt % NS) * STAGE;
-    const char* lb = la + A_B;
-    LT2_READ(0, la, lb, 0);
-    LT2_READ(1, la, lb, 1);
-    if (kt + NS - 1 < nk) {
-      char* na = smem + ((kt + NS - 1) % NS) * STAGE;
-      stage_dma32w4<false, 256>(na, g.A, g.lda, g.M, m0, (kt + NS - 1) * BKP);
-      stage_dma32w4<TB, 128>(na + A_B, g.B, g.ldb, g.N, n0, (kt + NS - 1) * BKP);
-    }
-    if (NRD == 6) LT2_WAIT(0, 6); else LT2_WAIT(0, 8);
-    LT2_MFMA(0);
-    LT2_WAIT(1, 0);
-    LT2_MFMA(1);
-  }
-#undef LT2_READ
-#undef LT2_WAIT
-#undef LT2_MFMA
-  __syncthreads();  // every wave is done with the operand stages: they become the epilogue scratch
-  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    emit_subtile<EPI>(g, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-template <bool TB, int EPI>
-int launch2x_one(const GemmArgs& g, hipStream_t st) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2x_kernel<TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
-    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 72 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm2x_kernel<TB, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), P2_LDS, st, g);
-  return LT_OK;
-}
-template <bool TB>
-int launch2x(const GemmArgs& g, int epi, hipStream_t st) {
-  switch (epi) {
-    case EPI_BF16: return launch2x_one<TB, EPI_BF16>(g, st);
-    case EPI_BF16_GELU: return launch2x_one<TB, EPI_BF16_GELU>(g, st);
-    case EPI_RESID: return launch2x_one<TB, EPI_RESID>(g, st);
-    case EPI_F32: return launch2x_one<TB, EPI_F32>(g, st);
-    case EPI_BF16_GELUGRAD: return launch2x_one<TB, EPI_BF16_GELUGRAD>(g, st);
-    default: lt_set_error("lt_gemm_bf16: epilogue %d not available in the two-blocks-per-CU kernel", epi); return LT_ERR_INVALID;
-  }
-}
 }  // namespace g256
 
 // ---- plain reference-grade GEMM (one thread per output; cross-check for the MFMA kernel) -------
@@ -1046,14 +891,6 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   // ---- 256-row LDS-DMA kernel for the large GEMMs (forward / dgrad over tokens; wgrad with slab split-K)
   const bool same_t = d->trans_a == d->trans_b || !d->trans_a;  // (N,N), (N,T), (T,T)
   const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
-  static const int use_2x = [] { const char* e = getenv("LT_GEMM_2X"); return e ? atoi(e) : 0; }();   // LT_GEMM_2X=1: two-blocks-per-CU kernel for the short-K, narrow-N forward / dgrad GEMMs (2: for all of them)
-  if ((d->force_kernel == 5 || (use_2x && d->force_kernel == 0 && d->M >= 4096 && (use_2x > 1 || (d->N <= 1024 && d->K <= 1024)))) && eligible && batch == 1 && !d->trans_a && d->split_k <= 1 &&
-      d->epilogue != LT_EPI_F32_ACCUM && d->K % 32 == 0 && d->N >= 128) {
-    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 128);
-    rc = d->trans_b ? g256::launch2x<true>(g, d->epilogue, st) : g256::launch2x<false>(g, d->epilogue, st);
-    if (rc != LT_OK) return rc;
-    LT_CHECK_LAUNCH("lt_gemm_bf16");
-  }
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= 128 &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
   if (d->force_kernel == 2 || d->force_kernel == 8) {
