@@ -85,7 +85,8 @@ int lt_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * Token path (vision_transformer.py:307-329 prepare_tokens_with_masks; patch_embed.py:86-114)
  * ------------------------------------------------------------------------------------------ */
 /* separable 4-tap image resize (the bicubic pad-resize to the next multiple of the patch size, patch_embed.py:90-99):
- * out[p,y,x] = sum_{a,b<4} wy[y,a]*wx[x,b]*in[p, iy[y,a], ix[x,b]]; taps precomputed on the host from F.interpolate */
+ * out[p,y,x] = sum_{a,b<4} wy[y,a]*wx[x,b]*in[p, iy[y,a], ix[x,b]]; taps precomputed on the host from F.interpolate.
+ * The four tap tables ([Ho,4] / [Wo,4]) must be 16-byte aligned (LT_ERR_INVALID otherwise). */
 int lt_resize_4tap(const float* in, float* out, const int32_t* iy, const float* wy, const int32_t* ix, const float* wx,
                    int planes, int H, int W, int Ho, int Wo, void* stream);
 /* img f32 [B,C,H,W] -> cols bf16 [B*gh*gw, kpad], k = (c*p + py)*p + px, zero padded to kpad */
