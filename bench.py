@@ -91,7 +91,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
-    ap.add_argument("--prefetch-masks", action="store_true", help="sample the iBOT masks one step ahead on a background thread (same random stream)")
+    ap.add_argument("--prefetch-masks", action="store_true", help="sample the iBOT masks one step ahead in a background process (same random stream)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every launch on one stream (clean per-kernel durations)")
     args = ap.parse_args()
 

@@ -308,7 +308,7 @@ class DINOv2:
         # data parallel: all-reduce the head gradients and each transformer block's gradients as soon as they are final,
         # underneath the rest of backward (what DDP's bucket hooks do in the reference); LT_GRAD_OVERLAP=0 reduces after it
         self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
-        # iBOT masks of the coming steps sampled on a background thread (same `random` stream as the in-line call); off by
+        # iBOT masks of the coming steps sampled in a background process (same `random` stream as the in-line call); off by
         # default so that `random.seed()` between steps keeps its in-line meaning -- a training loop switches it on once
         self.prefetch_masks = False
         self._mask_producer: Optional[MaskProducer] = None
@@ -322,7 +322,7 @@ class DINOv2:
 
     # ------------------------------------------------------------------ reference-compatible views
     def close(self) -> None:
-        """Stop background helpers (the mask-sampling thread of `prefetch_masks`)."""
+        """Stop background helpers (the mask-sampling process of `prefetch_masks`)."""
         if self._mask_producer is not None:
             self._mask_producer.close()
             self._mask_producer = None

@@ -193,7 +193,8 @@ def test_distillation_host_logic_matches_oracle_and_reference_fixture():
 
 
 def test_mask_producer_continues_the_global_random_stream():
-    """Background mask sampling hands out exactly the masks the in-line calls would have drawn from `random`."""
+    """Background mask sampling in a spawned process hands out exactly the masks the in-line calls would have
+    drawn from `random`."""
     import random
 
     import torch
@@ -211,4 +212,4 @@ def test_mask_producer_continues_the_global_random_stream():
             assert all(torch.equal(got[k], ref[k]) for k in ("collated_masks", "mask_indices_list", "masks_weight"))
     finally:
         prod.close()
-    assert not prod._thread.is_alive()
+    assert not prod._proc.is_alive()
