@@ -213,3 +213,26 @@ def test_mask_producer_continues_the_global_random_stream():
     finally:
         prod.close()
     assert not prod._proc.is_alive()
+
+
+def test_flat_params_span_is_contiguous_per_prefix():
+    """`FlatParams.span` (what the per-block gradient all-reduce slices by): exact [lo, hi) of a run of tensors, chunk padding
+    included, and a loud error for prefixes that do not form one run."""
+    import pytest
+    import torch
+
+    from lightly_train_amd.params import CHUNK, FlatParams
+
+    named = [("backbone.cls", torch.zeros(3)), ("backbone.blocks.0.w", torch.zeros(CHUNK + 5)), ("backbone.blocks.0.b", torch.zeros(7)),
+             ("backbone.blocks.1.w", torch.zeros(2 * CHUNK)), ("backbone.norm", torch.zeros(9)), ("head.a", torch.zeros(CHUNK)), ("ihead.a", torch.zeros(1))]
+    fp = FlatParams(named, "cpu", with_grad=True)
+    assert fp.span(("backbone.blocks.0.",)) == (CHUNK, 4 * CHUNK)            # 3 -> 1 chunk, CHUNK+5 -> 2 chunks, 7 -> 1 chunk
+    assert fp.span(("backbone.blocks.1.",)) == (4 * CHUNK, 6 * CHUNK)
+    assert fp.span(("head.", "ihead.")) == (7 * CHUNK, fp.numel) and fp.numel == 9 * CHUNK
+    spans = [fp.span(("backbone.cls",)), fp.span(("backbone.blocks.0.",)), fp.span(("backbone.blocks.1.",)), fp.span(("backbone.norm",)),
+             fp.span(("head.", "ihead."))]
+    assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))   # a partition of the buffer
+    with pytest.raises(ValueError):
+        fp.span(("backbone.cls", "backbone.norm"))    # two separate runs
+    with pytest.raises(ValueError):
+        fp.span(("nothing.",))
