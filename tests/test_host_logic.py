@@ -236,3 +236,20 @@ def test_flat_params_span_is_contiguous_per_prefix():
         fp.span(("backbone.cls", "backbone.norm"))    # two separate runs
     with pytest.raises(ValueError):
         fp.span(("nothing.",))
+
+
+def test_bench_flop_accounting_matches_the_survey_table():
+    """`bench.step_flops_per_image` is the numerator of `roofline.step_frac_of_mfma_peak`: it has to reproduce SURVEY.md 8(d)'s
+    algorithmic GFLOP-per-image table (teacher fwd + heads + 3 x (student fwd + heads), 59 masked tokens per image at patch 16)."""
+    import importlib.util
+
+    import pytest
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = {("vit_small", 37): 124.3, ("vit_small", 50): 138.2, ("vit_base", 37): 446.4, ("vit_base", 50): 500.8}
+    for (model, n_l), gf in table.items():
+        a = bench.MODELS[model]
+        got = bench.step_flops_per_image(a["embed_dim"], a["depth"], 4 * a["embed_dim"], 197, n_l, 8, 65536, 2048, 256, 59) / 1e9
+        assert got == pytest.approx(gf, abs=0.15), (model, n_l, got)
