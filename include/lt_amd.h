@@ -11,7 +11,9 @@
  *     (a hipStream_t passed as void*; NULL = default stream);
  *   - bf16 tensors are raw uint16 bfloat16 bits; "f32" = IEEE float; row-major, last dim contiguous;
  *   - return 0 (LT_OK) or a negative code; lt_last_error() returns a thread-local message;
- *   - re-entrant per stream, no global state.
+ *   - re-entrant per stream; the library allocates nothing.  The only process-global state is the scratch of the deterministic
+ *     grad-norm reduction (lt_sumsq_f32: 16 slots of per-block partials in device memory, handed out round-robin, i.e. at most
+ *     16 lt_sumsq_f32 launches may be in flight at once) and the one-time hipFuncSetAttribute of the 128-KiB-LDS GEMM kernels.
  */
 #ifndef LT_AMD_H
 #define LT_AMD_H
@@ -212,6 +214,7 @@ int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* st
 /* Q[r,k] *= 1/(colsum[k]*K); then row-normalise: Q[r,:] /= (rowsum(r) * n_total); final: Q *= final_mul */
 int lt_sk_iter(float* Q, const float* colsum, int rows, int K, float n_total, float final_mul, void* stream);
 /* KoLeo (lightly.loss.KoLeoLoss, call site dinov2.py:377-380): *loss += weight*L(x), dx += weight*dL/dx.
+ * weight == 0: value only -- *loss += L(x) and dx is not touched (the reference logs the term at weight 0 too, dinov2.py:377-396).
  * ws: f32 workspace of 2*n*D + 2*n floats, nn: int32 workspace [n] */
 int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, int ld_dx, int n, int D, float eps, float weight,
                      float* ws, int32_t* nn, void* stream);
@@ -225,14 +228,17 @@ int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, int ld_dx, 
  * At most 16 calls may be in flight on different streams at once. */
 int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream);
 /* AdamW (torch.optim.AdamW semantics, decoupled wd). clip_coef = min(1, max_norm/(||g||+1e-6)) is computed on
- * device from *sumsq.  lr = seg_lr[seg]*lr_factor (0 if seg_frozen[seg] && freeze); wd = seg_wd_on[seg] ? wd : 0.
+ * device from *sumsq.  lr = seg_lr[seg]*lr_factor (0 if seg_frozen[seg] & freeze: both are bit masks, bit 0 = last-layer freeze
+ * (dinov2.py:627-635), bit 1 = backbone freeze (dinov2.py:619-625)); wd = seg_wd_on[seg] ? wd : 0.  beta1 / beta2 are doubles so that
+ * 1 - beta and the bias corrections 1 - beta^step are formed in double like torch.optim.AdamW does on Python floats.
  * Also writes the bf16 shadow copy of the updated parameters. */
 int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int32_t* seg_of_chunk,
                   const float* seg_lr, const uint8_t* seg_wd_on, const uint8_t* seg_frozen, int freeze,
-                  float lr_factor, float wd, float beta1, float beta2, float eps, int step, const float* sumsq,
+                  float lr_factor, float wd, double beta1, double beta2, float eps, int step, const float* sumsq,
                   float max_norm, void* stream);
-/* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow */
-int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, float m, void* stream);
+/* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow.  m is a double: 1 - m (~1e-6 at the end of the
+ * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
+int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);
 
 #ifdef __cplusplus
 }

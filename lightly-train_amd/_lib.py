@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID, EPI_F32, EPI_BF16_GELUGRAD, EPI_F32_ACCUM = range(6)
+ABI_VERSION = 2   # lt_abi_version() of include/lt_amd.h this binding was written against
 
 # name -> argtypes (every function returns int status except lt_last_error)
 SIGNATURES: dict[str, list[Any]] = {
@@ -71,8 +72,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_sk_iter": [vp, vp, i32, i32, f32, f32, vp],
     "lt_koleo_fwd_bwd": [vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],
     "lt_sumsq_f32": [vp, vp, i64, vp],
-    "lt_adamw_flat": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, vp, f32, vp],
-    "lt_ema_flat": [vp, vp, vp, i64, f32, vp],
+    "lt_adamw_flat": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, f32, f32, C.c_double, C.c_double, f32, i32, vp, f32, vp],
+    "lt_ema_flat": [vp, vp, vp, i64, C.c_double, vp],
 }
 
 _lib: C.CDLL | None = None
@@ -101,6 +102,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, also loud
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    if lib.lt_abi_version() != ABI_VERSION:   # a stale build of another signature set would corrupt arguments silently
+        raise LtAmdError(f"{LIB_PATH} has ABI version {lib.lt_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -1,0 +1,187 @@
+"""Checkpoint / export formats of the reference for the flat-storage method objects.
+
+What the reference writes and reads:
+  * `checkpoint["state_dict"]` = `method.state_dict()` of the Lightning module (LT/_checkpoint.py:101-123): keys
+    `{teacher,student}_embedding_model.wrapped_model._model.<vit key>`, `{teacher,student}_head.{dino_head,ibot_head}.<head key>`,
+    `dino_loss.center`, `ibot_loss.center` (LT/_methods/dinov2/dinov2.py:196-257); models built with `block_chunks > 0`
+    (vitl14 / vitg14 YAMLs) name their blocks `blocks.<chunk>.<i>.` instead of `blocks.<i>.`
+    (dinov2_vit_src/models/vision_transformer.py:160-172);
+  * `checkpoint["optimizer_states"][0]` = `torch.optim.AdamW.state_dict()` over the fused parameter groups of
+    `get_optimizer_with_decay` / `get_fused_param_groups` (LT/_methods/dinov2/utils.py:191-273): parameter indices run over the
+    groups in order, a group holds its members in `named_parameters()` order (student backbone first, then the head);
+  * the exported model = `torch.save(get_model().state_dict())` of the (EMA) teacher backbone
+    (LT/_models/dinov2_vit/dinov2_vit_package.py:146-162).
+
+Everything here is name / layout bookkeeping on torch tensors (plumbing): it runs on any device and is unit-tested on CPU."""
+from __future__ import annotations
+
+import re
+from typing import Any, Dict, List, Mapping, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .params import FlatParams
+
+_CHUNKED = re.compile(r"^blocks\.(\d+)\.(\d+)\.")
+_PLAIN = re.compile(r"^blocks\.(\d+)\.")
+
+
+def vit_key_to_flat(key: str) -> str:
+    """`blocks.<chunk>.<i>.x` (block_chunks > 0: the inner index is the global block index, chunks are padded with Identity)
+    -> `blocks.<i>.x`; every other key unchanged."""
+    m = _CHUNKED.match(key)
+    return f"blocks.{m.group(2)}." + key[m.end():] if m else key
+
+
+def vit_key_from_flat(key: str, depth: int, block_chunks: int) -> str:
+    """Inverse of `vit_key_to_flat` for a model of `depth` blocks split into `block_chunks` chunks (0 = unchunked)."""
+    if not block_chunks:
+        return key
+    m = _PLAIN.match(key)
+    if not m:
+        return key
+    i = int(m.group(1))
+    chunk = i // (depth // block_chunks)
+    return f"blocks.{chunk}.{i}." + key[m.end():]
+
+
+def method_key_to_flat(key: str, separate_ibot: bool) -> Optional[Tuple[str, str]]:
+    """reference method.state_dict() key -> (role, flat name) with role in {"student", "teacher"}; None for the keys that are
+    aliases of shared tensors (ibot_head.* when the iBOT head IS the DINO head) or not parameters of the flat storage."""
+    for role in ("student", "teacher"):
+        pre = f"{role}_embedding_model.wrapped_model._model."
+        if key.startswith(pre):
+            return role, "backbone." + vit_key_to_flat(key[len(pre):])
+        pre = f"{role}_head.dino_head."
+        if key.startswith(pre):
+            return role, "head." + key[len(pre):]
+        pre = f"{role}_head.ibot_head."
+        if key.startswith(pre):
+            return (role, "ihead." + key[len(pre):]) if separate_ibot else None
+    return None
+
+
+def method_state_dict(student: FlatParams, teacher: FlatParams, centers: Mapping[str, Tensor], separate_ibot: bool,
+                      depth: int, block_chunks: int = 0) -> Dict[str, Tensor]:
+    """The reference's `method.state_dict()` from the flat storages (key order: teacher backbone, student backbone, teacher heads,
+    student heads, loss centers -- the registration order of dinov2.py:196-257)."""
+    out: Dict[str, Tensor] = {}
+    for role, fp in (("teacher", teacher), ("student", student)):
+        for n in fp.names:
+            if n.startswith("backbone."):
+                out[f"{role}_embedding_model.wrapped_model._model.{vit_key_from_flat(n[9:], depth, block_chunks)}"] = fp.p[n].detach().clone()
+    for role, fp in (("teacher", teacher), ("student", student)):
+        for n in fp.names:
+            if n.startswith("head."):
+                out[f"{role}_head.dino_head.{n[5:]}"] = fp.p[n].detach().clone()
+        # a shared head is one module registered under two names: both prefixes appear in the reference's state_dict
+        src = "ihead." if separate_ibot else "head."
+        for n in fp.names:
+            if n.startswith(src):
+                out[f"{role}_head.ibot_head.{n[len(src):]}"] = fp.p[n].detach().clone()
+    for k, v in centers.items():
+        out[k] = v.detach().clone()
+    return out
+
+
+def load_method_state_dict(sd: Mapping[str, Tensor], student: FlatParams, teacher: FlatParams, separate_ibot: bool,
+                           strict: bool = True) -> Dict[str, Tensor]:
+    """Copy a reference `method.state_dict()` into the flat storages (fp32 master copies AND their bf16 shadows).  Returns the
+    non-parameter entries (`dino_loss.center`, `ibot_loss.center`) for the caller.  strict: every flat tensor must be present
+    with its shape, and every key must be understood."""
+    seen = {"student": set(), "teacher": set()}
+    extra: Dict[str, Tensor] = {}
+    fps = {"student": student, "teacher": teacher}
+    for k, v in sd.items():
+        hit = method_key_to_flat(k, separate_ibot)
+        if hit is None:
+            if k in ("dino_loss.center", "ibot_loss.center"):
+                extra[k] = v
+            elif strict and not (k.endswith("_input_mean") or k.endswith("_input_std") or ".ibot_head." in k):
+                raise KeyError(f"unexpected key in state_dict: {k}")
+            continue
+        role, name = hit
+        fp = fps[role]
+        if name not in fp.p:
+            if strict:
+                raise KeyError(f"unexpected key in state_dict: {k} (-> {name})")
+            continue
+        if tuple(v.shape) != tuple(fp.shapes[name]):
+            raise ValueError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(fp.shapes[name])}")
+        fp.p[name].copy_(v.to(fp.device, torch.float32))
+        seen[role].add(name)
+    if strict:
+        for role, fp in fps.items():
+            missing = [n for n in fp.names if n not in seen[role]]
+            if missing:
+                raise KeyError(f"missing keys for the {role}: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+    for fp in fps.values():
+        fp.bf16.copy_(fp.data)
+    return extra
+
+
+def fused_groups(param_groups: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+    """get_fused_param_groups (utils.py:253-273) over per-parameter entries {"name", "flat", "lr", "weight_decay", "head",
+    "last_layer"}: groups in order of first appearance, named after their first member, members in appearance order."""
+    fused: Dict[Tuple[Any, ...], Dict[str, Any]] = {}
+    for g in param_groups:
+        key = (g["lr"], g["weight_decay"], g["head"], g["last_layer"])
+        if key not in fused:
+            fused[key] = dict(g, members=[g["flat"]])
+        else:
+            fused[key]["members"].append(g["flat"])
+    return list(fused.values())
+
+
+def _view(flat: Tensor, fp: FlatParams, name: str) -> Tensor:
+    o = fp.offsets[name]
+    return flat[o:o + fp.p[name].numel()].view(fp.shapes[name])
+
+
+def optimizer_state_dict(student: FlatParams, exp_avg: Tensor, exp_avg_sq: Tensor, opt_step: int,
+                         param_groups: List[Dict[str, Any]], hyper: Dict[str, Any]) -> Dict[str, Any]:
+    """`torch.optim.AdamW.state_dict()` of the reference's optimizer: {"state": {idx: {step, exp_avg, exp_avg_sq}},
+    "param_groups": [{..., "params": [idx, ...]}]}.  `param_groups`: one entry per flat tensor (see `fused_groups`), `hyper`:
+    the group fields shared by all groups (betas, eps, ...); per-group "lr" / "weight_decay" are the values currently in effect."""
+    state: Dict[int, Dict[str, Tensor]] = {}
+    groups: List[Dict[str, Any]] = []
+    idx = 0
+    for g in fused_groups(param_groups):
+        ids = []
+        for n in g["members"]:
+            if opt_step > 0:   # torch creates the per-parameter state lazily at the first step
+                state[idx] = {"step": torch.tensor(float(opt_step)), "exp_avg": _view(exp_avg, student, n).detach().clone(),
+                              "exp_avg_sq": _view(exp_avg_sq, student, n).detach().clone()}
+            ids.append(idx)
+            idx += 1
+        grp = dict(hyper)
+        grp.update(name=g["name"], lr=g["lr_now"], initial_lr=g["lr"], weight_decay=g["wd_now"], params=ids)
+        groups.append(grp)
+    return {"state": state, "param_groups": groups}
+
+
+def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_avg: Tensor, exp_avg_sq: Tensor,
+                              param_groups: List[Dict[str, Any]]) -> int:
+    """Inverse of `optimizer_state_dict`: fills the flat moment buffers and returns the optimizer step count.  The group
+    structure of the checkpoint must be the fused structure of this model (same sizes, same order)."""
+    fg = fused_groups(param_groups)
+    if len(osd["param_groups"]) != len(fg):
+        raise ValueError(f"optimizer state has {len(osd['param_groups'])} parameter groups, this model has {len(fg)}")
+    steps = set()
+    for g, og in zip(fg, osd["param_groups"]):
+        if len(og["params"]) != len(g["members"]):
+            raise ValueError(f"parameter group {og.get('name', '?')}: {len(og['params'])} parameters in the checkpoint vs {len(g['members'])}")
+        for n, idx in zip(g["members"], og["params"]):
+            st = osd["state"].get(idx)
+            if st is None:
+                continue
+            for key, buf in (("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+                v = _view(buf, student, n)
+                if tuple(st[key].shape) != tuple(v.shape):
+                    raise ValueError(f"optimizer state of {n}: shape {tuple(st[key].shape)} vs {tuple(v.shape)}")
+                v.copy_(st[key].to(v.device, torch.float32))
+            steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"parameters disagree on the optimizer step count: {sorted(steps)}")
+    return steps.pop() if steps else 0

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void koleo_nn_kernel(const float* __restrict__
     nn[i] = j;
     // L = -(1/n) sum log(dist + eps);  dL/du = -(1/n) * 1/(dist+eps) * u/dist
     coef[i] = -weight / ((float)n * (dist + eps) * fmaxf(dist, 1e-30f));
-    atomicAdd(loss, -weight * __logf(dist + eps) / (float)n);
+    atomicAdd(loss, -(weight == 0.f ? 1.f : weight) * __logf(dist + eps) / (float)n);   // weight 0: report the unweighted term
   }
 }
 // dxn[i] += c_i*u_i ; dxn[nn(i)] -= c_i*u_i  (atomics: several i may share a neighbour)
@@ -394,6 +394,7 @@ extern "C" int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, 
   if (e != hipSuccess) { lt_set_error("lt_koleo_fwd_bwd: memset failed"); return LT_ERR_HIP; }
   hipLaunchKernelGGL(koleo_normalize_kernel, dim3(n), dim3(256), 0, ST, x, ld, xn, inv, D, eps);
   hipLaunchKernelGGL(koleo_nn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, loss, n, D, eps, weight);
+  if (weight == 0.f) { LT_CHECK_LAUNCH("lt_koleo_fwd_bwd"); }   // value only (the reference logs the term even when it is not trained on)
   hipLaunchKernelGGL(koleo_dxn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, D, eps);
   hipLaunchKernelGGL(koleo_dx_kernel, dim3(n), dim3(256), 0, ST, xn, dxn, inv, dx, ld_dx, D);
   LT_CHECK_LAUNCH("lt_koleo_fwd_bwd");

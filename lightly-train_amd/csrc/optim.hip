@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long n,
                                                     const int32_t* __restrict__ seg_of_chunk, const float* __restrict__ seg_lr,
                                                     const uint8_t* __restrict__ seg_wd_on, const uint8_t* __restrict__ seg_frozen,
-                                                    int freeze, float lr_factor, float wd, float beta1, float beta2, float eps,
+                                                    int freeze, float lr_factor, float wd, float beta1, float beta2, float om1, float om2, float eps,
                                                     float bc1, float bc2_sqrt, const float* __restrict__ sumsq, float max_norm) {
   const long chunk = blockIdx.x;
   const int seg = seg_of_chunk[chunk];
   float lr = seg_lr[seg] * lr_factor;
-  if (freeze && seg_frozen[seg]) lr = 0.f;
+  if (freeze & seg_frozen[seg]) lr = 0.f;   // bit 0: last-layer freeze, bit 1: backbone freeze (dinov2.py:619-635)
   const float wdv = seg_wd_on[seg] ? wd : 0.f;
   float clip = 1.f;
   if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (int e = 0; e < 4; ++e) {
     const float gr = G[e] * clip;
     P[e] *= 1.f - lr * wdv;                      // decoupled weight decay (torch AdamW order)
-    M[e] = M[e] + (gr - M[e]) * (1.f - beta1);   // lerp form used by torch
-    V[e] = V[e] * beta2 + gr * gr * (1.f - beta2);
+    M[e] = M[e] + (gr - M[e]) * om1;             // lerp form used by torch; om = 1 - beta formed in double on the host
+    V[e] = V[e] * beta2 + gr * gr * om2;
     const float denom = sqrtf(V[e]) / bc2_sqrt + eps;
     P[e] -= (lr / bc1) * (M[e] / denom);
   }
@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf2(pp.x, pp.y), pack_bf2(pp.z, pp.w));
 }
 
+// mom and om = 1 - mom are both formed in double on the host: near the end of the cosine schedule 1 - m ~ 1e-6 and `1.f - mom` would be
+// quantised to 2^-24 steps (percent-level relative error); the reference computes 1 - m in Python floats (_torch_helpers.py:75-96).
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, bf16_t* __restrict__ tb, long n,
-                                                  float mom) {
+                                                  float mom, float om) {
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
-  const float om = 1.f - mom;
   for (; i + 3 < n; i += stride) {
     float4 a = *reinterpret_cast<float4*>(t + i);
     const float4 b = *reinterpret_cast<const float4*>(s + i);
@@ -109,23 +110,24 @@ extern "C" int lt_sumsq_f32(const float* g, float* out, int64_t n, void* stream)
 
 extern "C" int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int32_t* seg_of_chunk,
                              const float* seg_lr, const uint8_t* seg_wd_on, const uint8_t* seg_frozen, int freeze,
-                             float lr_factor, float wd, float beta1, float beta2, float eps, int step, const float* sumsq,
+                             float lr_factor, float wd, double beta1, double beta2, float eps, int step, const float* sumsq,
                              float max_norm, void* stream) {
   LT_CHECK_ARG(p && g && m && v && seg_of_chunk && seg_lr && seg_wd_on && seg_frozen, "lt_adamw_flat: null pointer");
   LT_CHECK_ARG(n % 1024 == 0, "lt_adamw_flat: n must be a multiple of the 1024-element chunk (n=%ld)", (long)n);
   LT_CHECK_ARG(step >= 1 && (max_norm <= 0.f || sumsq), "lt_adamw_flat: step must be >= 1 and sumsq given when clipping");
   if (n == 0) return LT_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  // bias corrections in double like torch.optim.AdamW (1 - beta ** step on Python floats): powf loses ~3e-5 relative at step 1
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, m, v, (bf16_t*)p_bf16, (long)n, seg_of_chunk,
-                     seg_lr, seg_wd_on, seg_frozen, freeze, lr_factor, wd, beta1, beta2, eps, bc1, bc2_sqrt, sumsq, max_norm);
+                     seg_lr, seg_wd_on, seg_frozen, freeze, lr_factor, wd, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, bc1, bc2_sqrt, sumsq, max_norm);
   LT_CHECK_LAUNCH("lt_adamw_flat");
 }
 
-extern "C" int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, float m, void* stream) {
+extern "C" int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream) {
   LT_CHECK_ARG(teacher && student && n % 4 == 0, "lt_ema_flat: bad arguments");
   if (n == 0) return LT_OK;
   const int grid = (int)min((long)2048, (long)lt_cdiv(n, 1024));
-  hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, ST, teacher, student, (bf16_t*)teacher_bf16, (long)n, m);
+  hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, ST, teacher, student, (bf16_t*)teacher_bf16, (long)n, (float)m, (float)(1.0 - m));
   LT_CHECK_LAUNCH("lt_ema_flat");
 }

@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from . import ops
+from . import checkpoint, ops
 from .masking import MaskingGenerator, MaskProducer, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
@@ -263,6 +263,12 @@ class DINOv2:
             t_named += [("ihead." + n, tis[n]) for n in order_h]
         self.student = FlatParams(s_named, self.device, True)
         self.teacher = FlatParams(t_named, self.device, False)
+        if self.world > 1:
+            # what DDP does when it wraps the module: every replica starts from rank 0's parameters (ranks built from different
+            # seeds / states would otherwise diverge silently)
+            for fp in (self.student, self.teacher):
+                dist.broadcast(fp.data, src=0)
+                fp.bf16.copy_(fp.data)
         self.s_vit = ViTEngine(vit_cfg, self.student, "backbone.")
         self.t_vit = ViTEngine(vit_cfg, self.teacher, "backbone.")
         self.s_head = HeadEngine(self.student, "head.", D, a)
@@ -292,10 +298,13 @@ class DINOv2:
         dev = self.device
         self.seg_lr = torch.tensor([g_["lr"] for g_ in self.param_groups], dtype=torch.float32, device=dev)
         self.seg_wd_on = torch.tensor([1 if g_["weight_decay"] != 0.0 else 0 for g_ in self.param_groups], dtype=torch.uint8, device=dev)
-        self.seg_frozen = torch.tensor([1 if g_["last_layer"] else 0 for g_ in self.param_groups], dtype=torch.uint8, device=dev)
+        # freeze masks of on_before_optimizer_step (dinov2.py:619-635): bit 0 = "last_layer" groups, bit 1 = groups without "head" in
+        # their name (the backbone)
+        self.seg_frozen = torch.tensor([(1 if g_["last_layer"] else 0) | (0 if g_["head"] else 2) for g_ in self.param_groups],
+                                       dtype=torch.uint8, device=dev)
         self.warmup_steps = min(total_steps - 1, a.warmup_steps)
         self._sumsq = torch.zeros(1, device=dev)
-        self._loss_slots = torch.zeros(4, device=dev)
+        self._loss_slots = torch.zeros(5, device=dev)   # weighted dino_global, dino_local, ibot, koleo; [4] = unweighted KoLeo value at weight 0
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
@@ -303,7 +312,9 @@ class DINOv2:
         # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
         # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
         self.activation_checkpointing = False
-        self._drop_gen = torch.Generator().manual_seed(seed + 7919)  # host RNG of the stochastic-depth draws
+        # host RNG of the stochastic-depth draws: per-rank stream (the reference draws from each rank's device RNG)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self._drop_gen = torch.Generator().manual_seed(seed + 7919 + 104729 * rank)
         self._grad_sync: Optional[GradSync] = None
         # data parallel: all-reduce the head gradients and each transformer block's gradients as soon as they are final,
         # underneath the rest of backward (what DDP's bucket hooks do in the reference); LT_GRAD_OVERLAP=0 reduces after it
@@ -328,23 +339,67 @@ class DINOv2:
             self._mask_producer = None
 
     def state_dict(self) -> Dict[str, Tensor]:
-        out: Dict[str, Tensor] = {}
-        for role, fp in (("teacher", self.teacher), ("student", self.student)):
-            for n in fp.names:
-                if n.startswith("backbone."):
-                    out[f"{role}_embedding_model.wrapped_model._model.{n[9:]}"] = fp.p[n].detach().clone()
-                elif n.startswith("ihead."):
-                    out[f"{role}_head.ibot_head.{n[6:]}"] = fp.p[n].detach().clone()
-                else:
-                    for hname in (("dino_head",) if self.method_args.ibot_separate_head else ("dino_head", "ibot_head")):
-                        out[f"{role}_head.{hname}.{n[5:]}"] = fp.p[n].detach().clone()
-        out["dino_loss.center"] = self.dino_center.clone()
-        out["ibot_loss.center"] = self.ibot_center.clone()
+        """`method.state_dict()` with the reference's keys (what Lightning stores as checkpoint["state_dict"])."""
+        return checkpoint.method_state_dict(self.student, self.teacher, {"dino_loss.center": self.dino_center, "ibot_loss.center": self.ibot_center},
+                                            self.method_args.ibot_separate_head, self.cfg.depth, self.cfg.block_chunks)
+
+    def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
+        """Load a `method.state_dict()` written by the reference (or by `state_dict()`): fp32 master weights, their bf16 shadows
+        and every derived cache (weight-normed prototype matrices, padded patch-embedding matrices), loss centers included.
+        Pending (not yet applied) center updates of the running step are dropped, as in a freshly constructed reference module."""
+        extra = checkpoint.load_method_state_dict(sd, self.student, self.teacher, self.method_args.ibot_separate_head, strict)
+        if "dino_loss.center" in extra:
+            self.dino_center.copy_(extra["dino_loss.center"].to(self.device, torch.float32).view_as(self.dino_center))
+        if "ibot_loss.center" in extra:
+            self.ibot_center.copy_(extra["ibot_loss.center"].to(self.device, torch.float32).view_as(self.ibot_center))
+        self._pending.clear()
+        self._refresh_derived()
+
+    def _refresh_derived(self) -> None:
+        for h in {id(x): x for x in (self.s_head, self.t_head, self.s_ihead, self.t_ihead)}.values():
+            h.refresh_weightnorm()
+        self.s_vit.refresh_padded_weights()
+        self.t_vit.refresh_padded_weights()
+
+    def _group_entries(self) -> List[Dict[str, Any]]:
+        """Per-tensor optimizer entries in the reference's `named_parameters()` order, with the values currently in effect."""
+        a, k, total = self.method_args, self.trainer.global_step, self.trainer.estimated_stepping_batches
+        lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, a.min_lr / self.base_lr)
+        wd = cosine_schedule(min(max(k - 1, 0), total), total, a.weight_decay_start, a.weight_decay_end) if k > 0 else a.weight_decay_start
+        out = []
+        for n, g_ in zip(self.student.names, self.param_groups):
+            out.append(dict(g_, flat=n, lr_now=g_["lr"] * lr_factor, wd_now=wd if g_["weight_decay"] != 0.0 else 0.0))
         return out
+
+    def optimizer_state_dict(self) -> Dict[str, Any]:
+        """`torch.optim.AdamW.state_dict()` of the reference's optimizer (fused groups of utils.py:191-273) from the flat moments."""
+        a = self.method_args
+        hyper = dict(betas=tuple(a.betas), eps=a.eps, amsgrad=False, maximize=False, foreach=True, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=True)
+        return checkpoint.optimizer_state_dict(self.student, self.exp_avg, self.exp_avg_sq, self.opt_step, self._group_entries(), hyper)
+
+    def load_optimizer_state_dict(self, osd: Mapping[str, Any]) -> None:
+        self.opt_step = checkpoint.load_optimizer_state_dict(osd, self.student, self.exp_avg, self.exp_avg_sq, self._group_entries())
+
+    def checkpoint_dict(self) -> Dict[str, Any]:
+        """The parts of a Lightning checkpoint this step owns (LT/_checkpoint.py:101-123; Lightning's `dump_checkpoint`):
+        module state, optimizer state, scheduler position, global step."""
+        return {"state_dict": self.state_dict(), "optimizer_states": [self.optimizer_state_dict()],
+                "lr_schedulers": [{"last_epoch": self.trainer.global_step, "warmup_epochs": self.warmup_steps,
+                                   "max_epochs": self.trainer.estimated_stepping_batches}],
+                "global_step": self.trainer.global_step, "epoch": 0}
+
+    def load_checkpoint_dict(self, ckpt: Mapping[str, Any], strict: bool = True) -> None:
+        """Resume: inverse of `checkpoint_dict()`; also accepts a checkpoint written around the reference's own module."""
+        self.load_state_dict(ckpt["state_dict"], strict=strict)
+        if ckpt.get("optimizer_states"):
+            self.load_optimizer_state_dict(ckpt["optimizer_states"][0])
+        self.trainer.global_step = int(ckpt.get("global_step", self.opt_step))
 
     def export_backbone_state_dict(self) -> Dict[str, Tensor]:
         """What the reference exports (EMA teacher backbone, dinov2_vit_package.py:146-162)."""
-        return {n[9:]: self.teacher.p[n].detach().clone() for n in self.teacher.names if n.startswith("backbone.")}
+        return {checkpoint.vit_key_from_flat(n[9:], self.cfg.depth, self.cfg.block_chunks): self.teacher.p[n].detach().clone()
+                for n in self.teacher.names if n.startswith("backbone.")}
 
     @property
     def world(self) -> int:
@@ -409,8 +464,11 @@ class DINOv2:
         M = int(midx.shape[0])
         mw = masks["masks_weight"].to(torch.float32)
         patch_rows = ((midx // n_p) * Ng + 1 + n_reg + midx % n_p).to(dev, non_blocking=True)
-        cap_M = int(n_crops * a.mask_probability) * max(int(0.5 * n_p), 1)
-        assert M <= cap_M
+        # a masked crop holds at most int(n_p * ratio_max) patches (MaskingGenerator.__call__ caps the total, utils.py:120-152);
+        # the 0.5 of `max_num_patches` only bounds one block.  Buffers are sized for the worst case of this configuration.
+        cap_M = int(n_crops * a.mask_probability) * max(int(n_p * max(a.mask_ratio_max, 0.5)), 1)
+        if M > cap_M:
+            raise ValueError(f"{M} masked patches exceed the capacity {cap_M} implied by mask_ratio_max={a.mask_ratio_max}")
 
         lv = torch.cat(views[n_global:]).to(dev, torch.float32) if n_local > 0 else None
         n_p_l = (-(-lv.shape[2] // p)) * (-(-lv.shape[3] // p)) if lv is not None else 0
@@ -528,9 +586,10 @@ class DINOv2:
         dxn_g.zero_()
         kws = ws.get("koleo.ws", (2 * B * D + 2 * B,), torch.float32)
         knn = ws.get("koleo.nn", (B,), torch.int32)
-        if a.koleo_loss_weight != 0.0 and B > 1:
+        if B > 1:   # weight 0: the kernel only evaluates the term (logged by the reference regardless of its weight)
+            kslot = self._loss_slots[3:] if a.koleo_loss_weight != 0.0 else self._loss_slots[4:]
             for c in range(2):  # per global-crop chunk, dinov2.py:377-380
-                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, self._loss_slots[3:], dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
+                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
 
         # ---------------- backward
         side = self.side_stream if self.overlap_streams else None
@@ -606,14 +665,14 @@ class DINOv2:
             "train_loss/dino_global_loss": ls[0] / a.dino_loss_weight if a.dino_loss_weight else ls[0],
             "train_loss/dino_local_loss": ls[1] / a.dino_loss_weight if a.dino_loss_weight else ls[1],
             "train_loss/ibot_loss": ls[2] / a.ibot_loss_weight if a.ibot_loss_weight else ls[2],
-            "train_loss/koleo_loss": ls[3] / a.koleo_loss_weight if a.koleo_loss_weight else ls[3],
+            "train_loss/koleo_loss": ls[3] / a.koleo_loss_weight if a.koleo_loss_weight else ls[4],
         }
         self._last_masks = masks
         s_patch_logits = sh["logits"][Rd:Rs] if not sep else shi["logits"][:M]
         self._last = dict(t_cls_logits=t_logits[:2 * B], t_patch_logits=t_logits[2 * B:Rt], t_probs=t_probs[:Rt],
                           s_cls_logits=sh["logits"][:2 * B], s_local_logits=sh["logits"][2 * B:Rd], s_patch_logits=s_patch_logits,
                           B=B, M=M, Rl=Rl)
-        return TrainingStepResult(loss=ls.sum(), log_dict=logs)
+        return TrainingStepResult(loss=ls[:4].sum(), log_dict=logs)
 
     def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:
         """`train_loss` + `log_dict` averaged over ranks in one coalesced all-reduce (what `Method.training_step` logs with
@@ -659,7 +718,7 @@ class DINOv2:
         total = self.trainer.estimated_stepping_batches
         wd = cosine_schedule(k, total, a.weight_decay_start, a.weight_decay_end)
         lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, a.min_lr / self.base_lr)
-        freeze = k < a.student_freeze_last_layer_steps
+        freeze = (1 if k < a.student_freeze_last_layer_steps else 0) | (2 if k < a.student_freeze_backbone_steps else 0)
         self.allreduce_gradients()
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)

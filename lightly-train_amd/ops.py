@@ -348,7 +348,7 @@ def sumsq(g: Tensor, out: Tensor) -> None:
 
 
 def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], seg_of_chunk: Tensor, seg_lr: Tensor,
-               seg_wd_on: Tensor, seg_frozen: Tensor, freeze: bool, lr_factor: float, wd: float, beta1: float, beta2: float,
+               seg_wd_on: Tensor, seg_frozen: Tensor, freeze: int, lr_factor: float, wd: float, beta1: float, beta2: float,
                eps: float, step: int, sumsq_t: Optional[Tensor], max_norm: float) -> None:
     check(_lib.load().lt_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(seg_of_chunk), _p(seg_lr), _p(seg_wd_on),
                                     _p(seg_frozen), int(freeze), lr_factor, wd, beta1, beta2, eps, step, _p(sumsq_t), max_norm,

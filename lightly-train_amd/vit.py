@@ -42,6 +42,7 @@ class ViTConfig:
     rope_rescale: Optional[float] = None  # training-mode coordinate augmentation of a DINOv3 *student*: log-uniform rescale
                                           # in [1/r, r], drawn per block (rope_position_encoding.py:104-109; 2 for vits16..vitl16)
     mask_k_bias: bool = False           # DINOv3 LinearKMaskedBias: the K third of the qkv bias is held at zero (no gradient)
+    block_chunks: int = 0               # checkpoint key naming only: the vitl14 / vitg14 YAMLs build `blocks.<chunk>.<i>.` (FSDP chunks)
 
     @property
     def swiglu(self) -> bool:

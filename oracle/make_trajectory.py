@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE ONLY.  100-optimizer-step loss trajectories written by the REFERENCE's own DINOv2 class
+(imported from /root/reference through oracle/ref_harness.py, Lightning hook order of ReferenceRunner) -- the north-star
+item "loss trajectory matching the reference to 1e-3 over 100 synthetic steps".
+
+For each KoLeo weight (0.1 = reference default, 0.0) three runs from the SAME initial state, views and iBOT masks:
+  * "fp32"      the reference on CPU in fp32                                     -> the trajectory the HIP step is held to
+  * "bf16"      the reference under torch.autocast("cpu", bfloat16) around training_step_impl, i.e. what Lightning's
+                precision="bf16-mixed" does (forward under autocast, fp32 master weights / optimizer) -> how far the
+                reference's OWN mixed-precision path drifts from its fp32 path on this trajectory
+  * "fp32_perturbed"  fp32 with the initial student weights perturbed by 1 ulp-scale noise (relative 1e-7) -> the
+                trajectory's sensitivity to rounding at the fp32 level (chaos floor of the KoLeo nearest-neighbour term)
+
+Run in the build container:  python -m oracle.make_trajectory      (writes tests/golden/trajectory_d64.pt, ~70 KiB;
+the initial state is the one of tests/golden/step_d64_softmax.pt -- asserted here)
+The HIP step reproduces views (seed 5000 + s) and masks (random.seed(900 + s) before each step: the mask sampler is
+bit-identical to the reference's, tests/test_host_logic.py) on the GPU box; nothing else of the reference travels.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as H  # noqa: E402
+from oracle.make_golden import synth_views  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+KEYS = ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss", "grad_norm")
+CFG = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0),
+           method_kwargs=dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64),
+           cfg=dict(patch_size=16, num_heads=1, depth=2), b=8, g_size=96, l_size=48, n_local=2)
+
+
+def run(koleo: float, steps: int, mode: str, init_state=None):
+    """One trajectory of the reference class.  Returns (per-step logs, initial split state)."""
+    mk = dict(CFG["method_kwargs"], koleo_loss_weight=koleo)
+    m = H.build_reference_method(arch=CFG["arch"], patch_size=16, img_size=CFG["g_size"], model_kwargs=CFG["model_kwargs"],
+                                 method_kwargs=mk, global_batch_size=CFG["b"], total_steps=steps + 1, seed=1234)
+    if mode == "fp32_perturbed":
+        g = torch.Generator().manual_seed(99)
+        with torch.no_grad():
+            for p in m.student_embedding_model.parameters():
+                p.mul_(1.0 + 1e-7 * torch.randn(p.shape, generator=g))
+    r = H.ReferenceRunner(m)
+    init = r.split_state()
+    if mode == "bf16":
+        inner = m.training_step_impl
+
+        def autocast_step(batch, batch_idx):
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                return inner(batch, batch_idx)
+
+        m.training_step_impl = autocast_step
+    rows = []
+    for s in range(steps):
+        views = synth_views(5000 + s, CFG["b"], CFG["g_size"], CFG["l_size"], CFG["n_local"])
+        random.seed(900 + s)
+        logs = r.train_step(views)
+        rows.append({k: float(logs[k]) for k in KEYS})
+        if s < 3 or s % 20 == 19:
+            print(mode, koleo, s, {k: round(v, 5) for k, v in rows[-1].items()}, flush=True)
+    return rows, init
+
+
+def main() -> None:
+    steps = 100
+    out = {"cfg": CFG, "steps": steps, "view_seed0": 5000, "mask_seed0": 900, "runs": {}}
+    for koleo in (0.1, 0.0):
+        for mode in ("fp32", "bf16", "fp32_perturbed"):
+            rows, init = run(koleo, steps, mode)
+            out["runs"][(koleo, mode)] = rows
+            if mode == "fp32":   # same seed, same config => the initial state of tests/golden/step_d64_softmax.pt (not stored twice)
+                fx = torch.load(os.path.join(OUT, "step_d64_softmax.pt"), weights_only=False)
+                for part in ("student_backbone", "student_head", "teacher_head"):
+                    for k, v in init[part].items():
+                        assert torch.equal(v, fx["init"][part][k]), (part, k)
+    # deviations of the reference's own alternative paths from its fp32 path
+    summary = {}
+    for koleo in (0.1, 0.0):
+        ref = out["runs"][(koleo, "fp32")]
+        for mode in ("bf16", "fp32_perturbed"):
+            alt = out["runs"][(koleo, mode)]
+            summary[(koleo, mode)] = {k: max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for a, b in zip(alt, ref)) for k in KEYS}
+            print("max rel dev vs fp32", koleo, mode, {k: f"{v:.2e}" for k, v in summary[(koleo, mode)].items()})
+    out["summary"] = summary
+    path = os.path.join(OUT, "trajectory_d64.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

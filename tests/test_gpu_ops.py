@@ -389,7 +389,8 @@ def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (3, 37, 2, 64), (2, 50, 1, 64), (1, 300, 2, 64), (2, 128, 2, 64),
                                        (3, 50, 6, 64), (2, 64, 4, 64), (2, 257, 2, 64), (1, 600, 1, 64), (2, 65, 2, 64),
-                                       (4, 17, 2, 4), (2, 5, 2, 8)])
+                                       (4, 17, 2, 4), (2, 5, 2, 8),
+                                       (1, 1370, 2, 64), (2, 1374, 1, 64)])   # BASELINE cfg5: ViT-L/14 at 518^2 = 37x37 + cls (+ 4 registers)
 def test_attention(B, N, H, dh):
     o = ops()
     g = torch.Generator().manual_seed(N + dh)

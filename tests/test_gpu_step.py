@@ -273,28 +273,246 @@ def test_full_size_head_properties():
     assert float(loss) == pytest.approx(float(ref), rel=1e-4)
 
 
-def test_loss_trajectory_100_steps_matches_oracle():
-    """North-star item: the loss trajectory over 100 optimizer steps on identical synthetic batches (same views, same
-    iBOT masks, reference-generated initial state) against the fp32 CPU oracle.  KoLeo off (the ill-conditioned term, see
-    the module docstring): total loss within 2e-3 relative at EVERY step (observed max 9.8e-4), DINO terms 4e-3 (1.5e-3),
-    iBOT 2e-3 (2.8e-4) -- bf16 MFMA operands against fp32, through 100 AdamW + EMA updates."""
+def _install_gemm_spy():
+    """Record which MFMA GEMM kernel family every lt_gemm_bf16 call of a step dispatches to, by mirroring the dispatcher's
+    size gate (gemm.hip `big`: forward / dgrad M >= 2048 rows, wgrad K >= 8192 and M >= 256, K % 64 == 0, N >= 128)."""
+    from lightly_train_amd import ops
+
+    calls = []
+    orig = ops.gemm
+
+    def spy(a, b, out, *, M, N, K, trans_a=False, trans_b=False, **kw):
+        big = K % 64 == 0 and N % 8 == 0 and N >= 128 and ((not trans_a and M >= 2048) or (trans_a and K >= 8192 and M >= 256))
+        kind = "wgrad" if trans_a else ("dgrad" if trans_b else "fwd")
+        calls.append((kind, "gemm256" if big else "gemm128", M, N, K, kw.get("epilogue", 0)))
+        return orig(a, b, out, M=M, N=N, K=K, trans_a=trans_a, trans_b=trans_b, **kw)
+
+    ops.gemm = spy
+    return calls, lambda: setattr(ops, "gemm", orig)
+
+
+def test_vitb_batch16_step_dispatches_gemm256q_and_matches_oracle():
+    """The benchmark's kernels INSIDE a checked step: ViT-B/16 (D=768, 12 heads, 12 blocks, LayerScale 1e-5), K = 65 536
+    prototypes, 2 x 224^2 + 8 x 98^2 crops, batch 16 => 6304 global / 6400 local token rows (>= 2048: every forward and dgrad
+    token GEMM runs the 256x256 four-phase `gemm256q` kernel with its GELU / LayerScale+residual / GELU' epilogues) and wgrad
+    contractions of K = 6304 .. 12800 rows (the slab split-K `gemm256q<T,T>` for K >= 8192), the register-resident 65 536-wide
+    softmax / CE kernels and both attention kernels -- against the fp32 CPU oracle on identical inputs:
+      loss terms 2e-3 relative, total gradient norm 2e-2, and PER-TENSOR gradients for EVERY parameter (all 12 blocks):
+      6e-2 of max|grad| (KoLeo off: with it the in-branch gradients are ill-conditioned at init, see the module docstring)."""
+    import json
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(41)
+    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    args = DINOv2Args(koleo_loss_weight=0.0)
+    b = 16
+    m = DINOv2(vc, args, global_batch_size=b, total_steps=100, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    o = O.OracleDINOv2(bsd, shs, dict(patch_size=16, num_heads=12, depth=12), args=dict(koleo_loss_weight=0.0), global_batch_size=b, total_steps=100,
+                       teacher_head=ths)
+    views = [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(8)]
+    random.seed(6)
+    calls, undo = _install_gemm_spy()
+    try:
+        res = m.training_step_impl({"views": views}, 0)
+    finally:
+        undo()
+    torch.cuda.synchronize()
+    # the step really went through the 256-row kernels, in all three roles and with the heavy epilogues
+    from lightly_train_amd import ops
+    big = [c for c in calls if c[1] == "gemm256"]
+    assert {c[0] for c in big} == {"fwd", "dgrad", "wgrad"}
+    assert {ops.EPI_BF16_GELU, ops.EPI_RESID, ops.EPI_BF16_GELUGRAD, ops.EPI_BF16, ops.EPI_F32_ACCUM} <= {c[5] for c in big}
+    tok = [c for c in calls if c[0] in ("fwd", "dgrad") and c[2] in (2 * b * 197, 8 * b * 50)]
+    assert tok and all(c[1] == "gemm256" for c in tok), [c for c in tok if c[1] != "gemm256"][:3]
+
+    loss, ologs = o.forward_loss(views, m._last_masks)
+    loss.backward()
+    logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(float(ologs[k]), rel=2e-3), k
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+    sq_o = sq_r = 0.0
+    report, bad = {}, []
+    for n in m.student.names:
+        ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+        ours = m.student.g[n].cpu()
+        sq_o += float((ours.double() ** 2).sum()); sq_r += float((ref.double() ** 2).sum())
+        report[n] = rel(ours, ref)
+        if not report[n] < 6e-2:
+            bad.append((n, report[n]))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "vitb_b16_grad_report.json"), "w") as f:
+            json.dump({"max": max(report.values()), "per_tensor": report, "gemm_calls": len(calls), "gemm256_calls": len(big),
+                       "grad_norm_ours": sq_o ** 0.5, "grad_norm_oracle": sq_r ** 0.5, "loss": logs, "loss_oracle": {k: float(v) for k, v in ologs.items()}}, f, indent=1)
+    assert not bad, f"{len(bad)} of {len(report)} tensors off: {sorted(bad, key=lambda t: -t[1])[:8]}"
+    assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=2e-2)
+
+
+def test_koleo_gradients_per_tensor_at_a_well_conditioned_state():
+    """a17: KoLeo's own gradient checked per tensor, IN the branches too.  At the reference initialisation (LayerScale 1e-5) all
+    cls tokens coincide to ~1e-6 and the KoLeo gradient is ill-conditioned (tests/golden/trajectory_d64.pt: a 1e-7 relative
+    perturbation of the fp32 reference moves its own 100-step trajectory by 2.3e-3); with LayerScale 0.3 the cls tokens are
+    spread, nearest neighbours are stable, and the HIP KoLeo forward / backward must match the fp32 oracle like any other term."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(77)
+    vc = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=96, init_values=0.3)
+    bsd = init_vit_state(vc, g)
+    bsd["cls_token"] = torch.randn(1, 1, 64, generator=g) * 0.5
+    shs, ths = init_head_state(64, 128, 64, 512, g), init_head_state(64, 128, 64, 512, g)
+    b = 16
+    views = [torch.randn(b, 3, 96, 96, generator=g) for _ in range(2)] + [torch.randn(b, 3, 48, 48, generator=g) for _ in range(2)]
+    # KoLeo only (the other terms switched off) and KoLeo at 10x its default weight next to them
+    for kw in (dict(dino_loss_weight=0.0, ibot_loss_weight=0.0, koleo_loss_weight=1.0), dict(koleo_loss_weight=1.0)):
+        args = DINOv2Args(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, **kw)
+        m = DINOv2(vc, args, global_batch_size=b, total_steps=50, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+        o = O.OracleDINOv2(bsd, shs, dict(patch_size=16, num_heads=1, depth=2), args=dict(output_dim=512, hidden_dim=128, bottleneck_dim=64, **kw),
+                           global_batch_size=b, total_steps=50, teacher_head=ths)
+        random.seed(8)
+        res = m.training_step_impl({"views": views}, 0)
+        loss, ologs = o.forward_loss(views, m._last_masks)
+        loss.backward()
+        logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+        assert logs["koleo_loss"] == pytest.approx(float(ologs["koleo_loss"]), rel=2e-3)
+        assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+        for n in m.student.names:
+            ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
+            if ref is None or float(ref.abs().max()) == 0.0:   # heads get no gradient from KoLeo alone
+                assert float(m.student.g[n].abs().max()) == 0.0, n
+                continue
+            assert rel(m.student.g[n].cpu(), ref) < 5e-2, (kw, n)
+
+
+def test_koleo_value_is_logged_at_weight_zero():
+    """The reference logs the (unweighted) KoLeo term whatever its weight (dinov2.py:377-396)."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    m0, m1 = build(fx, koleo_loss_weight=0.0), build(fx)
+    r0 = m0.training_step_impl({"views": views}, 0, masks=rec["masks"])
+    r1 = m1.training_step_impl({"views": views}, 0, masks=rec["masks"])
+    k0, k1 = float(r0.log_dict["train_loss/koleo_loss"]), float(r1.log_dict["train_loss/koleo_loss"])
+    assert k0 == pytest.approx(k1, rel=1e-5) and k0 == pytest.approx(rec["logs"]["koleo_loss"], rel=3e-2)
+    assert float(r1.loss) - float(r0.loss) == pytest.approx(0.1 * k1, rel=1e-3)   # and it is not part of the loss at weight 0
+
+
+def test_student_freeze_backbone_steps():
+    """dinov2.py:619-625: lr = 0 for every non-head group while global_step < student_freeze_backbone_steps (weight decay is
+    lr-scaled, so the backbone does not move at all); the moments still integrate the gradients."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    m = build(fx, student_freeze_backbone_steps=1, student_freeze_last_layer_steps=0, koleo_loss_weight=0.0)
+    before = m.student.data.clone()
+    lo, hi = m.student.span(("backbone.",))
+    for s in range(2):
+        views = synth_views(700 + s, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        random.seed(s)
+        m.train_step(views)
+        moved_bb = not torch.equal(m.student.data[lo:hi], before[lo:hi])
+        moved_head = not torch.equal(m.student.data[hi:], before[hi:])
+        assert moved_head and moved_bb == (s == 1), (s, moved_bb, moved_head)
+        if s == 0:
+            assert float(m.exp_avg[lo:hi].abs().max()) > 0     # frozen, but Adam's moments keep integrating (torch semantics)
+            assert torch.equal(m.student.bf16[lo:hi].float(), before[lo:hi].to(torch.bfloat16).float())
+
+
+def test_resume_from_a_reference_checkpoint_reproduces_the_reference_next_step():
+    """f4: a checkpoint written around the reference's own module + torch AdamW after two steps (tests/golden/ckpt_d64.pt,
+    oracle/make_checkpoint.py) is loaded into a differently-initialised HIP method; it is exported back bit-identically, and
+    step three -- Adam moments, bias corrections, schedules, loss centers and EMA all resumed -- matches the reference's."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig
+
+    fx = torch.load(os.path.join(GOLD, "ckpt_d64.pt"), weights_only=False)
+    ck = fx["checkpoint"]
+    vc = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"])
+    m = DINOv2(vc, DINOv2Args(**fx["method_kwargs"]), global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", seed=99)
+    m.load_checkpoint_dict(ck)
+    assert m.trainer.global_step == 2 and m.opt_step == 2
+    sd = m.state_dict()
+    assert list(sd) == list(ck["state_dict"])
+    for k, v in ck["state_dict"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+    osd, rsd = m.optimizer_state_dict(), ck["optimizer_states"][0]
+    for g_o, g_r in zip(osd["param_groups"], rsd["param_groups"]):
+        assert g_o["name"] == g_r["name"] and g_o["params"] == g_r["params"]
+        assert g_o["lr"] == pytest.approx(g_r["lr"], rel=1e-9) and g_o["weight_decay"] == pytest.approx(g_r["weight_decay"], rel=1e-9)
+    for i, st in rsd["state"].items():
+        assert torch.equal(osd["state"][i]["exp_avg"].cpu(), st["exp_avg"]) and torch.equal(osd["state"][i]["exp_avg_sq"].cpu(), st["exp_avg_sq"])
+    # derived caches were refreshed by the load: the weight-normed prototype matrix is the checkpoint's, not the constructor's
+    v = ck["state_dict"]["student_head.dino_head.last_layer.parametrizations.weight.original1"]
+    wn = (v / v.norm(dim=1, keepdim=True)).to(torch.bfloat16).float()
+    assert rel(m.s_head.wn.float(), wn) < 1e-2
+    # ---- step three
+    s3 = fx["step3"]
+    views = synth_views(s3["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    before = {k: val.clone() for k, val in sd.items()}
+    res = m.training_step_impl({"views": views}, 0, masks=s3["masks"])
+    logs = {k.split("/")[-1]: float(val) for k, val in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(s3["logs"][k], rel=5e-3), k
+    assert logs["koleo_loss"] == pytest.approx(s3["logs"]["koleo_loss"], rel=3e-2)
+    m.optimizer_step()
+    assert float(m.last_grad_norm.sqrt()) == pytest.approx(s3["logs"]["grad_norm"], rel=8e-2)
+    m.on_train_batch_end()
+    after = m.state_dict()
+    agree = tot = 0
+    for k, ref in s3["state_after"].items():
+        if "center" in k:
+            continue
+        d_ref, d_our = ref - before[k].cpu(), after[k].cpu() - before[k].cpu()
+        scale = d_ref.abs().max().item()
+        if scale == 0:
+            assert d_our.abs().max().item() == 0, k
+            continue
+        assert d_our.abs().max().item() <= 1.1 * scale + 1e-9, k
+        agree += int(((d_our - d_ref).abs() <= 0.1 * scale).sum()); tot += d_ref.numel()
+    assert agree / tot > 0.95, f"only {agree / tot:.3f} of the resumed parameter updates agree with the reference"
+    assert rel(m.dino_center, s3["state_after"]["dino_loss.center"]) < 2e-2
+
+
+def test_loss_trajectory_100_steps_matches_the_reference():
+    """North-star item "loss trajectory matching the reference to 1e-3 over 100 synthetic steps": 100 optimizer steps (AdamW +
+    EMA every step) from a reference-generated initial state on identical views and iBOT masks, against the trajectory the
+    REFERENCE's own DINOv2 class wrote in fp32 (tests/golden/trajectory_d64.pt, oracle/make_trajectory.py).
+    KoLeo off: total loss within 1e-3 relative at EVERY one of the 100 steps -- bf16 MFMA operands against fp32.  For scale:
+    the reference's own bf16-mixed path (CPU autocast) deviates from its fp32 path by 1.7e-3 on this trajectory."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
 
-    worst, rows = trajectory.run("step_d64_softmax", 100, 0.0, quiet=True)
+    worst, rows, own = trajectory.run_vs_reference(0.0, 100, quiet=True)
     assert rows[-1][1] < rows[0][1] - 0.3          # it trains: 10.21 -> 9.79 (KoLeo off)
-    assert worst["loss"] < 2e-3 and worst["dino_global_loss"] < 4e-3 and worst["dino_local_loss"] < 4e-3 and worst["ibot_loss"] < 2e-3, worst
+    assert worst["loss"] < 1e-3, worst
+    assert worst["dino_global_loss"] < 2.5e-3 and worst["dino_local_loss"] < 2.5e-3 and worst["ibot_loss"] < 1e-3, worst
+    assert worst["loss"] < own["bf16"]["loss"]      # closer to the fp32 reference than the reference's own mixed-precision path
 
 
-def test_loss_trajectory_with_koleo_40_steps():
-    """Same with the default KoLeo weight 0.1: 40 steps, total loss within 8e-3 (observed 2.2e-3), DINO / iBOT terms 6e-3."""
+def test_loss_trajectory_with_koleo_stays_inside_the_reference_own_precision_band():
+    """Same with the reference default KoLeo weight 0.1.  The KoLeo term makes this trajectory chaotic at the 1e-3 level: the
+    fixture records that perturbing the fp32 reference's initial weights by 1e-7 (relative) moves ITS OWN total loss by 2.3e-3
+    within the 100 steps, and that its bf16-mixed path (what `precision="bf16-mixed"` trains with) deviates by 1.3e-2 -- no
+    bf16 implementation can hold 1e-3 here, the reference's included.  Asserted instead: over the 100 steps we stay inside the
+    reference's own bf16 band (observed 9e-3 < 1.3e-2), the well-conditioned terms stay tight, and the first 40 steps (before
+    nearest-neighbour assignments start to differ) hold 4e-3."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
 
-    worst, _ = trajectory.run("step_d64_softmax", 40, 0.1, quiet=True)
-    assert worst["loss"] < 8e-3 and worst["dino_global_loss"] < 6e-3 and worst["dino_local_loss"] < 6e-3 and worst["ibot_loss"] < 6e-3, worst
+    worst, rows, own = trajectory.run_vs_reference(0.1, 100, quiet=True)
+    assert own["fp32_perturbed"]["loss"] > 1e-3 and own["bf16"]["loss"] > 1e-2     # the fixture's evidence, re-read
+    assert worst["loss"] < own["bf16"]["loss"], (worst, own["bf16"])
+    assert worst["dino_global_loss"] < 6e-3 and worst["dino_local_loss"] < 6e-3 and worst["ibot_loss"] < 4e-3, worst
+    assert max(r[3]["loss"] for r in rows[:40]) < 4e-3
 
 
 def test_model_wrapper_forward_features_matches_oracle():
@@ -359,9 +577,10 @@ def test_vit_small_full_depth_step_matches_oracle():
 def test_baseline_config_shapes_step_matches_oracle():
     """BASELINE.json configs[1] at its real shapes except the batch: ViT-B/16 (D=768, 12 heads, 12 blocks, LayerScale 1e-5),
     2 x 224^2 + 8 x 98^2 crops, DINO/iBOT head 768-2048-2048-256 with K = 65536 prototypes, default loss weights (KoLeo off: it
-    is ill-conditioned at initialisation), batch 2 so that the fp32 CPU oracle finishes in seconds.  Exercises exactly
-    the kernels and tile shapes of the benchmark: the 256x256 GEMM on N = 768 / 2304 / 3072 / 65536, the register-resident
-    65536-wide softmax / CE rows, 197- and 50-token attention."""
+    is ill-conditioned at initialisation), batch 2 so that the fp32 CPU oracle finishes in seconds.  Exercises the
+    register-resident 65536-wide softmax / CE rows and the 197- / 50-token attention kernels of the benchmark; with 788 / 800
+    token rows every token GEMM of this test runs the 128x128 `gemm_kernel` (the 256x256 `gemm256q` kernels need M >= 2048 rows:
+    they are covered inside a step by test_vitb_batch16_step_dispatches_gemm256q_and_matches_oracle below)."""
     import lightly_train_amd  # noqa: F401
     from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
     from lightly_train_amd.vit import ViTConfig, init_vit_state

@@ -124,7 +124,7 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} declared in lt_amd.h but not exported"
     bound = set(_lib.SIGNATURES) | {"lt_last_error", "lt_attention_bwd_ws_floats"}
     assert declared == bound, f"header/binding mismatch: {declared ^ bound}"
-    assert lib.lt_abi_version() == 1
+    assert lib.lt_abi_version() == 2
     assert ctypes.sizeof(_lib.GemmDesc) >= 120
 
 
@@ -253,3 +253,52 @@ def test_bench_flop_accounting_matches_the_survey_table():
         a = bench.MODELS[model]
         got = bench.step_flops_per_image(a["embed_dim"], a["depth"], 4 * a["embed_dim"], 197, n_l, 8, 65536, 2048, 256, 59) / 1e9
         assert got == pytest.approx(gf, abs=0.15), (model, n_l, got)
+
+
+def test_checkpoint_written_by_the_reference_round_trips_through_the_flat_storage():
+    """f4: `method.state_dict()` + `AdamW.state_dict()` written around the reference's own module (oracle/make_checkpoint.py) load
+    into the flat parameter / moment buffers and are exported back bit-identically, key for key, group for group."""
+    from lightly_train_amd import checkpoint as CK
+    from lightly_train_amd.dinov2 import head_param_shapes as hps
+
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "ckpt_d64.pt"), weights_only=False)
+    ck = fx["checkpoint"]
+    cfg = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"])
+    a = DINOv2Args(**fx["method_kwargs"])
+    names = [("backbone." + n, torch.zeros(s)) for n, s in vit_param_shapes(cfg)] + [
+        ("head." + n, torch.zeros(s)) for n, s in hps(64, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim)]
+    student, teacher = FlatParams(names, "cpu", True), FlatParams(names, "cpu", False)
+    extra = CK.load_method_state_dict(ck["state_dict"], student, teacher, separate_ibot=False, strict=True)
+    back = CK.method_state_dict(student, teacher, extra, False, cfg.depth)
+    assert list(back) == list(ck["state_dict"])          # same keys in the same order
+    for k, v in ck["state_dict"].items():
+        assert torch.equal(back[k], v), k
+    assert torch.equal(student.bf16, student.data.to(torch.bfloat16))
+    # optimizer: the fused groups of get_optimizer_with_decay, indices and moments
+    base_lr = a.lr * math.sqrt(fx["b"] / a.reference_batch_size)
+    entries = []
+    for n, _ in names:
+        ref = n[9:] if n.startswith("backbone.") else "dino_head." + n[5:]
+        g = param_group_hparams(ref, n.startswith("backbone."), cfg.depth, base_lr, a)
+        entries.append(dict(g, flat=n, lr_now=0.0, wd_now=0.0))
+    osd = ck["optimizer_states"][0]
+    m, v = torch.zeros_like(student.data), torch.zeros_like(student.data)
+    step = CK.load_optimizer_state_dict(osd, student, m, v, entries)
+    assert step == 2 == ck["global_step"]
+    out = CK.optimizer_state_dict(student, m, v, step, entries, {})
+    assert [g["params"] for g in out["param_groups"]] == [g["params"] for g in osd["param_groups"]]
+    assert [g["name"] for g in out["param_groups"]] == [g["name"] for g in osd["param_groups"]]
+    for g_o, g_r in zip(out["param_groups"], osd["param_groups"]):
+        assert g_o["initial_lr"] == pytest.approx(g_r["initial_lr"], rel=1e-12)
+    for i, st in osd["state"].items():
+        assert torch.equal(out["state"][i]["exp_avg"], st["exp_avg"]) and torch.equal(out["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
+        assert float(out["state"][i]["step"]) == float(st["step"])
+    # chunked-block models (vitl14 / vitg14 YAMLs): blocks.<chunk>.<i>. <-> blocks.<i>.
+    assert CK.vit_key_to_flat("blocks.2.13.mlp.fc1.weight") == "blocks.13.mlp.fc1.weight"
+    assert CK.vit_key_from_flat("blocks.13.mlp.fc1.weight", 24, 4) == "blocks.2.13.mlp.fc1.weight"
+    assert CK.vit_key_from_flat("norm.weight", 24, 4) == "norm.weight"
+    with pytest.raises(KeyError):
+        CK.load_method_state_dict({k: v for k, v in ck["state_dict"].items() if "cls_token" not in k}, student, teacher, False, True)
+    with pytest.raises(ValueError):
+        CK.load_method_state_dict(dict(ck["state_dict"], **{"dino_loss.center": ck["state_dict"]["dino_loss.center"],
+                                                            "student_head.dino_head.mlp.0.bias": torch.zeros(3)}), student, teacher, False, True)
