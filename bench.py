@@ -35,6 +35,17 @@ MODELS = {
 }
 
 
+def kernel_sha16() -> str:
+    """sha256 (first 16 hex) of the GEMM kernel sources: stamps PMC measurements to the code they were taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "lt_common.h"):
+        with open(os.path.join(ROOT, "lightly-train_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def step_flops_per_image(D: int, depth: int, hidden: int, n_g: int, n_l: int, n_local: int, K: int, head_hidden: int,
                          bottleneck: int, m_tokens: float, p: int = 16, in_chans: int = 3) -> float:
     """Algorithmic FLOPs (2*MAC) per image, SURVEY.md 8(d): teacher fwd + heads_t + 3*(student fwd + heads_s)."""
@@ -51,27 +62,50 @@ def step_flops_per_image(D: int, depth: int, hidden: int, n_g: int, n_l: int, n_
     return teacher + 3 * student
 
 
-def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int) -> dict:
-    """The oracle (CPU port of the reference step, oracle/dinov2_oracle.py) timed on the host cores: a bounded
-    sample (batch 4, 1 warm-up + 1 timed step).  Reported baseline only."""
-    from oracle import dinov2_oracle as O
+def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 3) -> dict:
+    """CPU baseline (BASELINE.md section 3 / SURVEY 8(d)): a full training step (training_step_impl + backward + clip + AdamW + EMA)
+    in fp32 on the host cores, bounded sample: batch 4, 1 warm-up + `timed_steps` timed steps, MEDIAN step time.
+    kind "reference": the reference's own DINOv2 class driven through oracle/ref_harness.py -- only where /root/reference exists
+    (the build container; it cannot travel to the GPU box); kind "port": oracle/dinov2_oracle.py, the pinned restatement of that
+    step (bit-level equal losses, tests/test_oracle_pin.py).  Reported baseline only, never the measured path."""
+    import statistics
 
     b = 4
     g = torch.Generator().manual_seed(0)
     name = {768: "vit_base", 384: "vit_small", 1024: "vit_large", 192: "vit_tiny"}[arch["embed_dim"]]
-    sb, cfg = O.init_vit_params(name, patch_size=16, img_size=g_size, generator=g)
-    sh = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
-    th = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
-    o = O.OracleDINOv2(sb, sh, cfg, args=dict(output_dim=K), global_batch_size=b, total_steps=1000, teacher_head=th)
     views = [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
         torch.randn(b, 3, l_size, l_size, generator=g) for _ in range(n_local)]
+    kind, step = "port", None
+    try:
+        from oracle import ref_harness as H
+
+        if H.reference_available() and l_size % 16 == 0:   # the reference's wrapper cannot run 98^2 crops at patch 16 (SURVEY 8(d))
+            m = H.build_reference_method(arch=name, patch_size=16, img_size=g_size, method_kwargs=dict(output_dim=K), global_batch_size=b,
+                                         total_steps=1000)
+            runner = H.ReferenceRunner(m)
+            kind, step = "reference", (lambda: runner.train_step(views))
+    except Exception:
+        step = None
+    if step is None:
+        from oracle import dinov2_oracle as O
+
+        sb, cfg = O.init_vit_params(name, patch_size=16, img_size=g_size, generator=g)
+        sh = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
+        th = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
+        o = O.OracleDINOv2(sb, sh, cfg, args=dict(output_dim=K), global_batch_size=b, total_steps=1000, teacher_head=th)
+        step = lambda: o.train_step(views)   # noqa: E731
     random.seed(0)
-    o.train_step(views)
-    t0 = time.perf_counter()
-    o.train_step(views)
-    dt = time.perf_counter() - t0
-    return {"value": b / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/dinov2_oracle.py fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, 1 warm-up + 1 timed step"}
+    step()
+    times = []
+    for _ in range(timed_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    what = "the reference's own DINOv2.training_step_impl via oracle/ref_harness.py" if kind == "reference" else "oracle/dinov2_oracle.py"
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": f"{what}, fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, 1 warm-up + {timed_steps} timed steps, median "
+                      f"(step times {', '.join(f'{t:.2f}' for t in times)} s)"}
 
 
 def main() -> None:
@@ -227,18 +261,24 @@ def main() -> None:
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process; the committed value comes from
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01q_pmc_step_report.md, gfx950 corrections
         # applied by tools/pmc_step_traffic.py).  Only quoted for the configuration it was measured on.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01q_gemm_traffic.json")
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         default_cfg = (args.method == "dinov2" and args.model == "vit_base" and B == 128 and args.global_size == 224 and args.local_size == 98 and args.n_local == 8
                        and args.out_dim == 65536)
         if default_cfg and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("gemm_launches_per_step") == len(recs):
+            # the committed PMC measurement is only quoted for the kernels it was taken on: it carries the sha256 of the GEMM
+            # sources and the launch count of the step; a stale stamp (kernel edited since) is refused
+            if tj.get("gemm_launches_per_step") == len(recs) and tj.get("kernel_sha16") == kernel_sha16():
                 traffic = round(tj["traffic_bytes_per_launch"])
+                traffic_src = tj.get("profile", "profiles/gemm_traffic.json")
+            else:
+                traffic_src = "profiles/gemm_traffic.json is stale for this build (kernel sha / launch count differ): not quoted"
         roofline = {"bound": "mfma", "kernel": "gemm256q_kernel<TA,TB,EPI,SLAB> (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per GEMM launch, L2 memory-side (FETCH_SIZE x 2 + WRITE_SIZE), profiles/r01q_pmc_step_report.md",
+                    "traffic_unit": "bytes per GEMM launch, L2 memory-side (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes)",
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
                     "gemm_flops_per_step": fl, "step_algorithmic_gflop_per_image": round(gf_img, 1),
                     "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}

@@ -3,7 +3,9 @@
 /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE (KiB) is doubled (128-B requests tallied at 64 B for wide
 coalesced reads); WRITE_SIZE (KiB) is used as reported (it matched the algorithmic store bytes of six isolated
 GEMM shapes within 1 %, profiles/r01h_gemm_traffic.md)."""
-import csv, json, re, sys, collections
+import csv, json, os, re, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def load(path):
     per = collections.defaultdict(list)
@@ -24,7 +26,10 @@ print("| kernel | launches/step | read MB/launch (2 x FETCH_SIZE) | write MB/lau
 print("|---|---|---|---|")
 for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
     print(f"| `{k}` | {len(fetch[k]) // steps} | {2 * sum(fetch[k]) / len(fetch[k]) / 1e6:.0f} | {sum(write[k]) / len(write[k]) / 1e6:.0f} |")
-out = {"gemm_launches_per_step": n // steps, "read_bytes_per_launch": tot_f / n, "write_bytes_per_launch": tot_w / n,
+import bench  # noqa: E402  (kernel_sha16: the stamp bench.py checks before quoting this measurement)
+
+out = {"kernel_sha16": bench.kernel_sha16(), "profile": sys.argv[3] if len(sys.argv) > 3 else "profiles/gemm_traffic.json",
+       "gemm_launches_per_step": n // steps, "read_bytes_per_launch": tot_f / n, "write_bytes_per_launch": tot_w / n,
        "traffic_bytes_per_launch": (tot_f + tot_w) / n, "traffic_bytes_per_step": (tot_f + tot_w) / steps,
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 --single-stream; FETCH_SIZE doubled (gfx950)"}
 print()
