@@ -308,7 +308,7 @@ class ViTEngine:
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
                 drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None,
-                checkpoint: bool = False) -> Dict[str, Any]:
+                checkpoint: bool = False, capture_layers: Optional[Iterable[int]] = None, capture_norm: bool = True) -> Dict[str, Any]:
         """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
 
         drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
@@ -431,6 +431,19 @@ class ViTEngine:
         ctx["run_block"] = run_block
         blocks: List[Dict[str, Any]] = []
         block_in: List[Tensor] = []
+        # get_intermediate_layers (vision_transformer.py:386-480): outputs of the listed blocks, through the final norm
+        cap_set = set(int(c) for c in capture_layers) if capture_layers is not None else set()
+        captured: Dict[int, Tensor] = {}
+
+        def capture(i: int, xb: Tensor) -> None:
+            out = ws.get(f"{tag}.cap{i}", (B, N, D), torch.float32)
+            if capture_norm:
+                ops.layernorm_fwd(xb, self.w("norm.weight"), self.w("norm.bias"), T, D, y_f32=out, mean=ws.get(tag + ".capm", (T,), torch.float32),
+                                  rstd=ws.get(tag + ".capr", (T,), torch.float32), eps=cfg.ln_eps)
+            else:
+                out.view(T, D).copy_(xb)
+            captured[i] = out
+
         for i in range(cfg.depth):
             if save and checkpoint:
                 # activation checkpointing (reference _activation_checkpointing.py): keep only the block input, recompute the
@@ -447,7 +460,10 @@ class ViTEngine:
                 x, a_, m_ = run_block(i, x, f"{tag}.b{i}." if save else f"{tag}.tmp.", save, save)
                 if save:
                     blocks.append({"attn": a_, "mlp": m_})
+            if i in cap_set:
+                capture(i, x)
         ctx["block_in"] = block_in if (save and checkpoint) else None
+        ctx["captured"] = captured
         xn = ws.get(tag + ".xn", (B, N, D), torch.float32)
         mean = ws.get(tag + ".meanf", (T,), torch.float32)
         rstd = ws.get(tag + ".rstdf", (T,), torch.float32)
