@@ -121,7 +121,8 @@ def main() -> None:
     ap.add_argument("--out-dim", type=int, default=65536)
     ap.add_argument("--method", default="dinov2", choices=["dinov2", "distillationv3"],
                     help="dinov2 = the BASELINE metric; distillationv3 = SURVEY 8(a) a22: frozen DINOv3 ViT-L/16 teacher -> ViT student, one 224^2 view")
-    ap.add_argument("--student", default="dinov2", choices=["dinov2", "dinov3"], help="distillationv3 only: student ViT family (dinov3 = RoPE, storage tokens)")
+    ap.add_argument("--student", default="dinov2", choices=["dinov2", "dinov3", "resnet50"],
+                    help="distillationv3 only: student family -- dinov2 / dinov3 ViT of --model size, or torchvision's resnet50 (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
@@ -162,6 +163,10 @@ def main() -> None:
         tcfg = dinov3_vit_config(1024, 24, 16, patch_size=16, img_size=args.global_size)     # dinov3_vitl16
         if args.student == "dinov3":
             cfg = dinov3_vit_config(arch["embed_dim"], arch["depth"], arch["num_heads"], patch_size=16, img_size=args.global_size, rope_rescale=2.0)
+        elif args.student == "resnet50":
+            from lightly_train_amd.resnet import ResNetConfig
+
+            cfg = ResNetConfig()
         method = DistillationV3(cfg, tcfg, DistillationV3Args(), global_batch_size=B * world, total_steps=125_000, max_epochs=100, device=dev, seed=0)
         views = torch.randn(B, 3, args.global_size, args.global_size, generator=g).to(dev)
         if args.host_inputs:
@@ -220,7 +225,12 @@ def main() -> None:
         def vit_fwd(D: int, depth: int, T: int) -> float:
             return depth * (2 * T * 12 * D * D + 4 * T * T * D) + 2 * (n_g - 1) * D * 3 * 256
         # teacher forward (ViT-L/16, 1 + 4 + 196 tokens) + 3 x student forward; projection heads / similarity GEMMs are < 1 %
-        gf_img = (vit_fwd(1024, 24, n_g + 4) + 3 * vit_fwd(arch["embed_dim"], arch["depth"], n_g)) / 1e9
+        if args.student == "resnet50":
+            # torchvision resnet50 at 224^2: 4.09 GMAC forward (the published figure) = 8.18 GFLOP, scaled with the image area
+            s_fwd = 8.18e9 * (args.global_size / 224.0) ** 2
+        else:
+            s_fwd = vit_fwd(arch["embed_dim"], arch["depth"], n_g)
+        gf_img = (vit_fwd(1024, 24, n_g + 4) + 3 * s_fwd) / 1e9
     else:
         m_tokens = method._last["M"] / B
         gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
@@ -289,9 +299,10 @@ def main() -> None:
 
     if rank == 0:
         if args.method == "distillationv3":
-            metric = f"images/sec DistillationV3 DINOv3 ViT-L/16 teacher -> {args.student} {args.model}/16 student"
-            workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> {args.student} {args.model}/16 student, per-GPU batch {B}, "
-                        f"one {args.global_size}^2 view, queue 8192 (BASELINE config 4 names a torchvision/resnet50 student: not built)")
+            sname = "torchvision/resnet50" if args.student == "resnet50" else f"{args.student} {args.model}/16"
+            metric = f"images/sec DistillationV3 DINOv3 ViT-L/16 teacher -> {sname} student"
+            workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> {sname} student, per-GPU batch {B}, "
+                        f"one {args.global_size}^2 view, queue 8192" + (" (= BASELINE configs[3])" if args.student == "resnet50" else ""))
         else:
             metric = "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops"
             workload = (f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "

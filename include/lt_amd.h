@@ -240,6 +240,42 @@ int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
  * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
 int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolutional student (torchvision ResNet-50 of BASELINE configs[3]; reference wrapper LT/_models/torchvision/resnet.py:21-47,
+ * driven from LT/_methods/distillationv3/distillationv3.py:324-354).  Activations are NHWC bf16 = [B*H*W, C] matrices, so a
+ * convolution is lt_gemm_bf16 on an im2col matrix; weights are held [Cout][kh][kw][Cin].  C must be a multiple of 8.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* cols[(b,oy,ox)][(ky*KW+kx)*C + c] = x[b][oy*stride-pad+ky][ox*stride-pad+kx][c] (zero outside); ld = row stride of cols (>= KH*KW*C).
+ * KH = KW = 1 with stride 2 is the row gather of a strided 1x1 convolution (ResNet downsample path). */
+int lt_im2col_nhwc_bf16(const void* x, void* cols, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int ld, void* stream);
+/* transpose of the above (dgrad of the gather), deterministic gather form: dx[pixel] = sum of the dcols entries that read it (+ add[pixel]) */
+int lt_col2im_nhwc_bf16(const void* dcols, const void* add, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int ld,
+                        void* stream);
+/* stem: NCHW f32 image -> cols[(b,oy,ox)][c*KH*KW + ky*KW + kx] bf16 (the order of conv.weight.flatten(1)), zero-padded to ld columns */
+int lt_im2col_nchw_f32(const float* x, void* cols, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int ld, void* stream);
+/* training-mode BatchNorm (nn.BatchNorm2d / BatchNorm1d in train(): batch statistics over the rows of x bf16 [rows, C], fp32 math):
+ * y = act(gamma * (x - mean) * rstd + beta (+ resid)), act = ReLU if relu else identity; saves mean / rstd [C] for backward and
+ * updates the running estimates (momentum, unbiased variance) when given.  ws: lt_batchnorm_ws_floats(C) floats of scratch. */
+#define LT_BN_MAX_CHUNKS 512
+int64_t lt_batchnorm_ws_floats(int C);
+int lt_batchnorm_fwd(const void* x, const float* gamma, const float* beta, const void* resid, void* y, float* mean, float* rstd,
+                     float* running_mean, float* running_var, int64_t rows, int C, float eps, float momentum, int relu, float* ws, void* stream);
+/* eval-mode BatchNorm: the same affine map with caller-provided statistics (running_mean, 1/sqrt(running_var + eps)) */
+int lt_batchnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* resid, void* y,
+                       int64_t rows, int C, int relu, void* stream);
+/* backward of the training-mode forward: dz = dy * (y > 0) when y (the activated output) is given (stored to dz, which the residual path re-uses),
+ * else dz = dy; dgamma += sum dz*xhat, dbeta += sum dz, dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz*xhat)). */
+int lt_batchnorm_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* mean, const float* rstd, void* dz, void* dx,
+                     float* dgamma, float* dbeta, int64_t rows, int C, float* ws, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16 with the arg-max tap saved per element (uint8, first maximum in scan order wins) */
+int lt_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int lt_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, void* stream);
+/* AdaptiveAvgPool2d(1) over the n positions of every image: x bf16 [B, n, C] -> out bf16 [B, C] */
+int lt_token_mean_bf16(const void* x, void* out, int B, int n, int C, void* stream);
+/* gradient reaching the feature map: out[b,p,:] = d_tok[b,p,:] + d_pool[b,:] / n (either input may be null), bf16 out */
+int lt_pool_bwd_add(const float* d_tok, const float* d_pool, void* out_bf16, int B, int n, int C, void* stream);
+int lt_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

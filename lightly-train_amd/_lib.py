@@ -74,6 +74,17 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_sumsq_f32": [vp, vp, i64, vp],
     "lt_adamw_flat": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, f32, f32, C.c_double, C.c_double, f32, i32, vp, f32, vp],
     "lt_ema_flat": [vp, vp, vp, i64, C.c_double, vp],
+    "lt_im2col_nhwc_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lt_col2im_nhwc_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lt_im2col_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lt_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, vp],
+    "lt_batchnorm_apply": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "lt_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
+    "lt_maxpool3x3s2_fwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "lt_maxpool3x3s2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "lt_token_mean_bf16": [vp, vp, i32, i32, i32, vp],
+    "lt_pool_bwd_add": [vp, vp, vp, i32, i32, i32, vp],
+    "lt_add_bf16": [vp, vp, vp, i64, vp],
 }
 
 _lib: C.CDLL | None = None
@@ -98,6 +109,8 @@ def load() -> C.CDLL:
     lib.lt_last_error.argtypes = []
     lib.lt_attention_bwd_ws_floats.restype = C.c_int64
     lib.lt_attention_bwd_ws_floats.argtypes = [i32, i32, i32, i32]
+    lib.lt_batchnorm_ws_floats.restype = C.c_int64
+    lib.lt_batchnorm_ws_floats.argtypes = [i32]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, also loud
         fn.argtypes = argtypes

@@ -1,15 +1,19 @@
-"""DistillationV3 on MI355X: frozen ViT teacher -> ViT student, the whole step in HIP.
+"""DistillationV3 on MI355X: frozen ViT teacher -> ViT or ResNet student, the whole step in HIP.
 
 Mirrors LT/_methods/distillationv3/distillationv3.py: `DistillationV3Args` (:109-169), `DistillationV3.training_step_impl`
 (:235-273), `_mixup_data` (:356-368), `_forward_teacher` (:293-322), `_forward_student` (:324-354), `_update_queue` (:275-291),
 `DistillationV3Loss.forward` (distillationv3_loss.py:35-117), `configure_gradient_clipping` (:400-410, norm 1.0) and the generic
 `Method.configure_optimizers` (LT/_methods/method.py:89-121: AdamW, sqrt LR scaling, CosineWarmupScheduler).
 
-Teacher: DINOv3 ViT (RoPE, storage tokens; `dinov3.py`) or a DINOv2 ViT; student: DINOv2 ViT -- both on `vit.ViTEngine`.
-State-dict names follow the reference: `student_embedding_model.wrapped_model._model.*`, `student_projection_head_global.*`,
+Teacher: DINOv3 ViT (RoPE, storage tokens; `dinov3.py`) or a DINOv2 ViT on `vit.ViTEngine`; student: a DINOv2 / DINOv3 ViT on the
+same engine, or the torchvision ResNet-50 of BASELINE configs[3] on `resnet.ResNetEngine` (NHWC convolutions as MFMA GEMMs,
+training-mode BatchNorm): its layer4 map [B, 2048, 7, 7] is the token matrix [B*49, 2048], the pooled feature its average
+(`ResNetModelWrapper.forward_pool`, LT/_models/torchvision/resnet.py:40-44), the local projection is resized 7x7 -> 14x14.
+State-dict names follow the reference: `student_embedding_model.wrapped_model._model.*` (ViT) /
+`student_embedding_model.wrapped_model._features.*` (ResNet: the wrapper's IntermediateLayerGetter), `student_projection_head_global.*`,
 `student_projection_head_local.*`, `teacher_queue`.
 
-Not implemented (raise): convolutional students (torchvision/resnet50 of BASELINE config 4), LARS.
+Not implemented: LARS (lightly.utils.lars is not vendored in the reference tree; AdamW is the method's "auto" optimizer).
 """
 from __future__ import annotations
 
@@ -26,6 +30,7 @@ from . import ops
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import warmup_cosine_lr_factor
+from .resnet import ResNetConfig, ResNetEngine, flat_named, init_resnet_state
 from .vit import ViTConfig, ViTEngine, Workspace, _split_k, vit_param_shapes
 
 NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "pos_embed")
@@ -33,7 +38,8 @@ NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "
 
 @dataclass
 class DistillationV3Args:
-    """Method + AdamW arguments (distillationv3.py:109-193; weight_decay "auto" resolves to 0.04 for transformer students)."""
+    """Method + AdamW arguments (distillationv3.py:109-193).  weight_decay None = the reference's "auto": 0.04 for transformer
+    students, 1e-6 for convolutional ones (DistillationV3AdamWArgs.resolve_auto, :163-170)."""
     queue_size: int = 8192
     temperature_global: float = 0.07
     temperature_local: float = 0.07
@@ -43,7 +49,7 @@ class DistillationV3Args:
     lr: float = 0.0005
     betas: Tuple[float, float] = (0.9, 0.999)
     eps: float = 1e-8
-    weight_decay: float = 0.04
+    weight_decay: Optional[float] = None
     gradient_clip_val: float = 1.0
 
 
@@ -69,7 +75,7 @@ class _Trainer:
 
 
 class DistillationV3:
-    def __init__(self, student_cfg: ViTConfig, teacher_cfg: ViTConfig, method_args: Optional[DistillationV3Args] = None,
+    def __init__(self, student_cfg: "ViTConfig | ResNetConfig", teacher_cfg: ViTConfig, method_args: Optional[DistillationV3Args] = None,
                  global_batch_size: int = 128, total_steps: int = 100_000, max_epochs: int = 100, device: str | torch.device = "cuda",
                  student_state: Optional[Dict[str, Tensor]] = None, teacher_state: Optional[Dict[str, Tensor]] = None,
                  proj_global_state: Optional[Dict[str, Tensor]] = None, proj_local_state: Optional[Dict[str, Tensor]] = None,
@@ -78,11 +84,15 @@ class DistillationV3:
 
         self.method_args = a = method_args or DistillationV3Args()
         self.scfg, self.tcfg = student_cfg, teacher_cfg
+        self.conv_student = isinstance(student_cfg, ResNetConfig)
+        if a.weight_decay is None:
+            a.weight_decay = 1e-6 if self.conv_student else 0.04
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("DistillationV3 runs on an MI355X only (no CPU fallback for the HIP kernels)")
         g = torch.Generator().manual_seed(seed)
-        Ds, Dt = student_cfg.embed_dim, teacher_cfg.embed_dim
+        Ds, Dt = (student_cfg.feature_dim if self.conv_student else student_cfg.embed_dim), teacher_cfg.embed_dim
+        self.Ds = Ds
         def random_init(c: ViTConfig) -> Dict[str, Tensor]:
             sd = init_vit_state(c, g)
             if c.rope_base is not None:          # RoPE models have no positional table: the engine's slot stays zero
@@ -93,7 +103,10 @@ class DistillationV3:
                         sd[k][c.embed_dim:2 * c.embed_dim] = 0
             return sd
 
-        sb = student_state if student_state is not None else random_init(student_cfg)
+        if self.conv_student:
+            sb = student_state if student_state is not None else init_resnet_state(student_cfg, g)
+        else:
+            sb = student_state if student_state is not None else random_init(student_cfg)
         tb = teacher_state if teacher_state is not None else random_init(teacher_cfg)
 
         def lin(state: Optional[Dict[str, Tensor]]) -> Dict[str, Tensor]:
@@ -104,12 +117,21 @@ class DistillationV3:
             return {"weight": w, "bias": torch.empty(Dt).uniform_(-bound, bound, generator=g)}
 
         pg, pl = lin(proj_global_state), lin(proj_local_state)
-        named: List[Tuple[str, Tensor]] = [("backbone." + n, sb[n]) for n, _ in vit_param_shapes(student_cfg)]
+        if self.conv_student:
+            named: List[Tuple[str, Tensor]] = flat_named(student_cfg, sb, "backbone.")
+        else:
+            named = [("backbone." + n, sb[n]) for n, _ in vit_param_shapes(student_cfg)]
         named += [("proj_global.weight", pg["weight"]), ("proj_global.bias", pg["bias"]),
                   ("proj_local.weight", pl["weight"]), ("proj_local.bias", pl["bias"])]
         self.student = FlatParams(named, dev, True)
         self.teacher = FlatParams([(n, tb[n]) for n, _ in vit_param_shapes(teacher_cfg)], dev, False)
-        self.s_vit = ViTEngine(student_cfg, self.student, "backbone.")
+        if self.conv_student:
+            self.s_net = ResNetEngine(student_cfg, self.student, "backbone.", buffers=sb)
+            self.s_vit = None
+            # the classifier is part of the exported torchvision state_dict but not of the wrapper's trained parameters
+            self._fc = {k: sb[k].detach().clone() for k in ("fc.weight", "fc.bias") if k in sb}
+        else:
+            self.s_vit = ViTEngine(student_cfg, self.student, "backbone.")
         self.t_vit = ViTEngine(teacher_cfg, self.teacher, "")
         self.ws = Workspace(dev)
         self.teacher_queue = torch.zeros(a.queue_size, Dt, device=dev)
@@ -139,7 +161,7 @@ class DistillationV3:
         # data parallel: per-block gradient all-reduces issued during backward (see dinov2.py); LT_GRAD_OVERLAP=0 = after it
         self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
         self._proj_span = self.student.span(("proj_global.", "proj_local."))
-        self._block_spans = [self.student.span((f"backbone.blocks.{i}.",)) for i in range(student_cfg.depth)]
+        self._block_spans = [] if self.conv_student else [self.student.span((f"backbone.blocks.{i}.",)) for i in range(student_cfg.depth)]
         self._idx: Dict[Tuple[int, int, int], Tuple[Tensor, Tensor]] = {}
         self._resample_tabs: Dict[Tuple[int, int, int, int], Any] = {}
 
@@ -176,7 +198,7 @@ class DistillationV3:
     # ------------------------------------------------------------------ the step
     def training_step_impl(self, batch: Dict[str, Any], batch_idx: int, mix: Optional[Tuple[float, Tensor]] = None) -> TrainingStepResult:
         a, ws, dev = self.method_args, self.ws, self.device
-        Ds, Dt = self.scfg.embed_dim, self.tcfg.embed_dim
+        Ds, Dt = self.Ds, self.tcfg.embed_dim
         views = batch["views"][0].to(dev, torch.float32, non_blocking=True).contiguous()
         B = views.shape[0]
         # ---- mixup (:356-368): lambda ~ U(0,1), random permutation -- same host RNG draws, same order, as the reference
@@ -229,19 +251,30 @@ class DistillationV3:
 
         # ---- student forward
         s_rope = None
-        if self.scfg.rope_base is not None:   # DINOv3 student in training mode: per-block RoPE tables, drawn after the mixup draws
-            p_ = self.scfg.patch_size
-            s_rope = self.s_vit.rope_tables_train(-(-x.shape[2] // p_), -(-x.shape[3] // p_))
-        sc = self.s_vit.forward(ws, "s", x, None, save=True, rope_tables=s_rope)
-        Ns, pre_s = sc["N"], 1 + self.scfg.num_register_tokens
-        n_ps = Ns - pre_s
-        resize = (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"])   # bilinear resize of the student map onto the teacher grid (:338-345)
-        s_cls_rows, s_patch_rows = self._rows(B, Ns, pre_s)
-        sxn = sc["xn"].view(-1, Ds)
-        sg_in = ws.get("s.g_in", (B, Ds), torch.bfloat16)
-        sl_in = ws.get("s.l_in", (B * n_ps, Ds), torch.bfloat16)
-        ops.gather_rows(sxn, Ds, s_cls_rows, B, Ds, out_bf16=sg_in)
-        ops.gather_rows(sxn, Ds, s_patch_rows, B * n_ps, Ds, out_bf16=sl_in)
+        if self.conv_student:
+            # ResNet student (distillationv3.py:324-354 with ResNetModelWrapper): layer4 map as tokens, pooled = their average
+            sc = self.s_net.forward(ws, "s", x, save=True, train=True)
+            Ds = self.Ds
+            n_ps = sc["h"] * sc["w"]
+            sc["gh"], sc["gw"] = sc["h"], sc["w"]
+            resize = (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"])
+            sl_in = sc["feat"]                                                    # bf16 [B * n_ps (+pad), Ds]
+            sg_in = ws.get("s.g_in", (B, Ds), torch.bfloat16)
+            ops.token_mean(sl_in, sg_in, B, n_ps, Ds)
+        else:
+            if self.scfg.rope_base is not None:   # DINOv3 student in training mode: per-block RoPE tables, drawn after the mixup draws
+                p_ = self.scfg.patch_size
+                s_rope = self.s_vit.rope_tables_train(-(-x.shape[2] // p_), -(-x.shape[3] // p_))
+            sc = self.s_vit.forward(ws, "s", x, None, save=True, rope_tables=s_rope)
+            Ns, pre_s = sc["N"], 1 + self.scfg.num_register_tokens
+            n_ps = Ns - pre_s
+            resize = (sc["gh"], sc["gw"]) != (tc["gh"], tc["gw"])   # bilinear resize of the student map onto the teacher grid (:338-345)
+            s_cls_rows, s_patch_rows = self._rows(B, Ns, pre_s)
+            sxn = sc["xn"].view(-1, Ds)
+            sg_in = ws.get("s.g_in", (B, Ds), torch.bfloat16)
+            sl_in = ws.get("s.l_in", (B * n_ps, Ds), torch.bfloat16)
+            ops.gather_rows(sxn, Ds, s_cls_rows, B, Ds, out_bf16=sg_in)
+            ops.gather_rows(sxn, Ds, s_patch_rows, B * n_ps, Ds, out_bf16=sl_in)
         P = self.student
         n_pl = n_pt if resize else n_ps            # tokens per image of the (resized) student local features
         sg_raw = ws.get("s.g", (B, Dt), torch.float32)
@@ -303,34 +336,41 @@ class DistillationV3:
             tiles = ((Dt + 127) // 128) * ((Ds + 127) // 128)   # few output tiles, long contraction: split-K into slabs
             ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds,
                      split_k=_split_k(tiles, rows), workspace=slab)
-        dxn = ws.get("s.dxn", (B * Ns, Ds), torch.float32)
-        dxn.zero_()
         dcls = ws.get("s.dcls", (B, Ds), torch.float32)
         dpat = ws.get("s.dpat", (B * n_ps, Ds), torch.float32)
         ops.gemm(dsg, P.b["proj_global.weight"], dcls, M=B, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
         ops.gemm(dsl, P.b["proj_local.weight"], dpat, M=B * n_ps, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
-        ops.scatter_add_rows(dcls, s_cls_rows, dxn, Ds, B, Ds)
-        ops.scatter_add_rows(dpat, s_patch_rows, dxn, Ds, B * n_ps, Ds)
         sync = self._gradient_sync() if self.overlap_grad_reduce else None
         done_blocks: List[int] = []
         if sync is not None:
-            sync.start(*self._proj_span)   # projection heads are final: reduce them under the ViT backward
-        blk = self.scfg.depth
-        for ev in self.s_vit.backward_iter(ws, sc, dxn.view(B, Ns, Ds), side=self.side_stream):
-            if ev == "block":
-                blk -= 1
-                if sync is not None:   # block `blk` is final: LayerScale gradients, then its all-reduce, beside the rest of backward
-                    rs = self.reduce_stream
-                    rs.wait_event(main.record_event())
-                    rs.wait_event(self.side_stream.record_event())
-                    with torch.cuda.stream(rs):
-                        self.s_vit.finish_layerscale_grads(blocks=[blk], last_call=False)
-                        sync.start(*self._block_spans[blk])
-                    done_blocks.append(blk)
-        main.wait_stream(self.side_stream)
-        if sync is not None:
-            main.wait_stream(self.reduce_stream)
-        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.scfg.depth) if i not in done_blocks])
+            sync.start(*self._proj_span)   # projection heads are final: reduce them under the backbone backward
+        if self.conv_student:
+            # gradient reaching the layer4 map: the local path per position + the pooled path spread over the n positions
+            dfeat = ws.get("s.dfeat", (sc["feat"].shape[0], Ds), torch.bfloat16, zero=True)
+            ops.pool_bwd_add(dpat, dcls, dfeat, B, n_ps, Ds)
+            self.s_net.backward(ws, sc, dfeat, side=self.side_stream)
+            main.wait_stream(self.side_stream)
+        else:
+            dxn = ws.get("s.dxn", (B * Ns, Ds), torch.float32)
+            dxn.zero_()
+            ops.scatter_add_rows(dcls, s_cls_rows, dxn, Ds, B, Ds)
+            ops.scatter_add_rows(dpat, s_patch_rows, dxn, Ds, B * n_ps, Ds)
+            blk = self.scfg.depth
+            for ev in self.s_vit.backward_iter(ws, sc, dxn.view(B, Ns, Ds), side=self.side_stream):
+                if ev == "block":
+                    blk -= 1
+                    if sync is not None:   # block `blk` is final: LayerScale gradients, then its all-reduce, beside the rest of backward
+                        rs = self.reduce_stream
+                        rs.wait_event(main.record_event())
+                        rs.wait_event(self.side_stream.record_event())
+                        with torch.cuda.stream(rs):
+                            self.s_vit.finish_layerscale_grads(blocks=[blk], last_call=False)
+                            sync.start(*self._block_spans[blk])
+                        done_blocks.append(blk)
+            main.wait_stream(self.side_stream)
+            if sync is not None:
+                main.wait_stream(self.reduce_stream)
+            self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.scfg.depth) if i not in done_blocks])
 
         ls = self._loss_slots
         w = a.loss_local_weight
@@ -369,7 +409,7 @@ class DistillationV3:
         ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
                        self.seg_lr, self.seg_wd_on, self.seg_frozen, False, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
                        self.opt_step, self._sumsq, a.gradient_clip_val)
-        self.s_vit.refresh_padded_weights()
+        (self.s_net if self.conv_student else self.s_vit).refresh_padded_weights()
         self.last_grad_norm = self._sumsq
         self.trainer.global_step += 1
 
@@ -378,11 +418,28 @@ class DistillationV3:
         self.optimizer_step()
         return res
 
+    def export_backbone_state_dict(self) -> Dict[str, Tensor]:
+        """What the reference exports after distillation: `get_model().state_dict()` of the STUDENT (the torchvision ResNet with
+        its untouched classifier, or the ViT)."""
+        if self.conv_student:
+            return self.s_net.state_dict(extra=self._fc)
+        bb = {n[9:]: self.student.p[n].detach().clone() for n in self.student.names if n.startswith("backbone.")}
+        if self.scfg.rope_base is not None:
+            from .dinov3 import export_dinov3_state
+
+            bb = export_dinov3_state(bb, self.scfg)
+        return bb
+
     def state_dict(self) -> Dict[str, Tensor]:
         """Reference key names; the teacher is left out like `on_save_checkpoint` does (:415-423)."""
         out: Dict[str, Tensor] = {}
-        bb = {n[9:]: self.student.p[n].detach().clone() for n in self.student.names if n.startswith("backbone.")}
-        if self.scfg.rope_base is not None:
+        if self.conv_student:   # ResNetModelWrapper registers `_features` (conv1 .. layer4) and `_pool`; `fc` is not a submodule
+            for k, v in self.s_net.state_dict().items():
+                out["student_embedding_model.wrapped_model._features." + k] = v
+            bb = {}
+        else:
+            bb = {n[9:]: self.student.p[n].detach().clone() for n in self.student.names if n.startswith("backbone.")}
+        if not self.conv_student and self.scfg.rope_base is not None:
             from .dinov3 import export_dinov3_state
 
             bb = export_dinov3_state(bb, self.scfg)

@@ -357,3 +357,94 @@ def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tens
 
 def ema_flat(teacher: Tensor, student: Tensor, teacher_bf16: Optional[Tensor], m: float) -> None:
     check(_lib.load().lt_ema_flat(_p(teacher), _p(student), _p(teacher_bf16), teacher.numel(), m, _stream()), "lt_ema_flat")
+
+
+# ------------------------------------------------------------------------------------------ convolutional student (NHWC bf16)
+def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col_nhwc(x: Tensor, cols: Tensor, B: int, H: int, W: int, Cc: int, KH: int, KW: int, stride: int, pad: int) -> Tensor:
+    _chk(x, torch.bfloat16, "im2col.x")
+    _chk(cols, torch.bfloat16, "im2col.cols")
+    check(_lib.load().lt_im2col_nhwc_bf16(_p(x), _p(cols), B, H, W, Cc, KH, KW, stride, pad, cols.shape[-1], _stream()), "lt_im2col_nhwc_bf16")
+    return cols
+
+
+def col2im_nhwc(dcols: Tensor, dx: Tensor, B: int, H: int, W: int, Cc: int, KH: int, KW: int, stride: int, pad: int,
+                add: Optional[Tensor] = None) -> Tensor:
+    _chk(dcols, torch.bfloat16, "col2im.dcols")
+    _chk(dx, torch.bfloat16, "col2im.dx")
+    check(_lib.load().lt_col2im_nhwc_bf16(_p(dcols), _p(add), _p(dx), B, H, W, Cc, KH, KW, stride, pad, dcols.shape[-1], _stream()),
+          "lt_col2im_nhwc_bf16")
+    return dx
+
+
+def im2col_nchw_f32(img: Tensor, cols: Tensor, KH: int, KW: int, stride: int, pad: int) -> Tensor:
+    _chk(img, torch.float32, "im2col_nchw.img")
+    _chk(cols, torch.bfloat16, "im2col_nchw.cols")
+    B, Cin, H, W = img.shape
+    check(_lib.load().lt_im2col_nchw_f32(_p(img), _p(cols), B, Cin, H, W, KH, KW, stride, pad, cols.shape[-1], _stream()), "lt_im2col_nchw_f32")
+    return cols
+
+
+def batchnorm_ws_floats(Cc: int) -> int:
+    return int(_lib.load().lt_batchnorm_ws_floats(Cc))
+
+
+def batchnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, mean: Tensor, rstd: Tensor, rows: int, Cc: int, ws: Tensor,
+                  resid: Optional[Tensor] = None, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
+                  eps: float = 1e-5, momentum: float = 0.1, relu: bool = False) -> Tensor:
+    _chk(x, torch.bfloat16, "batchnorm.x")
+    _chk(y, torch.bfloat16, "batchnorm.y")
+    assert ws.numel() >= batchnorm_ws_floats(Cc) and ws.dtype == torch.float32
+    check(_lib.load().lt_batchnorm_fwd(_p(x), _p(gamma), _p(beta), _p(resid), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), rows, Cc,
+                                       eps, momentum, int(relu), _p(ws), _stream()), "lt_batchnorm_fwd")
+    return y
+
+
+def batchnorm_apply(x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, rows: int, Cc: int,
+                    resid: Optional[Tensor] = None, relu: bool = False) -> Tensor:
+    _chk(x, torch.bfloat16, "batchnorm_apply.x")
+    check(_lib.load().lt_batchnorm_apply(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(resid), _p(y), rows, Cc, int(relu), _stream()),
+          "lt_batchnorm_apply")
+    return y
+
+
+def batchnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx: Tensor, rows: int, Cc: int, ws: Tensor,
+                  y: Optional[Tensor] = None, dz: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None) -> Tensor:
+    _chk(dy, torch.bfloat16, "batchnorm_bwd.dy")
+    _chk(x, torch.bfloat16, "batchnorm_bwd.x")
+    assert ws.numel() >= batchnorm_ws_floats(Cc) and ws.dtype == torch.float32
+    check(_lib.load().lt_batchnorm_bwd(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, _p(ws),
+                                       _stream()), "lt_batchnorm_bwd")
+    return dx
+
+
+def maxpool3x3s2_fwd(x: Tensor, y: Tensor, idx: Tensor, B: int, H: int, W: int, Cc: int) -> None:
+    _chk(x, torch.bfloat16, "maxpool.x")
+    assert idx.dtype == torch.uint8
+    check(_lib.load().lt_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), B, H, W, Cc, _stream()), "lt_maxpool3x3s2_fwd")
+
+
+def maxpool3x3s2_bwd(dy: Tensor, idx: Tensor, dx: Tensor, B: int, H: int, W: int, Cc: int) -> None:
+    _chk(dy, torch.bfloat16, "maxpool_bwd.dy")
+    check(_lib.load().lt_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), B, H, W, Cc, _stream()), "lt_maxpool3x3s2_bwd")
+
+
+def token_mean(x: Tensor, out: Tensor, B: int, n: int, Cc: int) -> Tensor:
+    _chk(x, torch.bfloat16, "token_mean.x")
+    _chk(out, torch.bfloat16, "token_mean.out")
+    check(_lib.load().lt_token_mean_bf16(_p(x), _p(out), B, n, Cc, _stream()), "lt_token_mean_bf16")
+    return out
+
+
+def pool_bwd_add(d_tok: Optional[Tensor], d_pool: Optional[Tensor], out: Tensor, B: int, n: int, Cc: int) -> Tensor:
+    _chk(out, torch.bfloat16, "pool_bwd_add.out")
+    check(_lib.load().lt_pool_bwd_add(_p(d_tok), _p(d_pool), _p(out), B, n, Cc, _stream()), "lt_pool_bwd_add")
+    return out
+
+
+def add_bf16(a: Tensor, b: Tensor, out: Tensor) -> Tensor:
+    check(_lib.load().lt_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "lt_add_bf16")
+    return out

@@ -15,6 +15,7 @@ from torch import Tensor
 
 from . import dinov2_oracle as O2
 from . import dinov3_oracle as O3
+from . import resnet_oracle as OR
 
 NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "pos_embed")
 
@@ -42,8 +43,17 @@ class OracleDistillationV3:
                  global_batch_size: int, total_steps: int, max_epochs: int = 1, temperature_global: float = 0.07,
                  temperature_local: float = 0.07, loss_local_weight: float = 1.0, lr: float = 0.0005, weight_decay: float = 0.04,
                  reference_batch_size: int = 1536) -> None:
-        self.sb = {k: (v.detach().clone().requires_grad_(True) if not k.endswith(("bias_mask", "periods")) else v.detach().clone())
-                   for k, v in student_backbone.items()}
+        self.resnet = None
+        if student_cfg.get("kind") == "resnet":
+            # convolutional student (restated torchvision ResNet, oracle/resnet_oracle.py) in train() mode: batch-statistics BatchNorm.
+            # The trained parameters are those the reference's ResNetModelWrapper registers: conv1 .. layer4 (not the classifier).
+            self.resnet = OR.ResNet(tuple(student_cfg["layers"]), width=student_cfg.get("width", 64))
+            self.resnet.load_state_dict({k: v.detach().clone() for k, v in student_backbone.items()})
+            self.resnet.train()
+            self.sb = {n: p_ for n, p_ in self.resnet.named_parameters() if not n.startswith("fc.")}
+        else:
+            self.sb = {k: (v.detach().clone().requires_grad_(True) if not k.endswith(("bias_mask", "periods")) else v.detach().clone())
+                       for k, v in student_backbone.items()}
         self.pg = {k: v.detach().clone().requires_grad_(True) for k, v in proj_global.items()}
         self.pl = {k: v.detach().clone().requires_grad_(True) for k, v in proj_local.items()}
         self.teacher = {k: v.detach().clone() for k, v in teacher_state.items()}
@@ -77,7 +87,11 @@ class OracleDistillationV3:
             t = O3.dinov3_vit_forward(self.teacher, x, self.tcfg)
             tg = F.normalize(t["x_norm_clstoken"], dim=-1, p=2)
             tl = F.normalize(t["x_norm_patchtokens"], dim=-1, p=2)
-        if "rope_base" in self.scfg:     # DINOv3 student in training mode: one log-uniform RoPE rescale draw per block, after the
+        if self.resnet is not None:      # distillationv3.py:324-354 with ResNetModelWrapper.forward_features / forward_pool
+            fm = OR.features(self.resnet, x)                                   # [B, C, h, w]
+            s = {"cls": self.resnet.avgpool(fm).flatten(1), "patch": fm.permute(0, 2, 3, 1).flatten(1, 2)}
+            hw_s = (fm.shape[2], fm.shape[3])
+        elif "rope_base" in self.scfg:     # DINOv3 student in training mode: one log-uniform RoPE rescale draw per block, after the
             rmax = math.log(self.scfg["rope_rescale"]) if self.scfg.get("rope_rescale") else None   # mixup draws (same RNG order)
             rs = [torch.empty(1).uniform_(-rmax, rmax).exp() for _ in range(self.scfg["depth"])] if rmax is not None and rescales is None else rescales
             s3 = O3.dinov3_vit_forward(self.sb, x, self.scfg, rescales=rs)
@@ -87,8 +101,12 @@ class OracleDistillationV3:
         sg = F.linear(s["cls"], self.pg["weight"], self.pg["bias"])
         sl = F.linear(s["patch"], self.pl["weight"], self.pl["bias"])
         if sl.shape[1] != tl.shape[1]:      # bilinear resize onto the teacher grid (distillationv3.py:338-345)
-            ps_s, ps_t = self.scfg["patch_size"], self.tcfg["patch_size"]
-            hs, ws_ = x.shape[2] // ps_s, x.shape[3] // ps_s
+            ps_t = self.tcfg["patch_size"]
+            if self.resnet is not None:
+                hs, ws_ = hw_s
+            else:
+                ps_s = self.scfg["patch_size"]
+                hs, ws_ = x.shape[2] // ps_s, x.shape[3] // ps_s
             ht, wt = x.shape[2] // ps_t, x.shape[3] // ps_t
             sl = sl.reshape(sl.shape[0], hs, ws_, -1).permute(0, 3, 1, 2)
             sl = F.interpolate(sl, size=(ht, wt), mode="bilinear", align_corners=False)

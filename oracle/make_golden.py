@@ -210,6 +210,10 @@ def make_distill() -> None:
     make_distill_case("distill_v3_d64", img=64, s_patch=16, b=8)
     make_distill_case("distill_v3_d64_p14", img=112, s_patch=14, b=4)
     make_distill_case("distill_v3_d64_v3s", img=64, s_patch=16, b=8, s_kind="dinov3")   # DINOv3 student (train-mode RoPE rescale)
+    # convolutional student (BASELINE configs[3] names torchvision/resnet50): the reference's own ResNetModelWrapper + DistillationV3
+    # around the restated torchvision ResNet (oracle/resnet_oracle.py), tiny bottleneck net (1,1,1,1) x width 8 -> 2x2 map of 256
+    # channels at 64^2, resized bilinearly onto the teacher's 4x4 grid; weight decay "auto" -> 1e-6 (distillationv3.py:163-170)
+    make_distill_case("distill_v3_resnet", img=64, s_patch=16, b=8, s_kind="resnet")
 
 
 def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "dinov2") -> None:
@@ -227,7 +231,16 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "
                                  layerscale_init=0.5, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True,
                                  pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
     t.init_weights()
-    if s_kind == "dinov3":
+    if s_kind == "resnet":
+        from lightly_train._models.torchvision.resnet import ResNetModelWrapper
+        from oracle import resnet_oracle as OR
+
+        s_model = OR.ResNet((1, 1, 1, 1), width=8)
+        for n_, prm in s_model.named_parameters():    # BatchNorm affine is initialised to constants: randomise for a real test
+            if "bn" in n_ or "downsample.1" in n_:
+                prm.data.add_(0.2 * torch.randn_like(prm))
+        sw = ResNetModelWrapper(s_model)
+    elif s_kind == "dinov3":
         s_model = v3.DinoVisionTransformer(img_size=img, patch_size=s_patch, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
                                            layerscale_init=0.1, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4,
                                            mask_k_bias=True, pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32",
@@ -252,6 +265,8 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "
             "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},
             "proj_local": {k: v.detach().clone() for k, v in m.student_projection_head_local.state_dict().items()}}
     scfg = dict(patch_size=s_patch, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
+    if s_kind == "resnet":
+        scfg = dict(kind="resnet", layers=(1, 1, 1, 1), width=8)
     if s_kind == "dinov3":
         scfg.update(rope_base=100.0, rope_rescale=2.0, ln_eps=1e-5, n_storage_tokens=4, kind="dinov3")
     tcfg = dict(patch_size=16, num_heads=1, depth=2, rope_base=100.0, ln_eps=1e-5, embed_dim=64, n_storage_tokens=4, img_size=img)
@@ -287,8 +302,9 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "
              "proj_global": {k: v.detach().clone() for k, v in m.student_projection_head_global.state_dict().items()},
              "proj_local": {k: v.detach().clone() for k, v in m.student_projection_head_local.state_dict().items()},
              "queue": m.teacher_queue.detach().clone()}
+    osd = o.resnet.state_dict() if o.resnet is not None else o.sb    # parameters AND BatchNorm running statistics for the conv student
     for k, v in final["student_backbone"].items():
-        assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+        assert (osd[k].detach().float() - v.float()).abs().max().item() <= 2e-6 + 2e-5 * v.float().abs().max().item(), k
     assert (o.queue - final["queue"]).abs().max().item() < 1e-6
     torch.save({"b": b, "img": img, "total_steps": total, "queue_size": qsz, "weight_decay": float(oargs.weight_decay), "student_cfg": scfg,
                 "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final},

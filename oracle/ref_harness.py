@@ -181,6 +181,14 @@ def install() -> None:
     lus.CosineWarmupScheduler = O.CosineWarmupScheduler  # type: ignore[attr-defined]
     luo = importlib.import_module("lightly.utils.optim")
     luo.update_param_groups = O.update_param_groups  # type: ignore[attr-defined]
+    # torchvision is not installed: the convolutional student runs on the restated ResNet (oracle/resnet_oracle.py), registered
+    # where the reference's ResNetModelWrapper imports it from (LT/_models/torchvision/resnet.py:9-10)
+    from oracle import resnet_oracle as OR
+
+    tvm = importlib.import_module("torchvision.models")
+    tvm.ResNet = OR.ResNet  # type: ignore[attr-defined]
+    tvu = importlib.import_module("torchvision.models._utils")
+    tvu.IntermediateLayerGetter = OR.IntermediateLayerGetter  # type: ignore[attr-defined]
     ltu = importlib.import_module("lightly.transforms.utils")
     ltu.IMAGENET_NORMALIZE = {"mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}  # type: ignore[attr-defined]
     _INSTALLED = True

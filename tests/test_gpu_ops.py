@@ -578,3 +578,117 @@ def test_sumsq_is_deterministic_and_accumulates():
         ss = torch.full((1,), 5.0, device=DEV)
         o.sumsq(x, ss)
         assert abs(ss.item() - 5.0 - ref) < 2e-6 * ref + 1e-3
+
+
+# ------------------------------------------------------------------------------------------ convolutional student ops (csrc/conv.hip)
+def _nhwc(x):   # [B,C,H,W] -> NHWC rows [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("B,C,H,W,k,s,p", [(2, 16, 9, 11, 3, 1, 1), (3, 8, 12, 12, 3, 2, 1), (2, 32, 7, 7, 1, 2, 0), (1, 24, 5, 6, 3, 2, 1)])
+def test_im2col_col2im_nhwc(B, C, H, W, k, s, p):
+    """im2col (taps outer, channels inner) and its transpose against F.unfold / F.fold (which order columns channel-major)."""
+    o = ops()
+    g = torch.Generator().manual_seed(B * C + H)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    Ho, Wo = o.conv_out_size(H, k, s, p), o.conv_out_size(W, k, s, p)
+    cols = torch.empty(B * Ho * Wo, k * k * C, device=DEV, dtype=torch.bfloat16)
+    o.im2col_nhwc(_nhwc(x).to(DEV), cols, B, H, W, C, k, k, s, p)
+    ref = F.unfold(x.float(), k, padding=p, stride=s)                     # [B, C*k*k, L] (c outer, taps inner)
+    ref = ref.view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)
+    assert torch.equal(cols.float().cpu(), ref)
+    d = bf(torch.randn(B * Ho * Wo, k * k * C, generator=g))
+    add = bf(torch.randn(B * H * W, C, generator=g))
+    dx = torch.empty(B * H * W, C, device=DEV, dtype=torch.bfloat16)
+    o.col2im_nhwc(d.to(DEV), dx, B, H, W, C, k, k, s, p, add=add.to(DEV))
+    dref = d.float().view(B, Ho * Wo, k * k, C).permute(0, 3, 2, 1).reshape(B, C * k * k, Ho * Wo)
+    fold = F.fold(dref, (H, W), k, padding=p, stride=s)
+    want = _nhwc(fold) + add.float()
+    assert rel_err(dx, want) < 1e-2
+
+
+def test_im2col_nchw_stem():
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 20, 22, generator=g)
+    Ho, Wo = o.conv_out_size(20, 7, 2, 3), o.conv_out_size(22, 7, 2, 3)
+    cols = torch.empty(2 * Ho * Wo, 152, device=DEV, dtype=torch.bfloat16)
+    o.im2col_nchw_f32(x.to(DEV), cols, 7, 7, 2, 3)
+    ref = F.unfold(x, 7, padding=3, stride=2).permute(0, 2, 1).reshape(2 * Ho * Wo, 147)     # c outer, (ky,kx) inner = weight.flatten(1)
+    assert torch.equal(cols[:, :147].float().cpu(), bf(ref).float()) and cols[:, 147:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows,C,relu,resid", [(1000, 64, True, False), (77, 8, True, True), (4096, 256, False, False), (300, 2048, True, True),
+                                               (50000, 64, True, False)])
+def test_batchnorm_fwd_bwd(rows, C, relu, resid):
+    """Training-mode BatchNorm over rows (+ ReLU, + residual add) against F.batch_norm in fp32, running statistics included."""
+    o = ops()
+    g = torch.Generator().manual_seed(rows + C)
+    x = bf(torch.randn(rows, C, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    r = bf(torch.randn(rows, C, generator=g)) if resid else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r.float().clone().requires_grad_(True) if resid else None
+    pre = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if resid:
+        pre = pre + rr
+    ref = F.relu(pre) if relu else pre
+    y = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws = torch.empty(o.batchnorm_ws_floats(C), device=DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    o.batchnorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), y, mean, rstd, rows, C, ws, resid=r.to(DEV) if resid else None, running_mean=rmd,
+                    running_var=rvd, relu=relu)
+    assert rel_err(y, ref) < 1e-2
+    assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 1e-4
+    assert rel_err(mean, x.float().mean(0)) < 1e-4
+    dy = bf(torch.randn(rows, C, generator=g))
+    ref.backward(dy.float())
+    dz = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16) if relu else None
+    dx = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    o.batchnorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dx, rows, C, ws, y=y if relu else None, dz=dz, dgamma=dg, dbeta=db)
+    # the ReLU mask comes from the bf16-rounded output: elements whose pre-activation rounds to +-0 may differ -> norm-wise check
+    assert rel_err(dg, gr.grad) < 2e-2 and rel_err(db, br.grad) < 2e-2
+    assert rel_err(dx, xr.grad) < 3e-2
+    if resid and relu:
+        assert rel_err(dz, rr.grad) < 1e-2      # dz is also the gradient of the residual input
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 12, 12), (1, 8, 7, 9), (3, 64, 16, 16)])
+def test_maxpool3x3s2(B, C, H, W):
+    o = ops()
+    g = torch.Generator().manual_seed(C + H)
+    x = bf(torch.relu(torch.randn(B, C, H, W, generator=g)))           # ReLU output: ties at 0 exercise "first maximum wins"
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.empty(B * Ho * Wo, C, device=DEV, dtype=torch.bfloat16)
+    idx = torch.empty(B * Ho * Wo, C, device=DEV, dtype=torch.uint8)
+    o.maxpool3x3s2_fwd(_nhwc(x).to(DEV), y, idx, B, H, W, C)
+    assert torch.equal(y.float().cpu(), _nhwc(ref.detach()))
+    dy = bf(torch.randn(B, C, Ho, Wo, generator=g))
+    ref.backward(dy.float())
+    dx = torch.empty(B * H * W, C, device=DEV, dtype=torch.bfloat16)
+    o.maxpool3x3s2_bwd(_nhwc(dy).to(DEV), idx, dx, B, H, W, C)
+    assert rel_err(dx, _nhwc(xr.grad)) < 1e-2
+
+
+def test_token_mean_and_pool_backward():
+    o = ops()
+    g = torch.Generator().manual_seed(1)
+    B, n, C = 5, 49, 64
+    x = bf(torch.randn(B, n, C, generator=g))
+    out = torch.empty(B, C, device=DEV, dtype=torch.bfloat16)
+    o.token_mean(x.reshape(B * n, C).to(DEV), out, B, n, C)
+    assert rel_err(out, x.float().mean(1)) < 1e-2
+    dt, dp = torch.randn(B * n, C, generator=g), torch.randn(B, C, generator=g)
+    d = torch.empty(B * n, C, device=DEV, dtype=torch.bfloat16)
+    o.pool_bwd_add(dt.to(DEV), dp.to(DEV), d, B, n, C)
+    assert rel_err(d, dt.view(B, n, C) + dp[:, None] / n) < 1e-2
+    a, b_ = bf(torch.randn(64, 8, generator=g)), bf(torch.randn(64, 8, generator=g))
+    s = torch.empty(64, 8, device=DEV, dtype=torch.bfloat16)
+    o.add_bf16(a.to(DEV), b_.to(DEV), s)
+    assert rel_err(s, a.float() + b_.float()) < 1e-2
