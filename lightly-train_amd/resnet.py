@@ -153,6 +153,7 @@ class ResNetEngine:
             for k, init in ((".running_mean", torch.zeros(c)), (".running_var", torch.ones(c)), (".num_batches_tracked", torch.zeros((), dtype=torch.long))):
                 src = buffers[bn + k] if buffers is not None and (bn + k) in buffers else init
                 self.buffers[bn + k] = src.detach().clone().to(self.dev)
+        self.act_dtype = torch.bfloat16   # storage type of activations / activation gradients (the HIP ops only accept bf16)
         self.kreal = cfg.in_chans * 49
         self.kpad = (self.kreal + 7) // 8 * 8
         self.w_stem = torch.zeros(cfg.width, self.kpad, dtype=torch.bfloat16, device=self.dev)
@@ -193,7 +194,7 @@ class ResNetEngine:
         cfg = self.cfg
         B, Cin, H, W = img.shape
         Wd = cfg.width
-        bf = torch.bfloat16
+        bf = self.act_dtype
 
         def rows_pad(r: int) -> int:
             return (r + 63) // 64 * 64   # whole 64-row k-tiles for the weight-gradient GEMMs; pad rows stay zero
@@ -262,10 +263,10 @@ class ResNetEngine:
         `side`: optional second HIP stream for the weight-gradient GEMMs (they feed nothing but the optimizer)."""
         cfg = self.cfg
         B, tag = ctx["B"], ctx["tag"]
-        bf = torch.bfloat16
+        bf = self.act_dtype
         slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
         bnws = ws.get("bn.ws", (ops.batchnorm_ws_floats(max(2048, cfg.feature_dim)),), torch.float32)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream() if side is not None else None
 
         def wgrad(dy: Tensor, xin: Tensor, gview: Tensor, n_out: int, k_in: int, rows: int) -> None:
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)

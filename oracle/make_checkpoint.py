@@ -28,7 +28,9 @@ def main() -> None:
     from lightly_train._methods.dinov2 import utils as ref_utils
 
     b, g_size, l_size, n_local, total = 8, 96, 48, 2, 50
-    mk = dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, student_freeze_backbone_steps=1)
+    # KoLeo off: its in-branch gradients are ill-conditioned at initialisation (tests/golden/trajectory_d64.pt: a 1e-7 perturbation of the
+    # fp32 reference moves its own trajectory by 2e-3) and this fixture is about the resume mechanics, not about that term
+    mk = dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, student_freeze_backbone_steps=1, koleo_loss_weight=0.0)
     m = H.build_reference_method(arch="DinoVisionTransformer", patch_size=16, img_size=g_size,
                                  model_kwargs=dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0), method_kwargs=mk,
                                  global_batch_size=b, total_steps=total, seed=4321)

@@ -306,10 +306,70 @@ def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "
     for k, v in final["student_backbone"].items():
         assert (osd[k].detach().float() - v.float()).abs().max().item() <= 2e-6 + 2e-5 * v.float().abs().max().item(), k
     assert (o.queue - final["queue"]).abs().max().item() < 1e-6
+    extra = {}
+    if s_kind == "resnet":
+        extra["reference_bf16"] = _reference_bf16_resnet_run(init, teacher_state, steps, final, b, img, total, qsz)
     torch.save({"b": b, "img": img, "total_steps": total, "queue_size": qsz, "weight_decay": float(oargs.weight_decay), "student_cfg": scfg,
-                "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final},
+                "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final, **extra},
                os.path.join(OUT, name + ".pt"))
     print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")
+
+
+def _reference_bf16_resnet_run(init, teacher_state, steps, final, b, img, total, qsz):
+    """The reference's own DistillationV3 + ResNetModelWrapper once more from the same state and draws, but with training_step_impl
+    under torch.autocast("cpu", bfloat16) (= precision "bf16-mixed"): how far the reference's own mixed-precision path is from its
+    fp32 path on this fixture -- losses, grad-norm, and the fraction of parameter updates within 0.15 * lr * steps of the fp32 run
+    (the measure tests/test_gpu_distill.py applies to the HIP step).  BatchNorm networks at random init amplify bf16 rounding:
+    this is the yardstick for the tolerances of the convolutional student."""
+    from lightly_train._methods.distillationv3.distillationv3 import DistillationV3, DistillationV3AdamWArgs, DistillationV3Args
+    from lightly_train._models.dinov3.dinov3_src.models import vision_transformer as v3
+    from lightly_train._models.dinov3.dinov3_vit import DINOv3ViTModelWrapper
+    from lightly_train._models.embedding_model import EmbeddingModel
+    from lightly_train._models.torchvision.resnet import ResNetModelWrapper
+    from oracle import resnet_oracle as OR
+
+    t = v3.DinoVisionTransformer(img_size=img, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True,
+                                 layerscale_init=0.5, norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True,
+                                 pos_embed_rope_base=100.0, pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
+    t.load_state_dict(teacher_state)
+    s_model = OR.ResNet((1, 1, 1, 1), width=8)
+    s_model.load_state_dict(init["student_backbone"])
+    sw = ResNetModelWrapper(s_model)
+    margs = DistillationV3Args(queue_size=qsz, teacher=DINOv3ViTModelWrapper(t))
+    oargs = DistillationV3AdamWArgs()
+    oargs.resolve_auto(wrapped_model=sw)
+    m = DistillationV3(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=sw), global_batch_size=b,
+                       num_input_channels=3)
+    m.student_projection_head_global.load_state_dict(init["proj_global"])
+    m.student_projection_head_local.load_state_dict(init["proj_local"])
+    m.trainer = H.MockTrainer(total)
+    [opt], [sched] = m.configure_optimizers()
+    sched = sched["scheduler"]
+    logs = []
+    for step, rec in enumerate(steps):
+        x = torch.randn(b, 3, img, img, generator=torch.Generator().manual_seed(rec["x_seed"]))
+        torch.manual_seed(300 + step)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            res = m.training_step_impl({"views": [x], "filename": []}, 0)
+        res.loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_([p for g_ in opt.param_groups for p in g_["params"]], 1.0)
+        opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+        m.trainer.global_step += 1
+        logs.append({"loss": float(res.loss.detach()), "global_loss": float(res.log_dict["train_loss/global_loss"]),
+                     "local_loss": float(res.log_dict["train_loss/local_loss"]), "grad_norm": float(gnorm)})
+    lr = steps[-1]["logs"]["lr"]
+    agree = tot = 0
+    for k, v in final["student_backbone"].items():
+        if k.startswith("fc.") or k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue
+        ours = s_model.state_dict()[k]
+        if (v - init["student_backbone"][k]).abs().max().item() == 0:
+            continue
+        agree += int(((ours - v).abs() <= 0.15 * lr * len(steps)).sum()); tot += v.numel()
+    out = {"logs": logs, "update_agreement": agree / tot,
+           "max_rel_dev": {k: max(abs(a[k] - r["logs"][k]) / max(abs(r["logs"][k]), 1e-12) for a, r in zip(logs, steps)) for k in logs[0]}}
+    print("reference bf16-autocast vs its fp32 run:", out["update_agreement"], out["max_rel_dev"])
+    return out
 
 
 def make_dinov3_vit() -> None:

@@ -384,12 +384,20 @@ def test_koleo_gradients_per_tensor_at_a_well_conditioned_state():
         logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
         assert logs["koleo_loss"] == pytest.approx(float(ologs["koleo_loss"]), rel=2e-3)
         assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+        report = {}
         for n in m.student.names:
             ref = (o.sb[n[9:]] if n.startswith("backbone.") else o.sh[n[5:]]).grad
             if ref is None or float(ref.abs().max()) == 0.0:   # heads get no gradient from KoLeo alone
                 assert float(m.student.g[n].abs().max()) == 0.0, n
                 continue
-            assert rel(m.student.g[n].cpu(), ref) < 5e-2, (kw, n)
+            report[n] = rel(m.student.g[n].cpu(), ref)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            import json
+            with open(os.path.join(out_dir, f"koleo_grad_report_{len(kw)}.json"), "w") as f:
+                json.dump(report, f, indent=1)
+        bad = {n: r for n, r in report.items() if not r < 5e-2}
+        assert not bad, (kw, sorted(bad.items(), key=lambda t: -t[1])[:8])
 
 
 def test_koleo_value_is_logged_at_weight_zero():
@@ -460,9 +468,9 @@ def test_resume_from_a_reference_checkpoint_reproduces_the_reference_next_step()
     logs = {k.split("/")[-1]: float(val) for k, val in res.log_dict.items()}
     for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
         assert logs[k] == pytest.approx(s3["logs"][k], rel=5e-3), k
-    assert logs["koleo_loss"] == pytest.approx(s3["logs"]["koleo_loss"], rel=3e-2)
+    assert logs["koleo_loss"] == pytest.approx(s3["logs"]["koleo_loss"], rel=3e-2)     # logged although its weight is 0 in this fixture
     m.optimizer_step()
-    assert float(m.last_grad_norm.sqrt()) == pytest.approx(s3["logs"]["grad_norm"], rel=8e-2)
+    assert float(m.last_grad_norm.sqrt()) == pytest.approx(s3["logs"]["grad_norm"], rel=3e-2)
     m.on_train_batch_end()
     after = m.state_dict()
     agree = tot = 0
@@ -529,7 +537,7 @@ def test_model_wrapper_forward_features_matches_oracle():
     g = torch.Generator().manual_seed(11)
     x = torch.randn(3, 3, 96, 96, generator=g)
     masks = torch.rand(3, 36, generator=g) < 0.3
-    out = w.forward_features(x, masks)
+    out = {k: v.clone() for k, v in w.forward_features(x, masks).items()}   # views into the wrapper's workspace: the next forward reuses it
     ref = O.vit_forward(sb, x, dict(patch_size=16, num_heads=1, depth=2), masks=masks)
     assert out["features"].shape == (3, 64, 6, 6) and w.feature_dim() == 64 and w.patch_size() == 16
     assert rel(out["cls_token"], ref["cls"]) < 2e-2
@@ -543,7 +551,7 @@ def test_model_wrapper_forward_features_matches_oracle():
     cap = {}
     O.vit_forward(sb, x, dict(patch_size=16, num_heads=1, depth=2), capture=cap)
     normed = [torch.nn.functional.layer_norm(cap[f"block{i}"], (64,), sb["norm.weight"], sb["norm.bias"], 1e-6) for i in range(2)]
-    ms = w.forward_multiscale_features(x, [0, 1])
+    ms = [{k: v.clone() for k, v in d_.items()} for d_ in w.forward_multiscale_features(x, [0, 1])]
     assert len(ms) == 2 and w.multiscale_feature_dims() == [64, 64]
     for i in range(2):
         assert rel(ms[i]["cls_token"], normed[i][:, 0]) < 2e-2
