@@ -39,7 +39,7 @@ class ResNetConfig:
 
     @property
     def feature_dim(self) -> int:
-        return self.width * 8 * self.expansion
+        return self.width * 2 ** (len(self.layers) - 1) * self.expansion
 
 
 ARCHS: Dict[str, Dict[str, Any]] = {

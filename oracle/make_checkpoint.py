@@ -54,14 +54,31 @@ def main() -> None:
             "lr_schedulers": [{k: v for k, v in r.sched.state_dict().items() if k != "lr_lambdas"}],
             "global_step": m.trainer.global_step, "epoch": 0}
     ckpt = torch.load(_roundtrip(ckpt), weights_only=False)   # detach the saved tensors from the live optimizer state
+    # ---- a true resume: a FRESH reference module (other seed) restored from the checkpoint alone, as Lightning does on `ckpt_path=`
+    # (module state, optimizer state, scheduler position, global step).  What is not in a checkpoint is gone on both sides -- notably the
+    # DINO / iBOT center update that was still pending (computed at step 2, applied lazily at the start of step 3, dinov2_loss.py:135-160).
+    m2 = H.build_reference_method(arch="DinoVisionTransformer", patch_size=16, img_size=g_size,
+                                  model_kwargs=dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0), method_kwargs=mk,
+                                  global_batch_size=b, total_steps=total, seed=999)
+    r2 = H.ReferenceRunner(m2)
+    import copy
+
+    loaded = copy.deepcopy(ckpt)     # torch's Optimizer.load_state_dict may alias the tensors it is given ("step" is then bumped in place)
+    m2.load_state_dict(loaded["state_dict"])
+    r2.optim.load_state_dict(loaded["optimizer_states"][0])
+    r2.sched.load_state_dict(dict(ckpt["lr_schedulers"][0], lr_lambdas=[{} for _ in r2.optim.param_groups]))
+    m2.trainer.global_step = ckpt["global_step"]
     random.seed(312)
-    logs = r.train_step(synth_views(3002, b, g_size, l_size, n_local))
+    logs = r2.train_step(synth_views(3002, b, g_size, l_size, n_local))
+    random.seed(312)
+    live = r.train_step(synth_views(3002, b, g_size, l_size, n_local))    # the uninterrupted run, for the record (differs: pending centers)
+    m, r = m2, r2
     keep_t = ("teacher_embedding_model.wrapped_model._model.blocks.1.mlp.fc1.weight", "teacher_head.dino_head.mlp.0.weight",
               "teacher_head.dino_head.last_layer.parametrizations.weight.original1")
     after = {k: v.detach() for k, v in m.state_dict().items() if ".ibot_head." not in k and (k.startswith("student_") or k in keep_t or "center" in k)}
     fixture = {"cfg": dict(patch_size=16, num_heads=1, depth=2, embed_dim=64), "method_kwargs": mk, "b": b, "g_size": g_size, "l_size": l_size,
                "n_local": n_local, "total_steps": total, "pre_logs": pre_logs, "checkpoint": ckpt,
-               "step3": {"view_seed": 3002, "masks": cap["masks"], "logs": logs, "state_after": after,
+               "step3": {"view_seed": 3002, "masks": cap["masks"], "logs": logs, "logs_uninterrupted_run": live, "state_after": after,
                          "optimizer_after": r.optim.state_dict()["state"][0]}}
     path = os.path.join(OUT, "ckpt_d64.pt")
     torch.save(fixture, path)
