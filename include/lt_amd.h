@@ -276,6 +276,16 @@ int lt_token_mean_bf16(const void* x, void* out, int B, int n, int C, void* stre
 int lt_pool_bwd_add(const float* d_tok, const float* d_pool, void* out_bf16, int B, int n, int C, void* stream);
 int lt_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host-side (CPU) helper: the iBOT block masks of one step (MaskingGenerator + create_collated_masks, LT/_methods/dinov2/utils.py:41-152)
+ * sampled in C++ from CPython's own Mersenne-Twister stream.  mt_state[624] / *mt_pos = the words of random.getstate()[1]; both are
+ * advanced in place so that random.setstate() continues the stream exactly where the reference's Python loop would have left it.
+ * ratio_edges[n_masked_crops + 1] = numpy.linspace(mask_ratio_min, mask_ratio_max, n_masked_crops + 1); masks: uint8 [n_crops, H*W],
+ * returned in the final (shuffled) order.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int lt_sample_block_masks(uint32_t* mt_state, int* mt_pos, const double* ratio_edges, int n_masked_crops, int n_crops, int H, int W,
+                          int max_num_patches, int min_num_patches, double log_aspect_min, double log_aspect_max, uint8_t* masks);
+
 #ifdef __cplusplus
 }
 #endif

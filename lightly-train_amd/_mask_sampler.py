@@ -73,6 +73,29 @@ def sample_mask_grids(mask_ratio_min: float, mask_ratio_max: float, n_masked_cro
     return np.stack(grids)
 
 
+def sample_mask_grids_native(mask_ratio_min: float, mask_ratio_max: float, n_masked_crops: int, n_crops: int,
+                             mask_generator: MaskingGenerator) -> np.ndarray:
+    """Same result and same consumption of the `random` stream as `sample_mask_grids`, computed by `lt_sample_block_masks`
+    (csrc/host_masks.cpp: the sampler in C++ on CPython's own Mersenne-Twister state): ~0.1 ms instead of ~13 ms for 256 crops."""
+    import ctypes as C
+
+    from . import _lib
+
+    rng = mask_generator.rng
+    version, internal, gauss = rng.getstate()
+    state = (C.c_uint32 * 624)(*internal[:624])
+    pos = C.c_int(internal[624])
+    edges = np.ascontiguousarray(np.linspace(mask_ratio_min, mask_ratio_max, n_masked_crops + 1), dtype=np.float64)
+    H, W = mask_generator.get_shape()
+    out = np.zeros((n_crops, H, W), dtype=np.uint8)
+    rc = _lib.load().lt_sample_block_masks(C.cast(state, C.c_void_p), C.cast(C.pointer(pos), C.c_void_p), edges.ctypes.data, n_masked_crops, n_crops, H, W,
+                                           mask_generator.max_num_patches, mask_generator.min_num_patches, mask_generator.log_aspect_ratio[0],
+                                           mask_generator.log_aspect_ratio[1], out.ctypes.data)
+    _lib.check(rc, "lt_sample_block_masks")
+    rng.setstate((version, tuple(state) + (pos.value,), gauss))
+    return out.astype(bool)
+
+
 def producer_main(key: Tuple[Any, ...], rng_state: Any, conn: Any) -> None:
     """Body of the producer process: sample step after step and push the grids down the pipe (a full pipe blocks the send, so
     the process stays one or two steps ahead and then sleeps)."""

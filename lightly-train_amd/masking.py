@@ -10,7 +10,7 @@ from typing import Any, Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from ._mask_sampler import MaskingGenerator, producer_main, sample_mask_grids
+from ._mask_sampler import MaskingGenerator, producer_main, sample_mask_grids, sample_mask_grids_native
 
 __all__ = ["MaskingGenerator", "MaskProducer", "collate_mask_grids", "create_collated_masks"]
 
@@ -24,8 +24,11 @@ def collate_mask_grids(grids: np.ndarray) -> Dict[str, torch.Tensor]:
 
 
 def create_collated_masks(mask_ratio_min: float, mask_ratio_max: float, n_masked_crops: int, n_crops: int,
-                          mask_generator: MaskingGenerator) -> Dict[str, torch.Tensor]:
-    return collate_mask_grids(sample_mask_grids(mask_ratio_min, mask_ratio_max, n_masked_crops, n_crops, mask_generator))
+                          mask_generator: MaskingGenerator, native: bool = True) -> Dict[str, torch.Tensor]:
+    """native=True: the C++ sampler of liblt_amd.so on the same `random` stream (bit-identical masks and stream position, tested);
+    native=False: the Python loop of the reference."""
+    sample = sample_mask_grids_native if native else sample_mask_grids
+    return collate_mask_grids(sample(mask_ratio_min, mask_ratio_max, n_masked_crops, n_crops, mask_generator))
 
 
 class MaskProducer:

@@ -304,3 +304,31 @@ def test_checkpoint_written_by_the_reference_round_trips_through_the_flat_storag
     with pytest.raises(ValueError):
         CK.load_method_state_dict(dict(ck["state_dict"], **{"dino_loss.center": ck["state_dict"]["dino_loss.center"],
                                                             "student_head.dino_head.mlp.0.bias": torch.zeros(3)}), student, teacher, False, True)
+
+
+@pytest.mark.parametrize("grid,n_masked,n_crops,seed", [((14, 14), 128, 256, 1), ((6, 6), 8, 16, 77), ((37, 37), 16, 32, 5), ((16, 16), 0, 4, 2),
+                                                        ((7, 9), 5, 5, 3), ((3, 3), 2, 4, 9)])
+def test_native_mask_sampler_continues_the_python_random_stream_bit_for_bit(grid, n_masked, n_crops, seed):
+    """f1: lt_sample_block_masks (csrc/host_masks.cpp) re-implements the reference's pure-Python mask sampler on CPython's own
+    Mersenne-Twister state: after `random.seed(s)` it must return exactly the masks of the Python loop (which is itself pinned
+    against the reference's fixture above) AND leave the `random` stream at exactly the same position."""
+    gen = masking.MaskingGenerator(input_size=grid, max_num_patches=int(0.5 * grid[0] * grid[1]))
+    for rep in range(3):     # consecutive steps continue the stream
+        st = random.getstate() if rep else None
+        if rep == 0:
+            random.seed(seed)
+            st = random.getstate()
+        a = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, gen, native=False)
+        after_py = random.getstate()
+        random.setstate(st)
+        b = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, gen, native=True)
+        assert random.getstate() == after_py
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    # a private random.Random (the background producer's stream) works the same way
+    r1, r2 = random.Random(11), random.Random(11)
+    g1 = masking.MaskingGenerator(input_size=grid, max_num_patches=int(0.5 * grid[0] * grid[1]), rng=r1)
+    g2 = masking.MaskingGenerator(input_size=grid, max_num_patches=int(0.5 * grid[0] * grid[1]), rng=r2)
+    a = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, g1, native=False)
+    b = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, g2, native=True)
+    assert torch.equal(a["collated_masks"], b["collated_masks"]) and r1.getstate() == r2.getstate()
