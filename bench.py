@@ -127,6 +127,10 @@ def main() -> None:
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
     ap.add_argument("--prefetch-masks", action="store_true", help="sample the iBOT masks one step ahead in a background process (same random stream)")
+    ap.add_argument("--real-pipeline", action="store_true",
+                    help="dinov2 only: every step's 2 + N views are produced INSIDE the timed region by the GPU multi-crop augmentation "
+                         "(lightly_train_amd.augment: RandomResizedCrop / flip / colour jitter / gray / blur / solarize / normalize) from decoded "
+                         "uint8 images resident in HBM -- the SURVEY 8(f).2 input pipeline; never the headline value")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: every launch on one stream (clean per-kernel durations)")
     args = ap.parse_args()
 
@@ -155,6 +159,7 @@ def main() -> None:
     arch = MODELS[args.model]
     cfg = ViTConfig(patch_size=16, img_size=args.global_size, init_values=1e-5, **arch)
     B = args.batch
+    aug = aug_src = None
     g = torch.Generator().manual_seed(1234 + rank)
     if args.method == "distillationv3":
         from lightly_train_amd.dinov3 import dinov3_vit_config
@@ -181,6 +186,16 @@ def main() -> None:
             torch.randn(B, 3, args.local_size, args.local_size, generator=g).to(dev) for _ in range(args.n_local)]
         if args.host_inputs:
             views = [v.cpu().pin_memory() for v in views]
+        if args.real_pipeline:
+            from lightly_train_amd.augment import GPUMultiCrop, dinov2_view_specs
+
+            # decoded ImageNet-like sources: uint8 HWC, 375 x 500 +- 20 %, packed in one HBM buffer (JPEG decoding is outside this path)
+            gi = torch.Generator().manual_seed(77 + rank)
+            hs = torch.randint(300, 450, (B,), generator=gi).tolist()
+            ws_ = torch.randint(400, 600, (B,), generator=gi).tolist()
+            srcs = [torch.randint(0, 256, (h, w, 3), generator=gi, dtype=torch.uint8) for h, w in zip(hs, ws_)]
+            aug = GPUMultiCrop(dinov2_view_specs(args.global_size, args.local_size, args.n_local), seed=5 + rank, device=dev)
+            aug_src = GPUMultiCrop.pack(srcs, dev)
     random.seed(100 + rank)
     torch.manual_seed(100 + rank)
 
@@ -200,6 +215,9 @@ def main() -> None:
 
             for b_ in ViewPrefetcher(batches(n), dev):
                 out = method.train_step(b_["views"] if isinstance(views, list) else b_["views"][0])
+        elif args.method == "dinov2" and aug is not None:
+            for _ in range(n):
+                out = method.train_step(aug(*aug_src))
         else:
             for _ in range(n):
                 out = method.train_step(views)
@@ -314,7 +332,9 @@ def main() -> None:
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
-                       "inputs": "pinned host memory (H2D inside the timed region, prefetched on a copy stream)" if args.host_inputs else "resident in HBM"},
+                       "inputs": ("pinned host memory (H2D inside the timed region, prefetched on a copy stream)" if args.host_inputs else
+                                  "decoded uint8 images resident in HBM; the 2 + N views are augmented on the GPU inside the timed region"
+                                  if args.real_pipeline else "resident in HBM")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

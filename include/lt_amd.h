@@ -286,6 +286,39 @@ int lt_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream
 int lt_sample_block_masks(uint32_t* mt_state, int* mt_pos, const double* ratio_edges, int n_masked_crops, int n_crops, int H, int W,
                           int max_num_patches, int min_num_patches, double log_aspect_min, double log_aspect_max, uint8_t* masks);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * GPU multi-crop augmentation: the DINO view pipeline of LT/_transforms/view_transform.py:133-215 /
+ * LT/_methods/dino/dino_transform.py:129-202 (RandomResizedCrop(INTER_AREA) -> HorizontalFlip -> ColorJitter -> ToGray ->
+ * GaussianBlur -> Solarize -> Normalize) from decoded uint8 HWC images resident in HBM.  The random parameters are drawn on the
+ * host and handed over as per-view records (device arrays); one call processes all n views of one output size S.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct lt_aug_crop_item {
+  int64_t src_off;          /* byte offset of the image inside the packed uint8 [H, W, 3] source buffer */
+  int32_t H, W;             /* source image size */
+  float x0, y0, cw, ch;     /* crop box in source pixels (RandomResizedCrop) */
+  int32_t flip;             /* HorizontalFlip fired */
+} lt_aug_crop_item;
+typedef struct lt_aug_color_item {
+  int32_t apply;            /* ColorJitter fired */
+  int32_t order;            /* the four ops in application order, 2 bits each: 0 brightness, 1 contrast, 2 saturation, 3 hue */
+  float fb, fc, fs, fh;     /* brightness / contrast / saturation factors, hue shift in turns */
+  int32_t gray;             /* ToGray fired */
+} lt_aug_color_item;
+typedef struct lt_aug_finish_item {
+  float sigma;              /* GaussianBlur sigma, 0 = not fired; kernel radius ceil(3 sigma) <= LT_AUG_MAX_RADIUS */
+  int32_t solarize;         /* Solarize fired: x >= threshold -> 1 - x */
+  float threshold;
+} lt_aug_finish_item;
+#define LT_AUG_MAX_RADIUS 6
+/* A: views f32 [n, 3, S, S] in [0,1] = area-resampled ("pixel area relation", cv2.INTER_AREA) crop of each item's box, flipped if asked */
+int lt_aug_crop_resize(const uint8_t* src, const lt_aug_crop_item* items, float* views, int n, int S, void* stream);
+/* B: in place: ColorJitter (torchvision semantics: brightness / contrast (blend with the view-wide mean luminance) / saturation / hue in
+ * the item's order, each clamped to [0,1]) then ToGray (0.299 R + 0.587 G + 0.114 B on all three channels) */
+int lt_aug_color(float* views, const lt_aug_color_item* items, int n, int S, void* stream);
+/* C: out f32 [n, 3, S, S] = Normalize(Solarize(GaussianBlur(views))); separable Gaussian, reflect-101 border.  mean3 / std3: HOST float[3] */
+int lt_aug_finish(const float* views, const lt_aug_finish_item* items, float* out, int n, int S, const float* mean3, const float* std3,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

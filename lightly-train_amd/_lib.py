@@ -85,6 +85,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_token_mean_bf16": [vp, vp, i32, i32, i32, vp],
     "lt_pool_bwd_add": [vp, vp, vp, i32, i32, i32, vp],
     "lt_add_bf16": [vp, vp, vp, i64, vp],
+    "lt_aug_crop_resize": [vp, vp, vp, i32, i32, vp],
+    "lt_aug_color": [vp, vp, i32, i32, vp],
+    "lt_aug_finish": [vp, vp, vp, i32, i32, vp, vp, vp],
     "lt_sample_block_masks": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_double, C.c_double, vp],
 }
 

@@ -77,24 +77,32 @@ __global__ __launch_bounds__(256) void col2im_nhwc_kernel(const bf16_t* __restri
     *reinterpret_cast<uint4*>(dx + pix * C + v * 8) = pack8(acc);
   }
 }
-// stem: NCHW f32 image -> cols[(b,oy,ox)][c*KH*KW + ky*KW + kx] bf16 (torch's weight.flatten(1) order), zero-padded to ld columns
+// stem: NCHW f32 image -> cols[(b,oy,ox)][c*KH*KW + ky*KW + kx] bf16 (torch's weight.flatten(1) order), zero-padded to ld columns.
+// One thread = 8 consecutive k of one row = one 16-byte store (ld % 8 == 0); the scattered 4-byte reads hit L1 / L2.
 __global__ __launch_bounds__(256) void im2col_nchw_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ cols, int B, int Cin, int H, int W,
                                                               int KH, int KW, int stride, int pad, int Ho, int Wo, int ld) {
-  const long total = (long)B * Ho * Wo * ld;
+  const int kv = ld >> 3;
+  const long total = (long)B * Ho * Wo * kv;
   const int kk = KH * KW, kreal = Cin * kk;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k = (int)(i % ld);
-    const long row = i / ld;
-    float val = 0.f;
-    if (k < kreal) {
-      const int c = k / kk, ky = (k % kk) / KW, kx = k % KW;
-      const int ox = (int)(row % Wo);
-      const int oy = (int)((row / Wo) % Ho);
-      const int b = (int)(row / ((long)Wo * Ho));
-      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[(((long)b * Cin + c) * H + iy) * W + ix];
+    const int k0 = (int)(i % kv) * 8;
+    const long row = i / kv;
+    const int ox = (int)(row % Wo);
+    const int oy = (int)((row / Wo) % Ho);
+    const int b = (int)(row / ((long)Wo * Ho));
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float val = 0.f;
+      if (k < kreal) {
+        const int c = k / kk, ky = (k % kk) / KW, kx = k % KW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[(((long)b * Cin + c) * H + iy) * W + ix];
+      }
+      f[j] = val;
     }
-    cols[i] = f2bf(val);
+    *reinterpret_cast<uint4*>(cols + row * ld + k0) = pack8(f);
   }
 }
 
@@ -156,14 +164,31 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_t* __restric
     partial[((long)(j >> 3) * G + blockIdx.y) * C + vg * 8 + (j & 7)] = s;
   }
 }
-// pass 2 forward: batch statistics (biased variance for normalisation, unbiased for the running estimate, torch semantics)
+// pass 2: block = 32 channels x 8 partial-lanes.  Every thread adds its share of the G per-block partials (g = lane, lane + 8, ...)
+// in double, the 8 lanes of a channel are then combined in lane order: a fixed summation tree (deterministic), ~G/8 pipelined
+// loads per thread instead of one thread walking all G partials of a channel (that serial walk took 140-170 us per layer).
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ partial, int G, int C, int c, int lane, double& s0, double& s1,
+                                                double (*red)[32][2]) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int g = lane; g < G; g += 8) { a += (double)partial[(long)g * C + c]; b += (double)partial[((long)G + g) * C + c]; }
+  }
+  red[lane][threadIdx.x & 31][0] = a;
+  red[lane][threadIdx.x & 31][1] = b;
+  __syncthreads();
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { s0 += red[l][threadIdx.x & 31][0]; s1 += red[l][threadIdx.x & 31][1]; }
+}
+// forward: batch statistics (biased variance for normalisation, unbiased for the running estimate, torch semantics)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int G, long rows, int C, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int g = 0; g < G; ++g) { s += (double)partial[(long)g * C + c]; ss += (double)partial[((long)G + g) * C + c]; }
+  __shared__ double red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s, ss;
+  bn_sum_partials(partial, G, C, c, lane, s, ss, red);
+  if (lane != 0 || c >= C) return;
   const double n = (double)rows;
   const double m = s / n;
   double var = ss / n - m * m;
@@ -173,13 +198,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
 }
-// pass 2 backward: dgamma += sum dz*xhat, dbeta += sum dz, and the two means the input gradient needs
+// backward: dgamma += sum dz*xhat, dbeta += sum dz, and the two means the input gradient needs
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, long rows, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int g = 0; g < G; ++g) { s += (double)partial[(long)g * C + c]; sx += (double)partial[((long)G + g) * C + c]; }
+  __shared__ double red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s, sx;
+  bn_sum_partials(partial, G, C, c, lane, s, sx, red);
+  if (lane != 0 || c >= C) return;
   if (dbeta) dbeta[c] += (float)s;
   if (dgamma) dgamma[c] += (float)sx;
   c1[c] = (float)(s / (double)rows);
@@ -376,11 +402,12 @@ extern "C" int lt_col2im_nhwc_bf16(const void* dcols, const void* add, void* dx,
   LT_CHECK_LAUNCH("lt_col2im_nhwc_bf16");
 }
 extern "C" int lt_im2col_nchw_f32(const float* x, void* cols, int B, int Cin, int H, int W, int KH, int KW, int stride, int pad, int ld, void* stream) {
-  LT_CHECK_ARG(x && cols && B > 0 && Cin > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && ld >= Cin * KH * KW,
-               "lt_im2col_nchw_f32: bad arguments");
+  LT_CHECK_ARG(x && cols && B > 0 && Cin > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && ld >= Cin * KH * KW && ld % 8 == 0 &&
+                   al16(cols),
+               "lt_im2col_nchw_f32: bad arguments (ld=%d must be >= Cin*KH*KW and a multiple of 8, cols 16-byte aligned)", ld);
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   LT_CHECK_ARG(Ho > 0 && Wo > 0, "lt_im2col_nchw_f32: empty output");
-  hipLaunchKernelGGL(im2col_nchw_f32_kernel, dim3(grid_for((long)B * Ho * Wo * ld)), dim3(256), 0, ST, x, (bf16_t*)cols, B, Cin, H, W, KH, KW, stride,
+  hipLaunchKernelGGL(im2col_nchw_f32_kernel, dim3(grid_for((long)B * Ho * Wo * (ld / 8))), dim3(256), 0, ST, x, (bf16_t*)cols, B, Cin, H, W, KH, KW, stride,
                      pad, Ho, Wo, ld);
   LT_CHECK_LAUNCH("lt_im2col_nchw_f32");
 }
@@ -409,7 +436,7 @@ extern "C" int lt_batchnorm_fwd(const void* x, const float* gamma, const float* 
   const BnGeom g = bn_geom(rows, C);
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lt_cdiv(C, 256)), dim3(256), 0, ST, ws, g.G, (long)rows, C, eps, momentum, mean, rstd, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, eps, momentum, mean, rstd, running_mean,
                      running_var);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)resid,
                      (bf16_t*)y, (long)rows, C, relu);
@@ -436,7 +463,7 @@ extern "C" int lt_batchnorm_bwd(const void* dy, const void* y, const void* x, co
   float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd,
                      (bf16_t*)dz, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lt_cdiv(C, 256)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, c1, c2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)(dz ? dz : dy), (const bf16_t*)x, mean, rstd,
                      gamma, c1, c2, (bf16_t*)dx, (long)rows, C);
   LT_CHECK_LAUNCH("lt_batchnorm_bwd");
