@@ -316,6 +316,9 @@ class DINOv2:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self._drop_gen = torch.Generator().manual_seed(seed + 7919 + 104729 * rank)
         self._grad_sync: Optional[GradSync] = None
+        # set to a list to collect (start, end) HIP events around the point where the optimizer has to wait for the gradient
+        # all-reduces: their elapsed time is the EXPOSED (not hidden under backward) communication time of a step
+        self.comm_events: Optional[List[Tuple[Any, Any]]] = None
         # data parallel: all-reduce the head gradients and each transformer block's gradients as soon as they are final,
         # underneath the rest of backward (what DDP's bucket hooks do in the reference); LT_GRAD_OVERLAP=0 reduces after it
         self.overlap_grad_reduce = os.environ.get("LT_GRAD_OVERLAP", "1") != "0"
@@ -719,7 +722,15 @@ class DINOv2:
         wd = cosine_schedule(k, total, a.weight_decay_start, a.weight_decay_end)
         lr_factor = warmup_cosine_lr_factor(k, self.warmup_steps, total, a.min_lr / self.base_lr)
         freeze = (1 if k < a.student_freeze_last_layer_steps else 0) | (2 if k < a.student_freeze_backbone_steps else 0)
+        ev0 = None
+        if self.comm_events is not None and self.world > 1:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         self.allreduce_gradients()
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.comm_events.append((ev0, ev1))
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1

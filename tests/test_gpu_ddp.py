@@ -222,3 +222,4 @@ def test_bench_contract_two_ranks():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
     assert out["value"] == pytest.approx(16 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1e3), rel=1e-2)
     assert out["roofline"]["launches_per_step"] > 0 and out["cpu_baseline"] is None
+    assert out["comm"]["exposed_allreduce_ms_per_step"] >= 0 and out["comm"]["gradient_bytes_per_step"] > 0
