@@ -70,6 +70,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_ce_fwd_bwd": [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp],
     "lt_sk_exp": [vp, vp, i64, f32, vp],
     "lt_sk_iter": [vp, vp, i32, i32, f32, f32, vp],
+    "lt_mse_fwd_bwd": [vp, vp, vp, i64, f32, vp, vp],
     "lt_koleo_fwd_bwd": [vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp],
     "lt_sumsq_f32": [vp, vp, i64, vp],
     "lt_adamw_flat": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, f32, f32, C.c_double, C.c_double, f32, i32, vp, f32, vp],

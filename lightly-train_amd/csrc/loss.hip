@@ -334,6 +334,44 @@ __global__ __launch_bounds__(256) void koleo_dx_kernel(const float* __restrict__
     dx[(long)i * ld_dx + d] += (dxn[(long)i * D + d] - xn[(long)i * D + d] * dot) * iv;
 }
 
+// ------------------------------------------------------------------------------------ MSE (DistillationV2Loss = nn.MSELoss(), mean over all elements)
+// loss += scale * sum (s - t)^2,  ds = 2 * scale * (s - t); two-level deterministic sum (per-block partials, last block adds them in order)
+constexpr int MSE_MAX_GRID = 1024;
+__device__ float mse_partials[MSE_MAX_GRID];
+__device__ unsigned mse_ticket;
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ ds, long n, float scale,
+                                                  float* __restrict__ loss) {
+  __shared__ float red[16];
+  __shared__ bool last;
+  float acc = 0.f;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 a = *reinterpret_cast<const float4*>(s + i), b = *reinterpret_cast<const float4*>(t + i);
+    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    if (ds) *reinterpret_cast<float4*>(ds + i) = make_float4(2.f * scale * d.x, 2.f * scale * d.y, 2.f * scale * d.z, 2.f * scale * d.w);
+  }
+  for (long j = i; j < n && j < i + 4; ++j) {
+    const float d = s[j] - t[j];
+    acc += d * d;
+    if (ds) ds[j] = 2.f * scale * d;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    mse_partials[blockIdx.x] = acc;
+    __threadfence();
+    last = atomicAdd(&mse_ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float tot = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) tot += __builtin_nontemporal_load(&mse_partials[b]);
+  tot = block_sum(tot, red);
+  if (threadIdx.x == 0) { *loss += scale * tot; mse_ticket = 0; }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -398,4 +436,12 @@ extern "C" int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, 
   hipLaunchKernelGGL(koleo_dxn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, D, eps);
   hipLaunchKernelGGL(koleo_dx_kernel, dim3(n), dim3(256), 0, ST, xn, dxn, inv, dx, ld_dx, D);
   LT_CHECK_LAUNCH("lt_koleo_fwd_bwd");
+}
+extern "C" int lt_mse_fwd_bwd(const float* s, const float* t, float* ds, int64_t n, float scale, float* loss, void* stream) {
+  LT_CHECK_ARG(s && t && loss && n >= 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)t & 15) == 0 && ((uintptr_t)ds & 15) == 0,
+               "lt_mse_fwd_bwd: bad arguments / alignment");
+  if (n == 0) return LT_OK;
+  const int grid = (int)min((long)MSE_MAX_GRID, (long)lt_cdiv(n, 1024));
+  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, ST, s, t, ds, (long)n, scale, loss);
+  LT_CHECK_LAUNCH("lt_mse_fwd_bwd");
 }

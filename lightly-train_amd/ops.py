@@ -342,6 +342,12 @@ def koleo_fwd_bwd(x: Tensor, ld: int, loss: Tensor, dx: Tensor, ld_dx: int, n: i
           "lt_koleo_fwd_bwd")
 
 
+def mse_fwd_bwd(s: Tensor, t: Tensor, ds: Optional[Tensor], n: int, scale: float, loss: Tensor) -> None:
+    _chk(s, torch.float32, "mse.s")
+    _chk(t, torch.float32, "mse.t")
+    check(_lib.load().lt_mse_fwd_bwd(_p(s), _p(t), _p(ds), n, scale, _p(loss), _stream()), "lt_mse_fwd_bwd")
+
+
 # ------------------------------------------------------------------------------------------ optimizer
 def sumsq(g: Tensor, out: Tensor) -> None:
     check(_lib.load().lt_sumsq_f32(_p(g), _p(out), g.numel(), _stream()), "lt_sumsq_f32")
