@@ -134,3 +134,78 @@ class OracleDistillationV3:
         self._set_lr()
         logs.update(loss=float(loss.detach()), grad_norm=float(gnorm))
         return logs
+
+
+class OracleDistillation12:
+    """Distillation (v1, LT/_methods/distillation/distillation.py:198-266 + distillation_loss.py:38-75) and DistillationV2
+    (LT/_methods/distillationv2/distillationv2.py:196-289 + distillationv2_loss.py:27-44) with a DINOv2 ViT teacher and student,
+    AdamW, the generic Method.configure_optimizers schedule, clip 1.0.  Pinned against tests/golden/distill_v{1,2}_d64.pt, written by
+    the reference's own classes (oracle/make_golden.py::make_distill12)."""
+
+    def __init__(self, kind: str, student_backbone: Dict[str, Tensor], student_cfg: Dict[str, Any], teacher_state: Dict[str, Tensor],
+                 teacher_cfg: Dict[str, Any], head: Dict[str, Tensor], queue_size: int, global_batch_size: int, total_steps: int, max_epochs: int = 1,
+                 temperature: float = 0.07, n_teacher_blocks: int = 2, lr: float = 0.0005, weight_decay: float = 0.0,
+                 reference_batch_size: int = 1536) -> None:
+        self.kind = kind
+        self.sb = {k: v.detach().clone().requires_grad_(True) for k, v in student_backbone.items()}
+        self.head = {k: v.detach().clone().requires_grad_(True) for k, v in head.items()}
+        self.teacher = {k: v.detach().clone() for k, v in teacher_state.items()}
+        self.scfg, self.tcfg, self.temp, self.nb = student_cfg, teacher_cfg, temperature, n_teacher_blocks
+        self.queue = torch.zeros(queue_size, teacher_state["cls_token"].shape[-1])
+        named = [("backbone." + k, v) for k, v in self.sb.items()] + [("head." + k, v) for k, v in self.head.items()]
+        dec = [p for n, p in named if decays(n, p)]
+        nod = [p for n, p in named if not decays(n, p)]
+        self.n_decay, self.n_no_decay = len(dec), len(nod)
+        scale = math.sqrt(global_batch_size / reference_batch_size)
+        self.opt = torch.optim.AdamW([{"params": dec}, {"params": nod, "weight_decay": 0.0}], lr=lr * scale, betas=(0.9, 0.999), eps=1e-8,
+                                     weight_decay=weight_decay)
+        warm_epochs = min(10, max_epochs / 10)
+        self.warmup = min(int(total_steps), int(total_steps / max_epochs * warm_epochs))
+        self.total, self.base_lr, self.step_idx = int(total_steps), lr * scale, 0
+        self._set_lr()
+
+    def _set_lr(self) -> None:
+        f = O2.cosine_warmup_factor(self.step_idx, self.warmup, self.total, 0.001)
+        for g in self.opt.param_groups:
+            g["lr"] = self.base_lr * f
+
+    def forward_loss(self, x: Tensor, lam: float, index: Tensor) -> Tensor:
+        x = lam * x + (1.0 - lam) * x[index]
+        w = self.head.get("weight", self.head.get("mlp.weight"))
+        bias = self.head.get("bias", self.head.get("mlp.bias"))
+        if self.kind == "v1":
+            with torch.no_grad():
+                tg = F.normalize(O2.vit_forward(self.teacher, x, self.tcfg)["cls"], dim=-1, p=2)
+            sg = F.normalize(F.linear(O2.vit_forward(self.sb, x, self.scfg)["cls"], w, bias), dim=-1, p=2)
+            B, Q = tg.shape[0], self.queue.shape[0]
+            with torch.no_grad():
+                if B >= Q:
+                    self.queue = tg[:Q].clone()
+                else:
+                    self.queue[B:] = self.queue[:-B].clone()
+                    self.queue[:B] = tg
+            kl = torch.nn.KLDivLoss(reduction="batchmean", log_target=False)
+            return kl(F.log_softmax(sg @ self.queue.t() / self.temp, dim=-1), F.softmax(tg @ self.queue.t() / self.temp, dim=-1))
+        with torch.no_grad():
+            cap: Dict[str, Tensor] = {}
+            O2.vit_forward(self.teacher, x, self.tcfg, capture=cap)
+            depth = self.tcfg["depth"]
+            feats = [F.layer_norm(cap[f"block{i}"], (cap[f"block{i}"].shape[-1],), self.teacher["norm.weight"], self.teacher["norm.bias"], 1e-6)[:, 1:]
+                     for i in range(depth - self.nb, depth)]
+            tf = torch.cat(feats, dim=-1)                                           # [B, n_pt, nb * Dt]
+        sp = F.linear(O2.vit_forward(self.sb, x, self.scfg)["patch"], w, bias)      # [B, n_ps, nb * Dt]
+        ps_s, ps_t = self.scfg["patch_size"], self.tcfg["patch_size"]
+        hs, ws_, ht, wt = x.shape[2] // ps_s, x.shape[3] // ps_s, x.shape[2] // ps_t, x.shape[3] // ps_t
+        sp = sp.reshape(sp.shape[0], hs, ws_, -1).permute(0, 3, 1, 2)
+        sp = F.interpolate(sp, size=(ht, wt), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+        return F.mse_loss(tf, sp)
+
+    def train_step(self, x: Tensor, lam: float, index: Tensor) -> Dict[str, float]:
+        loss = self.forward_loss(x, lam, index)
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_([p for g in self.opt.param_groups for p in g["params"]], 1.0)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        self.step_idx += 1
+        self._set_lr()
+        return {"loss": float(loss.detach()), "grad_norm": float(gnorm)}

@@ -177,6 +177,10 @@ def main() -> None:
     if "--dinov3-only" in sys.argv:
         make_dinov3_vit()
         return
+    if "--distill12-only" in sys.argv:
+        make_distill12("v1")
+        make_distill12("v2")
+        return
     if "--distill-only" in sys.argv:
         make_distill()
         return
@@ -214,6 +218,91 @@ def make_distill() -> None:
     # around the restated torchvision ResNet (oracle/resnet_oracle.py), tiny bottleneck net (1,1,1,1) x width 8 -> 2x2 map of 256
     # channels at 64^2, resized bilinearly onto the teacher's 4x4 grid; weight decay "auto" -> 1e-6 (distillationv3.py:163-170)
     make_distill_case("distill_v3_resnet", img=64, s_patch=16, b=8, s_kind="resnet")
+
+
+def make_distill12(kind: str) -> None:
+    """(f) Distillation (v1: pooled feature vs a queue, KL) and DistillationV2 (patch features of the last 2 teacher blocks, MSE): the
+    reference's own classes with a frozen DINOv2 ViT teacher (D = 64, /14: 4x4 tokens at 56^2 ... here 8x8 at 112^2) and a DINOv2 ViT
+    student (/16: 7x7 tokens, resized onto the teacher grid in v2), AdamW (the reference's "auto" LARS lives in un-vendored LightlySSL),
+    3 optimizer steps.  `get_teacher` (which resolves a model NAME through the package registry) is replaced by a function that
+    returns the locally built teacher; everything else is the reference's code."""
+    H.install()
+    import importlib
+
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as v2
+    from lightly_train._models.embedding_model import EmbeddingModel
+    from lightly_train._optim.adamw_args import AdamWArgs
+    from oracle import distill_oracle as OD
+
+    img, b, total, qsz = 112, 8, 20, 32
+    torch.manual_seed(977)
+    t = v2.DinoVisionTransformer(img_size=img, patch_size=14, embed_dim=64, depth=3, num_heads=1, mlp_ratio=4.0, init_values=0.5, drop_path_rate=0.0,
+                                 ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    for n_, prm in t.named_parameters():   # biases / LayerNorm affine are initialised to constants: randomise for a real test
+        if n_.endswith(".bias") or "norm" in n_:
+            prm.data.add_(0.1 * torch.randn_like(prm))
+    t.eval()
+    for prm in t.parameters():
+        prm.requires_grad_(False)
+    s_model = v2.DinoVisionTransformer(img_size=img, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
+                                       drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    sw = DINOv2ViTModelWrapper(s_model)
+    if kind == "v1":
+        mod = importlib.import_module("lightly_train._methods.distillation.distillation")
+        margs = mod.DistillationArgs(queue_size=qsz, teacher="local")
+        oargs = mod.DistillationAdamWArgs()
+        cls = mod.Distillation
+    else:
+        mod = importlib.import_module("lightly_train._methods.distillationv2.distillationv2")
+        margs = mod.DistillationV2Args(teacher="local")
+        oargs = AdamWArgs()
+        cls = mod.DistillationV2
+    mod.get_teacher = lambda *a, **k: t      # the registry lookup by name is outside this path
+    m = cls(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=sw), global_batch_size=b, num_input_channels=3)
+    m.trainer = H.MockTrainer(total)
+    [opt], [sched] = m.configure_optimizers()
+    sched = sched["scheduler"]
+    head = m.student_projection_head
+    init = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
+            "head": {k: v.detach().clone() for k, v in head.state_dict().items()}}
+    teacher_state = {k: v.detach().clone() for k, v in t.state_dict().items()}
+    scfg = dict(patch_size=16, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
+    tcfg = dict(patch_size=14, num_heads=1, depth=3, img_size=img, embed_dim=64, init_values=0.5)
+    o = OD.OracleDistillation12(kind, init["student_backbone"], scfg, teacher_state, tcfg, init["head"], qsz, b, total, lr=float(oargs.lr),
+                                weight_decay=float(oargs.weight_decay))
+    assert (o.n_decay, o.n_no_decay) == tuple(len(g["params"]) for g in opt.param_groups), ((o.n_decay, o.n_no_decay), [len(g["params"]) for g in opt.param_groups])
+    steps = []
+    for step in range(3):
+        x = torch.randn(b, 3, img, img, generator=torch.Generator().manual_seed(2100 + step))
+        torch.manual_seed(400 + step)
+        lam = torch.empty(1).uniform_(0.0, 1.0).item()
+        index = torch.randperm(b)
+        torch.manual_seed(400 + step)
+        lr_now = opt.param_groups[0]["lr"]
+        res = m.training_step_impl({"views": [x], "filename": []}, 0)
+        res.loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], 1.0)
+        opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+        m.trainer.global_step += 1
+        logs = {"loss": float(res.loss.detach()), "grad_norm": float(gnorm), "lr": lr_now}
+        ol = o.train_step(x, lam, index)
+        for k in ("loss", "grad_norm"):
+            assert abs(ol[k] - logs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (kind, step, k, ol[k], logs[k])
+        steps.append({"x_seed": 2100 + step, "lam": lam, "index": index.clone(), "logs": logs})
+        print("distill", kind, step, {k: round(v, 6) for k, v in logs.items()})
+    final = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
+             "head": {k: v.detach().clone() for k, v in head.state_dict().items()}}
+    if kind == "v1":
+        final["queue"] = m.teacher_queue.detach().clone()
+        assert (o.queue - final["queue"]).abs().max().item() < 1e-6
+    for k, v in final["student_backbone"].items():
+        assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+    name = "distill_" + kind + "_d64"
+    torch.save({"kind": kind, "b": b, "img": img, "total_steps": total, "queue_size": qsz, "lr": float(oargs.lr), "weight_decay": float(oargs.weight_decay),
+                "student_cfg": scfg, "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final,
+                "state_dict_keys": list(m.state_dict().keys())}, os.path.join(OUT, name + ".pt"))
+    print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")
 
 
 def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "dinov2") -> None:

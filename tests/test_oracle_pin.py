@@ -229,3 +229,24 @@ def test_restated_resnet50_anchors():
     w = sd["layer3.2.conv2.weight"]
     assert torch.equal(E.from_flat_layout("layer3.2.conv2.weight", E.to_flat_layout("layer3.2.conv2.weight", w)), w)
     assert E.to_flat_layout("layer3.2.conv2.weight", w).shape == (256, 3, 3, 256) and E.to_flat_layout("conv1.weight", sd["conv1.weight"]).shape == (64, 3, 7, 7)
+
+
+@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64"])
+def test_distillation_v1_v2_oracle_matches_reference_fixture(name):
+    """oracle/distill_oracle.py::OracleDistillation12 against 3 optimizer steps of the reference's own Distillation / DistillationV2
+    classes (tests/golden/distill_v{1,2}_d64.pt): loss, grad-norm, LR, final parameters, queue."""
+    from oracle import distill_oracle as OD
+
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    o = OD.OracleDistillation12(fx["kind"], fx["init"]["student_backbone"], fx["student_cfg"], fx["teacher_state"], fx["teacher_cfg"], fx["init"]["head"],
+                                fx["queue_size"], fx["b"], fx["total_steps"], lr=fx["lr"], weight_decay=fx["weight_decay"])
+    for rec in fx["steps"]:
+        x = torch.randn(fx["b"], 3, fx["img"], fx["img"], generator=torch.Generator().manual_seed(rec["x_seed"]))
+        assert o.opt.param_groups[0]["lr"] == pytest.approx(rec["logs"]["lr"], rel=1e-6)
+        logs = o.train_step(x, rec["lam"], rec["index"])
+        for k in ("loss", "grad_norm"):
+            assert logs[k] == pytest.approx(rec["logs"][k], rel=2e-5, abs=2e-7), k
+    for k, v in fx["final"]["student_backbone"].items():
+        assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+    for k, v in fx["final"]["head"].items():
+        assert (o.head[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
