@@ -788,6 +788,181 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
   store_td_tile(scratch, dv, dqkv + (long)b * N * ts + 2L * H * DH + h * DH, ts, k0, N);
 }
 
+// ================================================================================================ backward, fused
+// One pass for 65..224 tokens (the global crops: 197 / 201 tokens): S, P, dP and dS are formed ONCE per (query tile, key tile)
+// and feed all three products (20 MFMAs per tile pair instead of 28; one exp, one read of q / k / v / dO and no delta buffer).
+// One 8-wave block per (b, h):
+//   phase A  wave w owns key tile w (K, V fragments and the dK / dV accumulators in registers) and walks the query side, staged
+//            through LDS in chunks of 64 rows exactly like attn_bwd_dkdv_v2_kernel (row + transposable images of Q and dO, the
+//            next chunk's loads in flight in registers; delta = rowsum(dO * O) is formed while staging).  Every dS tile also goes
+//            to LDS as bf16 rows dS[q][key]: the contraction index of dQ = dS K is the key, which the C layout keeps in LANES, so
+//            that product needs the tile transposed through memory whatever the schedule.
+//   phase B  the waves write their K fragments into a transposable image (over the dead Q / dO images) and wave w forms
+//            dQ^T[d][q] of query tile w = K^T dS^T over all keys: dS rows are read as B fragments (two ds_read_b64 per lane, row
+//            stride 456 B = 2 * 57 dwords: the 32 rows of a lane group land on 32 distinct bank pairs).
+// LDS: 4 x 8 KiB images + 512 B (lse, delta) + 224 x 456 B dS = 132.3 KiB -> one block per CU; dK / dV / dQ leave through a
+// wave-private transpose scratch laid over the dS area once every wave is done reading it.
+constexpr int FB_CH = 64, FB_IMG = FB_CH * 128, FB_MAXN = 224, FB_DS = 456;
+constexpr int FB_LDS = 4 * FB_IMG + 2 * FB_CH * (int)sizeof(float) + FB_MAXN * FB_DS;
+
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsQ = smem;
+  char* ldsQt = smem + FB_IMG;
+  char* ldsD = smem + 2 * FB_IMG;
+  char* ldsDt = smem + 3 * FB_IMG;
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * FB_IMG);   // lse [64], delta [64] of the staged chunk
+  char* ldsS = smem + 4 * FB_IMG + 2 * FB_CH * sizeof(float);
+  char* ldsKt = smem;                                          // phase B: transposable image of K over the images
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, hi = l >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int k0 = wave * 32;
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qst = qkv + (long)b * N * ts + h * DH;
+  const bf16_t* dst = dout + (long)b * N * tso + h * DH;
+  const bf16_t* ost = out + (long)b * N * tso + h * DH;
+  const bf16_t* kb = qkv + (long)b * N * ts + (long)H * DH + h * DH;
+  const bf16_t* vb = qkv + (long)b * N * ts + 2L * H * DH + h * DH;
+  const float* lrow = lse + ((long)b * H + h) * N;
+  const bool active = k0 < N;
+  const bool key_ok = k0 + (l & 31) < N;
+  const int sr = tid >> 3, sc = tid & 7;   // staging: thread -> (chunk row, 16-byte piece)
+
+  uint4 qr, dr, orr;
+  float l_reg = INFINITY;
+  auto load_chunk = [&](int tok0) {
+    const int tok = tok0 + sr;
+    qr = dr = orr = make_uint4(0, 0, 0, 0);
+    if (tok < N) {
+      qr = *reinterpret_cast<const uint4*>(qst + (long)tok * ts + sc * 8);
+      dr = *reinterpret_cast<const uint4*>(dst + (long)tok * tso + sc * 8);
+      orr = *reinterpret_cast<const uint4*>(ost + (long)tok * tso + sc * 8);
+    }
+    if (tid < FB_CH) l_reg = tok0 + tid < N ? lrow[tok0 + tid] : INFINITY;
+  };
+  auto store_chunk = [&]() {
+    const int sb = sc >> 1, half = sc & 1;
+    const int rows_off = sr * 128 + ((sc ^ ((sr >> 1) & 7)) << 4);
+    const int tr_off = ((sr >> 2) * 4 + sb) * 128 + ((((sr & 3) + sb) & 3) << 5) + (half << 4);
+    *reinterpret_cast<uint4*>(ldsQ + rows_off) = qr;
+    *reinterpret_cast<uint4*>(ldsQt + tr_off) = qr;
+    *reinterpret_cast<uint4*>(ldsD + rows_off) = dr;
+    *reinterpret_cast<uint4*>(ldsDt + tr_off) = dr;
+    // delta[q] = sum_d dO[q,d] * O[q,d]: 8 elements per thread, the 8 threads of a row are consecutive lanes
+    const unsigned dw[4] = {dr.x, dr.y, dr.z, dr.w}, ow[4] = {orr.x, orr.y, orr.z, orr.w};
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = fmaf(bf2f((bf16_t)(dw[j] & 0xffff)), bf2f((bf16_t)(ow[j] & 0xffff)), acc);
+      acc = fmaf(bf2f((bf16_t)(dw[j] >> 16)), bf2f((bf16_t)(ow[j] >> 16)), acc);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sc == 0) ldsL[FB_CH + sr] = acc;
+    if (tid < FB_CH) ldsL[tid] = l_reg;
+  };
+
+  load_chunk(0);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global<true>(kb, ts, k0, N, ks); vf[ks] = frag_global<true>(vb, ts, k0, N, ks); }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+  store_chunk();
+  __syncthreads();
+  // ---- phase A
+  for (int c0 = 0; c0 < N; c0 += FB_CH) {
+    const bool more = c0 + FB_CH < N;
+    if (more) load_chunk(c0 + FB_CH);
+    if (active) {
+      const int ntile = min(2, (N - c0 + 31) / 32);
+      for (int it = 0; it < ntile; ++it) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
+        }
+        // rows = queries crow(e, hi), column = key lane
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
+          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g + j;
+            const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - dlv[j]) * scale;
+          }
+        }
+        union { bf16x8 v; unsigned u[4]; } p0, p1, d0, d1;
+        p0.v = pack8(s, 0); p1.v = pack8(s, 8); d0.v = pack8(dp, 0); d1.v = pack8(dp, 8);
+        // dS tile -> LDS rows (the bf16 values the dK product uses): register pair (2j, 2j+1) = two consecutive query rows
+        char* scol = ldsS + (size_t)(c0 + it * 32 + 4 * hi) * FB_DS + (k0 + (l & 31)) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned w = j < 4 ? d0.u[j] : d1.u[j - 4];
+          const int row = (2 * j & 3) + 8 * (2 * j >> 2);   // crow(2j, 0); the odd register is the next row
+          *reinterpret_cast<unsigned short*>(scol + row * FB_DS) = (unsigned short)(w & 0xffff);
+          *reinterpret_cast<unsigned short*>(scol + (row + 1) * FB_DS) = (unsigned short)(w >> 16);
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+    }
+  }
+  // ---- phase B
+  __syncthreads();   // the images are dead, every dS tile is in LDS
+  if (active) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {   // kf[ks] = 16 B of token k0 + (l & 31) at piece c = 2 ks + hi: the store_tr placement
+      const int r = k0 + (l & 31), c = ks * 2 + hi, sb = c >> 1, half = c & 1;
+      *reinterpret_cast<bf16x8*>(ldsKt + ((r >> 2) * 4 + sb) * 128 + ((((r & 3) + sb) & 3) << 5) + (half << 4)) = kf[ks];
+    }
+  }
+  __syncthreads();
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+  if (active) {   // query tile `wave`
+    const int nkb = 2 * ((N + 31) / 32);
+    const char* srow = ldsS + (size_t)(k0 + (l & 31)) * FB_DS + hi * 8;
+    for (int kbk = 0; kbk < nkb; ++kbk) {
+      // B fragment: lane -> query, k-slots -> keys kbk*16 + {4hi..4hi+3, 8+4hi..8+4hi+3} (the C-layout slot order of frag_tr)
+      union { struct { uint2 a, b; } s; bf16x8 v; } f;
+      f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
+      f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, kbk * 16), f.v, dq[db], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // dS and K^T are dead: the dS area becomes the store scratch
+  if (!active) return;
+  char* scratch = ldsS + wave * (32 * 144);
+  store_td_tile(scratch, dk, dqkv + (long)b * N * ts + (long)H * DH + h * DH, ts, k0, N);
+  store_td_tile(scratch, dv, dqkv + (long)b * N * ts + 2L * H * DH + h * DH, ts, k0, N);
+  store_qd_tile(scratch, dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, k0, N);
+}
+
 // ================================================================================================ generic head dims
 // one block (64 threads) per (b, h, q); scores in LDS (N <= 4096)
 __global__ void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N,
@@ -909,7 +1084,18 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
   const long total = (long)B * N * H;
   if (dh == DH) {
     const int nkt = lt_cdiv(N, 32);
-    static const int variant = [] { const char* e = getenv("LT_ATTN_BWD"); return e ? atoi(e) : 1; }();
+    static const int variant = [] { const char* e = getenv("LT_ATTN_BWD"); return e ? atoi(e) : 2; }();
+    if (variant >= 2 && N > 64 && N <= FB_MAXN) {   // one fused pass: S / dP / dS once, 20 instead of 28 MFMAs per tile pair
+      static bool fused_configured = false;
+      if (!fused_configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", FB_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
+        fused_configured = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * H), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, scale);
+      LT_CHECK_LAUNCH("lt_attention_bwd");
+    }
     if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels
       static bool configured = false;
       const int lds_dq = 3 * IMG, lds_kv = 4 * IMG + 2 * CH * (int)sizeof(float);

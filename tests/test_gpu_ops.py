@@ -391,7 +391,10 @@ def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
 @pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (3, 37, 2, 64), (2, 50, 1, 64), (1, 300, 2, 64), (2, 128, 2, 64),
                                        (3, 50, 6, 64), (2, 64, 4, 64), (2, 257, 2, 64), (1, 600, 1, 64), (2, 65, 2, 64),
                                        (4, 17, 2, 4), (2, 5, 2, 8),
-                                       (1, 1370, 2, 64), (2, 1374, 1, 64)])   # BASELINE cfg5: ViT-L/14 at 518^2 = 37x37 + cls (+ 4 registers)
+                                       (1, 1370, 2, 64), (2, 1374, 1, 64),    # BASELINE cfg5: ViT-L/14 at 518^2 = 37x37 + cls (+ 4 registers)
+                                       # fused backward (65..224 tokens): tile / chunk edges, 4 registers, the 224-token cap and one past it
+                                       (2, 201, 3, 64), (1, 224, 2, 64), (2, 225, 1, 64), (2, 193, 2, 64), (3, 96, 2, 64), (2, 100, 4, 64),
+                                       (130, 197, 2, 64)])
 def test_attention(B, N, H, dh):
     o = ops()
     g = torch.Generator().manual_seed(N + dh)
