@@ -807,7 +807,7 @@ constexpr int FB_LDS = 4 * FB_IMG + 2 * FB_CH * (int)sizeof(float) + FB_MAXN * F
 
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                             bf16_t* __restrict__ dqkv, int N, int H, int hpb, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsQ = smem;
   char* ldsQt = smem + FB_IMG;
@@ -817,30 +817,31 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
   char* ldsS = smem + 4 * FB_IMG + 2 * FB_CH * sizeof(float);
   char* ldsKt = smem;                                          // phase B: transposable image of K over the images
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, hi = l >> 5;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int groups = (H + hpb - 1) / hpb;
+  const int b = blockIdx.x / groups, h_begin = (blockIdx.x % groups) * hpb, h_end = min(H, h_begin + hpb);
   const int k0 = wave * 32;
   const long ts = 3L * H * DH, tso = (long)H * DH;
-  const bf16_t* qst = qkv + (long)b * N * ts + h * DH;
-  const bf16_t* dst = dout + (long)b * N * tso + h * DH;
-  const bf16_t* ost = out + (long)b * N * tso + h * DH;
-  const bf16_t* kb = qkv + (long)b * N * ts + (long)H * DH + h * DH;
-  const bf16_t* vb = qkv + (long)b * N * ts + 2L * H * DH + h * DH;
-  const float* lrow = lse + ((long)b * H + h) * N;
+  const bf16_t* qkv_b = qkv + (long)b * N * ts;
+  const bf16_t* dout_b = dout + (long)b * N * tso;
+  const bf16_t* out_b = out + (long)b * N * tso;
+  bf16_t* dqkv_b = dqkv + (long)b * N * ts;
   const bool active = k0 < N;
   const bool key_ok = k0 + (l & 31) < N;
   const int sr = tid >> 3, sc = tid & 7;   // staging: thread -> (chunk row, 16-byte piece)
 
+  // Prefetches are branch-free and carry no select: rows past the sequence end read (finite) row N-1 instead, and are
+  // neutralised where they are consumed -- a query row through lse = +inf (P = 0), a key row through `key_ok`.  A guarded or
+  // select-terminated load makes the waitcnt pass drain vmcnt(0) right behind the load, i.e. no prefetch at all.
   uint4 qr, dr, orr;
-  float l_reg = INFINITY;
-  auto load_chunk = [&](int tok0) {
-    const int tok = tok0 + sr;
-    qr = dr = orr = make_uint4(0, 0, 0, 0);
-    if (tok < N) {
-      qr = *reinterpret_cast<const uint4*>(qst + (long)tok * ts + sc * 8);
-      dr = *reinterpret_cast<const uint4*>(dst + (long)tok * tso + sc * 8);
-      orr = *reinterpret_cast<const uint4*>(ost + (long)tok * tso + sc * 8);
-    }
-    if (tid < FB_CH) l_reg = tok0 + tid < N ? lrow[tok0 + tid] : INFINITY;
+  float l_reg;
+  bool l_ok;
+  auto load_chunk = [&](int h, int tok0) {
+    const int tok = min(tok0 + sr, N - 1);
+    qr = *reinterpret_cast<const uint4*>(qkv_b + (long)tok * ts + h * DH + sc * 8);
+    dr = *reinterpret_cast<const uint4*>(dout_b + (long)tok * tso + h * DH + sc * 8);
+    orr = *reinterpret_cast<const uint4*>(out_b + (long)tok * tso + h * DH + sc * 8);
+    l_ok = tok0 + (tid & 63) < N;
+    l_reg = lse[((long)b * H + h) * N + min(tok0 + (tid & 63), N - 1)];
   };
   auto store_chunk = [&]() {
     const int sb = sc >> 1, half = sc & 1;
@@ -862,105 +863,121 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
     if (sc == 0) ldsL[FB_CH + sr] = acc;
-    if (tid < FB_CH) ldsL[tid] = l_reg;
+    if (tid < FB_CH) ldsL[tid] = l_ok ? l_reg : INFINITY;
+  };
+  bf16x8 kf[4], vf[4];
+  auto load_kv = [&](int h) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16_t* row = qkv_b + (long)min(k0 + (l & 31), N - 1) * ts + h * DH + ks * 16 + hi * 8;
+      kf[ks] = *reinterpret_cast<const bf16x8*>(row + (long)H * DH);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(row + 2L * H * DH);
+    }
   };
 
-  load_chunk(0);
-  bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global<true>(kb, ts, k0, N, ks); vf[ks] = frag_global<true>(vb, ts, k0, N, ks); }
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+  load_chunk(h_begin, 0);
+  load_kv(h_begin);
   store_chunk();
   __syncthreads();
-  // ---- phase A
-  for (int c0 = 0; c0 < N; c0 += FB_CH) {
-    const bool more = c0 + FB_CH < N;
-    if (more) load_chunk(c0 + FB_CH);
-    if (active) {
-      const int ntile = min(2, (N - c0 + 31) / 32);
-      for (int it = 0; it < ntile; ++it) {
-        f32x16 s, dp;
+  // The block walks its heads; everything the next head needs first (its chunk 0 and its K / V fragments) is requested while
+  // the current head still computes, so from the second head on no load latency is exposed and the stores drain underneath.
+  for (int h = h_begin; h < h_end; ++h) {
+    const bool next_head = h + 1 < h_end;
+    f32x16 dk[2], dv[2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+    // ---- phase A
+    for (int c0 = 0; c0 < N; c0 += FB_CH) {
+      const bool more = c0 + FB_CH < N;
+      load_chunk(more || !next_head ? h : h + 1, more ? c0 + FB_CH : 0);   // (the very last request of a block is a dummy)
+      if (active) {
+        const int ntile = min(2, (N - c0 + 31) / 32);
+        for (int it = 0; it < ntile; ++it) {
+          f32x16 s, dp;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
-        }
-        // rows = queries crow(e, hi), column = key lane
+          for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
-          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
-          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
-          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+          for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
+          }
+          // rows = queries crow(e, hi), column = key lane
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = 4 * g + j;
-            const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
-            s[e] = p;
-            dp[e] = p * (dp[e] - dlv[j]) * scale;
+          for (int g = 0; g < 4; ++g) {
+            const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+            const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+            const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = 4 * g + j;
+              const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
+              s[e] = p;
+              dp[e] = p * (dp[e] - dlv[j]) * scale;
+            }
+          }
+          union { bf16x8 v; unsigned u[4]; } p0, p1, d0, d1;
+          p0.v = pack8(s, 0); p1.v = pack8(s, 8); d0.v = pack8(dp, 0); d1.v = pack8(dp, 8);
+          // dS tile -> LDS rows (the bf16 values the dK product uses): register pair (2j, 2j+1) = two consecutive query rows
+          char* scol = ldsS + (size_t)(c0 + it * 32 + 4 * hi) * FB_DS + (k0 + (l & 31)) * 2;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned w = j < 4 ? d0.u[j] : d1.u[j - 4];
+            const int row = (2 * j & 3) + 8 * (2 * j >> 2);   // crow(2j, 0); the odd register is the next row
+            *reinterpret_cast<unsigned short*>(scol + row * FB_DS) = (unsigned short)(w & 0xffff);
+            *reinterpret_cast<unsigned short*>(scol + (row + 1) * FB_DS) = (unsigned short)(w >> 16);
+          }
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
           }
         }
-        union { bf16x8 v; unsigned u[4]; } p0, p1, d0, d1;
-        p0.v = pack8(s, 0); p1.v = pack8(s, 8); d0.v = pack8(dp, 0); d1.v = pack8(dp, 8);
-        // dS tile -> LDS rows (the bf16 values the dK product uses): register pair (2j, 2j+1) = two consecutive query rows
-        char* scol = ldsS + (size_t)(c0 + it * 32 + 4 * hi) * FB_DS + (k0 + (l & 31)) * 2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned w = j < 4 ? d0.u[j] : d1.u[j - 4];
-          const int row = (2 * j & 3) + 8 * (2 * j >> 2);   // crow(2j, 0); the odd register is the next row
-          *reinterpret_cast<unsigned short*>(scol + row * FB_DS) = (unsigned short)(w & 0xffff);
-          *reinterpret_cast<unsigned short*>(scol + (row + 1) * FB_DS) = (unsigned short)(w >> 16);
-        }
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
-        }
+      }
+      if (more) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
       }
     }
-    if (more) {
-      __syncthreads();
-      store_chunk();
-      __syncthreads();
-    }
-  }
-  // ---- phase B
-  __syncthreads();   // the images are dead, every dS tile is in LDS
-  if (active) {
+    // ---- phase B
+    __syncthreads();   // the images are dead, every dS tile is in LDS
+    if (active) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {   // kf[ks] = 16 B of token k0 + (l & 31) at piece c = 2 ks + hi: the store_tr placement
-      const int r = k0 + (l & 31), c = ks * 2 + hi, sb = c >> 1, half = c & 1;
-      *reinterpret_cast<bf16x8*>(ldsKt + ((r >> 2) * 4 + sb) * 128 + ((((r & 3) + sb) & 3) << 5) + (half << 4)) = kf[ks];
+      for (int ks = 0; ks < 4; ++ks) {   // kf[ks] = 16 B of token k0 + (l & 31) at piece c = 2 ks + hi: the store_tr placement
+        const int r = k0 + (l & 31), c = ks * 2 + hi, sb = c >> 1, half = c & 1;
+        *reinterpret_cast<bf16x8*>(ldsKt + ((r >> 2) * 4 + sb) * 128 + ((((r & 3) + sb) & 3) << 5) + (half << 4)) = kf[ks];
+      }
     }
-  }
-  __syncthreads();
-  f32x16 dq[2];
+    if (next_head) load_kv(h + 1);   // K went to LDS, V died with phase A
+    __syncthreads();
+    f32x16 dq[2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
-  if (active) {   // query tile `wave`
-    const int nkb = 2 * ((N + 31) / 32);
-    const char* srow = ldsS + (size_t)(k0 + (l & 31)) * FB_DS + hi * 8;
-    for (int kbk = 0; kbk < nkb; ++kbk) {
-      // B fragment: lane -> query, k-slots -> keys kbk*16 + {4hi..4hi+3, 8+4hi..8+4hi+3} (the C-layout slot order of frag_tr)
-      union { struct { uint2 a, b; } s; bf16x8 v; } f;
-      f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
-      f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
+    for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+    if (active) {   // query tile `wave`
+      const int nkb = 2 * ((N + 31) / 32);
+      const char* srow = ldsS + (size_t)(k0 + (l & 31)) * FB_DS + hi * 8;
+      for (int kbk = 0; kbk < nkb; ++kbk) {
+        // B fragment: lane -> query, k-slots -> keys kbk*16 + {4hi..4hi+3, 8+4hi..8+4hi+3} (the C-layout slot order of frag_tr)
+        union { struct { uint2 a, b; } s; bf16x8 v; } f;
+        f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
+        f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, kbk * 16), f.v, dq[db], 0, 0, 0);
+        for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, kbk * 16), f.v, dq[db], 0, 0, 0);
+      }
     }
+    __syncthreads();   // dS and K^T are dead: the dS area becomes the store scratch, the image area takes the next head
+    if (next_head) store_chunk();
+    if (active) {
+      char* scratch = ldsS + wave * (32 * 144);
+      store_td_tile(scratch, dk, dqkv_b + (long)H * DH + h * DH, ts, k0, N);
+      store_td_tile(scratch, dv, dqkv_b + 2L * H * DH + h * DH, ts, k0, N);
+      store_qd_tile(scratch, dq, 1.f, dqkv_b + h * DH, ts, k0, N);
+    }
+    if (next_head) __syncthreads();   // next head's images staged; every scratch is free before its dS tiles are written
   }
-  __syncthreads();   // dS and K^T are dead: the dS area becomes the store scratch
-  if (!active) return;
-  char* scratch = ldsS + wave * (32 * 144);
-  store_td_tile(scratch, dk, dqkv + (long)b * N * ts + (long)H * DH + h * DH, ts, k0, N);
-  store_td_tile(scratch, dv, dqkv + (long)b * N * ts + 2L * H * DH + h * DH, ts, k0, N);
-  store_qd_tile(scratch, dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, k0, N);
 }
 
 // ================================================================================================ generic head dims
@@ -1092,8 +1109,16 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
         if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", FB_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
         fused_configured = true;
       }
-      hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * H), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
-                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, scale);
+      // heads per block: as many as still leave >= 2 blocks per CU's worth of work items (a block hides the next head's loads
+      // behind the current head's compute, so longer walks are cheaper -- as long as the grid still fills the chip evenly)
+      static const int hpb_env = [] { const char* e = getenv("LT_ATTN_BWD_HPB"); return e ? atoi(e) : 0; }();
+      int hpb = hpb_env > 0 ? hpb_env : 1;
+      if (hpb_env <= 0)
+        for (int c = 2; c <= H; ++c)
+          if (H % c == 0 && (long)B * (H / c) >= 256) hpb = c;
+      hpb = min(hpb, H);
+      hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
       LT_CHECK_LAUNCH("lt_attention_bwd");
     }
     if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels
