@@ -827,6 +827,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
   bf16_t* dqkv_b = dqkv + (long)b * N * ts;
   const bool active = k0 < N;
   const bool key_ok = k0 + (l & 31) < N;
+  const float inv_scale = 1.f / scale, c_exp = scale * 1.4426950408889634f;
   const int sr = tid >> 3, sc = tid & 7;   // staging: thread -> (chunk row, 16-byte piece)
 
   // Prefetches are branch-free and carry no select: rows past the sequence end read (finite) row N-1 instead, and are
@@ -862,8 +863,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (sc == 0) ldsL[FB_CH + sr] = acc;
-    if (tid < FB_CH) ldsL[tid] = l_ok ? l_reg : INFINITY;
+    if (sc == 0) ldsL[FB_CH + sr] = -acc;                                  // dP accumulates onto -delta
+    if (tid < FB_CH) ldsL[tid] = l_ok ? -l_reg * inv_scale : -INFINITY;    // S accumulates onto -lse / scale (-inf: P = 0)
   };
   bf16x8 kf[4], vf[4];
   auto load_kv = [&](int h) {
@@ -893,28 +894,28 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
       if (active) {
         const int ntile = min(2, (N - c0 + 31) / 32);
         for (int it = 0; it < ntile; ++it) {
+          // the per-row statistics enter through the accumulators' initial values (rows = queries crow(e, hi), column = key
+          // lane): S - lse / scale and dP - delta come out of the MFMAs, and the reads sit in front of them, off the path
+          // between the MFMA results and the exponentials
           f32x16 s, dp;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+          for (int g = 0; g < 4; ++g) {
+            const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+            const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
+            s[4 * g] = key_ok ? ls.x : -INFINITY; s[4 * g + 1] = key_ok ? ls.y : -INFINITY;
+            s[4 * g + 2] = key_ok ? ls.z : -INFINITY; s[4 * g + 3] = key_ok ? ls.w : -INFINITY;
+            dp[4 * g] = dl.x; dp[4 * g + 1] = dl.y; dp[4 * g + 2] = dl.z; dp[4 * g + 3] = dl.w;
+          }
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
           }
-          // rows = queries crow(e, hi), column = key lane
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
-            const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
-            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
-            const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = 4 * g + j;
-              const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
-              s[e] = p;
-              dp[e] = p * (dp[e] - dlv[j]) * scale;
-            }
+          for (int e = 0; e < 16; ++e) {   // P = exp(scale S - lse) = exp2(c (S - lse / scale));  dS / scale = P (dP - delta)
+            const float pe = __builtin_amdgcn_exp2f(s[e] * c_exp);
+            s[e] = pe;
+            dp[e] *= pe;
           }
           union { bf16x8 v; unsigned u[4]; } p0, p1, d0, d1;
           p0.v = pack8(s, 0); p1.v = pack8(s, 8); d0.v = pack8(dp, 0); d1.v = pack8(dp, 8);
@@ -972,9 +973,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     if (next_head) store_chunk();
     if (active) {
       char* scratch = ldsS + wave * (32 * 144);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dk[0][e] *= scale; dk[1][e] *= scale; }   // dS was kept unscaled
       store_td_tile(scratch, dk, dqkv_b + (long)H * DH + h * DH, ts, k0, N);
       store_td_tile(scratch, dv, dqkv_b + 2L * H * DH + h * DH, ts, k0, N);
-      store_qd_tile(scratch, dq, 1.f, dqkv_b + h * DH, ts, k0, N);
+      store_qd_tile(scratch, dq, scale, dqkv_b + h * DH, ts, k0, N);
     }
     if (next_head) __syncthreads();   // next head's images staged; every scratch is free before its dS tiles are written
   }
@@ -1109,13 +1112,14 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
         if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", FB_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
         fused_configured = true;
       }
-      // heads per block: as many as still leave >= 2 blocks per CU's worth of work items (a block hides the next head's loads
-      // behind the current head's compute, so longer walks are cheaper -- as long as the grid still fills the chip evenly)
+      // heads per block: a block hides the next head's loads behind the current head's compute, so walks of a few heads are
+      // cheaper than single heads -- but the grid should still be >= 3 blocks per CU so that the rounds even out (B = 256,
+      // H = 12: 239 us with 12 heads per block = one block per CU, 224 us with 4, 257 us with 1)
       static const int hpb_env = [] { const char* e = getenv("LT_ATTN_BWD_HPB"); return e ? atoi(e) : 0; }();
       int hpb = hpb_env > 0 ? hpb_env : 1;
       if (hpb_env <= 0)
         for (int c = 2; c <= H; ++c)
-          if (H % c == 0 && (long)B * (H / c) >= 256) hpb = c;
+          if (H % c == 0 && (long)B * (H / c) >= 768) hpb = c;
       hpb = min(hpb, H);
       hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
                          (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
