@@ -1104,7 +1104,10 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
   const long total = (long)B * N * H;
   if (dh == DH) {
     const int nkt = lt_cdiv(N, 32);
-    static const int variant = [] { const char* e = getenv("LT_ATTN_BWD"); return e ? atoi(e) : 2; }();
+    // read per call (a getenv is noise beside a launch): tools/ab_step.py flips it between steps of ONE process, the only A/B that
+    // survives the box-to-box and minute-to-minute drift of whole-run timings
+    const char* variant_env = getenv("LT_ATTN_BWD");
+    const int variant = variant_env ? atoi(variant_env) : 2;
     if (variant >= 2 && N > 64 && N <= FB_MAXN) {   // one fused pass: S / dP / dS once, 20 instead of 28 MFMAs per tile pair
       static bool fused_configured = false;
       if (!fused_configured) {
