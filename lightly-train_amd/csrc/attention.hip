@@ -624,6 +624,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_v2_kernel(const bf16_t* _
   St::load(kr, kst, ts, 0, N);
   St::load(vr, vst, ts, 0, N);
   const float lse_q = (q < N) ? lse[((long)b * H + h) * N + q] : INFINITY;
+  const float s0 = -lse_q / scale, c_exp = scale * 1.4426950408889634f;   // S accumulates onto -lse / scale: P = exp2(c (S - lse / scale))
   bf16x8 qf[4], dof[4];
   float del_q = 0.f;   // delta[q] = sum_d dO[q,d] * O[q,d]
 #pragma unroll
@@ -648,20 +649,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_v2_kernel(const bf16_t* _
     if (active) {
       const int ntile = TWOHEAD ? (N + 31) / 32 : min(4, (N - c0 + 31) / 32);
       for (int t = 0; t < ntile; ++t) {
+        // the row statistics enter through the accumulators' initial values (keys past the end as -inf: P = 0), off the path
+        // between the MFMA results and the exponentials; dS stays unscaled until the store
         f32x16 s, dp;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { s[e] = c0 + t * 32 + crow(e, hi) < N ? s0 : -INFINITY; dp[e] = -del_q; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, tb + t, ks), qf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsV, tb + t, ks), dof[ks], dp, 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = c0 + t * 32 + crow(e, hi);
-          const float p = key < N ? __expf(s[e] * scale - lse_q) : 0.f;
-          dp[e] = p * (dp[e] - del_q) * scale;
-        }
+        for (int e = 0; e < 16; ++e) dp[e] *= __builtin_amdgcn_exp2f(s[e] * c_exp);
         const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 8);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_v2_kernel(const bf16_t* _
   }
   __syncthreads();   // the images become the store scratch
   if (!active) return;
-  store_qd_tile(smem + wave * (32 * 144), dq, 1.f, dqkv + (long)b * N * ts + h * DH, ts, q0, N);
+  store_qd_tile(smem + wave * (32 * 144), dq, scale, dqkv + (long)b * N * ts + h * DH, ts, q0, N);
 }
 
 template <int NW, bool TWOHEAD>
@@ -707,6 +706,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
   const bf16_t* vb = qkv + (long)b * N * ts + 2L * H * DH + h * DH;
   const bool active = k0 < N;
   const bool key_ok = k0 + (l & 31) < N;
+  const float inv_scale = 1.f / scale, c_exp = scale * 1.4426950408889634f;
 
   uint4 qr[St::PER], dr[St::PER];
   St::load(qr, qst, ts, 0, N);
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
       const int r = threadIdx.x;
       const int tok = TWOHEAD ? (r & 63) : tok0 + r;
       const long row = ((long)b * H + (TWOHEAD ? h0 + (r >> 6) : h)) * N + tok;
-      l_reg = tok < N ? lse[row] : INFINITY;
-      d_reg = tok < N ? delta[row] : 0.f;
+      l_reg = tok < N ? -lse[row] * inv_scale : -INFINITY;   // staged as accumulator initial values: S - lse / scale, dP - delta
+      d_reg = tok < N ? -delta[row] : 0.f;
     }
   };
   auto store_all = [&]() {
@@ -742,28 +742,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
       const int ntile = TWOHEAD ? (N + 31) / 32 : min(4, (N - c0 + 31) / 32);
       for (int t = 0; t < ntile; ++t) {
         const int it = tb + t;
+        // rows = queries crow(e, hi), column = key lane; statistics through the accumulators' initial values
         f32x16 s, dp;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[CH + it * 32 + 8 * g + 4 * hi]);
+          s[4 * g] = key_ok ? ls.x : -INFINITY; s[4 * g + 1] = key_ok ? ls.y : -INFINITY;
+          s[4 * g + 2] = key_ok ? ls.z : -INFINITY; s[4 * g + 3] = key_ok ? ls.w : -INFINITY;
+          dp[4 * g] = dl.x; dp[4 * g + 1] = dl.y; dp[4 * g + 2] = dl.z; dp[4 * g + 3] = dl.w;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
         }
-        // rows = queries crow(e,hi), col = key lane
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
-          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[CH + it * 32 + 8 * g + 4 * hi]);
-          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
-          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = 4 * g + j;
-            const float p = key_ok ? __expf(s[e] * scale - lsv[j]) : 0.f;
-            s[e] = p;
-            dp[e] = p * (dp[e] - dlv[j]) * scale;
-          }
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[e] * c_exp);
+          s[e] = pe;
+          dp[e] *= pe;   // dS / scale
         }
         const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8), d0 = pack8(dp, 0), d1 = pack8(dp, 8);
 #pragma unroll
@@ -784,6 +782,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
   __syncthreads();   // images -> store scratch
   if (!active) return;
   char* scratch = smem + wave * (32 * 144);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] *= scale; dk[1][e] *= scale; }
   store_td_tile(scratch, dk, dqkv + (long)b * N * ts + (long)H * DH + h * DH, ts, k0, N);
   store_td_tile(scratch, dv, dqkv + (long)b * N * ts + 2L * H * DH + h * DH, ts, k0, N);
 }
@@ -1115,14 +1115,15 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
         if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", FB_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
         fused_configured = true;
       }
-      // heads per block: a block hides the next head's loads behind the current head's compute, so walks of a few heads are
-      // cheaper than single heads -- but the grid should still be >= 3 blocks per CU so that the rounds even out (B = 256,
-      // H = 12: 239 us with 12 heads per block = one block per CU, 224 us with 4, 257 us with 1)
-      static const int hpb_env = [] { const char* e = getenv("LT_ATTN_BWD_HPB"); return e ? atoi(e) : 0; }();
+      // heads per block: a block hides the next head's loads behind the current head's compute, so the longest walk that still
+      // gives every CU a block wins (B = 256, H = 12, launches of the six settings interleaved in one process: 233 / 215 / 211 /
+      // 208 / 205 / 201 us for 1 / 2 / 3 / 4 / 6 / 12 heads per block; inside the training step the choice is within noise)
+      const char* hpb_str = getenv("LT_ATTN_BWD_HPB");   // per call, like LT_ATTN_BWD
+      const int hpb_env = hpb_str ? atoi(hpb_str) : 0;
       int hpb = hpb_env > 0 ? hpb_env : 1;
       if (hpb_env <= 0)
         for (int c = 2; c <= H; ++c)
-          if (H % c == 0 && (long)B * (H / c) >= 768) hpb = c;
+          if (H % c == 0 && (long)B * (H / c) >= 256) hpb = c;
       hpb = min(hpb, H);
       hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
                          (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);

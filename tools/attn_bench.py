@@ -22,6 +22,29 @@ def bench(name, B, N, H=12, dh=64, iters=10):
     fl = 4.0 * B * H * N * N * dh
     print(f"{name:28s} B={B:5d} N={N:4d}: fwd {res['fwd']:7.1f} us ({fl / res['fwd'] / 1e6:6.1f} TF/s)   bwd {res['bwd']:7.1f} us ({2.5 * fl / res['bwd'] / 1e6:6.1f} TF/s)")
 
+if len(sys.argv) > 1 and sys.argv[1] == "ab":   # python tools/attn_bench.py ab NAME v1 v2 ...: backward at the global-crop shape,
+    # the per-call switch NAME alternating launch by launch in one process (medians of individually timed launches)
+    import statistics
+    name, vals = sys.argv[2], sys.argv[3:]
+    B, N, H, dh = 256, 197, 12, 64
+    qkv = torch.randn(B, N, 3 * H * dh, device="cuda").to(torch.bfloat16)
+    out = torch.empty(B, N, H * dh, device="cuda", dtype=torch.bfloat16); lse = torch.empty(B, H, N, device="cuda")
+    dout = torch.randn(B, N, H * dh, device="cuda").to(torch.bfloat16)
+    ws = torch.empty(ops.attention_bwd_ws_floats(B, N, H, dh), device="cuda"); dqkv = torch.empty_like(qkv)
+    ops.attention_fwd(qkv, out, lse, B, N, H, dh, dh ** -0.5)
+    t = {v: [] for v in vals}
+    for i in range(25 * len(vals)):
+        v = vals[i % len(vals)]
+        os.environ[name] = v
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention_bwd(qkv, out, dout, lse, ws, dqkv, B, N, H, dh, dh ** -0.5)
+        e1.record(); torch.cuda.synchronize()
+        if i >= 5 * len(vals):
+            t[v].append(e0.elapsed_time(e1) * 1e3)
+    for v in vals:
+        print(f"{name}={v}: median {statistics.median(t[v]):7.1f} us  min {min(t[v]):7.1f}")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "global":   # profiling runs: the global-crop shape only
     bench("global 224/16", 256, 197, iters=3)
     sys.exit(0)
