@@ -14,7 +14,12 @@ from ._lib import (EPI_BF16, EPI_BF16_GELU, EPI_BF16_GELUGRAD, EPI_F32, EPI_F32_
 __all__ = ["EPI_BF16", "EPI_BF16_GELU", "EPI_RESID", "EPI_F32", "EPI_BF16_GELUGRAD", "EPI_F32_ACCUM"]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the handle itself: no Stream object per launch (~1000 launches / step)
+
+
 def _stream() -> int:
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
