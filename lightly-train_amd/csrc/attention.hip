@@ -116,6 +116,14 @@ __device__ __forceinline__ void store_qd_tile(char* scratch, const f32x16 (&o)[2
                      pack_bf2(o[db][4 * g + 2] * mul_lane, o[db][4 * g + 3] * mul_lane));
     }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private scratch, no barrier needed
+  if (tok0 + 32 <= ntok_valid) {   // full tile: four reads, then four stores, no branch per row
+    uint4 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const uint4*>(scratch + (it * 8 + (l >> 3)) * 144 + (l & 7) * 16);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<uint4*>(dst + (long)(tok0 + it * 8 + (l >> 3)) * tok_stride + (l & 7) * 8) = v[it];
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int r = it * 8 + (l >> 3), c = l & 7;
@@ -584,6 +592,15 @@ __device__ __forceinline__ void store_td_tile(char* scratch, const f32x16 (&a)[2
     for (int e = 0; e < 16; ++e)
       *reinterpret_cast<bf16_t*>(scratch + crow(e, hi) * 144 + (db * 32 + (l & 31)) * 2) = f2bf(a[db][e]);
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private scratch
+  if (tok0 + 32 <= ntok_valid) {   // full tile: four reads, then four stores, no branch per row
+    uint4 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const uint4*>(scratch + (it * 8 + (l >> 3)) * 144 + (l & 7) * 16);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<uint4*>(dst + (long)(tok0 + it * 8 + (l >> 3)) * tok_stride + (l & 7) * 8) = v[it];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int r = it * 8 + (l >> 3), c = l & 7;
@@ -805,6 +822,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
 constexpr int FB_CH = 64, FB_IMG = FB_CH * 128, FB_MAXN = 224, FB_DS = 456;
 constexpr int FB_LDS = 4 * FB_IMG + 2 * FB_CH * (int)sizeof(float) + FB_MAXN * FB_DS;
 
+template <bool PF>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int N, int H, int hpb, float scale) {
@@ -911,6 +929,19 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
           }
+          // PF: request the transposed dO / Q fragments of this tile now, so that their LDS latency runs under the exponentials
+          // instead of between the dS rows and the dV / dK MFMAs (8 fragments = 32 registers, which the kernel has to spare)
+          bf16x8 tD[2][2], tQ[2][2];
+          if (PF) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) {
+                tD[db][hf] = frag_tr(ldsDt, db, it * 32 + 16 * hf);
+                tQ[db][hf] = frag_tr(ldsQt, db, it * 32 + 16 * hf);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {   // P = exp(scale S - lse) = exp2(c (S - lse / scale));  dS / scale = P (dP - delta)
             const float pe = __builtin_amdgcn_exp2f(s[e] * c_exp);
@@ -930,10 +961,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
           }
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, PF ? tD[db][0] : frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, PF ? tD[db][1] : frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, PF ? tQ[db][0] : frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, PF ? tQ[db][1] : frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
           }
         }
       }
@@ -960,7 +991,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
     if (active) {   // query tile `wave`
       const int nkb = 2 * ((N + 31) / 32);
       const char* srow = ldsS + (size_t)(k0 + (l & 31)) * FB_DS + hi * 8;
-      for (int kbk = 0; kbk < nkb; ++kbk) {
+#pragma unroll 2
+      for (int kbk = 0; kbk < nkb; ++kbk) {   // nkb is even
         // B fragment: lane -> query, k-slots -> keys kbk*16 + {4hi..4hi+3, 8+4hi..8+4hi+3} (the C-layout slot order of frag_tr)
         union { struct { uint2 a, b; } s; bf16x8 v; } f;
         f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
@@ -1111,7 +1143,9 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
     if (variant >= 2 && N > 64 && N <= FB_MAXN) {   // one fused pass: S / dP / dS once, 20 instead of 28 MFMAs per tile pair
       static bool fused_configured = false;
       if (!fused_configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
         if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", FB_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
         fused_configured = true;
       }
@@ -1125,8 +1159,13 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
         for (int c = 2; c <= H; ++c)
           if (H % c == 0 && (long)B * (H / c) >= 256) hpb = c;
       hpb = min(hpb, H);
-      hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
-                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
+      const char* pf_str = getenv("LT_ATTN_BWD_PF");
+      if (pf_str ? atoi(pf_str) != 0 : true)
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                           (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
+      else
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                           (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
       LT_CHECK_LAUNCH("lt_attention_bwd");
     }
     if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels

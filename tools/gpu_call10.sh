@@ -2,5 +2,5 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 120 python tools/attn_bench.py ab LT_ATTN_BWD_HPB 1 2 3 4 6 12 2>&1 | tail -6
-timeout 120 python tools/attn_bench.py ab LT_ATTN_BWD 1 2 2>&1 | tail -2) | tee gpurun_out/r02j_attn_ab.log
+timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "attention" 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-300 | tail -8
+(timeout 120 python tools/attn_bench.py ab LT_ATTN_BWD 1 2 2>&1 | tail -2; timeout 120 python tools/attn_bench.py 2>&1 | tail -5) | tee gpurun_out/r02j_attn_ab2.log
