@@ -1,5 +1,10 @@
 """GEMM micro-benchmark over the ViT-S/16 step's shapes (D = 384, per-GPU batch 128: 50 432 global / 51 200 local token rows),
-each shape with the per-call dispatch switches alternating launch by launch in one process (medians).
+each shape with a per-call dispatch switch alternating launch by launch in one process (medians).
+
+The two switches it flips (LT_GEMM_NSPLIT: 256-wide kernel on the first 256 m columns + 128-wide kernel on the rest;
+LT_GEMM_SCORE_COLS: wgrad tile scoring that counts the empty columns of the last tile) existed in a throw-away build of
+`lt_gemm_bf16`'s dispatcher only -- the result (profiles/r02m_gemm_vits_dispatch_ab.log: mixed, not shipped) is why; with the shipped
+library both columns time the same kernel and the tool is a plain ViT-S shape benchmark.
 
   python tools/gemm_bench_vits.py
 """
