@@ -173,7 +173,8 @@ __device__ __forceinline__ void emit_rows(const GemmArgs& g, const float* wl, in
       *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     } else if (EPI == EPI_BF16_GELU) {
       if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(gelu_f(v.x), gelu_f(v.y)), pack_bf2(gelu_f(v.z), gelu_f(v.w)));
+      gelu2(v.x, v.y); gelu2(v.z, v.w);
+      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     } else if (EPI == EPI_RESID) {
       if (g.C2) *reinterpret_cast<uint2*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
       const float sc = g.branch_scale * rsc[it];
@@ -184,8 +185,8 @@ __device__ __forceinline__ void emit_rows(const GemmArgs& g, const float* wl, in
     } else if (EPI == EPI_BF16_GELUGRAD) {
       const uint2 a = a2[it];
       const float p0 = bf2f((bf16_t)(a.x & 0xffff)), p1 = bf2f((bf16_t)(a.x >> 16)), p2 = bf2f((bf16_t)(a.y & 0xffff)), p3 = bf2f((bf16_t)(a.y >> 16));
-      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) =
-          make_uint2(pack_bf2(v.x * gelu_grad_f(p0), v.y * gelu_grad_f(p1)), pack_bf2(v.z * gelu_grad_f(p2), v.w * gelu_grad_f(p3)));
+      mul_gelu_grad2(v.x, v.y, p0, p1); mul_gelu_grad2(v.z, v.w, p2, p3);
+      *reinterpret_cast<uint2*>((bf16_t*)g.C + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     } else if (EPI == EPI_F32_ACCUM) {
       float* c = (float*)g.C + o;
       if (atomic) { atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w); }
@@ -220,13 +221,12 @@ __device__ __forceinline__ void emit_rows_wide(const GemmArgs& g, const float* w
       if (g.C2) *reinterpret_cast<uint4*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) =
             make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 8; e += 2) gelu2(v[e], v[e + 1]);
     } else if (EPI == EPI_BF16_GELUGRAD) {
       const unsigned a[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[2 * e] *= gelu_grad_f(bf2f((bf16_t)(a[e] & 0xffff)));
-        v[2 * e + 1] *= gelu_grad_f(bf2f((bf16_t)(a[e] >> 16)));
+        mul_gelu_grad2(v[2 * e], v[2 * e + 1], bf2f((bf16_t)(a[e] & 0xffff)), bf2f((bf16_t)(a[e] >> 16)));
       }
     }
     *reinterpret_cast<uint4*>((bf16_t*)g.C + o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));

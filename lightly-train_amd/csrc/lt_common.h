@@ -109,4 +109,50 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// The same evaluation on a PAIR of values, written on 2-vectors so that the rational / polynomial part compiles to
+// v_pk_fma_f32 / v_pk_mul_f32 (two fp32 operations per lane and issue slot); constants folded (1/sqrt2 into p, 1/2 into the
+// polynomial, -log2(e)/2 into the exponent: v_exp_f32 is a base-2 exponential).  The GELU epilogues of the token GEMMs are
+// VALU-bound, not HBM-bound -- storing the pre-activations as a second output costs nothing, the GELU arithmetic costs 72 us
+// of a 391-us fc1 launch (tools/gelu_probe.py) -- so issue slots are what this buys: 33 per pair instead of 2 x 22.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& h, f32x2& ex) {   // h = erfc(|x| / sqrt2) / 2,  ex = exp(-x^2 / 2)
+  const f32x2 one = {1.f, 1.f};
+  const f32x2 den = __builtin_elementwise_abs(x) * 0.2316418882f + one;
+  f32x2 t, arg = x * x * -0.7213475204f;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  ex.x = __builtin_amdgcn_exp2f(arg.x); ex.y = __builtin_amdgcn_exp2f(arg.y);
+  f32x2 poly = t * 0.5307027145f + (-0.7265760135f);
+  poly = poly * t + 0.7107068705f;
+  poly = poly * t + (-0.142248368f);
+  poly = poly * t + 0.127414796f;
+  h = poly * t * ex;
+}
+__device__ __forceinline__ void gelu2(float& a, float& b) {
+#ifdef LT_GELU_SCALAR
+  a = gelu_f(a); b = gelu_f(b);
+#else
+  const f32x2 x = {a, b};
+  f32x2 h, ex;
+  gelu_parts2(x, h, ex);
+  const f32x2 xh = x * h;
+  a = a >= 0.f ? a - xh.x : xh.x;      // x * cdf, cdf = 1 - h | h
+  b = b >= 0.f ? b - xh.y : xh.y;
+#endif
+}
+// (a, b) *= GELU'(pa, pb)
+__device__ __forceinline__ void mul_gelu_grad2(float& a, float& b, float pa, float pb) {
+#ifdef LT_GELU_SCALAR
+  a *= gelu_grad_f(pa); b *= gelu_grad_f(pb);
+#else
+  const f32x2 x = {pa, pb};
+  f32x2 h, ex;
+  gelu_parts2(x, h, ex);
+  const f32x2 xpdf = x * ex * 0.3989422804014327f;   // x * pdf(x)
+  const f32x2 one = {1.f, 1.f};
+  const f32x2 up = one - h + xpdf, dn = h + xpdf;     // cdf + x pdf for x >= 0 | x < 0
+  a *= pa >= 0.f ? up.x : dn.x;
+  b *= pb >= 0.f ? up.y : dn.y;
+#endif
+}
+
 static inline int lt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
