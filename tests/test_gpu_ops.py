@@ -51,7 +51,7 @@ def test_gemm_layouts(M, N, K, ta, tb):
     assert rel_err(out, ref) < 1e-5, f"mfma gemm mismatch ta={ta} tb={tb}"
 
 
-@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8)] +
+@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8, 9)] +
                          # automatic dispatch on ViT-S widths: N = 256 m + r, r <= 128 => 256-wide kernel + 128-wide kernel on the last columns
                          [(2309, 384, 384, 0), (4096, 1152, 384, 0), (2048, 328, 1536, 0), (2100, 640, 128, 0)])
 @pytest.mark.parametrize("tb", [False, True])
