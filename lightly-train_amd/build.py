@@ -17,7 +17,7 @@ OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "liblt_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"] + (["-DLT_1W_DEBUG_SYNC"] if __import__("os").environ.get("LT_1W_DEBUG_SYNC") else [])
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:

@@ -763,10 +763,9 @@ __global__ __launch_bounds__(256) void gemm1w_kernel(const GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // Fragments are kept as the raw 64-bit halves the LDS instructions return until the wait that covers them: the reads are
-  // asm (invisible to the waitcnt pass), so a register move the compiler inserts between a read and its wait -- e.g. to assemble
-  // the two halves of a transposing read into one 128-bit tuple -- would copy registers the LDS has not written yet.  (Seen:
-  // one 16-column block of B wrong now and then.)  The halves are assembled AFTER the wait, where a move is harmless.
+  // The LDS reads are asm (invisible to the waitcnt pass) and the hardware fills their registers later, so no compiler-made copy
+  // of a result may run before the wait that covers it: results stay in the registers the instructions name until LT_WAIT (the two
+  // halves of a transposing read are assembled into one 128-bit fragment AFTER it), and no read sits under a branch (see ks 3).
   bf16x8 qa[2][4], qb[2][4];   // ds_read_b128 results (K-contiguous operands: A always, B of a forward GEMM)
   s16x4 rb[2][4][2];           // ds_read_b64_tr_b16 halves (B of a dgrad GEMM)
   bf16x8 fb[4];
