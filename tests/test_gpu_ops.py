@@ -396,7 +396,9 @@ def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
                                        (1, 1370, 2, 64), (2, 1374, 1, 64),    # BASELINE cfg5: ViT-L/14 at 518^2 = 37x37 + cls (+ 4 registers)
                                        # fused backward (65..224 tokens): tile / chunk edges, 4 registers, the 224-token cap and one past it
                                        (2, 201, 3, 64), (1, 224, 2, 64), (2, 225, 1, 64), (2, 193, 2, 64), (3, 96, 2, 64), (2, 100, 4, 64),
-                                       (130, 197, 2, 64)])
+                                       (130, 197, 2, 64),
+                                       # packed block-diagonal backward (32..64 tokens: several images per 224-token sequence, ragged last sequence)
+                                       (9, 37, 2, 64), (5, 50, 2, 64), (7, 33, 2, 64), (5, 32, 2, 64), (4, 48, 3, 64), (33, 50, 4, 64), (7, 64, 2, 64)])
 def test_attention(B, N, H, dh):
     o = ops()
     g = torch.Generator().manual_seed(N + dh)
