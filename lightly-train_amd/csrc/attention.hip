@@ -807,8 +807,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
 
 // ================================================================================================ backward, fused
 // One pass for 65..224 tokens (the global crops: 197 / 201 tokens): S, P, dP and dS are formed ONCE per (query tile, key tile)
-// and feed all three products (20 MFMAs per tile pair instead of 28; one exp, one read of q / k / v / dO and no delta buffer).
-// One 8-wave block per (b, h):
+// and feed all three products (20 MFMAs per tile pair instead of 28; one exp, one read of q / k / v / dO / O and no delta buffer;
+// replaces the autograd backward of LT/_models/dinov2_vit/dinov2_vit_src/layers/attention.py:49-66 for these lengths).
+// One 8-wave block per (image, group of `hpb` heads), walking its heads:
 //   phase A  wave w owns key tile w (K, V fragments and the dK / dV accumulators in registers) and walks the query side, staged
 //            through LDS in chunks of 64 rows exactly like attn_bwd_dkdv_v2_kernel (row + transposable images of Q and dO, the
 //            next chunk's loads in flight in registers; delta = rowsum(dO * O) is formed while staging).  Every dS tile also goes
@@ -817,6 +818,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v2_kernel(const bf16_t*
 //   phase B  the waves write their K fragments into a transposable image (over the dead Q / dO images) and wave w forms
 //            dQ^T[d][q] of query tile w = K^T dS^T over all keys: dS rows are read as B fragments (two ds_read_b64 per lane, row
 //            stride 456 B = 2 * 57 dwords: the 32 rows of a lane group land on 32 distinct bank pairs).
+//   walk     everything the next head needs first (its chunk 0, its K / V fragments) is requested while the current head still
+//            computes, so only a block's first head pays a load latency; the stores of a head drain under the next one.
+// The row statistics enter the MFMAs as accumulator initial values (S - lse / scale, dP - delta; -inf for keys past the end), the
+// exponential is v_exp_f32 on a folded scale, dS stays unscaled until the store (exact for the power-of-two scale of head_dim 64).
+// PF: the transposed dO / Q fragments of a tile are requested before its exponentials instead of behind them.
 // LDS: 4 x 8 KiB images + 512 B (lse, delta) + 224 x 456 B dS = 132.3 KiB -> one block per CU; dK / dV / dQ leave through a
 // wave-private transpose scratch laid over the dS area once every wave is done reading it.
 constexpr int FB_CH = 64, FB_IMG = FB_CH * 128, FB_MAXN = 224, FB_DS = 456;
