@@ -4,6 +4,7 @@
 (box-to-box +-1.5 %, and a box drifts by several percent over its first minutes).
 
   python tools/ab_step.py LT_ATTN_BWD 1 2 [--steps 30]
+  python tools/ab_step.py two_bwd_chains 0 1 --attr        # a scheduling switch of the method object instead of an environment variable
 """
 import argparse
 import os
@@ -24,6 +25,7 @@ ap.add_argument("name")
 ap.add_argument("values", nargs="+")
 ap.add_argument("--steps", type=int, default=30, help="timed steps per value")
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--attr", action="store_true", help="NAME is an attribute of the DINOv2 method object (e.g. two_bwd_chains, overlap_streams) and the values are ints")
 a = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -38,7 +40,10 @@ torch.cuda.synchronize()
 t = {v: [] for v in a.values}
 for i in range(a.steps * len(a.values)):
     v = a.values[i % len(a.values)]
-    os.environ[a.name] = v
+    if a.attr:
+        setattr(m, a.name, type(getattr(m, a.name))(int(v)))
+    else:
+        os.environ[a.name] = v
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     m.train_step(views)
