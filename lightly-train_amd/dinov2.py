@@ -145,6 +145,7 @@ class HeadEngine:
     def __init__(self, params: FlatParams, prefix: str, in_dim: int, args: DINOv2Args) -> None:
         self.P, self.prefix = params, prefix
         self.in_dim, self.hid, self.bn, self.K = in_dim, args.hidden_dim, args.dino_bottleneck_dim, args.output_dim
+        self.pad_wgrad_rows = True   # see backward(): weight-gradient GEMMs over a row count padded to whole K-tiles
         dev = params.device
         self.wn = torch.empty(self.K, self.bn, dtype=torch.bfloat16, device=dev)        # normalised prototype matrix (bf16)
         self.dwn = torch.zeros(self.K, self.bn, dtype=torch.float32, device=dev) if params.grad is not None else None
@@ -183,31 +184,40 @@ class HeadEngine:
         R, cap, tag = c["R"], c["cap"], c["tag"]
         hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
 
-        def split(n_out: int, k_in: int) -> int:
-            return _split_k(((n_out + 127) // 128) * ((k_in + 127) // 128), R)
+        slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
 
-        ops.gemm(dlogits, c["zn"], self.dwn, M=K, N=bn, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                 split_k=split(K, bn), lda=K, ldb=bn)
+        def wgrad(dy: Tensor, xin: Tensor, out: Tensor, n_out: int, k_in: int) -> None:
+            """dW[n_out, k_in] += dy[:R]^T xin[:R].  The row count of a step (2B + local + masked rows) is data dependent and rarely a
+            multiple of 64; the <= 63 rows up to the next multiple are zeroed in both operands (both: a stale pad row could hold a NaN
+            bit pattern) so that the contraction runs in whole K-tiles on the 256-row slab kernel with its deterministic split-K
+            reduction -- ragged, these four GEMMs fell to the 128-row kernel and fp32 atomics (1.3 ms per step at 0.3 PF/s)."""
+            kpad = (R + 63) // 64 * 64
+            if self.pad_wgrad_rows and kpad != R and kpad <= dy.shape[0] and kpad <= xin.shape[0]:
+                dy[R:kpad].zero_()
+                xin[R:kpad].zero_()
+            else:
+                kpad = R
+            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                     split_k=_split_k(tiles, kpad), lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None)
+
+        wgrad(dlogits, c["zn"], self.dwn, K, bn)
         dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
         # [R, bn] output = only ~35 tiles but a 65 536-long contraction: split-K into slabs, accumulate into zeros
         dzn.zero_()
-        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=2,
-                 workspace=ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32))
+        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=2, workspace=slab)
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         ops.colsum_bf16(dz, self.gw("mlp.4.bias"), R, bn)
-        ops.gemm(dz, c["h2"], self.gw("mlp.4.weight"), M=bn, N=hid, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                 split_k=split(bn, hid), lda=bn, ldb=hid)
+        wgrad(dz, c["h2"], self.gw("mlp.4.weight"), bn, hid)
         dh2 = ws.get(tag + ".dh2", (cap, hid), torch.bfloat16)
         ops.gemm(dz, self.wb("mlp.4.weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
         ops.colsum_bf16(dh2, self.gw("mlp.2.bias"), R, hid)
-        ops.gemm(dh2, c["h1"], self.gw("mlp.2.weight"), M=hid, N=hid, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                 split_k=split(hid, hid), lda=hid, ldb=hid)
+        wgrad(dh2, c["h1"], self.gw("mlp.2.weight"), hid, hid)
         dh1 = ws.get(tag + ".dh1", (cap, hid), torch.bfloat16)
         ops.gemm(dh2, self.wb("mlp.2.weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
         ops.colsum_bf16(dh1, self.gw("mlp.0.bias"), R, hid)
-        ops.gemm(dh1, c["x"], self.gw("mlp.0.weight"), M=hid, N=D, K=R, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                 split_k=split(hid, D), lda=hid, ldb=D)
+        wgrad(dh1, c["x"], self.gw("mlp.0.weight"), hid, D)
         dx = ws.get(tag + ".dx", (cap, D), torch.float32)
         ops.gemm(dh1, self.wb("mlp.0.weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
         return dx
