@@ -398,8 +398,11 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
 // DMA one [ROWS x 64] operand tile into its LDS image (ROWS/8 one-KiB wave-instructions, ROWS/64 per wave)
-template <bool TR, int ROWS, int NWAVES = 8>
-__device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0) {
+// KT (K not a multiple of 64: the last K-tile is partial): k indices past the end are clamped to the last valid chunk / row, so
+// the tile holds duplicates there instead of whatever follows the operand in memory; the A image's duplicates are then
+// overwritten with zeros (zero_tail below), which makes the B image's irrelevant.  `kdim` = K.
+template <bool TR, int ROWS, int NWAVES = 8, bool KT = false>
+__device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0, int kdim = 0) {
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   constexpr int PER_WAVE = ROWS / 8 / NWAVES, NB = ROWS / 16;
 #pragma unroll
@@ -410,16 +413,32 @@ __device__ __forceinline__ void stage_dma(char* lds, const bf16_t* __restrict__ 
       const int row = blk * 8 + (l >> 3), slot = l & 7;
       const int c = slot ^ ((row >> 1) & 7);
       const int gr = min(row0 + row, rows - 1);
-      src = P + (size_t)gr * ld + k0 + c * 8;
+      src = P + (size_t)gr * ld + (KT ? min(k0 + c * 8, kdim - 8) : k0 + c * 8);
     } else {
       const int p = blk * 8 + (l >> 3), slot = l & 7;
       const int q = p / NB, b = p % NB;
       const int kr = ((slot >> 1) - b) & 3;
       int col = row0 + b * 16 + (slot & 1) * 8;
       if (col >= rows) col = 0;
-      src = P + (size_t)(k0 + q * 4 + kr) * ld + col;
+      src = P + (size_t)(KT ? min(k0 + q * 4 + kr, kdim - 1) : k0 + q * 4 + kr) * ld + col;
     }
     __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + blk * 1024), 16, 0, 0);
+  }
+}
+
+// After a wave's DMAs of a partial K-tile have landed (its own vmcnt wait): zero the 16-byte pieces of the K-contiguous image whose
+// source chunk lies past K -- each lane overwrites exactly the piece its own DMA instruction wrote (same address arithmetic as
+// stage_dma<false>), so no other wave's in-flight DMA can undo it.  `ctail` = first invalid chunk of the tile = (K % 64) / 8.
+template <int ROWS, int NWAVES = 8>
+__device__ __forceinline__ void zero_tail(char* lds, int ctail) {
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  constexpr int PER_WAVE = ROWS / 8 / NWAVES;
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int blk = w * PER_WAVE + j;
+    const int row = blk * 8 + (l >> 3), slot = l & 7;
+    const int c = slot ^ ((row >> 1) & 7);
+    if (c >= ctail) *reinterpret_cast<uint4*>(lds + blk * 1024 + l * 16) = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -578,7 +597,10 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
 // lgkmcnt(0) precedes the reader's first barrier of that phase (WAR); every wave's vmcnt wait precedes its first barrier of
 // P4 and the data is first read in the next phase (RAW, one barrier more for the staggered group).  LDS-DMA returns in issue
 // order, which is what makes the counted vmcnt wait meaningful.
-template <bool TA, bool TB, int EPI, bool SLAB>
+// KT: K % 64 != 0 (K % 8 == 0): forward / dgrad layouts only (A K-contiguous).  The last K-tile is loaded with clamped k indices and
+// the A halves' tail pieces are zeroed by the waves that loaded them, right after the vmcnt wait that retires the tile and before
+// the barrier that publishes it (SwiGLU widths: 2736 = 42.75 tiles, 5472).
+template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false>
 __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HB = 128 * 128, BUF = 4 * HB;
@@ -597,7 +619,8 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int kbeg = slice * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg) / BK;
+  const int nk = KT ? (kend - kbeg + BK - 1) / BK : (kend - kbeg) / BK;
+  const int ctail = KT ? ((g.K & (BK - 1)) >> 3) : 8;   // first invalid 8-element chunk of the last tile (8: none)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
 
@@ -613,8 +636,17 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   do {                                                                                                           \
     char* dst_ = smem + ((TILE) & 1) * BUF + (H) * HB;                                                           \
     const int k0_ = kbeg + (TILE) * BK;                                                                          \
-    if ((H) < 2) stage_dma<TA, 128>(dst_, g.A, g.lda, g.M, m0 + (H) * 128, k0_);                                 \
-    else stage_dma<TB, 128>(dst_, g.B, g.ldb, g.N, n0 + ((H) - 2) * 128, k0_);                                   \
+    if ((H) < 2) stage_dma<TA, 128, 8, KT>(dst_, g.A, g.lda, g.M, m0 + (H) * 128, k0_, g.K);                     \
+    else stage_dma<TB, 128, 8, KT>(dst_, g.B, g.ldb, g.N, n0 + ((H) - 2) * 128, k0_, g.K);                       \
+  } while (0)
+// the partial last tile has landed (this wave's share): clear the A pieces past K
+#define LT_ZERO_TAIL(TILE)                                                   \
+  do {                                                                       \
+    if (KT && ctail != 0 && (TILE) == nk - 1) {                              \
+      zero_tail<128>(smem + ((TILE) & 1) * BUF, ctail);                      \
+      zero_tail<128>(smem + ((TILE) & 1) * BUF + HB, ctail);                 \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                    \
+    }                                                                        \
   } while (0)
 #define LT_PHASE_SYNC_IN()                      \
   do {                                          \
@@ -637,6 +669,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   }
   if (nk > 1) { LT_DMA_HALF(1, 2); LT_DMA_HALF(1, 3); LT_DMA_HALF(1, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6): tile 0 landed
   else __builtin_amdgcn_s_waitcnt(0xF70);                                                                      // vmcnt(0)
+  LT_ZERO_TAIL(0);
   // lgkmcnt(0) on every path into the loop: otherwise the waitcnt pass has to assume the kernel-argument loads may still be
   // pending at the loop header and waits lgkmcnt(0) before the first DMA address computation of every iteration -- which,
   // the counter being shared, also waits for the LDS reads just issued
@@ -692,6 +725,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     // since (6 DMA instructions) are outstanding: its youngest DMA has had three phases to land
     if (t + 2 < nk) { LT_DMA_HALF(t + 2, 3); LT_DMA_HALF(t + 2, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6)
     else __builtin_amdgcn_s_waitcnt(0xF70);
+    LT_ZERO_TAIL(t + 1);
     LT_PHASE_SYNC_IN();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -701,6 +735,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
 #undef LT_DMA_HALF
+#undef LT_ZERO_TAIL
 #undef LT_PHASE_SYNC_IN
 #undef LT_PHASE_SYNC_OUT
   __syncthreads();
@@ -910,17 +945,29 @@ int launch_1w(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
   }
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB>
+template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false>
 int launch_q_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<TA, TB, EPI, SLAB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<TA, TB, EPI, SLAB, KT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm256q_kernel<TA, TB, EPI, SLAB>), grid, dim3(NT2), LDS_BYTES, st, g);
+  hipLaunchKernelGGL((gemm256q_kernel<TA, TB, EPI, SLAB, KT>), grid, dim3(NT2), LDS_BYTES, st, g);
   return LT_OK;
+}
+// partial last K-tile (forward / dgrad layouts)
+template <bool TB>
+int launch_q_ktail(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_q_one<false, TB, EPI_BF16, false, true>(g, grid, st);
+    case EPI_BF16_GELU: return launch_q_one<false, TB, EPI_BF16_GELU, false, true>(g, grid, st);
+    case EPI_RESID: return launch_q_one<false, TB, EPI_RESID, false, true>(g, grid, st);
+    case EPI_F32: return launch_q_one<false, TB, EPI_F32, false, true>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_q_one<false, TB, EPI_BF16_GELUGRAD, false, true>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: no partial-K-tile kernel for epilogue %d", epi); return LT_ERR_INVALID;
+  }
 }
 template <bool TA, bool TB>
 int launch_q(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
@@ -1072,12 +1119,23 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
                    al(d->aux, d->ldaux, 2) && al(d->bias, 4, 4) && al(d->gamma, 4, 4);
   // ---- 256-row LDS-DMA kernel for the large GEMMs (forward / dgrad over tokens; wgrad with slab split-K)
   const bool same_t = d->trans_a == d->trans_b || !d->trans_a;  // (N,N), (N,T), (T,T)
-  const bool eligible = vec && same_t && d->K % BK == 0 && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
-  bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= 128 &&
+  // K % 64 != 0: the four-phase kernel's partial-last-tile variant, forward / dgrad layouts and non-accumulating epilogues only
+  const bool ktail = d->K % BK != 0 && d->K % 8 == 0 && d->K > BK && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM;
+  const bool eligible = vec && same_t && (d->K % BK == 0 || ktail) && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
+  bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= (ktail ? 256 : 128) &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
   if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 9) {
-    LT_CHECK_ARG(eligible, "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
+    LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
+  }
+  if (big && ktail) {
+    LT_CHECK_ARG(d->N >= 256 || d->force_kernel == 8, "lt_gemm_bf16: partial K-tile needs the 256-wide kernel");
+    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 256);
+    g.k_per_split = lt_cdiv(d->K, BK) * BK;
+    dim3 gridk(g.tiles_m * g.tiles_n, 1);
+    rc = d->trans_b ? g256::launch_q_ktail<true>(g, d->epilogue, gridk, st) : g256::launch_q_ktail<false>(g, d->epilogue, gridk, st);
+    if (rc != LT_OK) return rc;
+    LT_CHECK_LAUNCH("lt_gemm_bf16");
   }
   // LT_GEMM_1W (read per call: tools/ab_step.py flips it between steps): 1 = the one-wave-per-SIMD kernel for every eligible
   // forward / dgrad GEMM, 2 = for the K-contiguous (forward) layouts only
