@@ -1122,8 +1122,14 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   // K % 64 != 0: the four-phase kernel's partial-last-tile variant, forward / dgrad layouts and non-accumulating epilogues only
   const bool ktail = d->K % BK != 0 && d->K % 8 == 0 && d->K > BK && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM;
   const bool eligible = vec && same_t && (d->K % BK == 0 || ktail) && d->N % 8 == 0 && (!d->trans_a || d->M % 8 == 0);
+  // weight gradients with few output rows (the 64- and 128-channel convolutions of a ResNet): a 256-row tile is mostly padding, but
+  // the slab split-K kernel at a quarter of its rate still beats the 128-row kernel's atomics by 2x (LT_GEMM_WGRAD_MIN_M, per call)
+  const char* env_wm = getenv("LT_GEMM_WGRAD_MIN_M");
+  const int wgrad_min_m = env_wm ? atoi(env_wm) : 64;
+  const char* env_wk = getenv("LT_GEMM_WGRAD_MIN_K");   // shortest contraction the slab kernel takes (layer4 of a ResNet-50 at 224^2: 6272 rows)
+  const int wgrad_min_k = env_wk ? atoi(env_wk) : 4096;   // 8192 -> 4096: ResNet-50 distillation step 43.4 -> 42.5 ms
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= (ktail ? 256 : 128) &&
-             ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= 8192 && d->M >= 256));
+             ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= wgrad_min_k && d->M >= wgrad_min_m));
   if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 9) {
     LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
