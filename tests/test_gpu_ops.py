@@ -84,10 +84,12 @@ def test_gemm_256_kernel(M, N, K, tb, fk):
     assert rel_err(ob, ref * x.grad) < 6e-3
 
 
-@pytest.mark.parametrize("fk", [2, 8])
-@pytest.mark.parametrize("M,N,K", [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)])
+@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)] for f in (2, 8)] +
+                         # automatic dispatch: few output rows (ResNet layer1 / layer2 convolutions) and a layer4-sized contraction
+                         [(64, 576, 16384, 0), (128, 1152, 8192, 0), (512, 4608, 6272, 0), (2048, 512, 4096, 0)])
 def test_gemm_256_wgrad_slab_and_atomic(M, N, K, fk):
-    """dW[M,N] += dY[K,M]^T X[K,N] on the 256-row kernel: deterministic slab split-K and the atomic variant."""
+    """dW[M,N] += dY[K,M]^T X[K,N] on the 256-row kernel (forced, or as the dispatcher picks it for weight gradients with >= 64 output
+    rows over >= 4096 contraction rows): deterministic slab split-K and the atomic variant."""
     o = ops()
     g = torch.Generator().manual_seed(K)
     dY = bf(torch.randn(K, M, generator=g)).to(DEV)
