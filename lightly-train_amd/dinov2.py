@@ -319,6 +319,8 @@ class DINOv2:
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
+        # backward of the last block's MLP branch only at the token rows the loss reads (cls + masked patches): vit.backward_iter
+        self.sparse_last_mlp = os.environ.get("LT_SPARSE_LAST_MLP", "1") != "0"
         # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
         # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
         self.activation_checkpointing = False
@@ -638,12 +640,18 @@ class DINOv2:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
+        sp_g = sp_l = {}
+        if self.sparse_last_mlp:   # rows at which dxn is non-zero: global cls + masked patches; local cls
+            sp_g = dict(sparse_rows=torch.cat([ix["s_cls"][:2 * B], patch_rows[:M]]), n_sparse=2 * B + M, sparse_cap=2 * B + cap_M)
+            if sl is not None:
+                sp_l = dict(sparse_rows=ix["l_cls"], n_sparse=Rl, sparse_cap=Rl)
         if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
             # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
             # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
             lstream2 = self.local_bwd_stream
             lstream2.wait_event(main.record_event())
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, **sp_l)),
+                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, **sp_g))]
             live = [True, True]
             blk = self.cfg.depth
             while any(live):
@@ -660,9 +668,10 @@ class DINOv2:
                     pass
         else:
             if sl is not None:
-                self.s_vit.backward(ws, sl, dxn_l, side=side)
+                for _ in self.s_vit.backward_iter(ws, sl, dxn_l, side=side, **sp_l):
+                    pass
             blk = self.cfg.depth
-            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side):
+            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side, **sp_g):
                 if ev == "block":
                     blk -= 1
                     reduce_block(blk, (main, side))
