@@ -319,7 +319,7 @@ class DINOv2:
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
-        # backward of the last block's MLP branch only at the token rows the loss reads (cls + masked patches): vit.backward_iter
+        # the last block's MLP branch, forward and backward, only at the token rows the losses read (cls + masked patches): vit.forward
         self.sparse_last_mlp = os.environ.get("LT_SPARSE_LAST_MLP", "1") != "0"
         # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
         # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
@@ -494,6 +494,10 @@ class DINOv2:
         self.student.grad.zero_()
         self._loss_slots.zero_()
 
+        # the losses read the final tokens at the cls rows and the masked patch rows only: the last block's MLP branch runs there alone
+        # (index tensors built on the main stream, before the teacher stream forks off it)
+        rows_g = (torch.cat([ix["s_cls"][:2 * B], patch_rows[:M]]), 2 * B + M) if self.sparse_last_mlp else None
+        rows_l = (ix["l_cls"], n_local * B) if (self.sparse_last_mlp and n_local > 0) else None
         # ---------------- teacher (no grad) : dinov2.py:399-472 -- on its own stream, concurrent with the student forward
         main = torch.cuda.current_stream()
         tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
@@ -501,7 +505,7 @@ class DINOv2:
         torch.cuda.set_stream(tstream)
         if a.center_method == "softmax":
             self._apply_center_updates()
-        tctx = self.t_vit.forward(ws, "t", gv, None, save=False)
+        tctx = self.t_vit.forward(ws, "t", gv, None, save=False, last_mlp_rows=rows_g)
         Rt, cap_t = 2 * B + M, 2 * B + cap_M
         t_in = ws.get("t.head_in", (cap_t, D), torch.bfloat16)
         txn = tctx["xn"].view(-1, D)
@@ -554,13 +558,16 @@ class DINOv2:
         if lstream is not None:
             lstream.wait_event(main.record_event())
             with torch.cuda.stream(lstream):
-                sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing)
+                sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing,
+                                        last_mlp_rows=rows_l)
                 local_done = lstream.record_event()
-        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g, checkpoint=self.activation_checkpointing)
+        sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g, checkpoint=self.activation_checkpointing,
+                                last_mlp_rows=rows_g)
         if lstream is not None:
             main.wait_event(local_done)
         elif lv is not None:
-            sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing)
+            sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing,
+                                    last_mlp_rows=rows_l)
         Rl = n_local * B
         Rd = 2 * B + Rl                      # rows of the DINO head: global cls + local cls
         Rs, cap_s = Rd + M, Rd + cap_M       # student row layout [2B cls | Rl local cls | M masked patches]
@@ -640,18 +647,12 @@ class DINOv2:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
-        sp_g = sp_l = {}
-        if self.sparse_last_mlp:   # rows at which dxn is non-zero: global cls + masked patches; local cls
-            sp_g = dict(sparse_rows=torch.cat([ix["s_cls"][:2 * B], patch_rows[:M]]), n_sparse=2 * B + M, sparse_cap=2 * B + cap_M)
-            if sl is not None:
-                sp_l = dict(sparse_rows=ix["l_cls"], n_sparse=Rl, sparse_cap=Rl)
         if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
             # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
             # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
             lstream2 = self.local_bwd_stream
             lstream2.wait_event(main.record_event())
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, **sp_l)),
-                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, **sp_g))]
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
             live = [True, True]
             blk = self.cfg.depth
             while any(live):
@@ -668,10 +669,9 @@ class DINOv2:
                     pass
         else:
             if sl is not None:
-                for _ in self.s_vit.backward_iter(ws, sl, dxn_l, side=side, **sp_l):
-                    pass
+                self.s_vit.backward(ws, sl, dxn_l, side=side)
             blk = self.cfg.depth
-            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side, **sp_g):
+            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side):
                 if ev == "block":
                     blk -= 1
                     reduce_block(blk, (main, side))

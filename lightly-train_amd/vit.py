@@ -308,11 +308,19 @@ class ViTEngine:
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
                 drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None,
-                checkpoint: bool = False, capture_layers: Optional[Iterable[int]] = None, capture_norm: bool = True) -> Dict[str, Any]:
+                checkpoint: bool = False, capture_layers: Optional[Iterable[int]] = None, capture_norm: bool = True,
+                last_mlp_rows: Optional[Tuple[Tensor, int]] = None) -> Dict[str, Any]:
         """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
 
         drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
-        ("subset", brange int64[s]) | ("persample", scale f32[B]) -- see make_drop_plan / layers/block.py:90-141."""
+        ("subset", brange int64[s]) | ("persample", scale f32[B]) -- see make_drop_plan / layers/block.py:90-141.
+
+        last_mlp_rows = (idx int64 [>= R] on the device, R): the caller reads the output only at these token rows (the DINOv2
+        losses: cls rows and masked patch rows).  Tokens do not interact after the last attention, so the last block's MLP branch
+        -- LayerNorm, fc1, GELU, fc2, LayerScale -- is evaluated on those R rows alone and added to them in place; every other row
+        of the output is the branch-free residual and must not be read.  The saved operands are the compact R-row ones, so the
+        backward of that branch runs on R rows as well (the same `mode == "subset"` path as batch-subset stochastic depth, at
+        scale 1): the rows skipped there would have multiplied exact zeros."""
         cfg = self.cfg
         B, C, H, W = img.shape
         p, D, Hh, dh, hid = cfg.patch_size, cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
@@ -355,6 +363,12 @@ class ViTEngine:
             if entry is None:
                 return br
             kind, val = entry
+            if kind == "rows":        # explicit token rows, branch at full scale (last_mlp_rows)
+                ridx, Rr = val
+                xs = ws.get(s + which + ".xs", (T, D), torch.float32)[:Rr]
+                ops.gather_rows(xin, D, ridx, Rr, D, out_f32=xs)
+                br.update(mode="subset", rows=Rr, nb=0, x=xs, idx=ridx, scale=1.0)
+                return br
             if kind == "persample":   # DropPath: per-image mask/keep expanded over the image's tokens
                 br["mode"] = "persample"
                 br["rowscale"] = val.to(torch.float32).repeat_interleave(N).to(self.dev, non_blocking=True)
@@ -376,6 +390,8 @@ class ViTEngine:
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
             e1 = drop_plan[2 * i] if drop_plan is not None else None
             e2 = drop_plan[2 * i + 1] if drop_plan is not None else None
+            if i == cfg.depth - 1 and e2 is None and last_mlp_rows is not None and 0 < last_mlp_rows[1] < T:
+                e2 = ("rows", last_mlp_rows)
             # ---------------- attention branch
             a = branch_setup(e1, s, "a", x)
             R, nb = a["rows"], a["nb"]
@@ -472,28 +488,6 @@ class ViTEngine:
         return ctx
 
     # ---- backward -------------------------------------------------------------------------------
-    def _sparse_branch(self, ws: Workspace, tag: str, m: Dict[str, Any], idx: Tensor, R: int, cap: int, hid: int) -> Dict[str, Any]:
-        """The saved operands of an MLP branch gathered at `R` token rows, shaped like a branch that ran on a row subset in forward
-        (`mode == "subset"`: backward_iter gathers the upstream gradient at `idx`, runs the branch on R rows and scatter-adds the
-        LayerNorm gradient back).  bf16 operands are moved as fp32 words of half the width: a bit-exact copy."""
-        D = self.cfg.embed_dim
-        cap = (cap + 63) // 64 * 64   # whole K-tiles for the weight-gradient GEMMs (their pad rows are zeroed by `wgrad`)
-
-        def g16(src: Tensor, name: str, C: int) -> Tensor:
-            out = ws.get(f"{tag}.sp.{name}", (cap, C), torch.bfloat16)
-            ops.gather_rows(src.view(torch.float32), C // 2, idx, R, C // 2, out_f32=out.view(torch.float32))
-            return out
-
-        xs = ws.get(tag + ".sp.x", (cap, D), torch.float32)
-        ops.gather_rows(m["x"], D, idx, R, D, out_f32=xs)
-        mean = ws.get(tag + ".sp.mean", (cap,), torch.float32)
-        rstd = ws.get(tag + ".sp.rstd", (cap,), torch.float32)
-        ops.gather_rows(m["mean"], 1, idx, R, 1, out_f32=mean)
-        ops.gather_rows(m["rstd"], 1, idx, R, 1, out_f32=rstd)
-        hp = m["hpre"]
-        return dict(mode="subset", rows=R, nb=0, x=xs, idx=idx, scale=1.0, rowscale=None, mean=mean, rstd=rstd, y=None,
-                    ln=g16(m["ln"], "ln", D), act=g16(m["act"], "act", hid), hpre=g16(hp, "hpre", hp.shape[1]))
-
     def backward(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> None:
         """Run `backward_iter` to completion on the current stream (the LayerScale gradients still need
         `finish_layerscale_grads` once all passes of the step are done)."""
@@ -520,21 +514,13 @@ class ViTEngine:
                     ops.layerscale_dgamma(self.wb(lin + ".weight"), self.gw(lin + ".weight"), self.w(lin + ".bias"), self.gw(lin + ".bias"),
                                           self.w(gname), self.gw(gname), D, k_in)
 
-    def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None,
-                      sparse_rows: Optional[Tensor] = None, n_sparse: int = 0, sparse_cap: int = 0) -> Iterator[str]:
+    def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Iterator[str]:
         """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
 
         Generator: yields "block" after enqueuing each transformer block and "tail" before the token-assembly /
         patch-embedding part, so that a caller can interleave the launches of two independent backward passes (global and
         local crops) on two streams.  Everything before "tail" only uses atomics or side-stream-ordered accumulations into
         the shared gradient buffer; the tail does plain read-modify-writes and must run after the other pass's tail.
-
-        `sparse_rows` (int64 [>= n_sparse] on the device, `n_sparse` of them used, `sparse_cap` = row capacity of the scratch
-        buffers): the token rows at which `dxn` is non-zero.  The loss reads the final-norm output only at the cls rows and the
-        masked patch rows (15 % of the global-crop rows, 2 % of the local-crop rows), the final LayerNorm backward is row-local
-        and so is everything in the last block's MLP branch: its backward then runs on those rows only (gathered operands, the
-        result scatter-added into the residual gradient) -- every skipped row would have contributed exact zeros.  From the
-        last block's attention on the gradient is dense and nothing else changes.
 
         `side`: optional second HIP stream for the weight-gradient GEMMs and bias column sums.  They depend only on
         tensors the main (dgrad) chain has already produced and feed nothing but the optimizer, so running them beside
@@ -570,11 +556,7 @@ class ViTEngine:
         fc2n = "mlp.w3" if cfg.swiglu else "mlp.fc2"
         cur = 0   # index into dDs of the branch about to be processed
         last = f"blocks.{cfg.depth - 1}."
-        mlp_last = None   # the last block's MLP branch on the rows that carry gradient (see `sparse_rows`)
-        if sparse_rows is not None and 0 < n_sparse < T and not ckpt and blocks_ctx[-1]["mlp"]["mode"] == "plain" and \
-                blocks_ctx[-1]["mlp"]["rowscale"] is None:
-            mlp_last = self._sparse_branch(ws, tag, blocks_ctx[-1]["mlp"], sparse_rows, n_sparse, max(sparse_cap, n_sparse), hid)
-        nxt = fuse_args(None if ckpt else (mlp_last or blocks_ctx[-1]["mlp"]), last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
+        nxt = fuse_args(None if ckpt else blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
         ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
                           self.gw("norm.weight"), self.gw("norm.bias"), T, D, **nxt)
         have = bool(nxt)   # dDs[cur] already holds the upstream gradient of the branch about to be processed
@@ -629,8 +611,6 @@ class ViTEngine:
             else:
                 blk = ctx["blocks"][i]
                 a, m = blk["attn"], blk["mlp"]
-                if i == cfg.depth - 1 and mlp_last is not None:
-                    m = mlp_last
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
             g2 = self.w(pre + "ls2.gamma") if self.has(pre + "ls2.gamma") else None
