@@ -349,6 +349,11 @@ def main() -> None:
                                   if args.real_pipeline else "resident in HBM")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if getattr(method, "sparse_last_mlp", False):
+            # every loss term, gradient and update of the reference step is computed; what is not computed are rows of the last block's
+            # MLP branch that no loss reads.  roofline.achieved counts the FLOPs of the GEMMs that ran;
+            # step_algorithmic_gflop_per_image / step_frac_of_mfma_peak keep the reference's dense count.
+            out["config"]["last_block_mlp"] = "evaluated on the token rows the losses read (cls + masked patches) only"
         if comm is not None:
             out["comm"] = comm
         print(json.dumps(out), flush=True)
