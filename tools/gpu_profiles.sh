@@ -3,7 +3,7 @@
 # the three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) over one default step, cfg2 (ViT-S) and cfg5 (ViT-L/14 518^2) kernel stats.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02F
+O=$R/gpurun_out/r02I
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -19,8 +19,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output
 cd $R
 for d in single multi vits cfg5; do python tools/rocprof_summary.py $(find $O/ks_$d -name "*.db" | head -1) 32 > $O/kernel_stats_$d.md 2>&1; done
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1); M=$(find $O/pmc_MFMA -name "*counter_collection.csv" | head -1)
-python tools/pmc_step_traffic.py $F $W profiles/r02F_pmc_step_report.md > $O/gemm_traffic.txt 2>&1
-python tools/pmc_step_report.py $F $W $M 62220251693056 > $O/pmc_step_report.md 2>&1
+python tools/pmc_step_traffic.py $F $W profiles/r02I_pmc_step_report.md > $O/gemm_traffic.txt 2>&1
+python tools/pmc_step_report.py $F $W $M 59187843301376 > $O/pmc_step_report.md 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench_default_full.log 2>&1
 rm -rf $O/ks_* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA
 ls -la $O; tail -3 $O/gemm_traffic.txt; tail -4 $O/pmc_step_report.md; tail -1 $O/bench_vits.log; tail -2 $O/cfg5.log; tail -1 $O/bench_default_full.log
