@@ -9,6 +9,7 @@ fp32 accumulation, fp32 residual stream / LayerNorm / softmax statistics.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, Iterable, Iterator, List, Optional, Tuple
 
@@ -412,6 +413,21 @@ class ViTEngine:
                          gamma=g1, resid=None, out2=y1, branch_scale=a["scale"])
                 ops.scatter_add_rows(delta, a["idx"], x, D, R, D)   # x += (b/s) * g1 * branch on the subset rows, in place
                 xm = x
+            elif e2 is not None and e2[0] == "rows" and a["rowscale"] is None and os.environ.get("LT_SPARSE_LAST_PROJ", "1") != "0":
+                # last block, output read at `ridx` only: the attention projection + LayerScale + residual are row-local too -- R rows of
+                # them, written into an otherwise ZERO block-middle tensor (finite everywhere: the final LayerNorm still runs densely)
+                ridx, Rr = e2[1]
+                att_r = ws.get(s + "att_r", (T, D), torch.bfloat16)
+                ops.gather_rows(att.view(torch.float32), D // 2, ridx, Rr, D // 2, out_f32=att_r.view(torch.float32))   # bf16 rows as fp32 words
+                x_r = ws.get(tag + ".x_r", (T, D), torch.float32)
+                ops.gather_rows(x, D, ridx, Rr, D, out_f32=x_r)
+                xm_r = ws.get(tag + ".xm_r", (T, D), torch.float32)
+                ops.gemm(att_r, self.wb(pre + "attn.proj.weight"), xm_r, M=Rr, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
+                         gamma=g1, resid=x_r, out2=y1)
+                xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
+                xm.zero_()
+                xm.index_copy_(0, ridx[:Rr], xm_r[:Rr])
+                a["proj_rows"] = dict(idx=ridx, R=Rr, att_r=att_r)
             else:
                 xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
                 ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
@@ -647,12 +663,27 @@ class ViTEngine:
             # ---- attention branch: xm = x + scale * g1 * proj(attn(qkv(ln1(rows))))
             R1, nb = a["rows"], a["nb"]
             dD = dDs[cur]
-            if not have:
-                din = branch_grad_in(a, ".dxs")
+            pr = a.get("proj_rows")
+            if pr is not None:
+                # the projection ran on `R` rows (forward): its gradients come from those rows of dx; d(att) is zero elsewhere
+                assert not have
+                Rr, ridx = pr["R"], pr["idx"]
+                dxs = ws.get(tag + ".dxs", (T, D), torch.float32)[:Rr]
+                ops.gather_rows(dx, D, ridx, Rr, D, out_f32=dxs)
                 before_write(dD)
-                ops.layerscale_bwd(din, None, g1, dD, None, R1, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
-            wgrad(dD, a["att"], pre + "attn.proj.weight", D, D, R1)
-            ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+                ops.layerscale_bwd(dxs, None, g1, dD, None, Rr, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=None, scale=1.0)
+                wgrad(dD, pr["att_r"], pre + "attn.proj.weight", D, D, Rr)
+                dAr = ws.get(tag + ".dAr", (T, D), torch.bfloat16)
+                ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dAr, M=Rr, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
+                dD2.zero_()
+                dD2.index_copy_(0, ridx[:Rr], dAr[:Rr])
+            else:
+                if not have:
+                    din = branch_grad_in(a, ".dxs")
+                    before_write(dD)
+                    ops.layerscale_bwd(din, None, g1, dD, None, R1, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
+                wgrad(dD, a["att"], pre + "attn.proj.weight", D, D, R1)
+                ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             before_write(dQ)
             ops.attention_bwd(a["qkv"], a["att"], dD2, a["lse"], aws, dQ, nb, N, Hh, dh, scale)
             if ctx.get("rope") is not None:   # gradients w.r.t. the un-rotated q / k: transposed rotation
