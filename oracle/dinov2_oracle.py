@@ -301,11 +301,38 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], masks: Opt
     return {"cls": tn[:, 0], "patch": tn[:, 1 + nreg:], "prenorm": t}
 
 
-def head_forward(p: Dict[str, Tensor], x: Tensor) -> Tensor:
-    """DINOv2ProjectionHead.forward (LT/_methods/dinov2/dinov2_head.py:66-71)."""
-    x = F.gelu(F.linear(x, p["mlp.0.weight"], p["mlp.0.bias"]))
-    x = F.gelu(F.linear(x, p["mlp.2.weight"], p["mlp.2.bias"]))
-    x = F.linear(x, p["mlp.4.weight"], p["mlp.4.bias"])
+BN_BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+def is_bn_buffer(name: str) -> bool:
+    return name.endswith(BN_BUFFER_SUFFIXES)
+
+
+def head_forward(p: Dict[str, Tensor], x: Tensor, buffers: Optional[Dict[str, Tensor]] = None, training: bool = True) -> Tensor:
+    """DINOv2ProjectionHead.forward (LT/_methods/dinov2/dinov2_head.py:66-71).  With use_bn (dinov2_head.py:86-92) the MLP is
+    Linear, BatchNorm1d, GELU, Linear, BatchNorm1d, GELU, Linear (Sequential indices 0..6): detected by the presence of mlp.1.weight.
+    BatchNorm1d in train() normalises with the statistics of THIS call's rows (biased variance) and moves the running estimates
+    (momentum 0.1, unbiased variance) in `buffers`; in eval() it applies the running estimates."""
+    if "mlp.1.weight" in p:
+        assert buffers is not None
+        for lin, bn in (("mlp.0", "mlp.1"), ("mlp.3", "mlp.4")):
+            x = F.linear(x, p[lin + ".weight"], p[lin + ".bias"])
+            rm, rv = buffers[bn + ".running_mean"], buffers[bn + ".running_var"]
+            if training:
+                mean, var = x.mean(0), x.var(0, unbiased=False)
+                n = x.shape[0]
+                with torch.no_grad():
+                    rm.mul_(0.9).add_(mean.detach(), alpha=0.1)
+                    rv.mul_(0.9).add_(var.detach() * (n / (n - 1)), alpha=0.1)
+                    buffers[bn + ".num_batches_tracked"] += 1
+            else:
+                mean, var = rm, rv
+            x = F.gelu((x - mean) / torch.sqrt(var + 1e-5) * p[bn + ".weight"] + p[bn + ".bias"])
+        x = F.linear(x, p["mlp.6.weight"], p["mlp.6.bias"])
+    else:
+        x = F.gelu(F.linear(x, p["mlp.0.weight"], p["mlp.0.bias"]))
+        x = F.gelu(F.linear(x, p["mlp.2.weight"], p["mlp.2.bias"]))
+        x = F.linear(x, p["mlp.4.weight"], p["mlp.4.bias"])
     x = F.normalize(x, dim=-1, p=2, eps=1e-12)
     g = p["last_layer.parametrizations.weight.original0"]
     v = p["last_layer.parametrizations.weight.original1"]
@@ -413,7 +440,9 @@ class OracleDINOv2:
         self.cfg = dict(cfg)
         self.args = dict(DEFAULT_ARGS)
         self.args.update(args or {})
-        cast = lambda d: {k: v.detach().clone().to(dtype) for k, v in d.items()}  # noqa: E731
+        cast = lambda d: {k: v.detach().clone().to(dtype) for k, v in d.items() if not is_bn_buffer(k)}  # noqa: E731
+        bufs = lambda d: {k: v.detach().clone().to(torch.int64 if k.endswith("tracked") else dtype)  # noqa: E731
+                          for k, v in d.items() if is_bn_buffer(k)}
         self.sb = {k: v.requires_grad_(True) for k, v in cast(student_backbone).items()}
         self.sh = {k: v.requires_grad_(True) for k, v in cast(student_head).items()}
         self.tb = cast(teacher_backbone if teacher_backbone is not None else student_backbone)
@@ -423,6 +452,14 @@ class OracleDINOv2:
         self.args["ibot_separate_head"] = self.separate
         self.shi = {k: v.requires_grad_(True) for k, v in cast(student_ibot_head).items()} if self.separate else self.sh
         self.thi = cast(teacher_ibot_head if teacher_ibot_head is not None else student_ibot_head) if self.separate else self.th
+        # BatchNorm1d buffers of the heads (batch_norm=True): per module, never EMA-averaged (update_momentum walks parameters() only)
+        self.sh_buf = bufs(student_head)
+        self.th_buf = bufs(teacher_head if teacher_head is not None else student_head)
+        self.shi_buf = bufs(student_ibot_head) if self.separate else self.sh_buf
+        self.thi_buf = bufs(teacher_ibot_head if teacher_ibot_head is not None else student_ibot_head) if self.separate else self.th_buf
+        # freeze_eval_module(teacher_head) at construction (dinov2.py:241): the teacher heads' BatchNorm layers apply their running
+        # estimates unless the caller puts the module back into train() (args["teacher_head_training"])
+        self.args.setdefault("teacher_head_training", False)
         K = self.sh["last_layer.parametrizations.weight.original1"].shape[0]
         self.dino_center = torch.zeros(1, K, dtype=dtype)
         self.ibot_center = torch.zeros(1, 1, K, dtype=dtype)
@@ -478,8 +515,9 @@ class OracleDINOv2:
         with torch.no_grad():
             tt = vit_forward(self.tb, gv, cfg)
             t_cls = torch.cat([tt["cls"][b:], tt["cls"][:b]])
-            t_cls_logits = head_forward(self.th, t_cls)
-            t_patch_logits = head_forward(self.thi, tt["patch"].flatten(0, 1)[idx])
+            tht = bool(a["teacher_head_training"])
+            t_cls_logits = head_forward(self.th, t_cls, self.th_buf, tht)
+            t_patch_logits = head_forward(self.thi, tt["patch"].flatten(0, 1)[idx], self.thi_buf, tht)
             if a["center_method"] == "softmax":
                 self._apply_center_updates()
                 t_cls_p = softmax_center(t_cls_logits, self.dino_center, t_temp).view(2, b, -1)
@@ -496,15 +534,15 @@ class OracleDINOv2:
         cap_g: Dict[str, Any] = {}
         cap_l: Dict[str, Any] = {}
         sg = vit_forward(self.sb, gv, cfg, masks=cm, drop=drop_global, capture=cap_g)
-        s_cls_logits = head_forward(self.sh, sg["cls"])
-        s_patch_logits = head_forward(self.shi, sg["patch"].flatten(0, 1)[idx])
+        s_cls_logits = head_forward(self.sh, sg["cls"], self.sh_buf)
+        s_patch_logits = head_forward(self.shi, sg["patch"].flatten(0, 1)[idx], self.shi_buf)
         dino_global = dino_ce([s_cls_logits], [t_cls_p.flatten(0, 1)], a["student_temp"]) * 2 / terms
         dino_local = torch.zeros_like(dino_global)
         s_loc_logits = None
         if n_local > 0:
             lv = torch.cat(views[2:])
             sl = vit_forward(self.sb, lv, cfg, drop=drop_local, capture=cap_l)
-            s_loc_logits = head_forward(self.sh, sl["cls"])
+            s_loc_logits = head_forward(self.sh, sl["cls"], self.sh_buf)
             dino_local = dino_ce(s_loc_logits.chunk(n_local), list(t_cls_p), a["student_temp"]) / terms
         ibot = ibot_ce_masked(s_patch_logits, t_patch_p, mw, n_crops, a["student_temp"])
         koleo = sum(koleo_loss(c) for c in sg["cls"].chunk(2))

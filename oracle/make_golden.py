@@ -37,13 +37,16 @@ def synth_views(seed: int, b: int, g_size: int, l_size: int, n_local: int):
 
 def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: dict, cfg: dict, b: int,
                       g_size: int, l_size: int, n_local: int, n_steps: int, total_steps: int,
-                      keep_params_every_step: bool = True) -> None:
+                      keep_params_every_step: bool = True, teacher_head_training: bool = False,
+                      twin_tol_later_steps: float = 2e-5) -> None:
     H.install()
     from lightly_train._methods.dinov2 import utils as ref_utils
 
     m = H.build_reference_method(arch=arch, patch_size=cfg["patch_size"], img_size=g_size,
                                  model_kwargs=model_kwargs, method_kwargs=method_kwargs,
                                  global_batch_size=b, total_steps=total_steps, seed=1234)
+    if teacher_head_training:   # what a Trainer that calls module.train() at fit start leaves behind (only BatchNorm heads care)
+        m.teacher_head.train()
     r = H.ReferenceRunner(m)
     init = r.split_state()
     # teacher backbone == deepcopy(student backbone) at init (dinov2.py:196-204): store once.
@@ -57,7 +60,8 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
         init_small["student_ibot_head"] = init["student_ibot_head"]
         init_small["teacher_ibot_head"] = init["teacher_ibot_head"]
     fixture = {"name": name, "cfg": cfg, "method_kwargs": method_kwargs, "b": b, "g_size": g_size, "l_size": l_size,
-               "n_local": n_local, "total_steps": total_steps, "init": init_small, "steps": []}
+               "n_local": n_local, "total_steps": total_steps, "init": init_small, "steps": [],
+               "teacher_head_training": teacher_head_training}
 
     # capture head outputs in call order: teacher(cls, patch), student(cls, patch, local)
     cap: dict = {}
@@ -94,7 +98,8 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
                        args=dict(output_dim=method_kwargs.get("output_dim", 65536),
                                  hidden_dim=method_kwargs.get("hidden_dim", 2048),
                                  bottleneck_dim=method_kwargs.get("dino_bottleneck_dim", 256),
-                                 center_method=method_kwargs.get("center_method", "softmax")),
+                                 center_method=method_kwargs.get("center_method", "softmax"),
+                                 teacher_head_training=teacher_head_training),
                        global_batch_size=b, total_steps=total_steps,
                        teacher_backbone=init["teacher_backbone"], teacher_head=init["teacher_head"],
                        student_ibot_head=init["student_ibot_head"] if separate else None,
@@ -107,8 +112,11 @@ def make_step_fixture(name: str, arch: str, model_kwargs: dict, method_kwargs: d
         logs = r.train_step(views)
         random.seed(77 + step)
         ologs = o.train_step(views)
+        tol = 2e-5 if step == 0 else twin_tol_later_steps
         for k in ("loss", "dino_global_loss", "dino_local_loss", "ibot_loss", "koleo_loss"):
-            assert abs(logs[k] - ologs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (name, step, k, logs[k], ologs[k])
+            if k == "koleo_loss" and tol > 2e-5:
+                continue
+            assert abs(logs[k] - ologs[k]) <= tol * max(1.0, abs(logs[k])), (name, step, k, logs[k], ologs[k])
         rec = {
             "view_seed": 1000 + step,
             "view_checksum": float(sum(v.double().sum() for v in views)),
@@ -174,6 +182,9 @@ def main() -> None:
     if "--reg4-only" in sys.argv:
         make_reg4_swiglu()
         return
+    if "--bn-only" in sys.argv:
+        make_bn_heads()
+        return
     if "--dinov3-only" in sys.argv:
         make_dinov3_vit()
         return
@@ -205,6 +216,21 @@ def main() -> None:
     make_reg4_swiglu()
     make_dinov3_vit()
     make_distill()
+
+
+def make_bn_heads() -> None:
+    """batch_norm=True (dinov2_head.py:86-92): BatchNorm1d after the two hidden Linear layers of every head.  Two steps with the
+    teacher heads as the reference constructs them (eval: running estimates), one step with them in train() (batch statistics).
+    LayerScale starts at 1.0 here: at the usual 1e-5 the cls rows of a fresh model agree to ~1e-5 relative, BatchNorm divides their
+    spread by sqrt(eps) and the step turns chaotic (the fp32 restatement and the reference then agree to 1e-7 on step 0 but only to
+    4 % in the local-crop logits one step later, and a bf16 run normalises rounding noise) -- nothing a parity fixture can pin."""
+    model = dict(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=1.0)
+    head = dict(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, batch_norm=True)
+    cfg = dict(patch_size=16, num_heads=1, depth=2)
+    make_step_fixture("step_d64_bn", "DinoVisionTransformer", model, head, cfg, b=8, g_size=96, l_size=48, n_local=2,
+                      n_steps=2, total_steps=50, keep_params_every_step=False)
+    make_step_fixture("step_d64_bn_sephead_ttrain", "DinoVisionTransformer", model, dict(head, ibot_separate_head=True), cfg, b=8,
+                      g_size=96, l_size=48, n_local=2, n_steps=1, total_steps=50, teacher_head_training=True)
 
 
 def make_distill() -> None:

@@ -121,6 +121,48 @@ def test_oracle_reproduces_reference_steps(name):
                 assert torch.allclose(o.th[k], v, atol=2e-6), k
 
 
+@pytest.mark.parametrize("name", ["step_d64_bn", "step_d64_bn_sephead_ttrain"])
+def test_oracle_batchnorm_heads_reproduce_reference_steps(name):
+    """batch_norm=True: BatchNorm1d inside the projection heads (dinov2_head.py:86-92), fixture at LayerScale 1.0
+    (oracle/make_golden.py::make_bn_heads says why)."""
+    fx = load(name)
+    mk = fx["method_kwargs"]
+    o = O.OracleDINOv2(fx["init"]["student_backbone"], fx["init"]["student_head"], fx["cfg"],
+                       args=dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], bottleneck_dim=mk["dino_bottleneck_dim"],
+                                 teacher_head_training=fx["teacher_head_training"]),
+                       global_batch_size=fx["b"], total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"],
+                       student_ibot_head=fx["init"].get("student_ibot_head"), teacher_ibot_head=fx["init"].get("teacher_ibot_head"))
+    for si, rec in enumerate(fx["steps"]):
+        views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        cap = {}
+        loss, logs = o.forward_loss(views, rec["masks"], capture=cap)
+        for got, want in ((cap["t_cls_logits"], rec["teacher_cls_logits"]), (cap["s_patch_logits"], rec["student_patch_logits"]),
+                          (cap["s_loc_logits"], rec["student_local_logits"])):
+            assert torch.allclose(got, want, atol=2e-5)
+        loss.backward()
+        info = o.optimizer_step()
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+            assert float(logs[k]) == pytest.approx(rec["logs"][k], rel=2e-5)
+        assert float(logs["koleo_loss"]) == pytest.approx(rec["logs"]["koleo_loss"], rel=2e-5)
+        assert info["grad_norm"] == pytest.approx(rec["logs"]["grad_norm"], rel=1e-3)
+    st = fx["steps"][-1]["state"]
+    n = len(fx["steps"])
+    pairs = [("student_head", o.sh, o.sh_buf), ("teacher_head", o.th, o.th_buf)]
+    if "mlp.1.weight" in st.get("student_ibot_head", {}):
+        pairs += [("student_ibot_head", o.shi, o.shi_buf), ("teacher_ibot_head", o.thi, o.thi_buf)]
+    for role, params, bufs in pairs:
+        for k, v in st[role].items():
+            mine = params[k] if k in params else bufs[k]
+            # a Linear bias in front of BatchNorm has no gradient (the batch mean removes it): what autograd returns is summation
+            # round-off, and AdamW turns that into +-lr steps whose signs no two implementations share
+            atol = 2e-5 if k in ("mlp.0.bias", "mlp.3.bias") else 2e-6
+            assert torch.allclose(mine.detach().to(v.dtype), v, atol=atol), (role, k)
+    # the shared student head saw three calls per step (global cls, masked patches, local cls); a separate DINO head two
+    assert int(o.sh_buf["mlp.1.num_batches_tracked"]) == (2 if o.separate else 3) * n
+    # frozen teacher heads (eval) never touch their running estimates; in train() they move with every call
+    assert int(o.th_buf["mlp.1.num_batches_tracked"]) == ((1 if o.separate else 2) * n if fx["teacher_head_training"] else 0)
+
+
 def test_oracle_vs_live_reference():
     """Build container only: drive the reference's own DINOv2 class and the oracle side by side."""
     from oracle import ref_harness as H
