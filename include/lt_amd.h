@@ -104,6 +104,12 @@ int lt_rope_apply(void* qkv_bf16, const float* sin_t, const float* cos_t, int B,
 int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream);
 int lt_swiglu_bwd(const void* x12_bf16, const void* dh_bf16, void* d12_bf16, int64_t rows, int H, void* stream);
 
+/* nn.GELU() (erf form) on n bf16 elements, and its backward dx = dy * gelu'(x) with x the saved pre-activation: the activation of the
+ * BatchNorm projection heads (reference dinov2_head.py:86-92: Linear, BatchNorm1d, GELU), where it cannot ride a GEMM epilogue.
+ * n % 8 == 0, tensors 16-byte aligned; in-place (y == x, dx == dy) is allowed. */
+int lt_gelu_fwd_bf16(const void* x, void* y, int64_t n, void* stream);
+int lt_gelu_bwd_bf16(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+
 /* out f32 [B, n_out, D] = sparse linear map of in f32 [B, n_in, D]: out[b,o,:] = sum_{a<taps} w[o,a] * in[b, idx[o,a], :]
  * (bilinear resize of the student's spatial features onto the teacher grid, distillationv3.py:338-345; backward = the
  * transposed table).  Tables int32 / f32 [n_out, taps], built by the caller from F.interpolate. */

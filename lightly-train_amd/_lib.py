@@ -41,6 +41,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_mixup": [vp, vp, f32, vp, i32, i64, vp],
     "lt_resample_tokens": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lt_rope_apply": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lt_gelu_fwd_bf16": [vp, vp, i64, vp],
+    "lt_gelu_bwd_bf16": [vp, vp, vp, i64, vp],
     "lt_swiglu_fwd": [vp, vp, i64, i32, vp],
     "lt_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
     "lt_assemble_tokens": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -63,10 +63,21 @@ def method_key_to_flat(key: str, separate_ibot: bool) -> Optional[Tuple[str, str
 
 
 def method_state_dict(student: FlatParams, teacher: FlatParams, centers: Mapping[str, Tensor], separate_ibot: bool,
-                      depth: int, block_chunks: int = 0) -> Dict[str, Tensor]:
+                      depth: int, block_chunks: int = 0,
+                      buffers: Optional[Mapping[Tuple[str, str], Mapping[str, Tensor]]] = None) -> Dict[str, Tensor]:
     """The reference's `method.state_dict()` from the flat storages (key order: teacher backbone, student backbone, teacher heads,
     student heads, loss centers -- the registration order of dinov2.py:196-257)."""
     out: Dict[str, Tensor] = {}
+
+    def emit(role: str, fp: FlatParams, n: str, src: str, dst: str) -> None:
+        out[f"{role}_head.{dst}.{n[len(src):]}"] = fp.p[n].detach().clone()
+        # BatchNorm1d buffers follow their module's parameters (weight, bias, running_mean, running_var, num_batches_tracked)
+        mod = n[len(src):].rsplit(".", 1)[0]
+        bufs = (buffers or {}).get((role, src), {})
+        if n.endswith(".bias") and f"{mod}.running_mean" in bufs:
+            for suffix in ("running_mean", "running_var", "num_batches_tracked"):
+                out[f"{role}_head.{dst}.{mod}.{suffix}"] = bufs[f"{mod}.{suffix}"].detach().clone()
+
     for role, fp in (("teacher", teacher), ("student", student)):
         for n in fp.names:
             if n.startswith("backbone."):
@@ -74,12 +85,12 @@ def method_state_dict(student: FlatParams, teacher: FlatParams, centers: Mapping
     for role, fp in (("teacher", teacher), ("student", student)):
         for n in fp.names:
             if n.startswith("head."):
-                out[f"{role}_head.dino_head.{n[5:]}"] = fp.p[n].detach().clone()
+                emit(role, fp, n, "head.", "dino_head")
         # a shared head is one module registered under two names: both prefixes appear in the reference's state_dict
         src = "ihead." if separate_ibot else "head."
         for n in fp.names:
             if n.startswith(src):
-                out[f"{role}_head.ibot_head.{n[len(src):]}"] = fp.p[n].detach().clone()
+                emit(role, fp, n, src, "ibot_head")
     for k, v in centers.items():
         out[k] = v.detach().clone()
     return out
@@ -103,6 +114,9 @@ def load_method_state_dict(sd: Mapping[str, Tensor], student: FlatParams, teache
             continue
         role, name = hit
         fp = fps[role]
+        if name.endswith(("running_mean", "running_var", "num_batches_tracked")) and "head." in name:
+            extra[k] = v   # BatchNorm1d buffers of the projection heads: the caller hands them to the head engines
+            continue
         if name not in fp.p:
             if strict:
                 raise KeyError(f"unexpected key in state_dict: {k} (-> {name})")

@@ -229,6 +229,33 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
   }
 }
 
+// nn.GELU() (erf form) as its own pass: the BatchNorm projection heads put a normalisation between the Linear and the activation, so
+// the GEMM epilogue cannot carry it.  bwd: dx = dy * gelu'(x) with x the saved pre-activation.
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nvec) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const uint4 a = *reinterpret_cast<const uint4*>(x + i * 8);
+    const bf16_t* pa = reinterpret_cast<const bf16_t*>(&a);
+    uint4 o;
+    bf16_t* po = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) po[j] = f2bf(gelu_f(bf2f(pa[j])));
+    *reinterpret_cast<uint4*>(y + i * 8) = o;
+  }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, long nvec) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const uint4 a = *reinterpret_cast<const uint4*>(x + i * 8);
+    const uint4 g = *reinterpret_cast<const uint4*>(dy + i * 8);
+    const bf16_t* pa = reinterpret_cast<const bf16_t*>(&a);
+    const bf16_t* pg = reinterpret_cast<const bf16_t*>(&g);
+    uint4 o;
+    bf16_t* po = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) po[j] = f2bf(bf2f(pg[j]) * gelu_grad_f(bf2f(pa[j])));
+    *reinterpret_cast<uint4*>(dx + i * 8) = o;
+  }
+}
+
 // d12 = [dh * x2 * silu'(x1) | dh * silu(x1)],  silu'(x) = s(x) * (1 + x * (1 - s(x)))
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ x12, const bf16_t* __restrict__ dh,
                                                          bf16_t* __restrict__ d12, long rows, int H) {
@@ -256,6 +283,26 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     *reinterpret_cast<uint4*>(d12 + r * 2 * H + c) = o1;
     *reinterpret_cast<uint4*>(d12 + r * 2 * H + H + c) = o2;
   }
+}
+
+extern "C" int lt_gelu_fwd_bf16(const void* x, void* y, int64_t n, void* stream) {
+  LT_CHECK_ARG(x && y && n >= 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+               "lt_gelu_fwd_bf16: bad arguments (n must be a multiple of 8, tensors 16-byte aligned)");
+  if (n == 0) return LT_OK;
+  const long nv = n >> 3;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)min((long)8192, (nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+                     nv);
+  LT_CHECK_LAUNCH("lt_gelu_fwd_bf16");
+}
+
+extern "C" int lt_gelu_bwd_bf16(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+  LT_CHECK_ARG(dy && x && dx && n >= 0 && n % 8 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0,
+               "lt_gelu_bwd_bf16: bad arguments (n must be a multiple of 8, tensors 16-byte aligned)");
+  if (n == 0) return LT_OK;
+  const long nv = n >> 3;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)min((long)8192, (nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)x, (bf16_t*)dx, nv);
+  LT_CHECK_LAUNCH("lt_gelu_bwd_bf16");
 }
 
 extern "C" int lt_swiglu_fwd(const void* x12_bf16, void* out_bf16, int64_t rows, int H, void* stream) {

@@ -16,7 +16,7 @@ import os
 
 import math
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Literal, Mapping, Optional, Tuple
+from typing import Any, Dict, List, Literal, Mapping, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -76,31 +76,48 @@ class TrainingStepResult:
     log_dict: Optional[Mapping[str, Any]] = None
 
 
-HEAD_KEYS = ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias",
-             "last_layer.parametrizations.weight.original0", "last_layer.parametrizations.weight.original1")
+WN_G, WN_V = "last_layer.parametrizations.weight.original0", "last_layer.parametrizations.weight.original1"
+BN_BUFFERS = ("running_mean", "running_var", "num_batches_tracked")
 
 
-def head_param_shapes(in_dim: int, hidden: int, bottleneck: int, out_dim: int) -> List[Tuple[str, Tuple[int, ...]]]:
-    return [("mlp.0.weight", (hidden, in_dim)), ("mlp.0.bias", (hidden,)), ("mlp.2.weight", (hidden, hidden)),
-            ("mlp.2.bias", (hidden,)), ("mlp.4.weight", (bottleneck, hidden)), ("mlp.4.bias", (bottleneck,)),
-            ("last_layer.parametrizations.weight.original0", (out_dim, 1)),
-            ("last_layer.parametrizations.weight.original1", (out_dim, bottleneck))]
+def head_layer_names(use_bn: bool) -> Tuple[Tuple[str, str, str], Tuple[str, ...]]:
+    """Sequential indices of _build_mlp (dinov2_head.py:74-99): Linear, [BatchNorm1d,] GELU, Linear, [BatchNorm1d,] GELU, Linear."""
+    return (("mlp.0", "mlp.3", "mlp.6"), ("mlp.1", "mlp.4")) if use_bn else (("mlp.0", "mlp.2", "mlp.4"), ())
 
 
-def init_head_state(in_dim: int, hidden: int, bottleneck: int, out_dim: int, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
-    """DINOv2ProjectionHead init (dinov2_head.py:32-65): trunc-normal(0.02)/zero-bias MLP, weight-norm g=1,
-    v = nn.Linear default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in)))."""
+def head_param_shapes(in_dim: int, hidden: int, bottleneck: int, out_dim: int, use_bn: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
+    """named_parameters() of one DINOv2ProjectionHead, in the reference's registration order."""
+    lin, bnl = head_layer_names(use_bn)
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for i, (l, shape) in enumerate(zip(lin, ((hidden, in_dim), (hidden, hidden), (bottleneck, hidden)))):
+        out += [(l + ".weight", shape), (l + ".bias", (shape[0],))]
+        if use_bn and i < 2:
+            out += [(bnl[i] + ".weight", (hidden,)), (bnl[i] + ".bias", (hidden,))]
+    return out + [(WN_G, (out_dim, 1)), (WN_V, (out_dim, bottleneck))]
+
+
+def init_head_state(in_dim: int, hidden: int, bottleneck: int, out_dim: int, generator: Optional[torch.Generator] = None,
+                    use_bn: bool = False) -> Dict[str, Tensor]:
+    """DINOv2ProjectionHead init (dinov2_head.py:32-65): trunc-normal(0.02)/zero-bias Linear layers, weight-norm g=1,
+    v = nn.Linear default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in))); BatchNorm1d layers at their defaults (weight 1, bias 0,
+    running_mean 0, running_var 1, num_batches_tracked 0 -- the buffers are part of the returned state, as in a state_dict)."""
+    bnl = head_layer_names(use_bn)[1]
     sd: Dict[str, Tensor] = {}
-    for name, shape in head_param_shapes(in_dim, hidden, bottleneck, out_dim):
-        if name.endswith("original0"):
+    for name, shape in head_param_shapes(in_dim, hidden, bottleneck, out_dim, use_bn):
+        is_bn = name.rsplit(".", 1)[0] in bnl
+        if name == WN_G or (is_bn and name.endswith(".weight")):
             sd[name] = torch.ones(shape)
-        elif name.endswith("original1"):
+        elif name == WN_V:
             bound = 1 / math.sqrt(bottleneck)
             sd[name] = torch.empty(shape).uniform_(-bound, bound, generator=generator)
         elif name.endswith(".weight"):
             sd[name] = torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=generator)
         else:
             sd[name] = torch.zeros(shape)
+        if is_bn and name.endswith(".bias"):
+            b = name.rsplit(".", 1)[0]
+            sd[b + ".running_mean"], sd[b + ".running_var"] = torch.zeros(hidden), torch.ones(hidden)
+            sd[b + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
     return sd
 
 
@@ -147,6 +164,17 @@ class HeadEngine:
         self.in_dim, self.hid, self.bn, self.K = in_dim, args.hidden_dim, args.dino_bottleneck_dim, args.output_dim
         self.pad_wgrad_rows = True   # see backward(): weight-gradient GEMMs over a row count padded to whole K-tiles
         dev = params.device
+        # batch_norm=True (dinov2_head.py:86-92): BatchNorm1d between each hidden Linear and its GELU.  The running estimates are
+        # buffers of THIS module: no gradient, not part of the EMA (update_momentum walks parameters() only), saved in the state_dict.
+        self.use_bn = bool(args.batch_norm)
+        self.lin, self.bnl = head_layer_names(self.use_bn)
+        self.bn_eps, self.bn_momentum = 1e-5, 0.1
+        self.buffers: Dict[str, Tensor] = {}
+        self.batches_tracked: Dict[str, int] = {}
+        for b in self.bnl:
+            self.buffers[b + ".running_mean"] = torch.zeros(self.hid, dtype=torch.float32, device=dev)
+            self.buffers[b + ".running_var"] = torch.ones(self.hid, dtype=torch.float32, device=dev)
+            self.batches_tracked[b] = 0
         self.wn = torch.empty(self.K, self.bn, dtype=torch.bfloat16, device=dev)        # normalised prototype matrix (bf16)
         self.dwn = torch.zeros(self.K, self.bn, dtype=torch.float32, device=dev) if params.grad is not None else None
 
@@ -160,24 +188,84 @@ class HeadEngine:
         return self.P.g[self.prefix + n]
 
     def refresh_weightnorm(self) -> None:
-        ops.weightnorm_fwd(self.w(HEAD_KEYS[7]), self.w(HEAD_KEYS[6]), self.wn, self.K, self.bn)
+        ops.weightnorm_fwd(self.w(WN_V), self.w(WN_G), self.wn, self.K, self.bn)
 
-    def forward(self, ws: Workspace, tag: str, x: Tensor, R: int, cap: int, save: bool) -> Dict[str, Tensor]:
+    def load_buffers(self, state: Mapping[str, Tensor], prefix: str = "") -> None:
+        """BatchNorm buffers from a head state / state_dict (keys `<prefix>mlp.N.running_mean` ...); absent keys keep their value."""
+        for b in self.bnl:
+            for suffix in ("running_mean", "running_var"):
+                k = f"{prefix}{b}.{suffix}"
+                if k in state:
+                    self.buffers[f"{b}.{suffix}"].copy_(state[k].to(self.buffers[f"{b}.{suffix}"].device, torch.float32))
+            k = f"{prefix}{b}.num_batches_tracked"
+            if k in state:
+                self.batches_tracked[b] = int(state[k])
+
+    def buffer_state(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for b in self.bnl:
+            out[b + ".running_mean"] = self.buffers[b + ".running_mean"].detach().clone()
+            out[b + ".running_var"] = self.buffers[b + ".running_var"].detach().clone()
+            out[b + ".num_batches_tracked"] = torch.tensor(self.batches_tracked[b], dtype=torch.int64)
+        return out
+
+    def _hidden_bn(self, ws: Workspace, tag: str, li: int, xin: Tensor, k_in: int, R: int, cap: int, segs: Sequence[Tuple[int, int]],
+                   training: bool) -> Dict[str, Tensor]:
+        """Linear -> BatchNorm1d -> GELU on rows [0, R).  `segs` = (first row, rows) of every reference call that these rows came
+        from: nn.BatchNorm1d normalises over the rows of ONE forward call, so each segment gets its own statistics, and in train()
+        each moves the running estimates once, in the order given (the reference's call order)."""
+        hid = self.hid
+        lin, bnn = self.lin[li], self.bnl[li]
+        y = ws.get(f"{tag}.y{li}", (cap, hid), torch.bfloat16)       # Linear output (BatchNorm input)
+        u = ws.get(f"{tag}.u{li}", (cap, hid), torch.bfloat16)       # BatchNorm output (GELU input)
+        h = ws.get(f"{tag}.h{li + 1}", (cap, hid), torch.bfloat16)
+        mean = ws.get(f"{tag}.bn{li}.mean", (len(segs), hid), torch.float32)
+        rstd = ws.get(f"{tag}.bn{li}.rstd", (len(segs), hid), torch.float32)
+        bnws = ws.get(f"{tag}.bnws", (ops.batchnorm_ws_floats(hid),), torch.float32)
+        ops.gemm(xin, self.wb(lin + ".weight"), y, M=R, N=hid, K=k_in, epilogue=ops.EPI_BF16, bias=self.w(lin + ".bias"))
+        gamma, beta = self.w(bnn + ".weight"), self.w(bnn + ".bias")
+        rm, rv = self.buffers[bnn + ".running_mean"], self.buffers[bnn + ".running_var"]
+        for si, (r0, n) in enumerate(segs):
+            if training:
+                if n < 2:
+                    raise ValueError(f"BatchNorm1d in train() needs more than 1 row per call, got {n}")   # as torch raises
+                ops.batchnorm_fwd(y[r0:r0 + n], gamma, beta, u[r0:r0 + n], mean[si], rstd[si], n, hid, bnws, running_mean=rm, running_var=rv,
+                                  eps=self.bn_eps, momentum=self.bn_momentum)
+                self.batches_tracked[bnn] += 1
+            else:
+                torch.rsqrt(rv + self.bn_eps, out=rstd[si])
+                ops.batchnorm_apply(y[r0:r0 + n], rm, rstd[si], gamma, beta, u[r0:r0 + n], n, hid)
+        ops.gelu_fwd(u, h, R * hid)
+        return dict(y=y, u=u, h=h, mean=mean, rstd=rstd)
+
+    def forward(self, ws: Workspace, tag: str, x: Tensor, R: int, cap: int, save: bool,
+                segs: Optional[Sequence[Tuple[int, int]]] = None, bn_training: bool = True) -> Dict[str, Any]:
         hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
-        h1 = ws.get(tag + ".h1", (cap, hid), torch.bfloat16)
-        h1p = ws.get(tag + ".h1p", (cap, hid), torch.bfloat16) if save else None
-        ops.gemm(x, self.wb("mlp.0.weight"), h1, M=R, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w("mlp.0.bias"), out2=h1p)
-        h2 = ws.get(tag + ".h2", (cap, hid), torch.bfloat16)
-        h2p = ws.get(tag + ".h2p", (cap, hid), torch.bfloat16) if save else None
-        ops.gemm(h1, self.wb("mlp.2.weight"), h2, M=R, N=hid, K=hid, epilogue=ops.EPI_BF16_GELU, bias=self.w("mlp.2.bias"), out2=h2p)
+        l0, l1, l2 = self.lin
+        bnc: List[Dict[str, Tensor]] = []
+        h1p = h2p = None
+        if self.use_bn:
+            segs = [(r0, n) for r0, n in (segs if segs is not None else [(0, R)]) if n > 0]
+            assert sum(n for _, n in segs) == R, "BatchNorm segments must cover the rows"
+            bnc.append(self._hidden_bn(ws, tag, 0, x, D, R, cap, segs, bn_training))
+            h1 = bnc[0]["h"]
+            bnc.append(self._hidden_bn(ws, tag, 1, h1, hid, R, cap, segs, bn_training))
+            h2 = bnc[1]["h"]
+        else:
+            h1 = ws.get(tag + ".h1", (cap, hid), torch.bfloat16)
+            h1p = ws.get(tag + ".h1p", (cap, hid), torch.bfloat16) if save else None
+            ops.gemm(x, self.wb(l0 + ".weight"), h1, M=R, N=hid, K=D, epilogue=ops.EPI_BF16_GELU, bias=self.w(l0 + ".bias"), out2=h1p)
+            h2 = ws.get(tag + ".h2", (cap, hid), torch.bfloat16)
+            h2p = ws.get(tag + ".h2p", (cap, hid), torch.bfloat16) if save else None
+            ops.gemm(h1, self.wb(l1 + ".weight"), h2, M=R, N=hid, K=hid, epilogue=ops.EPI_BF16_GELU, bias=self.w(l1 + ".bias"), out2=h2p)
         z = ws.get(tag + ".z", (cap, bn), torch.float32)
-        ops.gemm(h2, self.wb("mlp.4.weight"), z, M=R, N=bn, K=hid, epilogue=ops.EPI_F32, bias=self.w("mlp.4.bias"))
+        ops.gemm(h2, self.wb(l2 + ".weight"), z, M=R, N=bn, K=hid, epilogue=ops.EPI_F32, bias=self.w(l2 + ".bias"))
         zn = ws.get(tag + ".zn", (cap, bn), torch.bfloat16)
         inv = ws.get(tag + ".inv", (cap,), torch.float32)
         ops.l2norm_fwd(z, zn, inv, R, bn, 1e-12)
         logits = ws.get(tag + ".logits", (cap, K), torch.float32)
         ops.gemm(zn, self.wn, logits, M=R, N=K, K=bn, epilogue=ops.EPI_F32)
-        return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, zn=zn, inv=inv, logits=logits, R=R, cap=cap, tag=tag)
+        return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, zn=zn, inv=inv, logits=logits, R=R, cap=cap, tag=tag, bn=bnc, segs=segs)
 
     def backward(self, ws: Workspace, c: Dict[str, Any], dlogits: Tensor) -> Tensor:
         """dlogits bf16 [R,K] -> returns d(x) f32 [R, in_dim]; accumulates parameter grads."""
@@ -208,22 +296,42 @@ class HeadEngine:
         ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=2, workspace=slab)
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
-        ops.colsum_bf16(dz, self.gw("mlp.4.bias"), R, bn)
-        wgrad(dz, c["h2"], self.gw("mlp.4.weight"), bn, hid)
+        l0, l1, l2 = self.lin
+        ops.colsum_bf16(dz, self.gw(l2 + ".bias"), R, bn)
+        wgrad(dz, c["h2"], self.gw(l2 + ".weight"), bn, hid)
         dh2 = ws.get(tag + ".dh2", (cap, hid), torch.bfloat16)
-        ops.gemm(dz, self.wb("mlp.4.weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
-        ops.colsum_bf16(dh2, self.gw("mlp.2.bias"), R, hid)
-        wgrad(dh2, c["h1"], self.gw("mlp.2.weight"), hid, hid)
         dh1 = ws.get(tag + ".dh1", (cap, hid), torch.bfloat16)
-        ops.gemm(dh2, self.wb("mlp.2.weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
-        ops.colsum_bf16(dh1, self.gw("mlp.0.bias"), R, hid)
-        wgrad(dh1, c["x"], self.gw("mlp.0.weight"), hid, D)
+        if self.use_bn:
+            def bn_bwd(li: int, dh: Tensor) -> Tensor:
+                """d(GELU output) -> d(Linear output): GELU', then BatchNorm backward per segment (training-mode statistics)."""
+                b_, bnn = c["bn"][li], self.bnl[li]
+                ops.gelu_bwd(dh, b_["u"], dh, R * hid)
+                dy = ws.get(f"{tag}.dy{li}", (cap, hid), torch.bfloat16)
+                bnws = ws.get(f"{tag}.bnws", (ops.batchnorm_ws_floats(hid),), torch.float32)
+                for si, (r0, n) in enumerate(c["segs"]):
+                    ops.batchnorm_bwd(dh[r0:r0 + n], b_["y"][r0:r0 + n], self.w(bnn + ".weight"), b_["mean"][si], b_["rstd"][si],
+                                      dy[r0:r0 + n], n, hid, bnws, dgamma=self.gw(bnn + ".weight"), dbeta=self.gw(bnn + ".bias"))
+                return dy
+
+            ops.gemm(dz, self.wb(l2 + ".weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16)
+            dy1 = bn_bwd(1, dh2)
+            ops.colsum_bf16(dy1, self.gw(l1 + ".bias"), R, hid)
+            wgrad(dy1, c["h1"], self.gw(l1 + ".weight"), hid, hid)
+            ops.gemm(dy1, self.wb(l1 + ".weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
+            dh1 = bn_bwd(0, dh1)
+        else:
+            ops.gemm(dz, self.wb(l2 + ".weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
+            ops.colsum_bf16(dh2, self.gw(l1 + ".bias"), R, hid)
+            wgrad(dh2, c["h1"], self.gw(l1 + ".weight"), hid, hid)
+            ops.gemm(dh2, self.wb(l1 + ".weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
+        ops.colsum_bf16(dh1, self.gw(l0 + ".bias"), R, hid)
+        wgrad(dh1, c["x"], self.gw(l0 + ".weight"), hid, D)
         dx = ws.get(tag + ".dx", (cap, D), torch.float32)
-        ops.gemm(dh1, self.wb("mlp.0.weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
+        ops.gemm(dh1, self.wb(l0 + ".weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
         return dx
 
     def finish_weightnorm_grad(self) -> None:
-        ops.weightnorm_bwd(self.dwn, self.w(HEAD_KEYS[7]), self.w(HEAD_KEYS[6]), self.gw(HEAD_KEYS[7]), self.gw(HEAD_KEYS[6]), self.K, self.bn)
+        ops.weightnorm_bwd(self.dwn, self.w(WN_V), self.w(WN_G), self.gw(WN_V), self.gw(WN_G), self.K, self.bn)
         self.dwn.zero_()
 
 
@@ -247,8 +355,6 @@ class DINOv2:
                  teacher_ibot_head_state: Optional[Dict[str, Tensor]] = None) -> None:
         self.method_args = method_args or DINOv2Args()
         a = self.method_args
-        if a.batch_norm:
-            raise NotImplementedError("batch_norm heads are not implemented (reference default False)")
         if a.center_method not in ("softmax", "sinkhorn_knopp"):
             raise ValueError(f"Unknown centering method: {a.center_method}")
         self.cfg = vit_cfg
@@ -258,17 +364,18 @@ class DINOv2:
         g = torch.Generator().manual_seed(seed)
         D = vit_cfg.embed_dim
         bsd = backbone_state if backbone_state is not None else init_vit_state(vit_cfg, g)
-        shs = student_head_state if student_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
-        ths = teacher_head_state if teacher_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+        bn = a.batch_norm
+        shs = student_head_state if student_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g, bn)
+        ths = teacher_head_state if teacher_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g, bn)
         tbs = teacher_backbone_state if teacher_backbone_state is not None else bsd
         order_b = [n for n, _ in vit_param_shapes(vit_cfg)]
-        order_h = [n for n, _ in head_param_shapes(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim)]
+        order_h = [n for n, _ in head_param_shapes(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, bn)]
         s_named = [("backbone." + n, bsd[n]) for n in order_b] + [("head." + n, shs[n]) for n in order_h]
         t_named = [("backbone." + n, tbs[n]) for n in order_b] + [("head." + n, ths[n]) for n in order_h]
         if a.ibot_separate_head:
             # the reference builds the iBOT head with dino_bottleneck_dim too (dinov2.py:221-228) -- kept bug-compatible
-            sis = student_ibot_head_state if student_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
-            tis = teacher_ibot_head_state if teacher_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g)
+            sis = student_ibot_head_state if student_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g, bn)
+            tis = teacher_ibot_head_state if teacher_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g, bn)
             s_named += [("ihead." + n, sis[n]) for n in order_h]
             t_named += [("ihead." + n, tis[n]) for n in order_h]
         self.student = FlatParams(s_named, self.device, True)
@@ -287,6 +394,17 @@ class DINOv2:
         self.t_ihead = HeadEngine(self.teacher, "ihead.", D, a) if a.ibot_separate_head else self.t_head
         for h in {id(x): x for x in (self.s_head, self.t_head, self.s_ihead, self.t_ihead)}.values():
             h.refresh_weightnorm()
+        self.s_head.load_buffers(shs)
+        self.t_head.load_buffers(ths)
+        if a.ibot_separate_head:
+            self.s_ihead.load_buffers(sis)
+            self.t_ihead.load_buffers(tis)
+        # freeze_eval_module(self.teacher_head) (dinov2.py:63-67,241) leaves the teacher heads in eval(): their BatchNorm layers apply
+        # the running estimates, which nothing ever moves (no forward in train(), not in the EMA).  A Trainer that calls
+        # module.train() at fit start (Lightning < 2.2) flips them to batch statistics: set this attribute to get that behaviour.
+        self.teacher_head_training = False
+        if bn and self.world > 1:
+            raise NotImplementedError("batch_norm heads on more than one rank need SyncBatchNorm statistics (train_helpers.py:223)")
         K = a.output_dim
         self.dino_center = torch.zeros(1, K, device=self.device)
         self.ibot_center = torch.zeros(1, 1, K, device=self.device)
@@ -355,8 +473,10 @@ class DINOv2:
 
     def state_dict(self) -> Dict[str, Tensor]:
         """`method.state_dict()` with the reference's keys (what Lightning stores as checkpoint["state_dict"])."""
+        buffers = {("student", "head."): self.s_head.buffer_state(), ("teacher", "head."): self.t_head.buffer_state(),
+                   ("student", "ihead."): self.s_ihead.buffer_state(), ("teacher", "ihead."): self.t_ihead.buffer_state()}
         return checkpoint.method_state_dict(self.student, self.teacher, {"dino_loss.center": self.dino_center, "ibot_loss.center": self.ibot_center},
-                                            self.method_args.ibot_separate_head, self.cfg.depth, self.cfg.block_chunks)
+                                            self.method_args.ibot_separate_head, self.cfg.depth, self.cfg.block_chunks, buffers)
 
     def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
         """Load a `method.state_dict()` written by the reference (or by `state_dict()`): fp32 master weights, their bf16 shadows
@@ -367,6 +487,10 @@ class DINOv2:
             self.dino_center.copy_(extra["dino_loss.center"].to(self.device, torch.float32).view_as(self.dino_center))
         if "ibot_loss.center" in extra:
             self.ibot_center.copy_(extra["ibot_loss.center"].to(self.device, torch.float32).view_as(self.ibot_center))
+        for role, head, ihead in (("student", self.s_head, self.s_ihead), ("teacher", self.t_head, self.t_ihead)):
+            head.load_buffers(extra, f"{role}_head.dino_head.")
+            if ihead is not head:
+                ihead.load_buffers(extra, f"{role}_head.ibot_head.")
         self._pending.clear()
         self._refresh_derived()
 
@@ -514,10 +638,13 @@ class DINOv2:
         sep = a.ibot_separate_head
         t_logits = ws.get("t.logits_all", (cap_t, K), torch.float32) if sep else None
         if not sep:
-            t_logits = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False)["logits"]
+            t_logits = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False, segs=[(0, 2 * B), (2 * B, M)],
+                                           bn_training=self.teacher_head_training)["logits"]
         else:  # two heads: cls rows through dino_head, masked patch rows through ibot_head
-            t_logits[:2 * B].copy_(self.t_head.forward(ws, "th", t_in, 2 * B, 2 * B, save=False)["logits"][:2 * B])
-            t_logits[2 * B:Rt].copy_(self.t_ihead.forward(ws, "thi", t_in[2 * B:], M, cap_M, save=False)["logits"][:M])
+            t_logits[:2 * B].copy_(self.t_head.forward(ws, "th", t_in, 2 * B, 2 * B, save=False,
+                                                       bn_training=self.teacher_head_training)["logits"][:2 * B])
+            t_logits[2 * B:Rt].copy_(self.t_ihead.forward(ws, "thi", t_in[2 * B:], M, cap_M, save=False,
+                                                          bn_training=self.teacher_head_training)["logits"][:M])
         t_probs = ws.get("t.probs", (cap_t, K), torch.float32)
         if a.center_method == "softmax":
             ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
@@ -578,10 +705,11 @@ class DINOv2:
             ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B:Rd])
         ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in[Rd:Rs])
         if not sep:
-            sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True)
+            # BatchNorm segments in the reference's call order: global cls, masked patches (dinov2.py:487-503), local cls (:515)
+            sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True, segs=[(0, 2 * B), (Rd, M), (2 * B, Rl)])
             shi = None
         else:
-            sh = self.s_head.forward(ws, "sh", s_in, Rd, Rd, save=True)
+            sh = self.s_head.forward(ws, "sh", s_in, Rd, Rd, save=True, segs=[(0, 2 * B), (2 * B, Rl)])
             shi = self.s_ihead.forward(ws, "shi", s_in[Rd:], M, cap_M, save=True)
 
         # ---------------- losses : dinov2.py:335-387, dinov2_loss.py:117-133,246-268

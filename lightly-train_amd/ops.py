@@ -255,6 +255,23 @@ def rope_apply(qkv: Tensor, sin_t: Tensor, cos_t: Tensor, B: int, N: int, H: int
     check(_lib.load().lt_rope_apply(_p(qkv), _p(sin_t), _p(cos_t), B, N, H, dh, prefix, int(inverse), _stream()), "lt_rope_apply")
 
 
+def gelu_fwd(x: Tensor, y: Tensor, n: int) -> Tensor:
+    """y[:n] = gelu(x[:n]) on flat bf16 storage (erf form, nn.GELU())."""
+    _chk(x, torch.bfloat16, "gelu_fwd.x")
+    _chk(y, torch.bfloat16, "gelu_fwd.y")
+    check(_lib.load().lt_gelu_fwd_bf16(_p(x), _p(y), n, _stream()), "lt_gelu_fwd_bf16")
+    return y
+
+
+def gelu_bwd(dy: Tensor, x: Tensor, dx: Tensor, n: int) -> Tensor:
+    """dx[:n] = dy[:n] * gelu'(x[:n]), x the saved pre-activation."""
+    _chk(dy, torch.bfloat16, "gelu_bwd.dy")
+    _chk(x, torch.bfloat16, "gelu_bwd.x")
+    _chk(dx, torch.bfloat16, "gelu_bwd.dx")
+    check(_lib.load().lt_gelu_bwd_bf16(_p(dy), _p(x), _p(dx), n, _stream()), "lt_gelu_bwd_bf16")
+    return dx
+
+
 def swiglu_fwd(x12: Tensor, out: Tensor, rows: int, H: int) -> None:
     """out[rows, H] = silu(x12[:, :H]) * x12[:, H:]  (bf16, reference swiglu_ffn.py:31-35)."""
     _chk(x12, torch.bfloat16, "swiglu.x12"); _chk(out, torch.bfloat16, "swiglu.out")

@@ -704,3 +704,23 @@ def test_token_mean_and_pool_backward():
     s = torch.empty(64, 8, device=DEV, dtype=torch.bfloat16)
     o.add_bf16(a.to(DEV), b_.to(DEV), s)
     assert rel_err(s, a.float() + b_.float()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 4096, 24 * 2048 + 8])
+def test_gelu_elementwise_fwd_bwd(n):
+    """lt_gelu_fwd_bf16 / lt_gelu_bwd_bf16 (the activation of the BatchNorm projection heads) against torch's erf GELU in fp32."""
+    from lightly_train_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 2).to(torch.bfloat16).cuda()
+    dy = torch.randn(n, generator=g).to(torch.bfloat16).cuda()
+    y = torch.empty_like(x); dx = torch.empty_like(x)
+    ops.gelu_fwd(x, y, n)
+    ops.gelu_bwd(dy, x, dx, n)
+    xf = x.float().requires_grad_(True)
+    ref = torch.nn.functional.gelu(xf)
+    ref.backward(dy.float())
+    assert torch.allclose(y.float(), ref.detach(), atol=2e-2, rtol=1e-2)
+    assert torch.allclose(dx.float(), xf.grad, atol=2e-2, rtol=1e-2)
+    ops.gelu_bwd(dy, x, dy, n)      # in place
+    assert torch.equal(dy, dx)

@@ -48,7 +48,8 @@ def build(fx, **over):
                    num_register_tokens=cfgd.get("num_register_tokens", 0), interpolate_offset=cfgd.get("interpolate_offset", 0.1),
                    interpolate_antialias=cfgd.get("interpolate_antialias", False), **extra)
     kw = dict(output_dim=mk["output_dim"], hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"],
-              center_method=mk.get("center_method", "softmax"), ibot_separate_head=mk.get("ibot_separate_head", False))
+              center_method=mk.get("center_method", "softmax"), ibot_separate_head=mk.get("ibot_separate_head", False),
+              batch_norm=mk.get("batch_norm", False))
     kw.update(over)
     args = DINOv2Args(**kw)
     return DINOv2(vc, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=sb,
@@ -64,7 +65,8 @@ def oracle_for(fx, **over):
              center_method=mk.get("center_method", "softmax"))
     a.update(over)
     return O.OracleDINOv2(fx["init"]["student_backbone"], fx["init"]["student_head"], fx["cfg"], args=a, global_batch_size=fx["b"],
-                          total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"])
+                          total_steps=fx["total_steps"], teacher_head=fx["init"]["teacher_head"],
+                          student_ibot_head=fx["init"].get("student_ibot_head"), teacher_ibot_head=fx["init"].get("teacher_ibot_head"))
 
 
 @pytest.mark.parametrize("name", ["step_vittest_softmax", "step_vittest_sinkhorn", "step_vittest_sephead", "step_d64_softmax",
@@ -100,6 +102,92 @@ def test_step_matches_reference_fixture(name):
     assert "teacher_head.ibot_head.last_layer.parametrizations.weight.original1" in sd and "dino_loss.center" in sd
     if name == "step_vittest_sephead":  # separate iBOT head: its own parameters, trained and EMA-averaged
         assert not torch.equal(sd["student_head.ibot_head.mlp.0.weight"], sd["student_head.dino_head.mlp.0.weight"])
+
+
+@pytest.mark.parametrize("name", ["step_d64_bn", "step_d64_bn_sephead_ttrain"])
+def test_batchnorm_heads_match_reference_fixture(name):
+    """batch_norm=True (dinov2_head.py:86-92): Linear, BatchNorm1d, GELU in every projection head.  Statistics per reference call
+    (global cls / masked patches / local cls), teacher heads in eval() as constructed or in train() (the second fixture)."""
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    m = build(fx)
+    m.teacher_head_training = fx["teacher_head_training"]
+    sep = m.method_args.ibot_separate_head
+    for si, rec in enumerate(fx["steps"]):
+        views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+        L = m._last
+        for key, want in (("t_cls_logits", "teacher_cls_logits"), ("t_patch_logits", "teacher_patch_logits"), ("s_cls_logits", "student_cls_logits"),
+                          ("s_patch_logits", "student_patch_logits"), ("s_local_logits", "student_local_logits")):
+            # batch statistics over 16 rows whose spread is a fraction of their magnitude: the bf16 rounding of the Linear output
+            # (what autocast gives the reference's BatchNorm1d too) is a few % of that spread for single entries, 1 % in the norm
+            fro = float((L[key].float().cpu() - rec[want]).norm() / rec[want].norm())
+            assert rel(L[key], rec[want]) < 8e-2 and fro < 2.5e-2, (si, key)
+        logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+            assert logs[k] == pytest.approx(rec["logs"][k], rel=5e-3), (si, k)
+        assert logs["koleo_loss"] == pytest.approx(rec["logs"]["koleo_loss"], rel=3e-2)
+        assert float(res.loss) == pytest.approx(rec["logs"]["loss"], rel=1e-2)
+        m.optimizer_step()
+        assert float(m.last_grad_norm.sqrt()) == pytest.approx(rec["logs"]["grad_norm"], rel=8e-2)
+        m.on_train_batch_end()
+    sd = m.state_dict()
+    st = fx["steps"][-1]["state"]
+    n = len(fx["steps"])
+    roles = [("student_head", "student_head.dino_head."), ("teacher_head", "teacher_head.dino_head.")]
+    if sep:
+        roles += [("student_ibot_head", "student_head.ibot_head."), ("teacher_ibot_head", "teacher_head.ibot_head.")]
+    for role, pre in roles:
+        for k, v in st[role].items():
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[pre + k]) == int(v), (role, k)
+            elif k.endswith(("running_mean", "running_var")):
+                assert rel(sd[pre + k], v) < 2e-2, (role, k)
+            elif k in ("mlp.1.weight", "mlp.1.bias", "mlp.4.weight", "mlp.4.bias"):
+                assert torch.allclose(sd[pre + k].cpu(), v, atol=3e-4), (role, k)     # lr ~3e-5 per step: the update itself is the scale
+    if not sep:   # one module under two names
+        assert torch.equal(sd["student_head.ibot_head.mlp.4.running_var"], sd["student_head.dino_head.mlp.4.running_var"])
+    # the key order of the reference's state_dict: parameters and buffers of each BatchNorm1d together
+    keys = [k for k in sd if k.startswith("student_head.dino_head.mlp.1.")]
+    assert [k.rsplit(".", 1)[1] for k in keys] == ["weight", "bias", "running_mean", "running_var", "num_batches_tracked"]
+    # state_dict -> load_state_dict round trip carries the buffers
+    m2 = build(fx)
+    m2.load_state_dict(sd)
+    sd2 = m2.state_dict()
+    assert set(sd2) == set(sd)
+    for k in sd:
+        assert torch.equal(sd2[k].cpu(), sd[k].cpu()), k
+
+
+def test_batchnorm_heads_gradients_match_oracle():
+    fx = torch.load(os.path.join(GOLD, "step_d64_bn.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    m = build(fx, koleo_loss_weight=0.0)
+    o = oracle_for(fx, koleo_loss_weight=0.0)
+    res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+    loss, _ = o.forward_loss(views, rec["masks"])
+    loss.backward()
+    assert float(res.loss) == pytest.approx(float(loss.detach()), rel=2e-3)
+    sq_o = sq_r = 0.0
+    worst = (0.0, 0.0, "")
+    for n_ in m.student.names:
+        ref = (o.sb[n_[9:]] if n_.startswith("backbone.") else o.sh[n_[5:]]).grad
+        ours = m.student.g[n_].cpu()
+        if n_ in ("head.mlp.0.bias", "head.mlp.3.bias", "backbone.norm.bias"):
+            # no gradient reaches a bias in front of BatchNorm (the batch mean cancels it; the final LayerNorm's bias is such a
+            # shift of every head input, and the KoLeo weight is 0 here): both sides hold round-off only
+            scale = m.student.g["backbone.norm.weight" if n_.startswith("backbone.") else "head.mlp.1.bias"].abs().max()
+            print(n_, float(ours.abs().max()), float(scale))
+            assert float(ours.abs().max()) < 1e-1 * float(scale)
+            continue
+        sq_o += float((ours.double() ** 2).sum()); sq_r += float((ref.double() ** 2).sum())
+        # LayerScale 1.0 (the fixture's, see make_bn_heads) and 16-row batch statistics: single entries move by up to ~10 % of the
+        # tensor's largest entry under bf16, the tensors by a few % in the norm
+        fro = float((ours - ref).norm() / ref.norm())
+        worst = max(worst, (fro, rel(ours, ref), n_))
+        assert rel(ours, ref) < 1.5e-1 and fro < 8e-2, (n_, rel(ours, ref), fro)
+    print("worst", worst)
+    assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=3e-2)
 
 
 @pytest.mark.parametrize("name", ["step_vittest_softmax", "step_d64_softmax", "step_d64_reg4_swiglu14"])

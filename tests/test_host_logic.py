@@ -87,6 +87,41 @@ def test_param_groups_partition():
         assert a["lr"] == pytest.approx(b["lr"]) and a["weight_decay"] == b["weight_decay"] and a["last_layer"] == b["last_layer"]
 
 
+def test_batchnorm_head_names_shapes_and_param_groups():
+    """batch_norm=True: parameter names / order / shapes of the reference's head state (fixture written by the reference), the buffers
+    of init_head_state, and get_optimizer_with_decay's name rule (utils.py:239-242) -- which decays the BatchNorm weight ("mlp.1.weight"
+    has neither "norm" nor "gamma" in its name) but not its bias."""
+    from lightly_train_amd.dinov2 import init_head_state
+    from lightly_train_amd import checkpoint as CK
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_bn.pt"), weights_only=False)
+    sh = fx["init"]["student_head"]
+    shapes = head_param_shapes(64, 128, 64, 512, use_bn=True)
+    assert [n for n, _ in shapes] == [k for k in sh if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    assert all(tuple(sh[n].shape) == tuple(shape) for n, shape in shapes)
+    init = init_head_state(64, 128, 64, 512, torch.Generator().manual_seed(0), use_bn=True)
+    assert list(init) == list(sh)                       # the state_dict order, buffers included
+    for k in sh:
+        if ".1." in k or ".4." in k:
+            assert torch.equal(init[k].to(sh[k].dtype), sh[k]), k   # BatchNorm1d defaults
+    args = DINOv2Args(batch_norm=True)
+    hp = {n: param_group_hparams("dino_head." + n, False, 2, 0.004, args) for n, _ in shapes}
+    assert hp["mlp.1.weight"]["weight_decay"] != 0.0 and hp["mlp.1.bias"]["weight_decay"] == 0.0
+    for n, _ in shapes:
+        b = O.param_hparams("dino_head." + n, False, 2, 0.004, args.weight_decay_start)
+        assert hp[n]["weight_decay"] == b["weight_decay"] and hp[n]["lr"] == pytest.approx(b["lr"])
+    # state_dict with buffers: written in module order, read back into `extra` for the head engines
+    named = [("head." + n, init[n]) for n, _ in shapes]
+    student, teacher = FlatParams(named, "cpu", True), FlatParams(named, "cpu", False)
+    bufs = {k: v for k, v in init.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    bufs["mlp.4.running_var"] = torch.full((128,), 0.5)
+    sd = CK.method_state_dict(student, teacher, {}, False, 2, 0, {("student", "head."): bufs, ("teacher", "head."): bufs})
+    assert [k[len("student_head.dino_head."):] for k in sd if k.startswith("student_head.dino_head.")] == list(sh)
+    assert "teacher_head.ibot_head.mlp.4.running_var" in sd
+    extra = CK.load_method_state_dict(sd, student, teacher, separate_ibot=False, strict=True)
+    assert torch.equal(extra["student_head.dino_head.mlp.4.running_var"], bufs["mlp.4.running_var"])
+    assert int(extra["teacher_head.dino_head.mlp.1.num_batches_tracked"]) == 0
+
+
 def test_vit_param_names_match_reference_state_dict():
     fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_vittest_softmax.pt"), weights_only=False)
     sb = fx["init"]["student_backbone"]
