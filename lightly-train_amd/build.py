@@ -65,5 +65,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_timing() -> str:
+    """Diagnostic variant for tools/gemm_timeline.py: gemm.hip with -DLT_GEMM_TIMING (per-workgroup timestamps of the four-phase GEMM
+    kernel and the debug accessor lt_debug_gemm_timing), linked with the shipped objects as lib/liblt_amd_timing.so."""
+    build()
+    hipcc = _hipcc()
+    obj = os.path.join(OBJDIR, "gemm_timing.o")
+    out = os.path.join(os.path.dirname(LIB), "liblt_amd_timing.so")
+    src = [s_ for s_ in sources() if s_.endswith("gemm.hip")][0]
+    subprocess.run([hipcc, *FLAGS, "-DLT_GEMM_TIMING", "-x", "hip", "-c", src, "-o", obj], check=True)
+    others = [os.path.join(OBJDIR, os.path.basename(s_) + ".o") for s_ in sources() if not s_.endswith("gemm.hip")]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *others, obj, "-o", out], check=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    print(build_timing() if "--timing" in sys.argv else build(verbose=True))

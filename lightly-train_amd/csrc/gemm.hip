@@ -39,6 +39,20 @@ enum Epi : int {
   EPI_F32_ACCUM = LT_EPI_F32_ACCUM,
 };
 
+#ifdef LT_GEMM_TIMING
+// diagnostic build only (tools/gemm_timeline.py): per-workgroup timestamps of the four-phase kernel (100 MHz wall clock) and the CU it ran on
+__device__ unsigned long long lt_gemm_timing_buf[8 * 16384];
+#define LT_TSTAMP(slot)                                                                                      \
+  do {                                                                                                       \
+    if (threadIdx.x == 0) {                                                                                  \
+      const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;                                     \
+      if (L_ < 16384) lt_gemm_timing_buf[L_ * 8 + (slot)] = wall_clock64();                                  \
+    }                                                                                                        \
+  } while (0)
+#else
+#define LT_TSTAMP(slot) do { } while (0)
+#endif
+
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B;
   int M, N, K, lda, ldb;
@@ -623,6 +637,16 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   const int ctail = KT ? ((g.K & (BK - 1)) >> 3) : 8;   // first invalid 8-element chunk of the last tile (8: none)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
+  LT_TSTAMP(0);
+#ifdef LT_GEMM_TIMING
+  if (threadIdx.x == 0) {
+    const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (L_ < 16384) {
+      lt_gemm_timing_buf[L_ * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+      lt_gemm_timing_buf[L_ * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+  }
+#endif
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -677,6 +701,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  LT_TSTAMP(1);
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of each SIMD by one barrier
 
   bf16x8 fa[2][4], fb0[4], fb1[4];
@@ -739,28 +764,38 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 #undef LT_PHASE_SYNC_IN
 #undef LT_PHASE_SYNC_OUT
   __syncthreads();
+  LT_TSTAMP(2);
   GemmArgs ge = g;
   if (SLAB) {
     ge.C = (float*)g.C2 + (size_t)slice * g.M * g.N;
     ge.ldc = g.N; ge.alpha = 1.f; ge.bias = nullptr;
   }
   float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#define LT_STAGE_HALF(H)                                                                                          \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                                \
+      wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[(H) * 2 + ii][j][e];   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                        \
+    __builtin_amdgcn_wave_barrier();                                                                              \
+  } while (0)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    LT_STAGE_HALF(h);
     if (SLAB) emit_subtile<EPI_F32>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
     else emit_subtile<EPI>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, gridDim.y > 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+#undef LT_STAGE_HALF
+#ifdef LT_GEMM_TIMING
+  LT_TSTAMP(3);                                  // wave 0 has issued its last store
+  __builtin_amdgcn_s_waitcnt(0xF70);
+  LT_TSTAMP(6);                                  // ... and they have been acknowledged
+  __syncthreads();
+  LT_TSTAMP(7);                                  // every wave is through its epilogue
+#endif
 }
 
 // ---- one wave per SIMD ("1w" kernel, force_kernel 9: experiment) --------------------------------------------------------
@@ -921,6 +956,19 @@ __global__ __launch_bounds__(256) void gemm1w_kernel(const GemmArgs g) {
       __builtin_amdgcn_wave_barrier();
     }
 }
+
+#ifdef LT_GEMM_TIMING
+extern "C" int lt_debug_gemm_timing(void* host_dst, int64_t n_u64, int clear) {
+  hipDeviceSynchronize();
+  if (host_dst && hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lt_gemm_timing_buf), (size_t)n_u64 * 8) != hipSuccess) return LT_ERR_HIP;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(lt_gemm_timing_buf)) != hipSuccess) return LT_ERR_HIP;
+    hipMemset(p, 0, sizeof(unsigned long long) * 8 * 16384);
+  }
+  return LT_OK;
+}
+#endif
 
 template <bool TA, bool TB, int EPI>
 int launch_1w_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
