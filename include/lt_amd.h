@@ -245,6 +245,16 @@ int lt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
                   const float* seg_lr, const uint8_t* seg_wd_on, const uint8_t* seg_frozen, int freeze,
                   float lr_factor, float wd, double beta1, double beta2, float eps, int step, const float* sumsq,
                   float max_norm, void* stream);
+/* LARS as LT/_optim/lars_args.py:12-37 builds it from lightly.utils.lars (the "auto" optimizer of Distillation / DistillationV2,
+ * distillation.py:140-147,294; an option of DistillationV3, distillationv3.py:147-157): per parameter tensor (= segment), and only where
+ * the weight decay applies and both norms are non-zero, d = (g + wd p) * trust ||p|| / (||g|| + wd ||p|| + eps); then torch SGD's
+ * momentum rule on d (first_step: the buffer becomes a copy of d) and p -= lr d, lr = seg_lr[seg] * lr_factor.  g is taken as clipped by
+ * min(1, max_norm / (sqrt(*sumsq) + 1e-6)) as in lt_adamw_flat.  lt_lars_norms writes seg_norms [nseg][2] = (||p||, ||g|| unclipped):
+ * per-chunk partials in ws (2 n / 1024 floats), added per segment in chunk order (deterministic); seg_chunk_begin [nseg + 1]. */
+int lt_lars_norms(const float* p, const float* g, int64_t n, const int32_t* seg_chunk_begin, int nseg, float* ws, float* seg_norms, void* stream);
+int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
+                 const uint8_t* seg_wd_on, const float* seg_norms, float lr_factor, float wd, float momentum, float dampening, int nesterov,
+                 float trust, float eps, int first_step, const float* sumsq, float max_norm, void* stream);
 /* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow.  m is a double: 1 - m (~1e-6 at the end of the
  * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
 int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);

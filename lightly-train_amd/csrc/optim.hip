@@ -94,6 +94,62 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const f
   }
 }
 
+// ---- LARS (lightly.utils.lars.LARS as LT/_optim/lars_args.py builds it; the rule is stated in include/lt_amd.h) ----------------
+// Per parameter tensor: ||p||, ||g|| -> trust ratio -> momentum-SGD step.  Norms in two deterministic stages: one block per 1024-element
+// chunk leaves (sum p^2, sum g^2) in scratch, one block per segment adds its chunks in a fixed order (double accumulators).
+__global__ __launch_bounds__(256) void lars_chunk_norms_kernel(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ws) {
+  __shared__ float red[16];
+  const long i = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+  const float sp = block_sum(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w, red);
+  __syncthreads();
+  const float sg = block_sum(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w, red);
+  if (threadIdx.x == 0) { ws[2 * blockIdx.x] = sp; ws[2 * blockIdx.x + 1] = sg; }
+}
+__global__ __launch_bounds__(64) void lars_seg_norms_kernel(const float* __restrict__ ws, const int32_t* __restrict__ seg_chunk_begin,
+                                                            float* __restrict__ seg_norms) {
+  const int seg = blockIdx.x, c0 = seg_chunk_begin[seg], c1 = seg_chunk_begin[seg + 1];
+  double sp = 0.0, sg = 0.0;
+  for (int c = c0 + (int)threadIdx.x; c < c1; c += 64) { sp += (double)ws[2 * c]; sg += (double)ws[2 * c + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sp += __shfl_down(sp, o, 64); sg += __shfl_down(sg, o, 64); }
+  if (threadIdx.x == 0) { seg_norms[2 * seg] = (float)sqrt(sp); seg_norms[2 * seg + 1] = (float)sqrt(sg); }
+}
+__global__ __launch_bounds__(256) void lars_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, bf16_t* __restrict__ pb,
+                                                   const int32_t* __restrict__ seg_of_chunk, const float* __restrict__ seg_lr,
+                                                   const uint8_t* __restrict__ seg_wd_on, const float* __restrict__ seg_norms, float lr_factor, float wd,
+                                                   float momentum, float dampening, int nesterov, float trust, float eps, int first_step,
+                                                   const float* __restrict__ sumsq, float max_norm) {
+  const long chunk = blockIdx.x;
+  const int seg = seg_of_chunk[chunk];
+  const float lr = seg_lr[seg] * lr_factor;
+  float clip = 1.f;
+  if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));   // the optimizer sees the clipped gradient
+  const float wdv = seg_wd_on[seg] ? wd : 0.f;
+  const float p_norm = seg_norms[2 * seg], g_norm = seg_norms[2 * seg + 1] * clip;
+  const bool adapt = wdv != 0.f && p_norm != 0.f && g_norm != 0.f;
+  const float q = adapt ? p_norm / (g_norm + p_norm * wdv + eps) * trust : 1.f;
+  const float wadd = adapt ? wdv : 0.f;
+  const long i = chunk * 1024 + threadIdx.x * 4;
+  float4 pp = *reinterpret_cast<float4*>(p + i);
+  const float4 gg = *reinterpret_cast<const float4*>(g + i);
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (momentum != 0.f && !first_step) bb = *reinterpret_cast<float4*>(buf + i);
+  float* P = &pp.x; const float* G = &gg.x; float* B = &bb.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float d = (G[e] * clip + wadd * P[e]) * q;
+    if (momentum != 0.f) {
+      B[e] = first_step ? d : B[e] * momentum + (1.f - dampening) * d;     // torch SGD: the buffer starts as a copy of the first step
+      d = nesterov ? d + momentum * B[e] : B[e];
+    }
+    P[e] -= lr * d;
+  }
+  *reinterpret_cast<float4*>(p + i) = pp;
+  if (momentum != 0.f) *reinterpret_cast<float4*>(buf + i) = bb;
+  if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf2(pp.x, pp.y), pack_bf2(pp.z, pp.w));
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -130,4 +186,26 @@ extern "C" int lt_ema_flat(float* teacher, const float* student, void* teacher_b
   const int grid = (int)min((long)2048, (long)lt_cdiv(n, 1024));
   hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, ST, teacher, student, (bf16_t*)teacher_bf16, (long)n, (float)m, (float)(1.0 - m));
   LT_CHECK_LAUNCH("lt_ema_flat");
+}
+
+extern "C" int lt_lars_norms(const float* p, const float* g, int64_t n, const int32_t* seg_chunk_begin, int nseg, float* ws, float* seg_norms,
+                             void* stream) {
+  LT_CHECK_ARG(p && g && seg_chunk_begin && ws && seg_norms && nseg > 0 && n % 1024 == 0, "lt_lars_norms: bad arguments (n=%ld)", (long)n);
+  if (n == 0) return LT_OK;
+  hipLaunchKernelGGL(lars_chunk_norms_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, ws);
+  hipLaunchKernelGGL(lars_seg_norms_kernel, dim3((unsigned)nseg), dim3(64), 0, ST, ws, seg_chunk_begin, seg_norms);
+  LT_CHECK_LAUNCH("lt_lars_norms");
+}
+
+extern "C" int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
+                            const uint8_t* seg_wd_on, const float* seg_norms, float lr_factor, float wd, float momentum, float dampening,
+                            int nesterov, float trust, float eps, int first_step, const float* sumsq, float max_norm, void* stream) {
+  LT_CHECK_ARG(p && g && seg_of_chunk && seg_lr && seg_wd_on && seg_norms && (momentum == 0.f || buf), "lt_lars_flat: null pointer");
+  LT_CHECK_ARG(n % 1024 == 0, "lt_lars_flat: n must be a multiple of the 1024-element chunk (n=%ld)", (long)n);
+  LT_CHECK_ARG(max_norm <= 0.f || sumsq, "lt_lars_flat: sumsq must be given when clipping");
+  LT_CHECK_ARG(!nesterov || (momentum > 0.f && dampening == 0.f), "lt_lars_flat: Nesterov momentum requires a momentum and zero dampening");
+  if (n == 0) return LT_OK;
+  hipLaunchKernelGGL(lars_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, buf, (bf16_t*)p_bf16, seg_of_chunk, seg_lr, seg_wd_on, seg_norms,
+                     lr_factor, wd, momentum, dampening, nesterov, trust, eps, first_step, sumsq, max_norm);
+  LT_CHECK_LAUNCH("lt_lars_flat");
 }

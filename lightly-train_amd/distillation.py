@@ -7,16 +7,16 @@
     channel-concatenation of the last `n_teacher_blocks` blocks' normed patch tokens (`get_intermediate_layers(x, n, reshape=True)`),
     student feature map -> `student_projection_head.mlp` (a Linear for `n_projection_layers = 1`) -> bilinear resize onto the teacher
     grid -> MSE over all elements.
-Both train with gradient-clip 1.0 and the generic `Method.configure_optimizers` schedule (method.py:89-121).  The reference's "auto"
-optimizer for both is LARS from LightlySSL (`lightly.utils.lars`, not vendored in the reference tree): here AdamW -- v1's documented
-alternative `DistillationAdamWArgs` (lr 5e-4, weight decay 0), the generic `AdamWArgs` (lr 1e-3, weight decay 0.01) for v2.
+Both train with gradient-clip 1.0 and the generic `Method.configure_optimizers` schedule (method.py:89-121).  Optimizers: AdamW (v1's
+`DistillationAdamWArgs`: lr 5e-4, weight decay 0; the generic `AdamWArgs` for v2: lr 1e-3, weight decay 0.01 -- the default here) and
+`optimizer="lars"`, the reference's "auto" (`Distillation(V2)LARSArgs`: lr 1.8, momentum 0.9, weight decay 1e-6) on `lars.FlatLARS`.
 
 Students: a ViT on `vit.ViTEngine` or the torchvision ResNet on `resnet.ResNetEngine`; teacher: a DINOv2 / DINOv3 ViT.  State-dict
 names follow the reference (`student_embedding_model.wrapped_model.*`, `student_projection_head.*`, `teacher_queue`)."""
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Any, Dict, List, Mapping, Optional, Tuple
 
 import torch
@@ -25,6 +25,7 @@ from torch import Tensor
 
 from . import ops
 from .distillationv3 import TrainingStepResult, _Trainer, weight_decays
+from .lars import FlatLARS, LARSArgs
 from .parallel import GradSync
 from .params import FlatParams
 from .resnet import ResNetConfig, ResNetEngine, flat_named, init_resnet_state
@@ -44,6 +45,8 @@ class DistillationArgs:
     eps: float = 1e-8
     weight_decay: float = 0.0
     gradient_clip_val: float = 1.0
+    optimizer: str = "adamw"          # "lars": the reference's "auto" (DistillationLARSArgs, distillation.py:140-147)
+    lars: LARSArgs = field(default_factory=LARSArgs)
 
 
 @dataclass
@@ -59,6 +62,8 @@ class DistillationV2Args:
     eps: float = 1e-8
     weight_decay: float = 0.01
     gradient_clip_val: float = 1.0
+    optimizer: str = "adamw"          # "lars": the reference's "auto" (DistillationV2LARSArgs, distillationv2.py:106-113)
+    lars: LARSArgs = field(default_factory=LARSArgs)
 
 
 class _Student:
@@ -163,11 +168,14 @@ class _DistillBase:
         scale = global_batch_size / a.reference_batch_size
         if a.lr_scale_method == "sqrt":
             scale = math.sqrt(scale)
-        self.base_lr = a.lr * scale
+        if a.optimizer not in ("adamw", "lars"):
+            raise ValueError(f"Invalid optimizer type: '{a.optimizer}'")
+        self.base_lr = (a.lars.lr if a.optimizer == "lars" else a.lr) * scale
         warm_epochs = min(10, max(1, max_epochs) / 10)
         self.warmup_steps = min(int(total_steps), int(total_steps / max(1, max_epochs) * warm_epochs))
-        self.exp_avg = torch.zeros_like(self.student.data)
-        self.exp_avg_sq = torch.zeros_like(self.student.data)
+        self.lars = FlatLARS(self.student, a.lars) if a.optimizer == "lars" else None
+        self.exp_avg = torch.zeros_like(self.student.data) if self.lars is None else None
+        self.exp_avg_sq = torch.zeros_like(self.student.data) if self.lars is None else None
         nn_ = len(self.student.names)
         self.seg_lr = torch.full((nn_,), self.base_lr, dtype=torch.float32, device=dev)
         self.seg_wd_on = torch.tensor([1 if weight_decays(n, self.student.shapes[n]) else 0 for n in self.student.names], dtype=torch.uint8, device=dev)
@@ -221,9 +229,12 @@ class _DistillBase:
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1
-        ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
-                       self.seg_lr, self.seg_wd_on, self.seg_frozen, 0, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
-                       self.opt_step, self._sumsq, a.gradient_clip_val)
+        if self.lars is not None:
+            self.lars.step(self.seg_lr, self.seg_wd_on, lr_factor, self._sumsq, a.gradient_clip_val)
+        else:
+            ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
+                           self.seg_lr, self.seg_wd_on, self.seg_frozen, 0, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
+                           self.opt_step, self._sumsq, a.gradient_clip_val)
         self.s.net.refresh_padded_weights()
         self.last_grad_norm = self._sumsq
         self.trainer.global_step += 1

@@ -13,7 +13,7 @@ State-dict names follow the reference: `student_embedding_model.wrapped_model._m
 `student_embedding_model.wrapped_model._features.*` (ResNet: the wrapper's IntermediateLayerGetter), `student_projection_head_global.*`,
 `student_projection_head_local.*`, `teacher_queue`.
 
-Not implemented: LARS (lightly.utils.lars is not vendored in the reference tree; AdamW is the method's "auto" optimizer).
+Optimizers: AdamW (the method's "auto") and `optimizer="lars"` (DistillationV3LARSArgs) on `lars.FlatLARS`.
 """
 from __future__ import annotations
 
@@ -28,6 +28,7 @@ from torch import Tensor
 
 from . import ops
 from .parallel import GradSync
+from .lars import FlatLARS, LARSArgs
 from .params import FlatParams
 from .schedules import warmup_cosine_lr_factor
 from .resnet import ResNetConfig, ResNetEngine, flat_named, init_resnet_state
@@ -51,6 +52,8 @@ class DistillationV3Args:
     eps: float = 1e-8
     weight_decay: Optional[float] = None
     gradient_clip_val: float = 1.0
+    optimizer: str = "adamw"          # the method's "auto" (distillationv3.py:380-388); "lars": DistillationV3LARSArgs (:147-157)
+    lars: Optional[LARSArgs] = None   # None = DistillationV3LARSArgs' values
 
 
 @dataclass
@@ -141,11 +144,15 @@ class DistillationV3:
         scale = global_batch_size / a.reference_batch_size
         if a.lr_scale_method == "sqrt":
             scale = math.sqrt(scale)
-        self.base_lr = a.lr * scale
+        if a.optimizer not in ("adamw", "lars"):
+            raise ValueError(f"Invalid optimizer type: '{a.optimizer}'")
+        lars_args = (a.lars or LARSArgs()) if a.optimizer == "lars" else None
+        self.base_lr = (lars_args.lr if lars_args is not None else a.lr) * scale
         warm_epochs = min(10, max_epochs / 10)
         self.warmup_steps = min(int(total_steps), int(total_steps / max(1, max_epochs) * warm_epochs))
-        self.exp_avg = torch.zeros_like(self.student.data)
-        self.exp_avg_sq = torch.zeros_like(self.student.data)
+        self.lars = FlatLARS(self.student, lars_args) if lars_args is not None else None
+        self.exp_avg = torch.zeros_like(self.student.data) if self.lars is None else None
+        self.exp_avg_sq = torch.zeros_like(self.student.data) if self.lars is None else None
         self.seg_lr = torch.full((len(self.student.names),), self.base_lr, dtype=torch.float32, device=dev)
         self.seg_wd_on = torch.tensor([1 if weight_decays(n, self.student.shapes[n]) else 0 for n in self.student.names],
                                       dtype=torch.uint8, device=dev)
@@ -406,9 +413,12 @@ class DistillationV3:
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1
-        ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
-                       self.seg_lr, self.seg_wd_on, self.seg_frozen, False, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
-                       self.opt_step, self._sumsq, a.gradient_clip_val)
+        if self.lars is not None:
+            self.lars.step(self.seg_lr, self.seg_wd_on, lr_factor, self._sumsq, a.gradient_clip_val)
+        else:
+            ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
+                           self.seg_lr, self.seg_wd_on, self.seg_frozen, False, lr_factor, a.weight_decay, a.betas[0], a.betas[1], a.eps,
+                           self.opt_step, self._sumsq, a.gradient_clip_val)
         (self.s_net if self.conv_student else self.s_vit).refresh_padded_weights()
         self.last_grad_norm = self._sumsq
         self.trainer.global_step += 1

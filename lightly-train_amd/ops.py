@@ -383,6 +383,18 @@ def adamw_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tens
                                     _stream()), "lt_adamw_flat")
 
 
+def lars_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tensor], seg_of_chunk: Tensor, seg_chunk_begin: Tensor, seg_lr: Tensor,
+              seg_wd_on: Tensor, ws: Tensor, seg_norms: Tensor, lr_factor: float, wd: float, momentum: float, dampening: float, nesterov: bool,
+              trust: float, eps: float, first_step: bool, sumsq_t: Optional[Tensor], max_norm: float) -> None:
+    """One LARS step on flat storage (lt_lars_norms + lt_lars_flat).  ws: 2 * numel / 1024 floats, seg_norms: [segments, 2]."""
+    n, nseg = p.numel(), seg_lr.numel()
+    assert ws.numel() >= 2 * n // 1024 and seg_norms.numel() >= 2 * nseg and seg_chunk_begin.numel() == nseg + 1
+    lib = _lib.load()
+    check(lib.lt_lars_norms(_p(p), _p(g), n, _p(seg_chunk_begin), nseg, _p(ws), _p(seg_norms), _stream()), "lt_lars_norms")
+    check(lib.lt_lars_flat(_p(p), _p(g), _p(buf), _p(p_bf16), n, _p(seg_of_chunk), _p(seg_lr), _p(seg_wd_on), _p(seg_norms), lr_factor, wd, momentum,
+                           dampening, int(nesterov), trust, eps, int(first_step), _p(sumsq_t), max_norm, _stream()), "lt_lars_flat")
+
+
 def ema_flat(teacher: Tensor, student: Tensor, teacher_bf16: Optional[Tensor], m: float) -> None:
     check(_lib.load().lt_ema_flat(_p(teacher), _p(student), _p(teacher_bf16), teacher.numel(), m, _stream()), "lt_ema_flat")
 

@@ -145,7 +145,7 @@ class OracleDistillation12:
     def __init__(self, kind: str, student_backbone: Dict[str, Tensor], student_cfg: Dict[str, Any], teacher_state: Dict[str, Tensor],
                  teacher_cfg: Dict[str, Any], head: Dict[str, Tensor], queue_size: int, global_batch_size: int, total_steps: int, max_epochs: int = 1,
                  temperature: float = 0.07, n_teacher_blocks: int = 2, lr: float = 0.0005, weight_decay: float = 0.0,
-                 reference_batch_size: int = 1536) -> None:
+                 reference_batch_size: int = 1536, optimizer: str = "adamw", lars: Optional[Dict[str, Any]] = None) -> None:
         self.kind = kind
         self.sb = {k: v.detach().clone().requires_grad_(True) for k, v in student_backbone.items()}
         self.head = {k: v.detach().clone().requires_grad_(True) for k, v in head.items()}
@@ -157,8 +157,14 @@ class OracleDistillation12:
         nod = [p for n, p in named if not decays(n, p)]
         self.n_decay, self.n_no_decay = len(dec), len(nod)
         scale = math.sqrt(global_batch_size / reference_batch_size)
-        self.opt = torch.optim.AdamW([{"params": dec}, {"params": nod, "weight_decay": 0.0}], lr=lr * scale, betas=(0.9, 0.999), eps=1e-8,
-                                     weight_decay=weight_decay)
+        groups = [{"params": dec}, {"params": nod, "weight_decay": 0.0}]
+        if optimizer == "lars":   # the reference's "auto" optimizer (DistillationLARSArgs, distillation.py:140-147): oracle/lars_oracle.py
+            from oracle.lars_oracle import LARS
+            kw = dict(momentum=0.9, dampening=0.0, nesterov=False, trust_coefficient=0.001, eps=1e-8)
+            kw.update(lars or {})
+            self.opt = LARS(groups, lr=lr * scale, weight_decay=weight_decay, **kw)
+        else:
+            self.opt = torch.optim.AdamW(groups, lr=lr * scale, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
         warm_epochs = min(10, max_epochs / 10)
         self.warmup = min(int(total_steps), int(total_steps / max_epochs * warm_epochs))
         self.total, self.base_lr, self.step_idx = int(total_steps), lr * scale, 0

@@ -188,6 +188,9 @@ def main() -> None:
     if "--dinov3-only" in sys.argv:
         make_dinov3_vit()
         return
+    if "--lars-only" in sys.argv:
+        make_distill12("v1", optimizer="lars")
+        return
     if "--distill12-only" in sys.argv:
         make_distill12("v1")
         make_distill12("v2")
@@ -246,7 +249,7 @@ def make_distill() -> None:
     make_distill_case("distill_v3_resnet", img=64, s_patch=16, b=8, s_kind="resnet")
 
 
-def make_distill12(kind: str) -> None:
+def make_distill12(kind: str, optimizer: str = "adamw") -> None:
     """(f) Distillation (v1: pooled feature vs a queue, KL) and DistillationV2 (patch features of the last 2 teacher blocks, MSE): the
     reference's own classes with a frozen DINOv2 ViT teacher (D = 64, /14: 4x4 tokens at 56^2 ... here 8x8 at 112^2) and a DINOv2 ViT
     student (/16: 7x7 tokens, resized onto the teacher grid in v2), AdamW (the reference's "auto" LARS lives in un-vendored LightlySSL),
@@ -277,7 +280,9 @@ def make_distill12(kind: str) -> None:
     if kind == "v1":
         mod = importlib.import_module("lightly_train._methods.distillation.distillation")
         margs = mod.DistillationArgs(queue_size=qsz, teacher="local")
-        oargs = mod.DistillationAdamWArgs()
+        # "lars": the method's "auto" optimizer arguments (lr 1.8, momentum 0.9, weight decay 1e-6) around the restated
+        # lightly.utils.lars.LARS that ref_harness registers (oracle/lars_oracle.py: parity unpinned for the optimizer rule itself)
+        oargs = mod.DistillationLARSArgs() if optimizer == "lars" else mod.DistillationAdamWArgs()
         cls = mod.Distillation
     else:
         mod = importlib.import_module("lightly_train._methods.distillationv2.distillationv2")
@@ -296,7 +301,7 @@ def make_distill12(kind: str) -> None:
     scfg = dict(patch_size=16, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
     tcfg = dict(patch_size=14, num_heads=1, depth=3, img_size=img, embed_dim=64, init_values=0.5)
     o = OD.OracleDistillation12(kind, init["student_backbone"], scfg, teacher_state, tcfg, init["head"], qsz, b, total, lr=float(oargs.lr),
-                                weight_decay=float(oargs.weight_decay))
+                                weight_decay=float(oargs.weight_decay), optimizer=optimizer)
     assert (o.n_decay, o.n_no_decay) == tuple(len(g["params"]) for g in opt.param_groups), ((o.n_decay, o.n_no_decay), [len(g["params"]) for g in opt.param_groups])
     steps = []
     for step in range(3):
@@ -324,8 +329,8 @@ def make_distill12(kind: str) -> None:
         assert (o.queue - final["queue"]).abs().max().item() < 1e-6
     for k, v in final["student_backbone"].items():
         assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
-    name = "distill_" + kind + "_d64"
-    torch.save({"kind": kind, "b": b, "img": img, "total_steps": total, "queue_size": qsz, "lr": float(oargs.lr), "weight_decay": float(oargs.weight_decay),
+    name = "distill_" + kind + "_d64" + ("_lars" if optimizer == "lars" else "")
+    torch.save({"kind": kind, "optimizer": optimizer, "b": b, "img": img, "total_steps": total, "queue_size": qsz, "lr": float(oargs.lr), "weight_decay": float(oargs.weight_decay),
                 "student_cfg": scfg, "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final,
                 "state_dict_keys": list(m.state_dict().keys())}, os.path.join(OUT, name + ".pt"))
     print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")

@@ -181,6 +181,10 @@ def install() -> None:
     lus.CosineWarmupScheduler = O.CosineWarmupScheduler  # type: ignore[attr-defined]
     luo = importlib.import_module("lightly.utils.optim")
     luo.update_param_groups = O.update_param_groups  # type: ignore[attr-defined]
+    from oracle import lars_oracle
+
+    lul = importlib.import_module("lightly.utils.lars")
+    lul.LARS = lars_oracle.LARS  # type: ignore[attr-defined]
     # torchvision is not installed: the convolutional student runs on the restated ResNet (oracle/resnet_oracle.py), registered
     # where the reference's ResNetModelWrapper imports it from (LT/_models/torchvision/resnet.py:9-10)
     from oracle import resnet_oracle as OR

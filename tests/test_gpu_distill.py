@@ -20,7 +20,7 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
 
 
-def build(fx):
+def build(fx, **args_over):
     import lightly_train_amd  # noqa: F401
     from lightly_train_amd.dinov3 import convert_dinov3_state, dinov3_vit_config
     from lightly_train_amd.distillationv3 import DistillationV3, DistillationV3Args
@@ -42,7 +42,7 @@ def build(fx):
                          img_size=sc["img_size"], init_values=sc["init_values"])
     tcfg = dinov3_vit_config(tc["embed_dim"], tc["depth"], tc["num_heads"], patch_size=tc["patch_size"], img_size=tc["img_size"],
                              n_storage_tokens=tc["n_storage_tokens"], layerscale_init=0.5, rope_base=tc["rope_base"], ln_eps=tc["ln_eps"])
-    args = DistillationV3Args(queue_size=fx["queue_size"], weight_decay=fx["weight_decay"])
+    args = DistillationV3Args(queue_size=fx["queue_size"], weight_decay=fx["weight_decay"], **args_over)
     return DistillationV3(scfg, tcfg, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], max_epochs=1, device="cuda",
                           student_state=student_state, teacher_state=convert_dinov3_state(fx["teacher_state"], tcfg),
                           proj_global_state=fx["init"]["proj_global"], proj_local_state=fx["init"]["proj_local"])
@@ -95,6 +95,47 @@ def test_distillation_step_matches_reference_fixture(name):
     else:
         assert agree / tot > 0.95, agree / tot
     assert "student_projection_head_local.weight" in sd and "teacher_queue" in sd
+
+
+@pytest.mark.parametrize("name", ["distill_v3_d64", "distill_v3_resnet"])
+def test_distillationv3_lars_option_steps_like_the_flat_rule_on_the_same_gradients(name):
+    """optimizer="lars" (DistillationV3LARSArgs, distillationv3.py:147-157): the method hands its clipped gradients, lr schedule and
+    decay groups to lars.FlatLARS (the rule itself: test_gpu_ops.py::test_lars_flat_matches_oracle; the reference's orchestration of it:
+    the Distillation v1 fixture).  Here: the step taken equals the rule applied by hand to the gradients the method produced."""
+    from oracle.lars_oracle import LARS
+
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    m = build(fx, optimizer="lars")
+    assert m.lars is not None and m.exp_avg is None and m.base_lr == pytest.approx(1.8 * (fx["b"] / 1536) ** 0.5)
+    rec = fx["steps"][0]
+    x = torch.randn(fx["b"], 3, fx.get("img", 64), fx.get("img", 64), generator=torch.Generator().manual_seed(rec["x_seed"]))
+    torch.manual_seed(300)
+    losses = []
+    for step in range(3):
+        res = m.training_step_impl({"views": [x]}, 0)
+        losses.append(float(res.loss))
+        before = {n: m.student.p[n].detach().cpu().clone().requires_grad_(True) for n in m.student.names}
+        for n in m.student.names:
+            before[n].grad = m.student.g[n].detach().cpu().clone()
+        if step == 0:
+            dec = [n for i, n in enumerate(m.student.names) if int(m.seg_wd_on[i])]
+            nod = [n for i, n in enumerate(m.student.names) if not int(m.seg_wd_on[i])]
+            ref_params = before
+            ref = LARS([{"params": [before[n] for n in dec]}, {"params": [before[n] for n in nod], "weight_decay": 0.0}], lr=1.0, momentum=0.9,
+                       weight_decay=1e-6, trust_coefficient=0.001, eps=1e-8)
+        else:
+            for n in m.student.names:
+                ref_params[n].data.copy_(before[n].data); ref_params[n].grad = before[n].grad
+        from lightly_train_amd.schedules import warmup_cosine_lr_factor
+        f = warmup_cosine_lr_factor(m.trainer.global_step, m.warmup_steps, int(m.trainer.estimated_stepping_batches), 0.001)
+        torch.nn.utils.clip_grad_norm_(list(ref_params.values()), 1.0)
+        for g_ in ref.param_groups:
+            g_["lr"] = m.base_lr * f
+        ref.step()
+        m.optimizer_step()
+        for n in m.student.names:
+            assert torch.allclose(m.student.p[n].cpu(), ref_params[n].detach(), rtol=1e-4, atol=1e-6), (step, n)
+    assert all(l == l for l in losses)
 
 
 @pytest.mark.parametrize("name", ["distill_v3_d64", "distill_v3_d64_p14", "distill_v3_d64_v3s", "distill_v3_resnet"])

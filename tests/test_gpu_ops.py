@@ -724,3 +724,46 @@ def test_gelu_elementwise_fwd_bwd(n):
     assert torch.allclose(dx.float(), xf.grad, atol=2e-2, rtol=1e-2)
     ops.gelu_bwd(dy, x, dy, n)      # in place
     assert torch.equal(dy, dx)
+
+
+@pytest.mark.parametrize("nesterov,dampening,clip", [(False, 0.0, 0.0), (True, 0.0, 1.0), (False, 0.3, 0.5)])
+def test_lars_flat_matches_oracle(nesterov, dampening, clip):
+    """lt_lars_norms + lt_lars_flat on flat storage against oracle/lars_oracle.py (fp32 CPU), 3 steps: weight-decay and no-decay groups, a
+    tensor that is all zero (no trust ratio: plain step), a tensor whose gradient is zero, gradient clipping folded into the step."""
+    from lightly_train_amd import ops
+    from lightly_train_amd.lars import FlatLARS, LARSArgs
+    from lightly_train_amd.params import FlatParams
+    from oracle.lars_oracle import LARS
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [("w1", (64, 48)), ("b1", (64,)), ("w2", (700, 3)), ("zero", (33, 9)), ("nograd", (16, 16)), ("w3", (2100,))]
+    named = [(n, torch.zeros(sh) if n == "zero" else torch.randn(sh, generator=g) * 0.1) for n, sh in shapes]
+    decay = {"w1": True, "b1": False, "w2": True, "zero": True, "nograd": True, "w3": False}
+    fp = FlatParams(named, "cuda", True)
+    args = LARSArgs(lr=0.7, momentum=0.9, dampening=dampening, weight_decay=1e-3, nesterov=nesterov, trust_coefficient=0.01)
+    opt = FlatLARS(fp, args)
+    seg_lr = torch.full((len(named),), args.lr, device="cuda")
+    seg_wd = torch.tensor([1 if decay[n] else 0 for n, _ in named], dtype=torch.uint8, device="cuda")
+    ref_p = {n: t.clone().requires_grad_(True) for n, t in named}
+    ref = LARS([{"params": [ref_p[n] for n, _ in named if decay[n]]}, {"params": [ref_p[n] for n, _ in named if not decay[n]], "weight_decay": 0.0}],
+               lr=args.lr, momentum=args.momentum, dampening=dampening, weight_decay=args.weight_decay, nesterov=nesterov,
+               trust_coefficient=args.trust_coefficient, eps=args.eps)
+    sumsq = torch.zeros(1, device="cuda")
+    for step in range(3):
+        for n, t in named:
+            gr = torch.zeros_like(t) if n == "nograd" else torch.randn(t.shape, generator=g)
+            fp.g[n].copy_(gr)
+            ref_p[n].grad = gr.clone()
+        factor = 0.5 + 0.25 * step
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(list(ref_p.values()), clip)
+        for gr_ in ref.param_groups:
+            gr_["lr"] = args.lr * factor
+        ref.step()
+        sumsq.zero_()
+        ops.sumsq(fp.grad, sumsq)
+        opt.step(seg_lr, seg_wd, factor, sumsq if clip > 0 else None, clip)
+        for n, _ in named:
+            assert torch.allclose(fp.p[n].cpu(), ref_p[n].detach(), rtol=2e-5, atol=2e-6), (step, n)
+            assert torch.equal(fp.b[n].float().cpu(), fp.p[n].to(torch.bfloat16).float().cpu()), n
+    assert torch.equal(fp.p["nograd"].cpu(), named[4][1])     # zero gradient: no trust ratio, no decay, no step

@@ -367,3 +367,23 @@ def test_native_mask_sampler_continues_the_python_random_stream_bit_for_bit(grid
     a = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, g1, native=False)
     b = masking.create_collated_masks(0.1, 0.5, n_masked, n_crops, g2, native=True)
     assert torch.equal(a["collated_masks"], b["collated_masks"]) and r1.getstate() == r2.getstate()
+
+
+def test_lars_oracle_rule_by_hand():
+    """oracle/lars_oracle.py against the rule worked by hand on two tensors (the optimizer itself is un-vendored LightlySSL code: parity
+    unpinned, see its header): trust ratio only where the group decays, SGD momentum buffer seeded with the first step."""
+    from oracle.lars_oracle import LARS
+    w = torch.tensor([3.0, 4.0], requires_grad=True)      # ||w|| = 5
+    b = torch.tensor([1.0], requires_grad=True)
+    opt = LARS([{"params": [w]}, {"params": [b], "weight_decay": 0.0}], lr=0.5, momentum=0.9, weight_decay=0.1, trust_coefficient=0.01, eps=0.0)
+    w.grad, b.grad = torch.tensor([0.6, 0.8]), torch.tensor([2.0])   # ||g|| = 1
+    opt.step()
+    q = 0.01 * 5.0 / (1.0 + 5.0 * 0.1)
+    d = (torch.tensor([0.6, 0.8]) + 0.1 * torch.tensor([3.0, 4.0])) * q
+    assert torch.allclose(w.detach(), torch.tensor([3.0, 4.0]) - 0.5 * d)
+    assert torch.allclose(b.detach(), torch.tensor([1.0 - 0.5 * 2.0]))           # no decay group: plain SGD step
+    w0 = w.detach().clone()
+    w.grad, b.grad = torch.zeros(2), torch.tensor([1.0])
+    opt.step()
+    assert torch.allclose(w.detach(), w0 - 0.5 * 0.9 * d)                        # zero gradient: no trust ratio, momentum carries on
+    assert torch.allclose(b.detach(), torch.tensor([0.0 - 0.5 * (0.9 * 2.0 + 1.0)]))

@@ -273,7 +273,7 @@ def test_restated_resnet50_anchors():
     assert E.to_flat_layout("layer3.2.conv2.weight", w).shape == (256, 3, 3, 256) and E.to_flat_layout("conv1.weight", sd["conv1.weight"]).shape == (64, 3, 7, 7)
 
 
-@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64"])
+@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64", "distill_v1_d64_lars"])
 def test_distillation_v1_v2_oracle_matches_reference_fixture(name):
     """oracle/distill_oracle.py::OracleDistillation12 against 3 optimizer steps of the reference's own Distillation / DistillationV2
     classes (tests/golden/distill_v{1,2}_d64.pt): loss, grad-norm, LR, final parameters, queue."""
@@ -281,7 +281,10 @@ def test_distillation_v1_v2_oracle_matches_reference_fixture(name):
 
     fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     o = OD.OracleDistillation12(fx["kind"], fx["init"]["student_backbone"], fx["student_cfg"], fx["teacher_state"], fx["teacher_cfg"], fx["init"]["head"],
-                                fx["queue_size"], fx["b"], fx["total_steps"], lr=fx["lr"], weight_decay=fx["weight_decay"])
+                                fx["queue_size"], fx["b"], fx["total_steps"], lr=fx["lr"], weight_decay=fx["weight_decay"],
+                                optimizer=fx.get("optimizer", "adamw"))
+    # the _lars fixture: the reference's class with its "auto" optimizer arguments around the restated (unpinned) LARS rule -- what is
+    # pinned there is the reference's orchestration of it (param groups, lr scaling and schedule, clipping order)
     for rec in fx["steps"]:
         x = torch.randn(fx["b"], 3, fx["img"], fx["img"], generator=torch.Generator().manual_seed(rec["x_seed"]))
         assert o.opt.param_groups[0]["lr"] == pytest.approx(rec["logs"]["lr"], rel=1e-6)
