@@ -209,6 +209,13 @@ __device__ __forceinline__ void emit_rows(const GemmArgs& g, const float* wl, in
   }
 }
 
+// LT_NT_STORE (default 2): the bf16 outputs of the wide epilogue (1: the saved pre-activations, 2: the activations too) leave with
+// non-temporal stores.  A [256 x 256] output tile written through L2 evicts the operand panels the next workgroups of the same XCD are
+// about to read: with streaming stores the pipeline fill of a workgroup drops from 3.0-3.5 us to 1.3 us (tools/gemm_timeline.py: fc1
+// 337.7 -> 324.2 us, qkv 199.9 -> 193.4 us), -0.5 ms per step; the fp32 residual outputs gained nothing and stay cached.
+#ifndef LT_NT_STORE
+#define LT_NT_STORE 2
+#endif
 // bf16-output epilogues on a full sub-tile with 16-byte-aligned rows: 8 columns per lane, i.e. 16-byte stores (and 16-byte loads
 // of the saved pre-activations) -- half as many store instructions in the queue as the 8-byte form for the same bytes.
 template <int EPI>
@@ -232,8 +239,15 @@ __device__ __forceinline__ void emit_rows_wide(const GemmArgs& g, const float* w
                   w1.x * g.alpha + b1.x, w1.y * g.alpha + b1.y, w1.z * g.alpha + b1.z, w1.w * g.alpha + b1.w};
     const size_t o = (size_t)row * g.ldc + col;
     if (EPI == EPI_BF16_GELU) {
-      if (g.C2) *reinterpret_cast<uint4*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) =
-            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      if (g.C2) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+#if LT_NT_STORE >= 1
+        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col));
+#else
+        *reinterpret_cast<u32x4*>((bf16_t*)g.C2 + (size_t)row * g.ldc2 + col) = pk;
+#endif
+      }
 #pragma unroll
       for (int e = 0; e < 8; e += 2) gelu2(v[e], v[e + 1]);
     } else if (EPI == EPI_BF16_GELUGRAD) {
@@ -243,7 +257,15 @@ __device__ __forceinline__ void emit_rows_wide(const GemmArgs& g, const float* w
         mul_gelu_grad2(v[2 * e], v[2 * e + 1], bf2f((bf16_t)(a[e] & 0xffff)), bf2f((bf16_t)(a[e] >> 16)));
       }
     }
-    *reinterpret_cast<uint4*>((bf16_t*)g.C + o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+#if LT_NT_STORE >= 2
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>((bf16_t*)g.C + o));
+#else
+      *reinterpret_cast<u32x4*>((bf16_t*)g.C + o) = pk;
+#endif
+    }
   }
 }
 
@@ -637,6 +659,15 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   const int ctail = KT ? ((g.K & (BK - 1)) >> 3) : 8;   // first invalid 8-element chunk of the last tile (8: none)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
+#ifdef LT_GEMM_TIMING
+  if (g.sc > 0) {   // diagnostic build only: start delay of the first resident workgroups, (g.sc & 0xff) x 0.54 us per group, (g.sc >> 8) groups
+    const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (L_ < 256) {
+      const int n_ = ((L_ >> 3) % (int)(g.sc >> 8)) * (int)(g.sc & 0xff);
+      for (int i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
   LT_TSTAMP(0);
 #ifdef LT_GEMM_TIMING
   if (threadIdx.x == 0) {
@@ -1147,6 +1178,9 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   g.rowscale = d->rowscale; g.branch_scale = d->branch_scale == 0.f ? 1.f : d->branch_scale;
   g.alpha = d->alpha;
   g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
+#ifdef LT_GEMM_TIMING
+  if (const char* e = getenv("LT_GEMM_STAGGER")) { int u = 0, gr = 2; sscanf(e, "%d,%d", &u, &gr); g.sc = (d->batch > 1) ? g.sc : (long)((gr << 8) | u); }
+#endif
   const int batch = d->batch > 1 ? d->batch : 1;
   LT_CHECK_ARG(batch == 1 || (!d->C2 && !d->resid && !d->aux && !d->rowscale && d->split_k <= 1 && d->force_kernel <= 1),
                "lt_gemm_bf16: batched launches support the plain epilogues of the 128x128 kernel only");

@@ -39,6 +39,8 @@ cases = [case("fc1 gelu+pre", G, 3072, 768, ops.EPI_BF16_GELU), case("qkv bf16",
          case("dfc1 f32", G, 768, 3072, ops.EPI_F32, True),
          case("resid 32 WGs", 8192, 256, 768, ops.EPI_RESID), case("resid 96 WGs", 8192, 768, 768, ops.EPI_RESID),
          case("resid 256 WGs", 65536, 256, 768, ops.EPI_RESID), case("f32 32 WGs", 8192, 256, 768, ops.EPI_F32, True)]
+if os.environ.get("LT_GEMM_STAGGER"):
+    print("start delays (diagnostic build):", os.environ["LT_GEMM_STAGGER"])
 buf = np.zeros(8 * 16384, dtype=np.uint64)
 print("shape            WGs  kernel   fill   loop(/Ktile)   epi-issue  +ack  all-waves   gap-on-CU  CUs  rounds   sum/CU   TF/s")
 for name, fn, nwg, flops in cases:
