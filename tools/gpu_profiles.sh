@@ -1,26 +1,30 @@
 #!/bin/bash
-# round-2 profile collection on the GPU box: rocprofv3 kernel stats (default bench, single-stream reference and shipped multi-stream),
-# the three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) over one default step, cfg2 (ViT-S) and cfg5 (ViT-L/14 518^2) kernel stats.
+# round-2 profile collection on the GPU box: default bench line, rocprofv3 kernel stats (single-stream reference and shipped multi-stream),
+# the three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) over one default step, the per-workgroup GEMM timeline, cfg2 / cfg5 bench lines.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02I
+T=${1:-r02L}
+O=$R/gpurun_out/$T
 mkdir -p $O
 export TMPDIR=/tmp
+cd $R
+python bench.py --steps 20 --warmup 5 > $O/bench_default_full.log 2>&1
+FL=$(python -c "import json,sys; print(int(json.loads(open('$O/bench_default_full.log').read().strip().splitlines()[-1])['roofline']['gemm_flops_per_step']))")
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-roofline"
 rocprofv3 --kernel-trace --stats -d $O/ks_single -o ks -- $B --steps 3 --warmup 1 --single-stream > $O/bench_single.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/ks_multi -o ks -- $B --steps 3 --warmup 1 > $O/bench_multi.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/ks_vits -o ks -- $B --steps 3 --warmup 1 --model vit_small > $O/bench_vits.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/ks_cfg5 -o ks -- python $R/tools/run_cfg5.py 32 > $O/cfg5.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- $B --steps 1 --warmup 1 --single-stream > $O/pmc_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_MFMA -o pmc -- $B --steps 1 --warmup 1 --single-stream > $O/pmc_MFMA.log 2>&1
 cd $R
-for d in single multi vits cfg5; do python tools/rocprof_summary.py $(find $O/ks_$d -name "*.db" | head -1) 32 > $O/kernel_stats_$d.md 2>&1; done
+for d in single multi; do python tools/rocprof_summary.py $(find $O/ks_$d -name "*.db" | head -1) 32 > $O/kernel_stats_$d.md 2>&1; done
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1); M=$(find $O/pmc_MFMA -name "*counter_collection.csv" | head -1)
-python tools/pmc_step_traffic.py $F $W profiles/r02I_pmc_step_report.md > $O/gemm_traffic.txt 2>&1
-python tools/pmc_step_report.py $F $W $M 59187843301376 > $O/pmc_step_report.md 2>&1
-python bench.py --steps 20 --warmup 5 > $O/bench_default_full.log 2>&1
+python tools/pmc_step_traffic.py $F $W profiles/${T}_pmc_step_report.md > $O/gemm_traffic.txt 2>&1
+python tools/pmc_step_report.py $F $W $M $FL > $O/pmc_step_report.md 2>&1
+python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
+$B --steps 10 --warmup 3 --model vit_small > $O/bench_vits.log 2>&1
+python tools/run_cfg5.py 32 > $O/cfg5.log 2>&1
 rm -rf $O/ks_* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA
 ls -la $O; tail -3 $O/gemm_traffic.txt; tail -4 $O/pmc_step_report.md; tail -1 $O/bench_vits.log; tail -2 $O/cfg5.log; tail -1 $O/bench_default_full.log
