@@ -286,6 +286,19 @@ int lt_batchnorm_apply(const void* x, const float* mean, const float* rstd, cons
  * else dz = dy; dgamma += sum dz*xhat, dbeta += sum dz, dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz*xhat)). */
 int lt_batchnorm_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* mean, const float* rstd, void* dz, void* dx,
                      float* dgamma, float* dbeta, int64_t rows, int C, float* ws, void* stream);
+/* The same two passes split around a collective: torch.nn.SyncBatchNorm, which Lightning's sync_batchnorm=True (the reference sets it whenever
+ * the accelerator is a GPU: LT/_commands/train_helpers.py:223,335-342) puts in place of every BatchNorm layer.  sums: doubles [2C + 1]
+ * on the device, (sum x, sum x^2, rows) for the forward and (sum dz, sum dz*xhat, rows) for the backward; the caller adds them over the
+ * ranks (one all-reduce) between the two calls.  Statistics, running estimates (unbiased over the GLOBAL row count) and the input-gradient
+ * means are formed from the reduced sums; dgamma / dbeta accumulate the LOCAL sums (the data-parallel gradient mean handles them). */
+int lt_batchnorm_stats(const void* x, int64_t rows, int C, float* ws, double* sums, void* stream);
+int lt_batchnorm_fwd_from_sums(const void* x, const double* sums, const float* gamma, const float* beta, const void* resid, void* y, float* mean,
+                               float* rstd, float* running_mean, float* running_var, int64_t rows, int C, float eps, float momentum, int relu,
+                               void* stream);
+int lt_batchnorm_bwd_sums(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dz, float* dgamma, float* dbeta,
+                          int64_t rows, int C, float* ws, double* sums, void* stream);
+int lt_batchnorm_bwd_from_sums(const void* dz, const void* x, const float* gamma, const float* mean, const float* rstd, const double* sums, void* dx,
+                               int64_t rows, int C, float* ws, void* stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) on NHWC bf16 with the arg-max tap saved per element (uint8, first maximum in scan order wins) */
 int lt_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int lt_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, void* stream);

@@ -90,6 +90,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_token_mean_bf16": [vp, vp, i32, i32, i32, vp],
     "lt_pool_bwd_add": [vp, vp, vp, i32, i32, i32, vp],
     "lt_add_bf16": [vp, vp, vp, i64, vp],
+    "lt_batchnorm_stats": [vp, i64, i32, vp, vp, vp],
+    "lt_batchnorm_fwd_from_sums": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
+    "lt_batchnorm_bwd_sums": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
+    "lt_batchnorm_bwd_from_sums": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "lt_aug_crop_resize": [vp, vp, vp, i32, i32, vp],
     "lt_aug_color": [vp, vp, i32, i32, vp],
     "lt_aug_finish": [vp, vp, vp, i32, i32, vp, vp, vp],

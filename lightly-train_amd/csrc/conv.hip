@@ -211,6 +211,52 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   c1[c] = (float)(s / (double)rows);
   c2[c] = (float)(sx / (double)rows);
 }
+// ---- SyncBatchNorm pieces: the per-rank raw sums leave the device-side reduction as doubles (one all-reduce over [2C + 1]: the last
+// element carries the row count), the statistics / input-gradient coefficients are then formed from the global sums.
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ partial, int G, long rows, int C, double* __restrict__ sums) {
+  __shared__ double red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s, ss;
+  bn_sum_partials(partial, G, C, c, lane, s, ss, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[2L * C] = (double)rows;
+  if (lane != 0 || c >= C) return;
+  sums[c] = s;
+  sums[(long)C + c] = ss;
+}
+__global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, float eps, float momentum, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = sums[2L * C];
+  const double m = sums[c] / n;
+  double var = sums[(long)C + c] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+}
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int G, long rows, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, double* __restrict__ sums) {
+  __shared__ double red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s, sx;
+  bn_sum_partials(partial, G, C, c, lane, s, sx, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[2L * C] = (double)rows;
+  if (lane != 0 || c >= C) return;
+  if (dbeta) dbeta[c] += (float)s;         // parameter gradients stay local: the data-parallel gradient mean treats them like every other one
+  if (dgamma) dgamma[c] += (float)sx;
+  sums[c] = s;
+  sums[(long)C + c] = sx;
+}
+__global__ __launch_bounds__(256) void bn_bwd_coefs_kernel(const double* __restrict__ sums, int C, float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = sums[2L * C];
+  c1[c] = (float)(sums[c] / n);
+  c2[c] = (float)(sums[(long)C + c] / n);
+}
 // y = act( gamma * (x - mean) * rstd + beta (+ resid) ), act = ReLU or identity
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const bf16_t* __restrict__ resid,
@@ -467,6 +513,49 @@ extern "C" int lt_batchnorm_bwd(const void* dy, const void* y, const void* x, co
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)(dz ? dz : dy), (const bf16_t*)x, mean, rstd,
                      gamma, c1, c2, (bf16_t*)dx, (long)rows, C);
   LT_CHECK_LAUNCH("lt_batchnorm_bwd");
+}
+
+/* SyncBatchNorm (torch.nn.SyncBatchNorm, which Lightning's sync_batchnorm=True puts in place of every BatchNorm layer: train_helpers.py:223,
+ * 335-342) in two halves around the caller's all-reduce.  sums: doubles [2C + 1] = (sum x, sum x^2, rows) resp. (sum dz, sum dz*xhat, rows). */
+extern "C" int lt_batchnorm_stats(const void* x, int64_t rows, int C, float* ws, double* sums, void* stream) {
+  LT_CHECK_ARG(x && ws && sums && rows > 0 && C > 0 && C % 8 == 0 && al16(x), "lt_batchnorm_stats: bad arguments (C=%d)", C);
+  const BnGeom g = bn_geom(rows, C);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, ws, (long)rows, C, g.vpb);
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, sums);
+  LT_CHECK_LAUNCH("lt_batchnorm_stats");
+}
+extern "C" int lt_batchnorm_fwd_from_sums(const void* x, const double* sums, const float* gamma, const float* beta, const void* resid, void* y,
+                                          float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C, float eps,
+                                          float momentum, int relu, void* stream) {
+  LT_CHECK_ARG(x && sums && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && C % 8 == 0 && al16(x) && al16(y) && al16(resid),
+               "lt_batchnorm_fwd_from_sums: bad arguments (C=%d)", C);
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(lt_cdiv(C, 256)), dim3(256), 0, ST, sums, C, eps, momentum, mean, rstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)resid,
+                     (bf16_t*)y, (long)rows, C, relu);
+  LT_CHECK_LAUNCH("lt_batchnorm_fwd_from_sums");
+}
+extern "C" int lt_batchnorm_bwd_sums(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dz, float* dgamma,
+                                     float* dbeta, int64_t rows, int C, float* ws, double* sums, void* stream) {
+  LT_CHECK_ARG(dy && x && mean && rstd && ws && sums && rows > 0 && C > 0 && C % 8 == 0, "lt_batchnorm_bwd_sums: bad arguments (C=%d)", C);
+  LT_CHECK_ARG(!y || dz, "lt_batchnorm_bwd_sums: a ReLU mask (y) needs a dz buffer for the masked upstream gradient");
+  LT_CHECK_ARG(al16(dy) && al16(y) && al16(x) && al16(dz), "lt_batchnorm_bwd_sums: tensors must be 16-byte aligned");
+  const BnGeom g = bn_geom(rows, C);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd,
+                     (bf16_t*)dz, ws, (long)rows, C, g.vpb);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, sums);
+  LT_CHECK_LAUNCH("lt_batchnorm_bwd_sums");
+}
+extern "C" int lt_batchnorm_bwd_from_sums(const void* dz, const void* x, const float* gamma, const float* mean, const float* rstd, const double* sums,
+                                          void* dx, int64_t rows, int C, float* ws, void* stream) {
+  LT_CHECK_ARG(dz && x && gamma && mean && rstd && sums && dx && ws && rows > 0 && C > 0 && C % 8 == 0 && al16(dz) && al16(x) && al16(dx),
+               "lt_batchnorm_bwd_from_sums: bad arguments (C=%d)", C);
+  float* c1 = ws + 2LL * LT_BN_MAX_CHUNKS * C;
+  float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(lt_cdiv(C, 256)), dim3(256), 0, ST, sums, C, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)dz, (const bf16_t*)x, mean, rstd, gamma, c1, c2,
+                     (bf16_t*)dx, (long)rows, C);
+  LT_CHECK_LAUNCH("lt_batchnorm_bwd_from_sums");
 }
 
 extern "C" int lt_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {

@@ -169,6 +169,8 @@ class HeadEngine:
         self.use_bn = bool(args.batch_norm)
         self.lin, self.bnl = head_layer_names(self.use_bn)
         self.bn_eps, self.bn_momentum = 1e-5, 0.1
+        from .resnet import default_bn_sync
+        self.bn_sync = default_bn_sync()   # SyncBatchNorm across ranks (train_helpers.py:223): statistics of a call over every rank's rows
         self.buffers: Dict[str, Tensor] = {}
         self.batches_tracked: Dict[str, int] = {}
         for b in self.bnl:
@@ -227,10 +229,10 @@ class HeadEngine:
         rm, rv = self.buffers[bnn + ".running_mean"], self.buffers[bnn + ".running_var"]
         for si, (r0, n) in enumerate(segs):
             if training:
-                if n < 2:
+                if n < 2 and self.bn_sync is None:
                     raise ValueError(f"BatchNorm1d in train() needs more than 1 row per call, got {n}")   # as torch raises
                 ops.batchnorm_fwd(y[r0:r0 + n], gamma, beta, u[r0:r0 + n], mean[si], rstd[si], n, hid, bnws, running_mean=rm, running_var=rv,
-                                  eps=self.bn_eps, momentum=self.bn_momentum)
+                                  eps=self.bn_eps, momentum=self.bn_momentum, sync=self.bn_sync)
                 self.batches_tracked[bnn] += 1
             else:
                 torch.rsqrt(rv + self.bn_eps, out=rstd[si])
@@ -245,7 +247,8 @@ class HeadEngine:
         bnc: List[Dict[str, Tensor]] = []
         h1p = h2p = None
         if self.use_bn:
-            segs = [(r0, n) for r0, n in (segs if segs is not None else [(0, R)]) if n > 0]
+            # with SyncBatchNorm a segment this rank has no rows for (no masked patch in its crops) still joins the collective
+            segs = [(r0, n) for r0, n in (segs if segs is not None else [(0, R)]) if n > 0 or self.bn_sync is not None]
             assert sum(n for _, n in segs) == R, "BatchNorm segments must cover the rows"
             bnc.append(self._hidden_bn(ws, tag, 0, x, D, R, cap, segs, bn_training))
             h1 = bnc[0]["h"]
@@ -310,7 +313,7 @@ class HeadEngine:
                 bnws = ws.get(f"{tag}.bnws", (ops.batchnorm_ws_floats(hid),), torch.float32)
                 for si, (r0, n) in enumerate(c["segs"]):
                     ops.batchnorm_bwd(dh[r0:r0 + n], b_["y"][r0:r0 + n], self.w(bnn + ".weight"), b_["mean"][si], b_["rstd"][si],
-                                      dy[r0:r0 + n], n, hid, bnws, dgamma=self.gw(bnn + ".weight"), dbeta=self.gw(bnn + ".bias"))
+                                      dy[r0:r0 + n], n, hid, bnws, dgamma=self.gw(bnn + ".weight"), dbeta=self.gw(bnn + ".bias"), sync=self.bn_sync)
                 return dy
 
             ops.gemm(dz, self.wb(l2 + ".weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16)
@@ -403,8 +406,6 @@ class DINOv2:
         # the running estimates, which nothing ever moves (no forward in train(), not in the EMA).  A Trainer that calls
         # module.train() at fit start (Lightning < 2.2) flips them to batch statistics: set this attribute to get that behaviour.
         self.teacher_head_training = False
-        if bn and self.world > 1:
-            raise NotImplementedError("batch_norm heads on more than one rank need SyncBatchNorm statistics (train_helpers.py:223)")
         K = a.output_dim
         self.dino_center = torch.zeros(1, K, device=self.device)
         self.ibot_center = torch.zeros(1, 1, K, device=self.device)

@@ -3,7 +3,7 @@ allocations and the HIP stream; every arithmetic op below runs in liblt_amd.so."
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Any, Optional
 
 import torch
 from torch import Tensor
@@ -434,12 +434,25 @@ def batchnorm_ws_floats(Cc: int) -> int:
 
 def batchnorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, mean: Tensor, rstd: Tensor, rows: int, Cc: int, ws: Tensor,
                   resid: Optional[Tensor] = None, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-                  eps: float = 1e-5, momentum: float = 0.1, relu: bool = False) -> Tensor:
+                  eps: float = 1e-5, momentum: float = 0.1, relu: bool = False, sync: Optional[Any] = None) -> Tensor:
+    """Training-mode BatchNorm.  sync: None, or a callable that adds a device tensor of doubles over the ranks in place (an all-reduce):
+    SyncBatchNorm -- the statistics and the running estimates then come from the rows of ALL ranks."""
     _chk(x, torch.bfloat16, "batchnorm.x")
     _chk(y, torch.bfloat16, "batchnorm.y")
     assert ws.numel() >= batchnorm_ws_floats(Cc) and ws.dtype == torch.float32
-    check(_lib.load().lt_batchnorm_fwd(_p(x), _p(gamma), _p(beta), _p(resid), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), rows, Cc,
-                                       eps, momentum, int(relu), _p(ws), _stream()), "lt_batchnorm_fwd")
+    lib = _lib.load()
+    if sync is None:
+        check(lib.lt_batchnorm_fwd(_p(x), _p(gamma), _p(beta), _p(resid), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), rows, Cc,
+                                   eps, momentum, int(relu), _p(ws), _stream()), "lt_batchnorm_fwd")
+        return y
+    sums = torch.zeros(2 * Cc + 1, dtype=torch.float64, device=x.device)
+    if rows > 0:
+        check(lib.lt_batchnorm_stats(_p(x), rows, Cc, _p(ws), _p(sums), _stream()), "lt_batchnorm_stats")
+    sync(sums)      # a rank without rows for this call still takes part in the collective
+    if rows == 0:
+        return y
+    check(lib.lt_batchnorm_fwd_from_sums(_p(x), _p(sums), _p(gamma), _p(beta), _p(resid), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                                         rows, Cc, eps, momentum, int(relu), _stream()), "lt_batchnorm_fwd_from_sums")
     return y
 
 
@@ -452,12 +465,26 @@ def batchnorm_apply(x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, beta: 
 
 
 def batchnorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dx: Tensor, rows: int, Cc: int, ws: Tensor,
-                  y: Optional[Tensor] = None, dz: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None) -> Tensor:
+                  y: Optional[Tensor] = None, dz: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+                  sync: Optional[Any] = None) -> Tensor:
     _chk(dy, torch.bfloat16, "batchnorm_bwd.dy")
     _chk(x, torch.bfloat16, "batchnorm_bwd.x")
     assert ws.numel() >= batchnorm_ws_floats(Cc) and ws.dtype == torch.float32
-    check(_lib.load().lt_batchnorm_bwd(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, _p(ws),
-                                       _stream()), "lt_batchnorm_bwd")
+    lib = _lib.load()
+    if sync is None:
+        check(lib.lt_batchnorm_bwd(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, _p(ws),
+                                   _stream()), "lt_batchnorm_bwd")
+        return dx
+    # SyncBatchNorm backward: the two means of the input gradient run over the rows of all ranks
+    sums = torch.zeros(2 * Cc + 1, dtype=torch.float64, device=x.device)
+    if rows > 0:
+        check(lib.lt_batchnorm_bwd_sums(_p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(dz), _p(dgamma), _p(dbeta), rows, Cc, _p(ws), _p(sums), _stream()),
+              "lt_batchnorm_bwd_sums")
+    sync(sums)
+    if rows == 0:
+        return dx
+    check(lib.lt_batchnorm_bwd_from_sums(_p(dz if dz is not None else dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(sums), _p(dx), rows, Cc, _p(ws),
+                                         _stream()), "lt_batchnorm_bwd_from_sums")
     return dx
 
 

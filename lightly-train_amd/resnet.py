@@ -142,6 +142,15 @@ def flat_named(cfg: ResNetConfig, sd: Dict[str, Tensor], prefix: str = "") -> Li
     return [(prefix + n, to_flat_layout(n, sd[n].float())) for n, _ in resnet_param_shapes(cfg)]
 
 
+def default_bn_sync():
+    """The all-reduce SyncBatchNorm needs, when this process is one of several ranks; None otherwise."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return lambda t: dist.all_reduce(t)
+    return None
+
+
 class ResNetEngine:
     """Runs one ResNet whose trained parameters live in a FlatParams under `prefix` (engine layout, see `to_flat_layout`)."""
 
@@ -154,6 +163,10 @@ class ResNetEngine:
                 src = buffers[bn + k] if buffers is not None and (bn + k) in buffers else init
                 self.buffers[bn + k] = src.detach().clone().to(self.dev)
         self.act_dtype = torch.bfloat16   # storage type of activations / activation gradients (the HIP ops only accept bf16)
+        # SyncBatchNorm: Lightning replaces every BatchNorm layer when sync_batchnorm=True, which the reference sets whenever the accelerator is a
+        # GPU (LT/_commands/train_helpers.py:223,335-342).  None = per-process statistics (one rank); else a callable that adds a device tensor
+        # of doubles over the ranks in place -- set by default as soon as a process group with more than one rank exists.
+        self.bn_sync = default_bn_sync()
         self.kreal = cfg.in_chans * 49
         self.kpad = (self.kreal + 7) // 8 * 8
         self.w_stem = torch.zeros(cfg.width, self.kpad, dtype=torch.bfloat16, device=self.dev)
@@ -181,7 +194,7 @@ class ResNetEngine:
         if train:
             ops.batchnorm_fwd(x, self.w(bn + ".weight"), self.w(bn + ".bias"), y, mean, rstd, rows, C, scratch, resid=resid,
                               running_mean=self.buffers[bn + ".running_mean"], running_var=self.buffers[bn + ".running_var"],
-                              eps=self.cfg.bn_eps, momentum=self.cfg.bn_momentum, relu=relu)
+                              eps=self.cfg.bn_eps, momentum=self.cfg.bn_momentum, relu=relu, sync=self.bn_sync)
             self.buffers[bn + ".num_batches_tracked"] += 1
         else:   # eval mode: the running estimates stand in for the batch statistics (plumbing: two [C] vectors)
             mean.copy_(self.buffers[bn + ".running_mean"])
@@ -287,7 +300,7 @@ class ResNetEngine:
 
         def bn_bwd(bn: str, dy: Tensor, y: Optional[Tensor], x: Tensor, mean: Tensor, rstd: Tensor, dz: Optional[Tensor], dx: Tensor, rows: int, C: int) -> None:
             ops.batchnorm_bwd(dy, x, self.w(bn + ".weight"), mean, rstd, dx, rows, C, bnws, y=y, dz=dz, dgamma=self.gw(bn + ".weight"),
-                              dbeta=self.gw(bn + ".bias"))
+                              dbeta=self.gw(bn + ".bias"), sync=self.bn_sync)
 
         def scratch(name: str, shape: Tuple[int, int]) -> Tensor:
             """View of a grow-only 1-D scratch buffer (main-stream temporaries whose shape changes from block to block)."""

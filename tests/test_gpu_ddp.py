@@ -223,3 +223,81 @@ def test_bench_contract_two_ranks():
     assert out["value"] == pytest.approx(16 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1e3), rel=1e-2)
     assert out["roofline"]["launches_per_step"] > 0 and out["cpu_baseline"] is None
     assert out["comm"]["exposed_allreduce_ms_per_step"] >= 0 and out["comm"]["gradient_bytes_per_step"] > 0
+
+
+def _resnet_case(rows_of_rank=None, sync=True):
+    """Forward + backward of a small bottleneck ResNet on (a slice of) one fixed batch; returns features, parameter gradients, buffers."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lightly_train_amd  # noqa: F401
+    import test_gpu_distill as TD
+    from lightly_train_amd.params import FlatParams
+    from lightly_train_amd.resnet import ResNetConfig, ResNetEngine, flat_named
+    from lightly_train_amd.vit import Workspace
+
+    cfg = ResNetConfig(layers=(1, 1), width=16)
+    g = torch.Generator().manual_seed(11)
+    sd = TD._perturbed_resnet_state(cfg, g)
+    B, S = 8, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    fp = FlatParams(flat_named(cfg, sd), "cuda", True)
+    eng = ResNetEngine(cfg, fp, "", buffers=sd)
+    if not sync:
+        eng.bn_sync = None
+    sl = slice(0, B) if rows_of_rank is None else rows_of_rank
+    ws = Workspace(torch.device("cuda"))
+    ctx = eng.forward(ws, "r", x[sl].cuda(), save=True, train=True)
+    hw = ctx["h"] * ctx["w"]
+    d_all = torch.randn(B * hw, cfg.feature_dim, generator=g) * 0.1
+    n = (sl.stop - sl.start) * hw
+    dfeat = torch.zeros_like(ctx["feat"])
+    dfeat[:n] = d_all[sl.start * hw: sl.stop * hw].to(torch.bfloat16).cuda()
+    fp.grad.zero_()
+    eng.backward(ws, ctx, dfeat)
+    torch.cuda.synchronize()
+    return (ctx["feat"][:n].float().cpu(), {k: fp.g[k].float().cpu().clone() for k in fp.names},
+            {k: v.float().cpu().clone() for k, v in eng.buffers.items()})
+
+
+def _syncbn_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.save(_resnet_case(slice(4 * rank, 4 * rank + 4)), os.path.join(out_dir, f"bn{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+    """SyncBatchNorm in the convolutional student (the reference trains with sync_batchnorm=True on GPUs, train_helpers.py:223): two ranks
+    holding half of a batch each produce the feature rows, the (rank-summed) parameter gradients and the running estimates of one process
+    on the whole batch -- up to the bf16 rounding flips a BatchNorm network amplifies -- while per-rank statistics (the control) do not."""
+    port = _free_port()
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"bn{i}.pt", weights_only=False) for i in range(2)]
+    feat_w, grad_w, buf_w = _resnet_case()
+    ctl = [_resnet_case(slice(4 * i, 4 * i + 4), sync=False) for i in range(2)]        # one process, per-part statistics
+
+    def fro(a, b):
+        return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+    e_sync = fro(torch.cat([r[0][0], r[1][0]]), feat_w)
+    e_ctl = fro(torch.cat([ctl[0][0], ctl[1][0]]), feat_w)
+    assert e_sync < 2e-2 and e_ctl > 4 * e_sync, (e_sync, e_ctl)
+    errs = {k: fro(r[0][1][k] + r[1][1][k], grad_w[k]) for k in grad_w}
+    errs_ctl = {k: fro(ctl[0][1][k] + ctl[1][1][k], grad_w[k]) for k in grad_w}
+    import statistics
+    assert statistics.median(errs.values()) < 4e-2 and max(errs.values()) < 0.2, sorted(errs.items(), key=lambda t: -t[1])[:5]
+    assert statistics.median(errs_ctl.values()) > 3 * statistics.median(errs.values()), (statistics.median(errs_ctl.values()), statistics.median(errs.values()))
+    for k in buf_w:
+        assert torch.equal(r[0][2][k], r[1][2][k]), k                              # both ranks end with the same running estimates
+        if k.endswith("running_var"):
+            assert fro(r[0][2][k], buf_w[k]) < 2e-2, k
+        elif k.endswith("running_mean"):
+            assert (r[0][2][k] - buf_w[k]).abs().max().item() < 2e-2, k

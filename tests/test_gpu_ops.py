@@ -767,3 +767,65 @@ def test_lars_flat_matches_oracle(nesterov, dampening, clip):
             assert torch.allclose(fp.p[n].cpu(), ref_p[n].detach(), rtol=2e-5, atol=2e-6), (step, n)
             assert torch.equal(fp.b[n].float().cpu(), fp.p[n].to(torch.bfloat16).float().cpu()), n
     assert torch.equal(fp.p["nograd"].cpu(), named[4][1])     # zero gradient: no trust ratio, no decay, no step
+
+
+@pytest.mark.parametrize("rows,C,relu", [(96, 64, True), (4100, 256, False)])
+def test_sync_batchnorm_halves_equal_the_whole(rows, C, relu):
+    """SyncBatchNorm (lt_batchnorm_stats / _fwd_from_sums / _bwd_sums / _bwd_from_sums around the caller's all-reduce): two "ranks" holding
+    the two parts of a batch -- the all-reduce played by adding the other part's sums -- give the outputs, running estimates, input
+    gradients and (summed) parameter gradients of training-mode BatchNorm over the whole batch."""
+    from lightly_train_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16).cuda()
+    dy = torch.randn(rows, C, generator=g).to(torch.bfloat16).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda(); beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    ws = torch.empty(ops.batchnorm_ws_floats(C), device="cuda")
+    cut = rows // 3 // 8 * 8 + 8          # unequal parts
+    parts = [(0, cut), (cut, rows - cut)]
+
+    def whole():
+        y = torch.empty_like(x); dx = torch.empty_like(x); dz = torch.empty_like(x)
+        mean = torch.empty(C, device="cuda"); rstd = torch.empty(C, device="cuda")
+        rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
+        dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+        ops.batchnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, ws, running_mean=rm, running_var=rv, relu=relu)
+        ops.batchnorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, ws, y=y if relu else None, dz=dz if relu else None, dgamma=dg, dbeta=db)
+        return y, dx, rm, rv, dg, db
+
+    def split():
+        y = torch.empty_like(x); dx = torch.empty_like(x); dz = torch.empty_like(x)
+        rms = [torch.zeros(C, device="cuda") for _ in parts]; rvs = [torch.ones(C, device="cuda") for _ in parts]
+        means = [torch.empty(C, device="cuda") for _ in parts]; rstds = [torch.empty(C, device="cuda") for _ in parts]
+        dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+        for phase in ("fwd", "bwd"):
+            own = []
+            for (r0, n) in parts:      # first pass: every part's own sums (what it would contribute to the all-reduce)
+                cap = []
+                def grab(t, cap=cap):
+                    cap.append(t.clone()); t.fill_(float("nan"))      # the result of this pass is discarded
+                    t[-1] = n; t[:-1] = 0; t[C:2 * C] = 1
+                if phase == "fwd":
+                    ops.batchnorm_fwd(x[r0:r0 + n], gamma, beta, torch.empty_like(x[r0:r0 + n]), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), n, C, ws, sync=grab)
+                else:
+                    i = parts.index((r0, n))
+                    ops.batchnorm_bwd(dy[r0:r0 + n], x[r0:r0 + n], gamma, means[i], rstds[i], torch.empty_like(x[r0:r0 + n]), n, C, ws,
+                                      y=y[r0:r0 + n] if relu else None, dz=torch.empty_like(x[r0:r0 + n]) if relu else None, sync=grab)
+                own.append(cap[0])
+            total = own[0] + own[1]
+            for i, (r0, n) in enumerate(parts):
+                allreduce = lambda t: t.copy_(total)
+                if phase == "fwd":
+                    ops.batchnorm_fwd(x[r0:r0 + n], gamma, beta, y[r0:r0 + n], means[i], rstds[i], n, C, ws, running_mean=rms[i], running_var=rvs[i],
+                                      relu=relu, sync=allreduce)
+                else:
+                    ops.batchnorm_bwd(dy[r0:r0 + n], x[r0:r0 + n], gamma, means[i], rstds[i], dx[r0:r0 + n], n, C, ws, y=y[r0:r0 + n] if relu else None,
+                                      dz=dz[r0:r0 + n] if relu else None, dgamma=dg, dbeta=db, sync=allreduce)
+        assert torch.equal(rms[0], rms[1]) and torch.equal(rvs[0], rvs[1])       # every rank ends with the same running estimates
+        return y, dx, rms[0], rvs[0], dg, db
+
+    yw, dxw, rmw, rvw, dgw, dbw = whole()
+    ys, dxs, rm_s, rv_s, dgs, dbs = split()
+    assert (ys.float() - yw.float()).abs().max().item() <= 2e-2 and float((ys.float() - yw.float()).abs().mean()) < 1e-4    # rounding flips only
+    assert float((dxs.float() - dxw.float()).abs().mean()) < 1e-4 and (dxs.float() - dxw.float()).abs().max().item() <= 3e-2
+    assert torch.allclose(rm_s, rmw, atol=1e-6) and torch.allclose(rv_s, rvw, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dgs, dgw, rtol=2e-3, atol=2e-2) and torch.allclose(dbs, dbw, rtol=2e-3, atol=2e-2)
