@@ -57,7 +57,8 @@ def emulate(ops):
         cols[: u.shape[0] * u.shape[1], : u.shape[2]] = u.reshape(-1, u.shape[2]).to(cols.dtype)
         return cols
 
-    def batchnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, ws, resid=None, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False):
+    def batchnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, ws, resid=None, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False, sync=None):
+        assert sync is None, "the emulation covers per-process statistics only"
         xf = x[:rows].float()
         m, v = xf.mean(0), xf.var(0, unbiased=False)
         mean.copy_(m); rstd.copy_((v + eps).rsqrt())
@@ -77,7 +78,8 @@ def emulate(ops):
         y[:rows] = (o.relu() if relu else o).to(y.dtype)
         return y
 
-    def batchnorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, ws, y=None, dz=None, dgamma=None, dbeta=None):
+    def batchnorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, ws, y=None, dz=None, dgamma=None, dbeta=None, sync=None):
+        assert sync is None
         d = dy[:rows].float()
         if y is not None:
             d = d * (y[:rows].float() > 0)
