@@ -31,5 +31,6 @@ for rounds in (1, 2, 4):
         (k1, t1), (k2, t2) = res[-2], res[-1]
         slope = (t2 - t1) / (k2 - k1)
         icpt = t2 - slope * k2
-        peak = 2.0 * 256 * 256 * 64 / slope * 256 / 1e6 if slope > 0 else 0   # TF/s of the steady-state K loop, whole chip
+        per_ktile_us = slope * 64 / rounds                                      # one 256 x 256 x 64 K-tile on every CU
+        peak = 256 * 2.0 * 256 * 256 * 64 / per_ktile_us / 1e6 if slope > 0 else 0   # TF/s of the steady-state K loop, whole chip
         print(f"rounds={rounds} {name:9s}: " + "  ".join(f"K={k}:{t:7.1f}" for k, t in res) + f"   us/64-K per round {slope * 64 / rounds:.3f}  fixed/round {icpt / rounds:6.2f} us  loop {peak:6.0f} TF/s")
