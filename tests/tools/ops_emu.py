@@ -32,9 +32,50 @@ def emulate(ops):
         o2 = out.reshape(-1, ldc or N)
         if epilogue == ops.EPI_F32_ACCUM:
             o2[:M, :N] += r
+        elif epilogue == ops.EPI_BF16_GELU:            # activation + (optionally) the saved pre-activation
+            if kw.get("out2") is not None:
+                kw["out2"].reshape(-1, N)[:M] = r.to(kw["out2"].dtype)
+            o2[:M, :N] = F.gelu(r).to(out.dtype)
+        elif epilogue == ops.EPI_BF16_GELUGRAD:        # dX * GELU'(saved pre-activation)
+            pre = kw["aux"].reshape(-1, N)[:M].float().detach().requires_grad_(True)
+            gp, = torch.autograd.grad(F.gelu(pre).sum(), pre)
+            o2[:M, :N] = (r * gp).to(out.dtype)
         else:
+            assert epilogue in (ops.EPI_BF16, ops.EPI_F32), epilogue
             o2[:M, :N] = r.to(out.dtype)
         return out
+
+    def l2norm_fwd(x, y, inv, rows, D, eps=1e-12):
+        n = x[:rows].float().norm(dim=1).clamp_min(eps)
+        inv[:rows] = 1.0 / n
+        y[:rows] = (x[:rows].float() / n[:, None]).to(y.dtype)
+
+    def l2norm_bwd(dy, x, inv, dx, rows, D):
+        yv = x[:rows].float() * inv[:rows, None]
+        d = dy[:rows].float()
+        dx[:rows] = ((d - yv * (yv * d).sum(1, keepdim=True)) * inv[:rows, None]).to(dx.dtype)
+
+    def weightnorm_fwd(v, g, w, K, D):
+        w.copy_((v * (g / v.norm(dim=1, keepdim=True))).to(w.dtype))
+
+    def weightnorm_bwd(dw, v, g, dv, dg, K, D):
+        n = v.norm(dim=1, keepdim=True)
+        vd = (v * dw).sum(1, keepdim=True)
+        dv += g / n * (dw - v * vd / n ** 2)
+        dg += vd / n
+
+    def colsum_bf16(x, out, rows, N):
+        out += x[:rows].float().sum(0)
+
+    def gelu_fwd(x, y, n):
+        y.view(-1)[:n] = F.gelu(x.reshape(-1)[:n].float()).to(y.dtype)
+        return y
+
+    def gelu_bwd(dy, x, dx, n):
+        pre = x.reshape(-1)[:n].float().detach().requires_grad_(True)
+        gp, = torch.autograd.grad(F.gelu(pre).sum(), pre)
+        dx.view(-1)[:n] = (dy.reshape(-1)[:n].float() * gp).to(dx.dtype)
+        return dx
 
     def im2col_nhwc(x, cols, B, H, W, C, KH, KW, stride, pad):
         u = F.unfold(_rows_to_nchw(x, B, H, W, C), (KH, KW), padding=pad, stride=stride)          # [B, C*KH*KW, L]
@@ -127,7 +168,9 @@ def emulate(ops):
                      ("batchnorm_fwd", batchnorm_fwd), ("batchnorm_apply", batchnorm_apply), ("batchnorm_bwd", batchnorm_bwd),
                      ("maxpool3x3s2_fwd", maxpool_fwd), ("maxpool3x3s2_bwd", maxpool_bwd), ("cast_pad_rows", cast_pad_rows),
                      ("unpad_accumulate", unpad_accumulate), ("add_bf16", add_bf16), ("token_mean", token_mean), ("pool_bwd_add", pool_bwd_add),
-                     ("batchnorm_ws_floats", lambda C: 8)):
+                     ("batchnorm_ws_floats", lambda C: 8), ("l2norm_fwd", l2norm_fwd), ("l2norm_bwd", l2norm_bwd),
+                     ("weightnorm_fwd", weightnorm_fwd), ("weightnorm_bwd", weightnorm_bwd), ("colsum_bf16", colsum_bf16), ("gelu_fwd", gelu_fwd),
+                     ("gelu_bwd", gelu_bwd)):
         patch(name, fn)
     try:
         yield
