@@ -418,7 +418,8 @@ class ViTEngine:
                 # them, written into an otherwise ZERO block-middle tensor (finite everywhere: the final LayerNorm still runs densely)
                 ridx, Rr = e2[1]
                 att_r = ws.get(s + "att_r", (T, D), torch.bfloat16)
-                ops.gather_rows(att.view(torch.float32), D // 2, ridx, Rr, D // 2, out_f32=att_r.view(torch.float32))   # bf16 rows as fp32 words
+                words = att.element_size() * D // 4    # a row as 32-bit words (bf16: D / 2): the row gather moves words, whatever they hold
+                ops.gather_rows(att.view(torch.float32), words, ridx, Rr, words, out_f32=att_r.view(torch.float32))
                 x_r = ws.get(tag + ".x_r", (T, D), torch.float32)
                 ops.gather_rows(x, D, ridx, Rr, D, out_f32=x_r)
                 xm_r = ws.get(tag + ".xm_r", (T, D), torch.float32)

@@ -40,10 +40,152 @@ def emulate(ops):
             pre = kw["aux"].reshape(-1, N)[:M].float().detach().requires_grad_(True)
             gp, = torch.autograd.grad(F.gelu(pre).sum(), pre)
             o2[:M, :N] = (r * gp).to(out.dtype)
+        elif epilogue == ops.EPI_RESID:                # C = resid + branch_scale * rowscale[m] * gamma * y, C2 = y
+            if kw.get("out2") is not None:
+                kw["out2"].reshape(-1, N)[:M] = r.to(kw["out2"].dtype)
+            br = r * (kw["gamma"] if kw.get("gamma") is not None else 1.0)
+            if kw.get("rowscale") is not None:
+                br = br * kw["rowscale"][:M, None]
+            bs = kw.get("branch_scale", 1.0) or 1.0
+            base = kw["resid"].reshape(-1, N)[:M].float() if kw.get("resid") is not None else 0.0
+            o2[:M, :N] = (base + bs * br).to(out.dtype)
         else:
             assert epilogue in (ops.EPI_BF16, ops.EPI_F32), epilogue
             o2[:M, :N] = r.to(out.dtype)
         return out
+
+    # ---- token path / norms / attention of the ViT engine (semantics: include/lt_amd.h) ----
+    def matmul_f32(a, b, out, M, N, K, trans_a=False, accumulate=False):
+        A = a.reshape(K, M).t() if trans_a else a.reshape(M, K)
+        r = A @ b.reshape(K, N)
+        if accumulate:
+            out.view(M, N).add_(r)
+        else:
+            out.view(M, N).copy_(r)
+        return out
+
+    def resize_4tap(img, iy, wy, ix, wx, Ho, Wo):
+        t = (img[:, :, iy.long(), :] * wy[None, None, :, :, None]).sum(3)                  # [B, C, Ho, W]
+        return (t[:, :, :, ix.long()] * wx[None, None, None]).sum(4).contiguous()          # [B, C, Ho, Wo]
+
+    def im2col(img, p_, kpad):
+        B, Cc, H, W = img.shape
+        u = F.unfold(img, (p_, p_), stride=p_).transpose(1, 2).reshape(-1, Cc * p_ * p_)   # k = (c*p + py)*p + px
+        cols = torch.zeros(u.shape[0], kpad, dtype=torch.float32)
+        cols[:, : u.shape[1]] = u
+        return cols
+
+    def assemble_tokens(patch, cls, pos, mask_token, masks, B, n_p, D, out=None, reg=None, n_reg=0):
+        x = out if out is not None else torch.empty(B, n_p + 1 + n_reg, D)
+        xv = x.view(B, n_p + 1 + n_reg, D)
+        pv = patch.float().reshape(B, n_p, D)
+        if masks is not None:
+            pv = torch.where(masks.view(B, n_p, 1).bool(), mask_token.view(1, 1, D), pv)
+        posv = pos.view(-1, D)
+        xv[:, 0] = cls.view(1, D) + posv[0]
+        if n_reg:
+            xv[:, 1:1 + n_reg] = reg.view(1, n_reg, D)
+        xv[:, 1 + n_reg:] = pv + posv[1:]
+        return x
+
+    def assemble_tokens_bwd(dx, masks, dpatch, dcls, dpos, dmask, B, n_p, D, dreg=None, n_reg=0):
+        d = dx.view(B, n_p + 1 + n_reg, D)
+        dp = d[:, 1 + n_reg:]
+        dcls.view(-1).add_(d[:, 0].sum(0))
+        dpos.view(-1, D)[0].add_(d[:, 0].sum(0))
+        dpos.view(-1, D)[1:].add_(dp.sum(0))
+        if n_reg:
+            dreg.view(n_reg, D).add_(d[:, 1:1 + n_reg].sum(0))
+        if masks is not None:
+            mk = masks.view(B, n_p, 1).bool()
+            dmask.view(-1).add_((dp * mk).sum((0, 1)))
+            dp = dp * (~mk)
+        dpatch.view(B * n_p, D).copy_(dp.reshape(B * n_p, D).to(dpatch.dtype))
+
+    def layernorm_fwd(x, w, b, rows, D, y_bf16=None, y_f32=None, mean=None, rstd=None, eps=1e-6):
+        xr = x.reshape(-1, D)[:rows]
+        m = xr.mean(1)
+        r = (xr.var(1, unbiased=False) + eps).rsqrt()
+        y = (xr - m[:, None]) * r[:, None] * w + b
+        if y_bf16 is not None:
+            y_bf16.reshape(-1, D)[:rows] = y.to(y_bf16.dtype)
+        if y_f32 is not None:
+            y_f32.reshape(-1, D)[:rows] = y
+        if mean is not None:
+            mean.view(-1)[:rows] = m
+        if rstd is not None:
+            rstd.view(-1)[:rows] = r
+
+    def layernorm_bwd(x, w, mean, rstd, dy, dres, dx, dw, db, rows, D, ws=None, dnext=None, gamma_next=None, rowscale_next=None,
+                      scale_next=1.0, dbias_next=None):
+        xr = x.reshape(-1, D)[:rows]
+        d = dy.reshape(-1, D)[:rows].float()
+        xh = (xr - mean.view(-1)[:rows, None]) * rstd.view(-1)[:rows, None]
+        dw += (d * xh).sum(0)
+        db += d.sum(0)
+        g = d * w
+        dxx = (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True)) * rstd.view(-1)[:rows, None]
+        if dres is not None:
+            dxx = dxx + dres.reshape(-1, D)[:rows]
+        dx.reshape(-1, D)[:rows] = dxx
+        if dnext is not None:
+            dn = dxx * (gamma_next if gamma_next is not None else 1.0) * scale_next
+            if rowscale_next is not None:
+                dn = dn * rowscale_next[:rows, None]
+            dnext.reshape(-1, D)[:rows] = dn.to(dnext.dtype)
+            if dbias_next is not None:
+                dbias_next += dn.sum(0)
+
+    def layerscale_bwd(dout, y, gamma, dy, dgamma, rows, D, dbias=None, rowscale=None, scale=1.0):
+        d = dout.reshape(-1, D)[:rows]
+        m = scale * (rowscale[:rows, None] if rowscale is not None else 1.0)
+        if gamma is not None and y is not None:
+            dgamma += (d * y.reshape(-1, D)[:rows].float() * m).sum(0)
+        o = d * (gamma if gamma is not None else 1.0) * m
+        dy.reshape(-1, D)[:rows] = o.to(dy.dtype)
+        if dbias is not None:
+            dbias += o.sum(0)
+
+    def layerscale_dgamma(w, dw, bias, dbias, gamma, dgamma, N, K):
+        acc = (w.float().view(N, K) * dw.view(N, K)).sum(1)
+        if bias is not None and dbias is not None:
+            acc = acc + bias * dbias
+        dgamma += torch.where(gamma.abs() > 1e-30, acc / gamma, torch.zeros_like(acc))
+
+    def gather_rows(src, ld, idx, M, D, out_bf16=None, out_f32=None):
+        r = src.reshape(-1, ld)[idx[:M], :D]
+        if out_bf16 is not None:
+            out_bf16.reshape(-1, D)[:M] = r.to(out_bf16.dtype)
+        if out_f32 is not None:
+            out_f32.reshape(-1, D)[:M] = r.float()
+
+    def scatter_add_rows(src, idx, dst, ld, M, D):
+        dst.reshape(-1, ld)[:, :D].index_add_(0, idx[:M], src.reshape(-1, D)[:M].to(dst.dtype))
+
+    def _attn(qkv, B, N, Hh, dh, scale):
+        q, k, v = qkv.reshape(B, N, 3, Hh, dh).float().permute(2, 0, 3, 1, 4)
+        return ((q * scale) @ k.transpose(-2, -1)).softmax(-1) @ v                          # [B, H, N, dh]
+
+    def attention_fwd(qkv, out, lse, B, N, Hh, dh, scale):
+        o = _attn(qkv.reshape(-1)[: B * N * 3 * Hh * dh], B, N, Hh, dh, scale)
+        out.reshape(-1)[: B * N * Hh * dh] = o.transpose(1, 2).reshape(-1).to(out.dtype)
+
+    def attention_bwd(qkv, out, dout, lse, ws, dqkv, B, N, Hh, dh, scale):
+        n = B * N * 3 * Hh * dh
+        leaf = qkv.reshape(-1)[:n].float().detach().clone().requires_grad_(True)
+        o = _attn(leaf, B, N, Hh, dh, scale).transpose(1, 2).reshape(B, N, Hh * dh)
+        g, = torch.autograd.grad(o, leaf, dout.reshape(-1)[: B * N * Hh * dh].float().view(B, N, Hh * dh))
+        dqkv.reshape(-1)[:n] = g.to(dqkv.dtype)
+
+    def swiglu_fwd(x12, out, rows, Hd):
+        a = x12.reshape(-1, 2 * Hd)[:rows].float()
+        out.reshape(-1, Hd)[:rows] = (F.silu(a[:, :Hd]) * a[:, Hd:]).to(out.dtype)
+
+    def swiglu_bwd(x12, dh_, d12, rows, Hd):
+        a = x12.reshape(-1, 2 * Hd)[:rows].float().detach().clone().requires_grad_(True)
+        o = F.silu(a[:, :Hd]) * a[:, Hd:]
+        g, = torch.autograd.grad(o, a, dh_.reshape(-1, Hd)[:rows].float())
+        d12.reshape(-1, 2 * Hd)[:rows] = g.to(d12.dtype)
 
     def l2norm_fwd(x, y, inv, rows, D, eps=1e-12):
         n = x[:rows].float().norm(dim=1).clamp_min(eps)
@@ -170,7 +312,12 @@ def emulate(ops):
                      ("unpad_accumulate", unpad_accumulate), ("add_bf16", add_bf16), ("token_mean", token_mean), ("pool_bwd_add", pool_bwd_add),
                      ("batchnorm_ws_floats", lambda C: 8), ("l2norm_fwd", l2norm_fwd), ("l2norm_bwd", l2norm_bwd),
                      ("weightnorm_fwd", weightnorm_fwd), ("weightnorm_bwd", weightnorm_bwd), ("colsum_bf16", colsum_bf16), ("gelu_fwd", gelu_fwd),
-                     ("gelu_bwd", gelu_bwd)):
+                     ("gelu_bwd", gelu_bwd), ("matmul_f32", matmul_f32), ("resize_4tap", resize_4tap), ("im2col", im2col),
+                     ("assemble_tokens", assemble_tokens), ("assemble_tokens_bwd", assemble_tokens_bwd), ("layernorm_fwd", layernorm_fwd),
+                     ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma),
+                     ("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("attention_fwd", attention_fwd),
+                     ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
+                     ("swiglu_bwd", swiglu_bwd)):
         patch(name, fn)
     try:
         yield
