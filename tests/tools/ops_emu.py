@@ -177,6 +177,90 @@ def emulate(ops):
         g, = torch.autograd.grad(o, leaf, dout.reshape(-1)[: B * N * Hh * dh].float().view(B, N, Hh * dh))
         dqkv.reshape(-1)[:n] = g.to(dqkv.dtype)
 
+    # ---- losses / optimizer of the DINOv2 method (semantics: include/lt_amd.h) ----
+    def softmax_center(logits, center, probs, rows, K, inv_temp):
+        z = logits.reshape(-1, K)[:rows]
+        if center is not None:
+            z = z - center.view(1, K)
+        probs.reshape(-1, K)[:rows] = torch.softmax(z * inv_temp, dim=-1)
+
+    def center_ema(center, colsum, scale, momentum, K):
+        center.view(-1).mul_(momentum).add_(colsum.view(-1) * (scale * (1.0 - momentum)))
+
+    def colsum_f32(x, out, rows, N, accumulate=False):
+        sres = x.reshape(-1, N)[:rows].sum(0)
+        if accumulate:
+            out.view(-1).add_(sres)
+        else:
+            out.view(-1).copy_(sres)
+
+    def scale_f32(dst, alpha):
+        dst.mul_(alpha)
+
+    def fill_f32(dst, value):
+        dst.fill_(value)
+
+    def ce_fwd_bwd(s_, teacher, ta, tb, row_weight, scale, inv_temp, loss, dlogits, rows, K, slot=None):
+        sl = s_.reshape(-1, K)[:rows]
+        t = teacher.reshape(-1, K)[ta[:rows].long()]
+        if tb is not None:
+            has = (tb[:rows] >= 0)
+            t = t + teacher.reshape(-1, K)[tb[:rows].clamp_min(0).long()] * has[:, None]
+        coef = scale * (row_weight[:rows] if row_weight is not None else torch.ones(rows))
+        lsm = torch.log_softmax(sl * inv_temp, dim=-1)
+        l = -(t * lsm).sum(-1) * coef
+        if slot is None:
+            loss[0] += l.sum()
+        else:
+            loss.index_add_(0, slot[:rows].long(), l)
+        if dlogits is not None:
+            dlogits.reshape(-1, K)[:rows] = ((coef * inv_temp)[:, None] * (lsm.exp() * t.sum(-1, keepdim=True) - t)).to(dlogits.dtype)
+
+    def sk_exp(logits, Q, inv_temp):
+        Q.reshape(-1)[: logits.numel()] = torch.exp(logits.reshape(-1) * inv_temp)
+
+    def sk_iter(Q, colsum, rows, K, n_total, final_mul):
+        q = Q.reshape(-1, K)[:rows]
+        q = q / (colsum.view(1, K) * K)
+        q = q / (q.sum(-1, keepdim=True) * n_total)
+        Q.reshape(-1, K)[:rows] = q * final_mul
+
+    def koleo_fwd_bwd(x, ld, loss, dx, ld_dx, n, D, weight, ws, nn, eps=1e-8):
+        from oracle import dinov2_oracle as O_
+        rows = torch.as_strided(x, (n, D), (ld, 1)).detach().clone().requires_grad_(True)
+        L = O_.koleo_loss(rows, eps=eps)
+        if weight == 0.0:
+            loss[0] += L.detach()
+            return
+        g, = torch.autograd.grad(L, rows)
+        loss[0] += weight * L.detach()
+        torch.as_strided(dx, (n, D), (ld_dx, 1)).add_(weight * g)
+
+    def sumsq(g, out):
+        out[0] += (g.double() ** 2).sum().float()
+
+    def adamw_flat(p_, g, m, v, p_bf16, seg_of_chunk, seg_lr, seg_wd_on, seg_frozen, freeze, lr_factor, wd, beta1, beta2, eps, step, sumsq_t, max_norm):
+        seg = seg_of_chunk.long().repeat_interleave(1024)
+        lr = seg_lr[seg] * lr_factor
+        lr = torch.where((seg_frozen[seg].int() & int(freeze)) != 0, torch.zeros_like(lr), lr)
+        wdv = torch.where(seg_wd_on[seg] != 0, torch.full_like(lr, wd), torch.zeros_like(lr))
+        clip = 1.0
+        if max_norm > 0:
+            clip = min(1.0, max_norm / (float(sumsq_t[0]) ** 0.5 + 1e-6))
+        gr = g * clip
+        p_.mul_(1 - lr * wdv)
+        m.add_((gr - m) * (1 - beta1))
+        v.mul_(beta2).add_(gr * gr * (1 - beta2))
+        bc1, bc2s = 1 - beta1 ** step, (1 - beta2 ** step) ** 0.5
+        p_.sub_(lr / bc1 * (m / (v.sqrt() / bc2s + eps)))
+        if p_bf16 is not None:
+            p_bf16.copy_(p_.to(p_bf16.dtype))
+
+    def ema_flat(teacher, student, teacher_bf16, m_):
+        teacher.mul_(m_).add_(student * (1.0 - m_))
+        if teacher_bf16 is not None:
+            teacher_bf16.copy_(teacher.to(teacher_bf16.dtype))
+
     def swiglu_fwd(x12, out, rows, Hd):
         a = x12.reshape(-1, 2 * Hd)[:rows].float()
         out.reshape(-1, Hd)[:rows] = (F.silu(a[:, :Hd]) * a[:, Hd:]).to(out.dtype)
@@ -317,7 +401,9 @@ def emulate(ops):
                      ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma),
                      ("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("attention_fwd", attention_fwd),
                      ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
-                     ("swiglu_bwd", swiglu_bwd)):
+                     ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
+                     ("scale_f32", scale_f32), ("fill_f32", fill_f32), ("ce_fwd_bwd", ce_fwd_bwd), ("sk_exp", sk_exp), ("sk_iter", sk_iter),
+                     ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat)):
         patch(name, fn)
     try:
         yield
