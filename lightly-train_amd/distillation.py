@@ -140,8 +140,7 @@ class _DistillBase:
         self.method_args = a = args
         self.scfg, self.tcfg = student_cfg, teacher_cfg
         self.device = dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError(f"{type(self).__name__} runs on an MI355X only (no CPU fallback for the HIP kernels)")
+        ops.require_device(dev, type(self).__name__)
         g = torch.Generator().manual_seed(seed)
         conv = isinstance(student_cfg, ResNetConfig)
         sb = student_state if student_state is not None else (init_resnet_state(student_cfg, g) if conv else init_vit_state(student_cfg, g))

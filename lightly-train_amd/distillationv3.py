@@ -91,8 +91,7 @@ class DistillationV3:
         if a.weight_decay is None:
             a.weight_decay = 1e-6 if self.conv_student else 0.04
         self.device = dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("DistillationV3 runs on an MI355X only (no CPU fallback for the HIP kernels)")
+        ops.require_device(dev, "DistillationV3")
         g = torch.Generator().manual_seed(seed)
         Ds, Dt = (student_cfg.feature_dim if self.conv_student else student_cfg.embed_dim), teacher_cfg.embed_dim
         self.Ds = Ds

@@ -35,6 +35,12 @@ def _chk(t: Tensor, dtype: torch.dtype, name: str) -> None:
         raise ValueError(f"{name}: expected contiguous device tensor of {dtype}, got {t.dtype} contiguous={t.is_contiguous()} cuda={t.is_cuda}")
 
 
+def require_device(dev: torch.device, who: str) -> None:
+    """The methods run on an MI355X only: there is no CPU path behind these wrappers."""
+    if torch.device(dev).type != "cuda":
+        raise RuntimeError(f"{who} runs on an MI355X only (no CPU fallback for the HIP kernels)")
+
+
 def device_info() -> dict:
     lib = _lib.load()
     name = C.create_string_buffer(128)

@@ -24,8 +24,8 @@ from lightly_train_amd.vit import ViTConfig, Workspace  # noqa: E402
 
 
 class F32Workspace(Workspace):
-    def get(self, name, shape, dtype):
-        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype)
+    def get(self, name, shape, dtype, **kw):
+        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype, **kw)
 
 
 class _NoStream:

@@ -25,8 +25,8 @@ pytestmark = pytest.mark.skipif(not H.reference_available(), reason="reference t
 
 
 class F32Workspace(Workspace):
-    def get(self, name, shape, dtype):  # exact arithmetic: every bf16 buffer of the engine becomes fp32
-        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype)
+    def get(self, name, shape, dtype, **kw):
+        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype, **kw)
 
 
 def build(use_bn: bool, D=24, hid=40, bott=16, K=72, seed=0):

@@ -23,8 +23,8 @@ from oracle import dinov2_oracle as O  # noqa: E402
 
 
 class F32Workspace(Workspace):
-    def get(self, name, shape, dtype):
-        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype)
+    def get(self, name, shape, dtype, **kw):
+        return super().get(name, shape, torch.float32 if dtype == torch.bfloat16 else dtype, **kw)
 
 
 class _NoStream:   # the engine orders its side stream against `torch.cuda.current_stream()`; there is none here

@@ -24,6 +24,18 @@ def emulate(ops):
         setattr(ops, name, fn)
 
     def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, epilogue=0, bias=None, lda=None, ldb=None, ldc=None, split_k=1, workspace=None, **kw):
+        nb = kw.pop("batch", 1) or 1
+        if nb > 1:   # independent problems of one shape, operands stride_* elements apart
+            sa, sb, sc = kw.pop("stride_a", 0), kw.pop("stride_b", 0), kw.pop("stride_c", 0)
+            la, lb, lc = lda or (M if trans_a else K), ldb or (N if trans_b else K), ldc or N
+            ra, rb = (K if trans_a else M), (K if trans_b else N)
+            af, bf_, of = a.reshape(-1), b.reshape(-1), out.reshape(-1)
+            for i in range(nb):
+                gemm(af[i * sa: i * sa + ra * la], bf_[i * sb: i * sb + rb * lb], of[i * sc: i * sc + M * lc], M=M, N=N, K=K, trans_a=trans_a, trans_b=trans_b,
+                     epilogue=epilogue, bias=bias, lda=lda, ldb=ldb, ldc=ldc, **kw)
+            return out
+        for k_ in ("stride_a", "stride_b", "stride_c"):
+            kw.pop(k_, None)
         A = (a.float().reshape(-1, lda or (M if trans_a else K))[:K, :M].t() if trans_a else a.float().reshape(-1, lda or K)[:M, :K])
         Bm = (b.float().reshape(-1, ldb or (N if trans_b else K))[:K, :N] if trans_b else b.float().reshape(-1, ldb or K)[:N, :K].t())
         r = A @ Bm
@@ -261,6 +273,71 @@ def emulate(ops):
         if teacher_bf16 is not None:
             teacher_bf16.copy_(teacher.to(teacher_bf16.dtype))
 
+    # ---- distillation methods ----
+    def resample_tokens(x, idx, w, out, B, n_in, n_out, D, taps):
+        xv = x.reshape(-1)[: B * n_in * D].view(B, n_in, D)
+        o = (xv[:, idx.long().view(-1)].view(B, n_out, taps, D) * w.view(1, n_out, taps, 1)).sum(2)
+        out.reshape(-1)[: B * n_out * D] = o.reshape(-1)
+
+    def kl_fwd_bwd(s_logits, t_logits, ld, inv_temp, coef, loss, dlogits, ldd, rows, K):
+        sv = torch.as_strided(s_logits, (rows, K), (ld, 1)); tv = torch.as_strided(t_logits, (rows, K), (ld, 1))
+        ls, lt = torch.log_softmax(sv * inv_temp, -1), torch.log_softmax(tv * inv_temp, -1)
+        loss[0] += coef * (lt.exp() * (lt - ls)).sum()
+        if dlogits is not None:
+            torch.as_strided(dlogits, (rows, K), (ldd, 1)).copy_((coef * inv_temp * (ls.exp() - lt.exp())).to(dlogits.dtype))
+
+    def cast_bf16(src, dst):
+        dst.reshape(-1)[: src.numel()] = src.reshape(-1).to(dst.dtype)
+
+    def symmetrize_bf16(d, g, batch, n, ld):
+        dv = torch.as_strided(d, (batch, n, n), (n * ld, ld, 1)).float()
+        torch.as_strided(g, (batch, n, n), (n * ld, ld, 1)).copy_((dv + dv.transpose(1, 2)).to(g.dtype))
+
+    def mixup(x, index, lam, out):
+        out.copy_(lam * x + (1.0 - lam) * x[index])
+
+    def mse_fwd_bwd(s_, t, ds, n, scale, loss):
+        d = s_.reshape(-1)[:n] - t.reshape(-1)[:n]
+        loss[0] += scale * (d * d).sum()
+        if ds is not None:
+            ds.reshape(-1)[:n] = 2.0 * scale * d
+
+    def lars_flat(p_, g, buf, p_bf16, seg_of_chunk, seg_chunk_begin, seg_lr, seg_wd_on, ws, seg_norms, lr_factor, wd, momentum, dampening, nesterov,
+                  trust, eps, first_step, sumsq_t, max_norm):
+        clip = 1.0
+        if max_norm > 0:
+            clip = min(1.0, max_norm / (float(sumsq_t[0]) ** 0.5 + 1e-6))
+        cb = seg_chunk_begin.tolist()
+        for si in range(len(cb) - 1):
+            sl = slice(cb[si] * 1024, cb[si + 1] * 1024)
+            pp, gg = p_[sl], g[sl] * clip
+            wdv = wd if int(seg_wd_on[si]) else 0.0
+            pn, gn = float(pp.norm()), float(gg.norm())
+            d = gg
+            if wdv != 0 and pn != 0 and gn != 0:
+                d = (gg + wdv * pp) * (pn / (gn + pn * wdv + eps) * trust)
+            if momentum != 0:
+                if first_step:
+                    buf[sl] = d
+                else:
+                    buf[sl] = buf[sl] * momentum + (1 - dampening) * d
+                d = d + momentum * buf[sl] if nesterov else buf[sl]
+            pp.sub_(float(seg_lr[si]) * lr_factor * d)
+        if p_bf16 is not None:
+            p_bf16.copy_(p_.to(p_bf16.dtype))
+
+    def rope_apply(qkv, sin_t, cos_t, B, N, Hh, dh, prefix, inverse=False):
+        v = qkv.reshape(-1)[: B * N * 3 * Hh * dh].view(B, N, 3, Hh, dh)
+        x = v[:, prefix:, :2].float()                                    # q and k of the patch tokens
+        s_, c_ = sin_t.view(1, -1, 1, 1, dh), cos_t.view(1, -1, 1, 1, dh)
+        x1, x2 = x[..., : dh // 2], x[..., dh // 2:]
+        if not inverse:
+            r = x * c_ + torch.cat([-x2, x1], -1) * s_                   # x cos + rotate_half(x) sin
+        else:                                                            # transposed rotation
+            y = x * s_
+            r = x * c_ + torch.cat([y[..., dh // 2:], -y[..., : dh // 2]], -1)
+        v[:, prefix:, :2] = r.to(v.dtype)
+
     def swiglu_fwd(x12, out, rows, Hd):
         a = x12.reshape(-1, 2 * Hd)[:rows].float()
         out.reshape(-1, Hd)[:rows] = (F.silu(a[:, :Hd]) * a[:, Hd:]).to(out.dtype)
@@ -403,7 +480,10 @@ def emulate(ops):
                      ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
                      ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
                      ("scale_f32", scale_f32), ("fill_f32", fill_f32), ("ce_fwd_bwd", ce_fwd_bwd), ("sk_exp", sk_exp), ("sk_iter", sk_iter),
-                     ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat)):
+                     ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat),
+                     ("resample_tokens", resample_tokens), ("kl_fwd_bwd", kl_fwd_bwd), ("cast_bf16", cast_bf16), ("symmetrize_bf16", symmetrize_bf16),
+                     ("mixup", mixup), ("mse_fwd_bwd", mse_fwd_bwd), ("lars_flat", lars_flat), ("rope_apply", rope_apply),
+                     ("require_device", lambda dev, who: None)):
         patch(name, fn)
     try:
         yield
