@@ -402,9 +402,17 @@ def emulate(ops):
         return cols
 
     def batchnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, ws, resid=None, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False, sync=None):
-        assert sync is None, "the emulation covers per-process statistics only"
         xf = x[:rows].float()
-        m, v = xf.mean(0), xf.var(0, unbiased=False)
+        if sync is None:
+            m, v, n = xf.mean(0), xf.var(0, unbiased=False), rows
+        else:   # SyncBatchNorm: (sum x, sum x^2, rows) summed over the ranks by the caller's all-reduce
+            sums = torch.cat([xf.double().sum(0), (xf.double() ** 2).sum(0), torch.tensor([float(rows)], dtype=torch.float64)])
+            sync(sums)
+            n = float(sums[-1])
+            m = (sums[:C] / n).float()
+            v = (sums[C:2 * C] / n - (sums[:C] / n) ** 2).clamp_min(0).float()
+            if rows == 0:
+                return y
         mean.copy_(m); rstd.copy_((v + eps).rsqrt())
         o = (xf - m) * rstd * gamma + beta
         if resid is not None:
@@ -412,7 +420,7 @@ def emulate(ops):
         y[:rows] = (o.relu() if relu else o).to(y.dtype)
         if running_mean is not None:
             running_mean.mul_(1 - momentum).add_(momentum * m)
-            running_var.mul_(1 - momentum).add_(momentum * v * rows / max(rows - 1, 1))
+            running_var.mul_(1 - momentum).add_(momentum * v * n / max(n - 1, 1))
         return y
 
     def batchnorm_apply(x, mean, rstd, gamma, beta, y, rows, C, resid=None, relu=False):
@@ -423,17 +431,24 @@ def emulate(ops):
         return y
 
     def batchnorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, ws, y=None, dz=None, dgamma=None, dbeta=None, sync=None):
-        assert sync is None
         d = dy[:rows].float()
         if y is not None:
             d = d * (y[:rows].float() > 0)
             dz[:rows] = d.to(dz.dtype)
         xh = (x[:rows].float() - mean) * rstd
         if dgamma is not None:
-            dgamma += (d * xh).sum(0)
+            dgamma += (d * xh).sum(0)          # parameter gradients: local sums (the data-parallel mean handles them)
         if dbeta is not None:
             dbeta += d.sum(0)
-        dx[:rows] = (gamma * rstd * (d - d.mean(0) - xh * (d * xh).mean(0))).to(dx.dtype)
+        if sync is None:
+            c1, c2 = d.mean(0), (d * xh).mean(0)
+        else:
+            sums = torch.cat([d.double().sum(0), (d * xh).double().sum(0), torch.tensor([float(rows)], dtype=torch.float64)])
+            sync(sums)
+            c1, c2 = (sums[:C] / sums[-1]).float(), (sums[C:2 * C] / sums[-1]).float()
+            if rows == 0:
+                return dx
+        dx[:rows] = (gamma * rstd * (d - c1 - xh * c2)).to(dx.dtype)
         return dx
 
     def maxpool_fwd(x, y, idx, B, H, W, C):
