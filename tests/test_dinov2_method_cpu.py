@@ -236,3 +236,102 @@ def test_hundred_step_trajectory_in_exact_arithmetic(koleo):
     band = tr["summary"][(koleo, "fp32_perturbed")]["loss"]
     print("worst relative deviation of the total loss", worst, "reference's own perturbed-fp32 band", band)
     assert worst < (2e-6 if koleo == 0.0 else max(3 * band, 5e-3)), worst
+
+
+def _fresh(vc, args_kw, b, seed, total=50):
+    """A method object and its restatement twin from one freshly drawn state (LayerScale away from 1e-5 so that every branch matters)."""
+    from lightly_train_amd.dinov2 import init_head_state
+    from lightly_train_amd.vit import init_vit_state
+    from oracle import dinov2_oracle as O
+
+    g = torch.Generator().manual_seed(seed)
+    bsd = init_vit_state(vc, g)
+    hk = (vc.embed_dim, args_kw["hidden_dim"], args_kw["dino_bottleneck_dim"], args_kw["output_dim"])
+    shs, ths = init_head_state(*hk, g), init_head_state(*hk, g)
+    fx = dict(cfg=dict(patch_size=vc.patch_size, num_heads=vc.num_heads, depth=vc.depth, drop_path_rate=vc.drop_path_rate,
+                       drop_path_uniform=vc.drop_path_uniform), method_kwargs=args_kw, b=b, g_size=vc.img_size, total_steps=total,
+              init=dict(student_backbone=bsd, student_head=shs, teacher_head=ths))
+    over = {k: v for k, v in args_kw.items() if k not in ("output_dim", "hidden_dim", "dino_bottleneck_dim")}
+    m = build_exact(fx, **over)
+    okw = {k: v for k, v in over.items() if k in O.DEFAULT_ARGS}
+    o = O.OracleDINOv2(bsd, shs, fx["cfg"], args=dict(output_dim=hk[3], hidden_dim=hk[1], bottleneck_dim=hk[2], **okw), global_batch_size=b,
+                       total_steps=total, teacher_head=ths)
+    return m, o, g
+
+
+def _compare_grads(m, o, tol=1e-3):
+    for n_ in m.student.names:
+        ref = (o.sb[n_[9:]] if n_.startswith("backbone.") else o.sh[n_[5:]]).grad
+        mine = m.student.g[n_]
+        assert (mine - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1e-12) + 1e-8, n_
+
+
+@pytest.mark.parametrize("rate,uniform", [(0.3, True), (0.1, True), (0.4, False)])
+@pytest.mark.parametrize("checkpointing", [False, True])
+def test_stochastic_depth_and_checkpointing_at_method_level(rate, uniform, checkpointing):
+    """Batch-subset stochastic depth (rate > 0.1), per-sample DropPath (rate <= 0.1) and their linspace mix with the restatement's draws
+    injected (the restatement reproduces the reference's draws under torch.manual_seed: tests/test_oracle_pin.py), with and without
+    activation checkpointing: loss terms and every gradient tensor."""
+    vc = ViTConfig(embed_dim=32, depth=3, num_heads=2, mlp_ratio=2.0, patch_size=16, img_size=64, init_values=0.3, drop_path_rate=rate,
+                   drop_path_uniform=uniform)
+    with ops_emu.emulate(ops):
+        m, o, g = _fresh(vc, dict(output_dim=128, hidden_dim=48, dino_bottleneck_dim=24, koleo_loss_weight=0.0), b=5, seed=31)
+        m.activation_checkpointing = checkpointing
+        views = [torch.randn(5, 3, 64, 64, generator=g) for _ in range(2)] + [torch.randn(5, 3, 32, 32, generator=g) for _ in range(3)]
+        import random
+        random.seed(11)
+        from lightly_train_amd.masking import MaskingGenerator, create_collated_masks
+        masks = create_collated_masks(0.1, 0.5, 5, 10, MaskingGenerator(input_size=(4, 4), max_num_patches=8))
+        torch.manual_seed(3)
+        cap = {}
+        loss, ologs = o.forward_loss(views, masks, capture=cap)
+        loss.backward()
+        assert any(d is not None for d in cap["drop_global"]) and any(d is not None for d in cap["drop_local"])
+        res = m.training_step_impl({"views": views, "drop_plan_global": cap["drop_global"], "drop_plan_local": cap["drop_local"]}, 0, masks=masks)
+        assert float(res.loss) == pytest.approx(float(loss.detach()), rel=3e-5)
+        _compare_grads(m, o)
+
+
+@pytest.mark.parametrize("n_local,b", [(0, 4), (3, 2), (8, 1)])
+def test_edge_crop_and_batch_configurations(n_local, b):
+    """No local crops (terms = 2), odd crop counts, batch 1: loss terms, gradients and one optimizer step."""
+    import random
+    vc = ViTConfig(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=16, img_size=64, init_values=0.3)
+    with ops_emu.emulate(ops):
+        m, o, g = _fresh(vc, dict(output_dim=128, hidden_dim=48, dino_bottleneck_dim=24, koleo_loss_weight=0.0), b=b, seed=100 + n_local)
+        views = [torch.randn(b, 3, 64, 64, generator=g) for _ in range(2)] + [torch.randn(b, 3, 32, 32, generator=g) for _ in range(n_local)]
+        random.seed(5)
+        res = m.training_step_impl({"views": views}, 0)
+        loss, ologs = o.forward_loss(views, m._last_masks)
+        loss.backward()
+        logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+            assert logs[k] == pytest.approx(float(ologs[k]), rel=3e-5, abs=1e-6), k
+        _compare_grads(m, o)
+        m.optimizer_step(); m.on_train_batch_end()
+        o.optimizer_step()
+        for n_ in m.student.names:
+            ref = (o.sb[n_[9:]] if n_.startswith("backbone.") else o.sh[n_[5:]]).detach()
+            assert torch.allclose(m.student.p[n_], ref, atol=3e-6), n_
+
+
+def test_backbone_and_last_layer_freezes_follow_the_reference_rule():
+    """on_before_optimizer_step (dinov2.py:619-635): lr = 0 for the backbone while global_step < student_freeze_backbone_steps and for
+    the prototype layer while < student_freeze_last_layer_steps; Adam's moments keep integrating."""
+    vc = ViTConfig(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=16, img_size=64, init_values=0.3)
+    kw = dict(output_dim=128, hidden_dim=48, dino_bottleneck_dim=24, koleo_loss_weight=0.0, student_freeze_last_layer_steps=2)
+    import random
+    with ops_emu.emulate(ops):
+        m, o, g = _fresh(vc, dict(kw, student_freeze_backbone_steps=1), b=3, seed=8)
+        before = m.student.data.clone()
+        lo, hi = m.student.span(("backbone.",))
+        for s in range(3):
+            views = [torch.randn(3, 3, 64, 64, generator=g) for _ in range(2)] + [torch.randn(3, 3, 32, 32, generator=g) for _ in range(2)]
+            random.seed(s)
+            m.train_step(views)
+            moved_bb = not torch.equal(m.student.data[lo:hi], before[lo:hi])
+            assert moved_bb == (s >= 1), s
+            moved_ll = not torch.equal(m.student.p["head.last_layer.parametrizations.weight.original1"],
+                                       before[m.student.offsets["head.last_layer.parametrizations.weight.original1"]:][: 128 * 24].view(128, 24))
+            assert moved_ll == (s >= 2), s
+            assert float(m.exp_avg[lo:hi].abs().max()) > 0          # frozen, but the moments integrate (torch semantics)
