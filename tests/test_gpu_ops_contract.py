@@ -1,0 +1,143 @@
+"""-m gpu: the plain-torch statements of the kernel contracts that the exact-arithmetic CPU tests run on (tests/tools/ops_emu.py) against
+the kernels themselves, for the fused ops whose semantics carry the orchestration (scales, row subsets, fused by-products): same random
+inputs through the HIP wrapper on the MI355X and through the stand-in on the CPU, outputs and by-products compared at the bf16 level.
+This closes the loop of DESIGN 3: kernel == contract (here and in tests/test_gpu_ops.py), contracts compose to the reference (CPU)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+
+
+def _both(call, tensors, outs):
+    """Run `call(ops, T)` with T = the tensors on the GPU (real wrappers) and on the CPU (stand-ins); returns {name: (gpu, cpu)} for `outs`."""
+    import lightly_train_amd  # noqa: F401
+    import ops_emu
+    from lightly_train_amd import ops
+
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in tensors.items()}
+    call(ops, dev)
+    torch.cuda.synchronize()
+    cpu = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tensors.items()}
+    with ops_emu.emulate(ops):
+        call(ops, cpu)
+    return {k: (dev[k].float().cpu(), cpu[k].float()) for k in outs}
+
+
+def _close(pair, rtol=2e-2, atol=2e-2):
+    a, b = pair
+    scale = b.abs().max().item() + 1e-12
+    assert (a - b).abs().max().item() <= atol * scale + 1e-6, ((a - b).abs().max().item(), scale)
+
+
+def test_gemm_residual_epilogue_with_row_and_branch_scale():
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 300, 64, 128
+    T = dict(a=torch.randn(M, K, generator=g).bfloat16(), b=(torch.randn(N, K, generator=g) * 0.1).bfloat16(), out=torch.zeros(M, N), out2=torch.zeros(M, N).bfloat16(),
+             bias=torch.randn(N, generator=g), gamma=torch.randn(N, generator=g), resid=torch.randn(M, N, generator=g), rs=torch.rand(M, generator=g))
+    r = _both(lambda ops, t: ops.gemm(t["a"], t["b"], t["out"], M=M, N=N, K=K, epilogue=ops.EPI_RESID, bias=t["bias"], gamma=t["gamma"], resid=t["resid"],
+                                     out2=t["out2"], rowscale=t["rs"], branch_scale=1.75), T, ["out", "out2"])
+    _close(r["out"]); _close(r["out2"])
+
+
+def test_gemm_gelu_and_gelugrad_epilogues():
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 260, 96, 64
+    T = dict(a=torch.randn(M, K, generator=g).bfloat16(), b=(torch.randn(N, K, generator=g) * 0.2).bfloat16(), out=torch.zeros(M, N).bfloat16(),
+             pre=torch.zeros(M, N).bfloat16(), bias=torch.randn(N, generator=g), aux=(torch.randn(M, N, generator=g) * 2).bfloat16(), dout=torch.zeros(M, N).bfloat16())
+    r = _both(lambda ops, t: (ops.gemm(t["a"], t["b"], t["out"], M=M, N=N, K=K, epilogue=ops.EPI_BF16_GELU, bias=t["bias"], out2=t["pre"]),
+                              ops.gemm(t["a"], t["b"], t["dout"], M=M, N=N, K=K, epilogue=ops.EPI_BF16_GELUGRAD, aux=t["aux"])), T, ["out", "pre", "dout"])
+    for k in r:
+        _close(r[k])
+
+
+def test_fused_layernorm_backward_and_layerscale():
+    g = torch.Generator().manual_seed(2)
+    R, D = 200, 64
+    x = torch.randn(R, D, generator=g)
+    T = dict(x=x, w=torch.randn(D, generator=g), mean=x.mean(1), rstd=(x.var(1, unbiased=False) + 1e-6).rsqrt(), dy=torch.randn(R, D, generator=g).bfloat16(),
+             dres=torch.randn(R, D, generator=g), dx=torch.zeros(R, D), dw=torch.zeros(D), db=torch.zeros(D), dnext=torch.zeros(R, D).bfloat16(),
+             gn=torch.randn(D, generator=g), rsn=torch.rand(R, generator=g), dbn=torch.zeros(D),
+             y=torch.randn(R, D, generator=g).bfloat16(), gam=torch.randn(D, generator=g), dy2=torch.zeros(R, D).bfloat16(), dgam=torch.zeros(D), dbias=torch.zeros(D))
+    r = _both(lambda ops, t: (ops.layernorm_bwd(t["x"], t["w"], t["mean"], t["rstd"], t["dy"], t["dres"], t["dx"], t["dw"], t["db"], R, D, dnext=t["dnext"],
+                                                gamma_next=t["gn"], rowscale_next=t["rsn"], scale_next=1.5, dbias_next=t["dbn"]),
+                              ops.layerscale_bwd(t["dres"], t["y"], t["gam"], t["dy2"], t["dgam"], R, D, dbias=t["dbias"], rowscale=t["rsn"], scale=0.75)),
+              T, ["dx", "dw", "db", "dnext", "dbn", "dy2", "dgam", "dbias"])
+    for k in r:
+        _close(r[k])
+
+
+def test_token_assembly_and_its_backward():
+    g = torch.Generator().manual_seed(3)
+    B, n_p, n_reg, D = 3, 10, 2, 32
+    N = n_p + 1 + n_reg
+    T = dict(patch=torch.randn(B * n_p, D, generator=g), cls=torch.randn(D, generator=g), pos=torch.randn(n_p + 1, D, generator=g), mt=torch.randn(D, generator=g),
+             masks=(torch.rand(B, n_p, generator=g) < 0.4).to(torch.uint8), reg=torch.randn(n_reg, D, generator=g), x=torch.zeros(B, N, D),
+             dxin=torch.randn(B, N, D, generator=g), dpatch=torch.zeros(B * n_p, D).bfloat16(), dcls=torch.zeros(D), dpos=torch.zeros(n_p + 1, D), dmask=torch.zeros(D),
+             dreg=torch.zeros(n_reg, D))
+    r = _both(lambda ops, t: (ops.assemble_tokens(t["patch"], t["cls"], t["pos"], t["mt"], t["masks"], B, n_p, D, out=t["x"], reg=t["reg"], n_reg=n_reg),
+                              ops.assemble_tokens_bwd(t["dxin"], t["masks"], t["dpatch"], t["dcls"], t["dpos"], t["dmask"], B, n_p, D, dreg=t["dreg"], n_reg=n_reg)),
+              T, ["x", "dpatch", "dcls", "dpos", "dmask", "dreg"])
+    for k in r:
+        _close(r[k], atol=1e-2)
+
+
+def test_cross_entropy_with_two_targets_slots_and_row_weights():
+    g = torch.Generator().manual_seed(4)
+    R, K, Tn = 40, 256, 24
+    T = dict(s=torch.randn(R, K, generator=g), t=torch.softmax(torch.randn(Tn, K, generator=g), -1), ta=torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32),
+             tb=torch.where(torch.rand(R, generator=g) < 0.5, torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32), torch.full((R,), -1, dtype=torch.int32)),
+             w=torch.rand(R, generator=g), slot=torch.randint(0, 3, (R,), generator=g, dtype=torch.int32), loss=torch.zeros(5), d=torch.zeros(R, K).bfloat16())
+    r = _both(lambda ops, t: ops.ce_fwd_bwd(t["s"], t["t"], t["ta"], t["tb"], t["w"], 0.7, 10.0, t["loss"], t["d"], R, K, slot=t["slot"]), T, ["loss", "d"])
+    _close(r["loss"], atol=1e-4); _close(r["d"])
+
+
+def test_softmax_center_sinkhorn_and_center_ema():
+    g = torch.Generator().manual_seed(5)
+    R, K = 48, 128
+    T = dict(l=torch.randn(R, K, generator=g), c=torch.randn(K, generator=g) * 0.1, p=torch.zeros(R, K), Q=torch.zeros(R, K), cs=torch.zeros(K),
+             cen=torch.randn(K, generator=g), colsum=torch.randn(K, generator=g))
+
+    def call(ops, t):
+        ops.softmax_center(t["l"], t["c"], t["p"], R, K, 1.0 / 0.05)
+        ops.sk_exp(t["l"], t["Q"], 1.0 / 0.3)
+        for it in range(3):
+            ops.colsum_f32(t["Q"], t["cs"], R, K)
+            ops.sk_iter(t["Q"], t["cs"], R, K, float(R), float(R) if it == 2 else 1.0)
+        ops.center_ema(t["cen"], t["colsum"], 0.25, 0.9, K)
+    r = _both(call, T, ["p", "Q", "cen"])
+    for k in r:
+        _close(r[k], atol=1e-4)
+
+
+def test_layerscale_gradient_from_the_weight_gradient_and_row_moves():
+    g = torch.Generator().manual_seed(6)
+    N, K, R, D = 32, 48, 50, 32
+    T = dict(w=(torch.randn(N, K, generator=g) * 0.2).bfloat16(), dw=torch.randn(N, K, generator=g), b=torch.randn(N, generator=g), dbv=torch.randn(N, generator=g),
+             gam=torch.randn(N, generator=g) + 2.0, dgam=torch.zeros(N), src=torch.randn(R, D, generator=g), idx=torch.randperm(R, generator=g)[:20],
+             ob=torch.zeros(20, D).bfloat16(), of=torch.zeros(20, D), dst=torch.randn(R, D, generator=g), add=torch.randn(20, D, generator=g))
+    r = _both(lambda ops, t: (ops.layerscale_dgamma(t["w"], t["dw"], t["b"], t["dbv"], t["gam"], t["dgam"], N, K),
+                              ops.gather_rows(t["src"], D, t["idx"], 20, D, out_bf16=t["ob"], out_f32=t["of"]),
+                              ops.scatter_add_rows(t["add"], t["idx"], t["dst"], D, 20, D)), T, ["dgam", "ob", "of", "dst"])
+    for k in r:
+        _close(r[k], atol=1e-2)
+
+
+def test_optimizer_and_ema_contracts():
+    g = torch.Generator().manual_seed(7)
+    n = 4096
+    T = dict(p=torch.randn(n, generator=g), gr=torch.randn(n, generator=g), m=torch.randn(n, generator=g) * 0.1, v=torch.rand(n, generator=g) * 0.1, pb=torch.zeros(n).bfloat16(),
+             soc=torch.tensor([0, 0, 1, 2], dtype=torch.int32), lr=torch.tensor([1e-2, 5e-3, 2e-2]), wd=torch.tensor([1, 0, 1], dtype=torch.uint8),
+             fr=torch.tensor([0, 1, 2], dtype=torch.uint8), ss=torch.zeros(1), tea=torch.randn(n, generator=g), tb=torch.zeros(n).bfloat16())
+
+    def call(ops, t):
+        ops.sumsq(t["gr"], t["ss"])
+        ops.adamw_flat(t["p"], t["gr"], t["m"], t["v"], t["pb"], t["soc"], t["lr"], t["wd"], t["fr"], 1, 0.5, 0.04, 0.9, 0.999, 1e-8, 3, t["ss"], 3.0)
+        ops.ema_flat(t["tea"], t["p"], t["tb"], 0.992)
+    r = _both(call, T, ["p", "m", "v", "pb", "ss", "tea", "tb"])
+    for k in r:
+        _close(r[k], atol=1e-5 if k not in ("pb", "tb") else 1e-2)
