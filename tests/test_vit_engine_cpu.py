@@ -146,3 +146,44 @@ def test_vit_engine_forward_backward_equals_autograd_of_the_restatement(name):
         e = rel(mine, t.grad) if t.grad.abs().max() > 0 else mine.abs().max().item()
         worst = max(worst, (n_, e), key=lambda z: z[1])
         assert e < 1e-4, (n_, e)
+
+
+def test_model_wrapper_surface_in_exact_arithmetic():
+    """ModelWrapper surface (LT/_models/dinov2_vit/dinov2_vit.py:55-128): forward_features with iBOT masks, forward_pool, n_blocks > 1,
+    forward_multiscale_features, the state_dict round trip of the exported backbone -- against the restatement, fp32 round-off."""
+    from lightly_train_amd.model_wrapper import DINOv2ViTModelWrapper
+
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_softmax.pt"), weights_only=False)
+    sb = fx["init"]["student_backbone"]
+    cfg = ViTConfig(embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=fx["g_size"])
+    ocfg = dict(patch_size=16, num_heads=1, depth=2)
+    with ops_emu.emulate(ops):
+        def exact(w):
+            w.ws = F32Workspace(torch.device("cpu"))
+            w.params.bf16 = w.params.data.clone()
+            w.params.b = {n: w.params.bf16[w.params.offsets[n]:w.params.offsets[n] + w.params.p[n].numel()].view(w.params.shapes[n]) for n in w.params.names}
+            return w
+
+        w = exact(DINOv2ViTModelWrapper(cfg, state=sb, device="cpu"))
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(3, 3, 96, 96, generator=g)
+        masks = torch.rand(3, 36, generator=g) < 0.3
+        out = {k: v.clone() for k, v in w.forward_features(x, masks).items()}
+        ref = O.vit_forward(sb, x, ocfg, masks=masks)
+        assert out["features"].shape == (3, 64, 6, 6)
+        assert torch.allclose(out["cls_token"], ref["cls"], atol=2e-5)
+        assert torch.allclose(out["features"].flatten(2).transpose(1, 2), ref["patch"], atol=2e-5)
+        assert torch.allclose(w.forward_pool(out)["pooled_features"].flatten(1), ref["cls"], atol=2e-5)     # the cls token (dinov2_vit.py:99-103)
+        cap = {}
+        O.vit_forward(sb, x, ocfg, capture=cap)
+        normed = [torch.nn.functional.layer_norm(cap[f"block{i}"], (64,), sb["norm.weight"], sb["norm.bias"], 1e-6) for i in range(2)]
+        ms = [{k: v.clone() for k, v in d_.items()} for d_ in w.forward_multiscale_features(x, [0, 1])]
+        for i in range(2):
+            assert torch.allclose(ms[i]["cls_token"], normed[i][:, 0], atol=2e-5)
+            assert torch.allclose(ms[i]["features"].flatten(2).transpose(1, 2), normed[i][:, 1:], atol=2e-5)
+        cat = w.forward_features(x, n_blocks=2)
+        assert torch.allclose(cat["cls_token"], torch.cat([normed[0][:, 0], normed[1][:, 0]], 1), atol=2e-5)
+        w2 = exact(DINOv2ViTModelWrapper(cfg, device="cpu"))
+        w2.get_model().load_state_dict(w.get_model().state_dict())
+        w2.params.bf16.copy_(w2.params.data)
+        assert torch.equal(w2.forward_features(x, masks)["cls_token"], out["cls_token"])
