@@ -335,3 +335,87 @@ def test_backbone_and_last_layer_freezes_follow_the_reference_rule():
                                        before[m.student.offsets["head.last_layer.parametrizations.weight.original1"]:][: 128 * 24].view(128, 24))
             assert moved_ll == (s >= 2), s
             assert float(m.exp_avg[lo:hi].abs().max()) > 0          # frozen, but the moments integrate (torch semantics)
+
+
+def _combo(seed: int):
+    """A configuration drawn from the options the method supports, deterministic in `seed`."""
+    import random as _r
+    r = _r.Random(seed)
+    patch = r.choice([16, 14])
+    g_size = r.choice([4, 5]) * patch
+    return dict(center=r.choice(["softmax", "sinkhorn_knopp"]), sep=r.random() < 0.4, bn=r.random() < 0.35, nreg=r.choice([0, 0, 2]), patch=patch, g_size=g_size,
+                l_size=r.choice([2 * patch, 2 * patch + 6, 3 * patch - 5]),      # multiples of the patch size and sizes the patch embedding pad-resizes
+                n_local=r.choice([0, 2, 5]), ffn=r.choice(["mlp", "mlp", "swiglufused"]), drop=r.choice([0.0, 0.0, 0.25]), b=r.choice([2, 3]),
+                antialias=r.random() < 0.3, sparse=r.random() < 0.7)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_drawn_configurations_equal_the_restatement(seed):
+    """Sixteen configurations drawn across the options that interact in the method object (centering method x shared / separate heads x
+    BatchNorm heads x register tokens x patch 14 / 16 x local crops whose size the patch embedding has to pad-resize x number of local
+    crops x MLP / SwiGLU x stochastic depth x antialiased positional embedding x last block on the read rows only): two optimizer steps
+    against the pinned restatement, loss terms 3e-5, every gradient tensor 1e-3 of its largest entry, parameters 3e-6."""
+    import random
+    from lightly_train_amd.dinov2 import init_head_state
+    from lightly_train_amd.vit import init_vit_state
+    from oracle import dinov2_oracle as O
+
+    c = _combo(seed)
+    vc = ViTConfig(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=c["patch"], img_size=c["g_size"], init_values=0.4, num_register_tokens=c["nreg"],
+                   ffn_layer=c["ffn"], drop_path_rate=c["drop"], interpolate_antialias=c["antialias"])
+    g = torch.Generator().manual_seed(1000 + seed)
+    bsd = init_vit_state(vc, g)
+    for k in bsd:
+        if k in ("cls_token", "register_tokens", "mask_token") or k.endswith(".bias"):
+            bsd[k] = bsd[k] + 0.2 * torch.randn(bsd[k].shape, generator=g)
+    hk = (32, 48, 24, 96)
+    heads = [init_head_state(*hk, g, c["bn"]) for _ in range(4)]
+    mk = dict(output_dim=96, hidden_dim=48, dino_bottleneck_dim=24, center_method=c["center"], ibot_separate_head=c["sep"], batch_norm=c["bn"])
+    fx = dict(cfg=dict(patch_size=c["patch"], num_heads=2, depth=2, num_register_tokens=c["nreg"], interpolate_antialias=c["antialias"], drop_path_rate=c["drop"],
+                       mlp_ratio=2.0, ffn_layer=c["ffn"]),
+              method_kwargs=mk, b=c["b"], g_size=c["g_size"], total_steps=40,
+              init=dict(student_backbone=bsd, student_head=heads[0], teacher_head=heads[1], student_ibot_head=heads[2] if c["sep"] else None,
+                        teacher_ibot_head=heads[3] if c["sep"] else None))
+    bn = c["bn"]
+    with ops_emu.emulate(ops):
+        m = build_exact(fx, koleo_loss_weight=0.0)
+        m.sparse_last_mlp = c["sparse"]
+        o = O.OracleDINOv2(bsd, heads[0], fx["cfg"], args=dict(output_dim=96, hidden_dim=48, bottleneck_dim=24, center_method=c["center"], koleo_loss_weight=0.0),
+                           global_batch_size=c["b"], total_steps=40, teacher_head=heads[1], student_ibot_head=heads[2] if c["sep"] else None,
+                           teacher_ibot_head=heads[3] if c["sep"] else None)
+        for s in range(2):
+            views = ([torch.randn(c["b"], 3, c["g_size"], c["g_size"], generator=g) for _ in range(2)]
+                     + [torch.randn(c["b"], 3, c["l_size"], c["l_size"], generator=g) for _ in range(c["n_local"])])
+            random.seed(50 + s)
+            from lightly_train_amd.masking import MaskingGenerator, create_collated_masks
+            gh = c["g_size"] // c["patch"]
+            masks = create_collated_masks(0.1, 0.5, c["b"], 2 * c["b"], MaskingGenerator(input_size=(gh, gh), max_num_patches=int(0.5 * gh * gh)))
+            torch.manual_seed(7 + s)
+            cap = {}
+            loss, ologs = o.forward_loss(views, masks, capture=cap)
+            loss.backward()
+            batch = {"views": views}
+            if c["drop"] > 0:
+                batch.update(drop_plan_global=cap["drop_global"], drop_plan_local=cap["drop_local"])
+            res = m.training_step_impl(batch, 0, masks=masks)
+            logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+            for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+                assert logs[k] == pytest.approx(float(ologs[k]), rel=3e-5, abs=3e-5), (c, s, k)
+            pairs = [("backbone.", o.sb), ("head.", o.sh)] + ([("ihead.", o.shi)] if o.separate else [])
+            noisy = lambda n_: bn and (n_.endswith(("mlp.0.bias", "mlp.3.bias")) or n_ == "backbone.norm.bias")     # noqa: E731
+            for n_ in m.student.names:
+                pre, od = next((p_, d) for p_, d in pairs if n_.startswith(p_))
+                ref = od[n_[len(pre):]].grad
+                if noisy(n_) or ref is None:
+                    continue
+                assert (m.student.g[n_] - ref).abs().max().item() <= 1e-3 * max(ref.abs().max().item(), 1e-12) + 1e-8, (c, s, n_)
+            info = m.optimizer_step(); m.on_train_batch_end()
+            o.optimizer_step()
+            lr_eff = m.base_lr * info["lr_factor"]
+            for n_ in m.student.names:
+                pre, od = next((p_, d) for p_, d in pairs if n_.startswith(p_))
+                if not noisy(n_):
+                    # AdamW's early steps are lr * sign(g) where |g| >> eps: the few elements whose gradient is round-off around zero may
+                    # take the other sign on the two sides -- bounded by 2 lr per step, and rare
+                    d = (m.student.p[n_] - od[n_[len(pre):]].detach()).abs()
+                    assert d.max().item() <= 2.2 * lr_eff * (s + 1) + 1e-7 and (d > 3e-6).float().mean().item() < 5e-3, (c, s, n_, d.max().item())
