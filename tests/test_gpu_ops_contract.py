@@ -141,3 +141,94 @@ def test_optimizer_and_ema_contracts():
     r = _both(call, T, ["p", "m", "v", "pb", "ss", "tea", "tb"])
     for k in r:
         _close(r[k], atol=1e-5 if k not in ("pb", "tb") else 1e-2)
+
+
+def test_attention_forward_and_backward():
+    g = torch.Generator().manual_seed(8)
+    for (B, N, H, dh) in ((3, 37, 2, 64), (2, 70, 1, 64), (2, 21, 2, 16)):
+        T = dict(qkv=(torch.randn(B, N, 3 * H * dh, generator=g) * 0.7).bfloat16(), out=torch.zeros(B, N, H * dh).bfloat16(), lse=torch.zeros(B, H, N),
+                 dout=torch.randn(B, N, H * dh, generator=g).bfloat16(), dqkv=torch.zeros(B, N, 3 * H * dh).bfloat16())
+
+        def call(ops, t):
+            ops.attention_fwd(t["qkv"], t["out"], t["lse"], B, N, H, dh, dh ** -0.5)
+            ws = torch.empty(max(8, ops.attention_bwd_ws_floats(B, N, H, dh)), device=t["qkv"].device)
+            ops.attention_bwd(t["qkv"], t["out"], t["dout"], t["lse"], ws, t["dqkv"], B, N, H, dh, dh ** -0.5)
+        r = _both(call, T, ["out", "dqkv"])
+        _close(r["out"]); _close(r["dqkv"], atol=3e-2)
+
+
+def test_patch_embedding_inputs_and_small_matmul():
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(2, 3, 28, 30, generator=g)
+    from lightly_train_amd import ops as real_ops
+    iy, wy = real_ops.bicubic_taps(28, 32); ix, wx = real_ops.bicubic_taps(30, 32)
+    T = dict(img=img, iy=iy, wy=wy, ix=ix, wx=wx, a=torch.randn(20, 12, generator=g), b=torch.randn(12, 16, generator=g), c=torch.randn(20, 16, generator=g),
+             w=torch.randn(8, 147, generator=g), wp=torch.zeros(8, 152).bfloat16(), acc=torch.randn(8, 147, generator=g), src=torch.randn(8, 152, generator=g))
+    res = {}
+
+    def call(ops, t):
+        res[t["img"].device.type] = (ops.resize_4tap(t["img"], t["iy"], t["wy"], t["ix"], t["wx"], 32, 32), )
+        res[t["img"].device.type] += (ops.im2col(res[t["img"].device.type][0], 8, 192), )
+        ops.matmul_f32(t["a"], t["b"], t["c"], 20, 16, 12, accumulate=True)
+        ops.cast_pad_rows(t["w"], t["wp"], 8, 147, 152)
+        ops.unpad_accumulate(t["src"], t["acc"], 8, 147, 152)
+    r = _both(call, T, ["c", "wp", "acc"])
+    for k in r:
+        _close(r[k], atol=1e-2)
+    _close((res["cuda"][0].float().cpu(), res["cpu"][0].float()), atol=1e-4)
+    _close((res["cuda"][1].float().cpu(), res["cpu"][1].float()), atol=1e-2)
+
+
+def test_head_pieces_batchnorm_and_gelu():
+    g = torch.Generator().manual_seed(10)
+    R, D, K = 50, 32, 96
+    x = torch.randn(R, D, generator=g)
+    T = dict(x=x, y=torch.zeros(R, D).bfloat16(), inv=torch.zeros(R), dy=torch.randn(R, D, generator=g), dx=torch.zeros(R, D).bfloat16(),
+             v=torch.randn(K, D, generator=g), gg=torch.rand(K, 1, generator=g) + 0.5, w=torch.zeros(K, D).bfloat16(), dw=torch.randn(K, D, generator=g),
+             dv=torch.zeros(K, D), dg=torch.zeros(K, 1), cs=torch.zeros(D), xb=torch.randn(R, D, generator=g).bfloat16(),
+             u=torch.zeros(R, D).bfloat16(), du=torch.zeros(R, D).bfloat16(), dyb=torch.randn(R, D, generator=g).bfloat16(),
+             gam=torch.rand(D, generator=g) + 0.5, bet=torch.randn(D, generator=g), bny=torch.zeros(R, D).bfloat16(), mean=torch.zeros(D), rstd=torch.zeros(D),
+             rm=torch.zeros(D), rv=torch.ones(D), bndx=torch.zeros(R, D).bfloat16(), dgam=torch.zeros(D), dbet=torch.zeros(D))
+
+    def call(ops, t):
+        ops.l2norm_fwd(t["x"], t["y"], t["inv"], R, D, 1e-12)
+        ops.l2norm_bwd(t["dy"], t["x"], t["inv"], t["dx"], R, D)
+        ops.weightnorm_fwd(t["v"], t["gg"], t["w"], K, D)
+        ops.weightnorm_bwd(t["dw"], t["v"], t["gg"], t["dv"], t["dg"], K, D)
+        ops.colsum_bf16(t["xb"], t["cs"], R, D)
+        ops.gelu_fwd(t["xb"], t["u"], R * D)
+        ops.gelu_bwd(t["dyb"], t["xb"], t["du"], R * D)
+        ws = torch.empty(max(8, ops.batchnorm_ws_floats(D)), device=t["x"].device)
+        ops.batchnorm_fwd(t["xb"], t["gam"], t["bet"], t["bny"], t["mean"], t["rstd"], R, D, ws, running_mean=t["rm"], running_var=t["rv"])
+        ops.batchnorm_bwd(t["dyb"], t["xb"], t["gam"], t["mean"], t["rstd"], t["bndx"], R, D, ws, dgamma=t["dgam"], dbeta=t["dbet"])
+    r = _both(call, T, ["y", "inv", "dx", "w", "dv", "dg", "cs", "u", "du", "bny", "mean", "rstd", "rm", "rv", "bndx", "dgam", "dbet"])
+    for k in r:
+        _close(r[k], atol=2e-2)
+
+
+def test_distillation_pieces_and_lars():
+    g = torch.Generator().manual_seed(11)
+    B, n_in, n_out, D, K = 2, 9, 16, 8, 64
+    from lightly_train_amd import ops as real_ops
+    (idx, w, taps), _ = real_ops.resample_tables(3, 3, 4, 4)
+    n = 3072
+    T = dict(x=torch.randn(B, n_in, D, generator=g), idx=idx, w=w, out=torch.zeros(B, n_out, D), s=torch.randn(10, K, generator=g), t=torch.randn(10, K, generator=g),
+             loss=torch.zeros(1), dl=torch.zeros(10, K).bfloat16(), d=torch.randn(B, 6, 8, generator=g).bfloat16(), gsym=torch.zeros(B, 6, 8).bfloat16(),
+             img=torch.randn(4, 3, 4, 4, generator=g), perm=torch.tensor([2, 0, 3, 1]), mix=torch.zeros(4, 3, 4, 4), ms=torch.randn(100, generator=g),
+             mt=torch.randn(100, generator=g), mds=torch.zeros(100), mloss=torch.zeros(1), xs=torch.randn(16, 2, 2, 8, generator=g).bfloat16(),
+             p=torch.randn(n, generator=g), gr=torch.randn(n, generator=g) * 0.1, buf=torch.randn(n, generator=g) * 0.01, pb=torch.zeros(n).bfloat16(),
+             soc=torch.tensor([0, 1, 2], dtype=torch.int32), scb=torch.tensor([0, 1, 2, 3], dtype=torch.int32), lr=torch.tensor([0.5, 0.5, 0.25]),
+             wd=torch.tensor([1, 0, 1], dtype=torch.uint8), lws=torch.zeros(8), sn=torch.zeros(3, 2), ss=torch.zeros(1))
+
+    def call(ops, t):
+        ops.resample_tokens(t["x"], t["idx"], t["w"], t["out"], B, n_in, n_out, D, taps)
+        ops.kl_fwd_bwd(t["s"], t["t"], K, 1.0 / 0.07, 0.3, t["loss"], t["dl"], K, 10, K)
+        ops.symmetrize_bf16(t["d"], t["gsym"], B, 6, 8)
+        ops.mixup(t["img"], t["perm"], 0.3, t["mix"])
+        ops.mse_fwd_bwd(t["ms"], t["mt"], t["mds"], 100, 0.01, t["mloss"])
+        ops.sumsq(t["gr"], t["ss"])
+        ops.lars_flat(t["p"], t["gr"], t["buf"], t["pb"], t["soc"], t["scb"], t["lr"], t["wd"], t["lws"], t["sn"], 0.5, 1e-3, 0.9, 0.0, False, 0.01, 1e-8, False,
+                      t["ss"], 1.0)
+    r = _both(call, T, ["out", "loss", "dl", "gsym", "mix", "mds", "mloss", "p", "buf", "pb"])
+    for k in r:
+        _close(r[k], atol=1e-2 if k in ("dl", "gsym", "pb") else 1e-4)
