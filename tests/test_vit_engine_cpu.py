@@ -81,6 +81,8 @@ CASES = {
     "no_layerscale": (dict(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=8, img_size=32, init_values=None), 2, 32, 32, True, None, False),
     "activation_checkpointing": (dict(embed_dim=32, depth=3, num_heads=2, mlp_ratio=2.0, patch_size=8, img_size=32, drop_path_rate=0.4,
                                       drop_path_uniform=True), 5, 32, 32, True, (0.4, True), "checkpoint"),
+    "one_input_channel": (dict(embed_dim=32, depth=1, num_heads=2, mlp_ratio=2.0, patch_size=8, img_size=32, in_chans=1), 2, 32, 32, True, None, False),
+    "four_input_channels_p14": (dict(embed_dim=32, depth=1, num_heads=2, mlp_ratio=2.0, patch_size=14, img_size=28, in_chans=4), 2, 28, 28, False, None, False),
     "last_block_on_read_rows": (dict(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=8, img_size=32), 4, 32, 32, True, None, True),
     "read_rows_with_subset_depth": (dict(embed_dim=32, depth=2, num_heads=2, mlp_ratio=2.0, patch_size=8, img_size=32, drop_path_rate=0.5,
                                          drop_path_uniform=True), 4, 32, 32, True, (0.5, True), True),
@@ -94,7 +96,7 @@ def test_vit_engine_forward_backward_equals_autograd_of_the_restatement(name):
     with ops_emu.emulate(ops):
         eng, fp, params, g = make(cfg, seed=len(name))
         p, D, nreg = cfg.patch_size, cfg.embed_dim, cfg.num_register_tokens
-        img = torch.randn(B, 3, H, W, generator=g)
+        img = torch.randn(B, cfg.in_chans, H, W, generator=g)
         gh, gw = -(-H // p), -(-W // p)
         n_p, N = gh * gw, gh * gw + 1 + nreg
         masks = None
