@@ -199,3 +199,65 @@ def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_a
     if len(steps) > 1:
         raise ValueError(f"parameters disagree on the optimizer step count: {sorted(steps)}")
     return steps.pop() if steps else 0
+
+
+# ---- the distillation methods (Distillation, DistillationV2, DistillationV3): model state in the reference's key names, optimizer state
+# in this package's flat layout (their reference optimizer is LARS / AdamW over two unnamed groups: there is no per-parameter key to keep)
+def distill_load_state_dict(m: Any, sd: Mapping[str, Tensor], head_map: Mapping[str, str], strict: bool = True) -> None:
+    """Inverse of the methods' `state_dict()`: `student_embedding_model.wrapped_model._model.*` (ViT / DINOv3 students) or `._features.*`
+    (torchvision ResNet students), the projection heads (`head_map`: reference prefix -> flat prefix) and `teacher_queue`; keys of the
+    frozen teacher, which `on_save_checkpoint` drops anyway, are ignored."""
+    fp: FlatParams = m.student
+    seen = set()
+    net = getattr(m, "s_net", None) or getattr(getattr(m, "s", None), "net", None)
+    conv = hasattr(net, "w_stem")
+    pre_vit, pre_conv = "student_embedding_model.wrapped_model._model.", "student_embedding_model.wrapped_model._features."
+    bb = {k[len(pre_conv if conv else pre_vit):]: v for k, v in sd.items() if k.startswith(pre_conv if conv else pre_vit)}
+    if conv:
+        net.load_state_dict(bb)
+        seen.update(n for n in fp.names if n.startswith("backbone."))
+    else:
+        scfg = getattr(m, "scfg")
+        if getattr(scfg, "rope_base", None) is not None:
+            from .dinov3 import convert_dinov3_state
+            bb = convert_dinov3_state(bb, scfg)
+        for k, v in bb.items():
+            n = "backbone." + k
+            if n in fp.p:
+                if tuple(v.shape) != tuple(fp.shapes[n]):
+                    raise ValueError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(fp.shapes[n])}")
+                fp.p[n].copy_(v.to(fp.device, torch.float32)); seen.add(n)
+            elif strict:
+                raise KeyError(f"unexpected key in state_dict: {k}")
+    for rp, fpre in head_map.items():
+        for k, v in sd.items():
+            if k.startswith(rp):
+                n = fpre + k[len(rp):]
+                fp.p[n].copy_(v.to(fp.device, torch.float32)); seen.add(n)
+    if strict:
+        missing = [n for n in fp.names if n not in seen]
+        if missing:
+            raise KeyError(f"missing keys for the student: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+    if "teacher_queue" in sd:
+        m.teacher_queue.copy_(sd["teacher_queue"].to(m.teacher_queue.device, torch.float32))
+    fp.bf16.copy_(fp.data)
+    for e in (getattr(m, "s_vit", None), net):
+        if e is not None:
+            e.refresh_padded_weights()
+
+
+def distill_optimizer_state(m: Any) -> Dict[str, Any]:
+    out: Dict[str, Any] = dict(opt_step=int(m.opt_step), global_step=int(m.trainer.global_step))
+    if m.lars is not None:
+        out["lars"] = m.lars.state()
+    else:
+        out["exp_avg"], out["exp_avg_sq"] = m.exp_avg.detach().clone(), m.exp_avg_sq.detach().clone()
+    return out
+
+
+def distill_load_optimizer_state(m: Any, st: Mapping[str, Any]) -> None:
+    m.opt_step, m.trainer.global_step = int(st["opt_step"]), int(st["global_step"])
+    if m.lars is not None:
+        m.lars.load_state(st["lars"])
+    else:
+        m.exp_avg.copy_(st["exp_avg"].to(m.exp_avg.device)); m.exp_avg_sq.copy_(st["exp_avg_sq"].to(m.exp_avg_sq.device))

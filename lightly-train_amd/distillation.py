@@ -249,6 +249,19 @@ class _DistillBase:
         return {"student_embedding_model.wrapped_model._model." + n[9:]: self.student.p[n].detach().clone()
                 for n in self.student.names if n.startswith("backbone.")}
 
+    def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
+        """Load what `state_dict()` (or the reference's Distillation / DistillationV2 `state_dict()`) wrote."""
+        from . import checkpoint
+        checkpoint.distill_load_state_dict(self, sd, {"student_projection_head.": "head."}, strict)
+
+    def optimizer_state(self) -> Dict[str, Any]:
+        from . import checkpoint
+        return checkpoint.distill_optimizer_state(self)
+
+    def load_optimizer_state(self, st: Mapping[str, Any]) -> None:
+        from . import checkpoint
+        checkpoint.distill_load_optimizer_state(self, st)
+
     def export_backbone_state_dict(self) -> Dict[str, Tensor]:
         if self.s.conv:
             return self.s.net.state_dict(extra=self._fc)

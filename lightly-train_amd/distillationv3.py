@@ -464,3 +464,17 @@ class DistillationV3:
                 out["student_projection_head_local." + n[11:]] = v
         out["teacher_queue"] = self.teacher_queue.detach().clone()
         return out
+
+    def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
+        """Load what `state_dict()` (or the reference's DistillationV3.state_dict()) wrote: student backbone, both projection heads, queue."""
+        from . import checkpoint
+        checkpoint.distill_load_state_dict(self, sd, {"student_projection_head_global.": "proj_global.", "student_projection_head_local.": "proj_local."}, strict)
+
+    def optimizer_state(self) -> Dict[str, Any]:
+        """Optimizer moments (AdamW) / momentum buffer (LARS) and the step counters, for an exact resume together with `state_dict()`."""
+        from . import checkpoint
+        return checkpoint.distill_optimizer_state(self)
+
+    def load_optimizer_state(self, st: Mapping[str, Any]) -> None:
+        from . import checkpoint
+        checkpoint.distill_load_optimizer_state(self, st)

@@ -45,3 +45,11 @@ class FlatLARS:
         ops.lars_flat(fp.data, fp.grad, self.momentum_buffer, fp.bf16, fp.seg_of_chunk, self.seg_chunk_begin, seg_lr, seg_wd_on, self.ws, self.seg_norms,
                       lr_factor, a.weight_decay, a.momentum, a.dampening, a.nesterov, a.trust_coefficient, a.eps, self.steps == 0, sumsq, max_norm)
         self.steps += 1
+
+    def state(self) -> dict:
+        return dict(momentum_buffer=None if self.momentum_buffer is None else self.momentum_buffer.detach().clone(), steps=self.steps)
+
+    def load_state(self, st: dict) -> None:
+        if self.momentum_buffer is not None and st.get("momentum_buffer") is not None:
+            self.momentum_buffer.copy_(st["momentum_buffer"].to(self.momentum_buffer.device))
+        self.steps = int(st["steps"])

@@ -162,3 +162,75 @@ def test_distillation_v3_reproduces_the_reference_fixture(name):
         sd = m.state_dict()
         conv = sc.get("kind") == "resnet"
         check_final(sd, fx, "student_embedding_model.wrapped_model." + ("_features." if conv else "_model."))
+
+
+def _build_any(name, fresh=False):
+    """The method object of a fixture; fresh=True: from a random state instead of the fixture's initial one (a resume target)."""
+    from lightly_train_amd.dinov3 import convert_dinov3_state, dinov3_vit_config
+    from lightly_train_amd.distillation import Distillation, DistillationArgs, DistillationV2, DistillationV2Args
+    from lightly_train_amd.distillationv3 import DistillationV3, DistillationV3Args
+    from lightly_train_amd.lars import LARSArgs
+
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    common = dict(global_batch_size=fx["b"], total_steps=fx["total_steps"], max_epochs=1, device="cpu", seed=77 if fresh else 0)
+    if "kind" in fx:      # v1 / v2
+        kw = dict(common, student_state=None if fresh else fx["init"]["student_backbone"], teacher_state=fx["teacher_state"],
+                  head_state=None if fresh else fx["init"]["head"])
+        scfg, tcfg = vit_cfg(fx["student_cfg"]), vit_cfg(fx["teacher_cfg"])
+        if fx.get("optimizer") == "lars":
+            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="lars", lars=LARSArgs(lr=fx["lr"], weight_decay=fx["weight_decay"])), **kw)
+        elif fx["kind"] == "v1":
+            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+        else:
+            m = DistillationV2(scfg, tcfg, DistillationV2Args(lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+        return fx, exactify(m), 400
+    sc, tc = fx["student_cfg"], fx["teacher_cfg"]
+    student_state = fx["init"]["student_backbone"]
+    if sc.get("kind") == "resnet":
+        from lightly_train_amd.resnet import ResNetConfig
+        scfg = ResNetConfig(layers=tuple(sc["layers"]), width=sc["width"])
+    elif sc.get("kind") == "dinov3":
+        scfg = dinov3_vit_config(sc["embed_dim"], sc["depth"], sc["num_heads"], patch_size=sc["patch_size"], img_size=sc["img_size"],
+                                 n_storage_tokens=sc["n_storage_tokens"], layerscale_init=sc["init_values"], rope_base=sc["rope_base"], ln_eps=sc["ln_eps"],
+                                 rope_rescale=sc["rope_rescale"])
+        student_state = convert_dinov3_state(student_state, scfg)
+    else:
+        scfg = vit_cfg(sc)
+    tcfg = dinov3_vit_config(tc["embed_dim"], tc["depth"], tc["num_heads"], patch_size=tc["patch_size"], img_size=tc["img_size"],
+                             n_storage_tokens=tc["n_storage_tokens"], layerscale_init=0.5, rope_base=tc["rope_base"], ln_eps=tc["ln_eps"])
+    m = DistillationV3(scfg, tcfg, DistillationV3Args(queue_size=fx["queue_size"], weight_decay=fx["weight_decay"]), teacher_state=convert_dinov3_state(fx["teacher_state"], tcfg),
+                       student_state=None if fresh else student_state, proj_global_state=None if fresh else fx["init"]["proj_global"],
+                       proj_local_state=None if fresh else fx["init"]["proj_local"], **common)
+    return fx, exactify(m), 300
+
+
+@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v1_d64_lars", "distill_v2_d64", "distill_v3_d64", "distill_v3_d64_v3s", "distill_v3_resnet"])
+def test_resume_of_the_distillation_methods_is_exact(name):
+    """f4 for the sibling methods: state_dict() + optimizer_state() after two steps, loaded into an object built from a DIFFERENT random
+    state, give the third step of the uninterrupted run bit for bit (parameters, BatchNorm buffers, queue)."""
+    with ops_emu.emulate(ops):
+        fx, a, seed0 = _build_any(name)
+        img = fx.get("img", 64)
+
+        def step(m, si):
+            x = torch.randn(fx["b"], 3, img, img, generator=torch.Generator().manual_seed(fx["steps"][si]["x_seed"]))
+            torch.manual_seed(seed0 + si)
+            m.training_step_impl({"views": [x]}, 0)
+            m.optimizer_step()
+
+        for si in range(2):
+            step(a, si)
+        sd, ost = a.state_dict(), a.optimizer_state()
+        step(a, 2)
+        _, b, _ = _build_any(name, fresh=True)
+        assert any(not torch.equal(v, b.state_dict()[k]) for k, v in sd.items())          # really a different object
+        b.load_state_dict(sd)
+        b.load_optimizer_state(ost)
+        assert all(torch.equal(v, b.state_dict()[k]) for k, v in sd.items())
+        step(b, 2)
+        fa, fb = a.state_dict(), b.state_dict()
+        assert list(fa) == list(fb)
+        for k in fa:
+            assert torch.equal(fa[k], fb[k]), k
+        with pytest.raises(KeyError):
+            b.load_state_dict({k: v for k, v in sd.items() if "projection_head" not in k})
