@@ -7,9 +7,11 @@
     channel-concatenation of the last `n_teacher_blocks` blocks' normed patch tokens (`get_intermediate_layers(x, n, reshape=True)`),
     student feature map -> `student_projection_head.mlp` (a Linear for `n_projection_layers = 1`) -> bilinear resize onto the teacher
     grid -> MSE over all elements.
-Both train with gradient-clip 1.0 and the generic `Method.configure_optimizers` schedule (method.py:89-121).  Optimizers: AdamW (v1's
-`DistillationAdamWArgs`: lr 5e-4, weight decay 0; the generic `AdamWArgs` for v2: lr 1e-3, weight decay 0.01 -- the default here) and
-`optimizer="lars"`, the reference's "auto" (`Distillation(V2)LARSArgs`: lr 1.8, momentum 0.9, weight decay 1e-6) on `lars.FlatLARS`.
+Both train with gradient-clip 1.0 and the generic `Method.configure_optimizers` schedule (method.py:89-121).  Optimizers: the default
+`optimizer="auto"` is the reference's "auto" = LARS (`Distillation(V2)LARSArgs`: lr 1.8, momentum 0.9, weight decay 1e-6;
+distillation.py:140-147,290-298, distillationv2.py:106-113,306-314) on `lars.FlatLARS`; `optimizer="adamw"` selects v1's
+`DistillationAdamWArgs` (lr 5e-4, weight decay 0) / the generic `AdamWArgs` for v2 (lr 1e-3, weight decay 0.01), whose values are the
+`lr` / `weight_decay` fields below.
 
 Students: a ViT on `vit.ViTEngine` or the torchvision ResNet on `resnet.ResNetEngine`; teacher: a DINOv2 / DINOv3 ViT.  State-dict
 names follow the reference (`student_embedding_model.wrapped_model.*`, `student_projection_head.*`, `teacher_queue`)."""
@@ -45,7 +47,7 @@ class DistillationArgs:
     eps: float = 1e-8
     weight_decay: float = 0.0
     gradient_clip_val: float = 1.0
-    optimizer: str = "adamw"          # "lars": the reference's "auto" (DistillationLARSArgs, distillation.py:140-147)
+    optimizer: str = "auto"           # "auto" = "lars" as in the reference (DistillationLARSArgs, distillation.py:140-147); "adamw": the fields above
     lars: LARSArgs = field(default_factory=LARSArgs)
 
 
@@ -62,7 +64,7 @@ class DistillationV2Args:
     eps: float = 1e-8
     weight_decay: float = 0.01
     gradient_clip_val: float = 1.0
-    optimizer: str = "adamw"          # "lars": the reference's "auto" (DistillationV2LARSArgs, distillationv2.py:106-113)
+    optimizer: str = "auto"           # "auto" = "lars" as in the reference (DistillationV2LARSArgs, distillationv2.py:106-113); "adamw": the fields above
     lars: LARSArgs = field(default_factory=LARSArgs)
 
 
@@ -167,12 +169,13 @@ class _DistillBase:
         scale = global_batch_size / a.reference_batch_size
         if a.lr_scale_method == "sqrt":
             scale = math.sqrt(scale)
-        if a.optimizer not in ("adamw", "lars"):
+        if a.optimizer not in ("auto", "adamw", "lars"):
             raise ValueError(f"Invalid optimizer type: '{a.optimizer}'")
-        self.base_lr = (a.lars.lr if a.optimizer == "lars" else a.lr) * scale
+        self.optimizer = "lars" if a.optimizer == "auto" else a.optimizer   # both methods map "auto" to their LARS arguments
+        self.base_lr = (a.lars.lr if self.optimizer == "lars" else a.lr) * scale
         warm_epochs = min(10, max(1, max_epochs) / 10)
         self.warmup_steps = min(int(total_steps), int(total_steps / max(1, max_epochs) * warm_epochs))
-        self.lars = FlatLARS(self.student, a.lars) if a.optimizer == "lars" else None
+        self.lars = FlatLARS(self.student, a.lars) if self.optimizer == "lars" else None
         self.exp_avg = torch.zeros_like(self.student.data) if self.lars is None else None
         self.exp_avg_sq = torch.zeros_like(self.student.data) if self.lars is None else None
         nn_ = len(self.student.names)

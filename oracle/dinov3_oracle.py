@@ -51,6 +51,7 @@ def dinov3_vit_forward(p: Dict[str, Tensor], x: Tensor, cfg: Dict[str, Any], res
     for i in range(depth):
         pre = f"blocks.{i}."
         sin, cos = rope_sincos(gh, gw, dh, cfg.get("rope_base", 100.0), None if rescales is None else rescales[i])
+        sin, cos = sin.to(x.device), cos.to(x.device)
         y = F.layer_norm(t, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
         bias = p[pre + "attn.qkv.bias"]
         if pre + "attn.qkv.bias_mask" in p:

@@ -98,9 +98,9 @@ def test_distillation_v1_v2_reproduce_the_reference_fixture(name):
             m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="lars",
                                                           lars=LARSArgs(lr=fx["lr"], weight_decay=fx["weight_decay"])), **kw)
         elif fx["kind"] == "v1":
-            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         else:
-            m = DistillationV2(scfg, tcfg, DistillationV2Args(lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         exactify(m)
         for si, rec in enumerate(fx["steps"]):
             x = torch.randn(fx["b"], 3, fx["img"], fx["img"], generator=torch.Generator().manual_seed(rec["x_seed"]))
@@ -180,9 +180,9 @@ def _build_any(name, fresh=False):
         if fx.get("optimizer") == "lars":
             m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="lars", lars=LARSArgs(lr=fx["lr"], weight_decay=fx["weight_decay"])), **kw)
         elif fx["kind"] == "v1":
-            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         else:
-            m = DistillationV2(scfg, tcfg, DistillationV2Args(lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         return fx, exactify(m), 400
     sc, tc = fx["student_cfg"], fx["teacher_cfg"]
     student_state = fx["init"]["student_backbone"]

@@ -35,8 +35,8 @@ def build(fx):
         return Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="lars",
                                                          lars=LARSArgs(lr=fx["lr"], weight_decay=fx["weight_decay"])), **kw)
     if fx["kind"] == "v1":
-        return Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
-    return DistillationV2(scfg, tcfg, DistillationV2Args(lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+        return Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+    return DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
 
 
 @pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64"])
@@ -132,7 +132,7 @@ def test_distillation_v2_with_resnet_student_runs_and_resizes():
     from lightly_train_amd.vit import ViTConfig
 
     tcfg = ViTConfig(embed_dim=64, depth=3, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=64, init_values=0.5)
-    m = DistillationV2(ResNetConfig(layers=(1, 1, 1, 1), width=8), tcfg, DistillationV2Args(lr=0.02), global_batch_size=1536, total_steps=40, max_epochs=1,
+    m = DistillationV2(ResNetConfig(layers=(1, 1, 1, 1), width=8), tcfg, DistillationV2Args(optimizer="adamw", lr=0.02), global_batch_size=1536, total_steps=40, max_epochs=1,
                        device="cuda", seed=3)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(16, 3, 64, 64, generator=g)
