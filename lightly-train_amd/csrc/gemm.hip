@@ -22,22 +22,16 @@
 // remapped to give each XCD's L2 a contiguous band of tiles sharing A-rows.
 #include <algorithm>
 
-#include "lt_common.h"
+#include "gemm_args.h"
 #include <cstdlib>
+
+using lt_gemm::GemmArgs;
+using namespace lt_gemm;
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
-
-enum Epi : int {
-  EPI_BF16 = LT_EPI_BF16,
-  EPI_BF16_GELU = LT_EPI_BF16_GELU,
-  EPI_RESID = LT_EPI_RESID,
-  EPI_F32 = LT_EPI_F32,
-  EPI_BF16_GELUGRAD = LT_EPI_BF16_GELUGRAD,
-  EPI_F32_ACCUM = LT_EPI_F32_ACCUM,
-};
 
 #ifdef LT_GEMM_TIMING
 // diagnostic build only (tools/gemm_timeline.py): per-workgroup timestamps of the four-phase kernel (100 MHz wall clock) and the CU it ran on
@@ -53,19 +47,6 @@ __device__ unsigned long long lt_gemm_timing_buf[8 * 16384];
 #define LT_TSTAMP(slot) do { } while (0)
 #endif
 
-struct GemmArgs {
-  const bf16_t* A; const bf16_t* B;
-  int M, N, K, lda, ldb;
-  void* C; int ldc;
-  void* C2; int ldc2;
-  const float* bias; const float* gamma;
-  const float* resid; int ldr;
-  const bf16_t* aux; int ldaux;
-  const float* rowscale; float branch_scale;
-  float alpha;
-  int tiles_m, tiles_n, k_per_split;
-  long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
-};
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p, bool ok) {
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -1215,6 +1196,19 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 9) {
     LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
+  }
+  // ---- persistent 192 x 256 kernel with the epilogue under the next tile's K-loop (gemm_p.hip).  force_kernel 10, or LT_GEMM_1P=1
+  // (read per call: tools/ab_step.py flips it between steps) for every eligible forward / dgrad GEMM of >= 2048 rows
+  {
+    const char* env_1p = getenv("LT_GEMM_1P");
+    const int use_1p = env_1p ? atoi(env_1p) : 0;
+    const bool elig = batch == 1 && gemm1p_eligible(g, d->epilogue, d->trans_a != 0);
+    if (d->force_kernel == 10) LT_CHECK_ARG(elig, "lt_gemm_bf16: shape / layout / epilogue not served by the persistent kernel (force_kernel 10)");
+    if (elig && (d->force_kernel == 10 || (use_1p && d->force_kernel == 0 && d->M >= 2048))) {
+      rc = gemm1p_launch(g, d->epilogue, d->trans_b != 0, st);
+      if (rc != LT_OK) return rc;
+      LT_CHECK_LAUNCH("lt_gemm_bf16");
+    }
   }
   if (big && ktail) {
     LT_CHECK_ARG(d->N >= 256 || d->force_kernel == 8, "lt_gemm_bf16: partial K-tile needs the 256-wide kernel");

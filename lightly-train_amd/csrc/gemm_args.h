@@ -1,0 +1,35 @@
+// Argument block shared by the MFMA GEMM kernels (gemm.hip: 128^2 / 256^2 tiles; gemm_p.hip: the persistent 192 x 256 kernel).
+#pragma once
+#include "lt_common.h"
+
+namespace lt_gemm {
+
+enum Epi : int {
+  EPI_BF16 = LT_EPI_BF16,
+  EPI_BF16_GELU = LT_EPI_BF16_GELU,
+  EPI_RESID = LT_EPI_RESID,
+  EPI_F32 = LT_EPI_F32,
+  EPI_BF16_GELUGRAD = LT_EPI_BF16_GELUGRAD,
+  EPI_F32_ACCUM = LT_EPI_F32_ACCUM,
+};
+
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* B;
+  int M, N, K, lda, ldb;
+  void* C; int ldc;
+  void* C2; int ldc2;
+  const float* bias; const float* gamma;
+  const float* resid; int ldr;
+  const bf16_t* aux; int ldaux;
+  const float* rowscale; float branch_scale;
+  float alpha;
+  int tiles_m, tiles_n, k_per_split;
+  long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
+};
+
+// gemm_p.hip: persistent kernel with the epilogue drained under the next tile's K-loop (forward / dgrad layouts, bf16-rounded branch
+// outputs: EPI_BF16, EPI_BF16_GELU, EPI_RESID without C2, EPI_BF16_GELUGRAD).  Returns LT_OK or an error code.
+bool gemm1p_eligible(const GemmArgs& g, int epi, bool trans_a);
+int gemm1p_launch(const GemmArgs& g, int epi, bool trans_b, hipStream_t st);
+
+}  // namespace lt_gemm
