@@ -632,7 +632,15 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     slice = w / ntiles; id = w - slice * ntiles;
   }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  // tile order inside a k-slice: bands of `band` column tiles, row-major inside a band, so that the ~32 tiles an XCD holds at a time
+  // form a block of (32 / band) tile rows x band tile columns sharing A AND B panels in its L2, instead of 2.7 rows x all 12 columns
+  // (the [N, K] weight of the N = 2304 / 3072 GEMMs does not fit one 4 MiB L2 beside the A panels and was re-fetched per tile row)
+  int tm, tn;
+  if (g.band > 0 && g.band < g.tiles_n) {
+    const int per_band = g.tiles_m * g.band, full_b = g.tiles_n / g.band;
+    if (id < full_b * per_band) { const int bnd = id / per_band, r = id - bnd * per_band; tm = r / g.band; tn = bnd * g.band + (r - tm * g.band); }
+    else { const int rem_b = g.tiles_n - full_b * g.band, r = id - full_b * per_band; tm = r / rem_b; tn = full_b * g.band + (r - tm * rem_b); }
+  } else { tm = id / g.tiles_n; tn = id % g.tiles_n; }
   const int m0 = tm * 256, n0 = tn * 256;
   const int kbeg = slice * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -1159,6 +1167,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   g.rowscale = d->rowscale; g.branch_scale = d->branch_scale == 0.f ? 1.f : d->branch_scale;
   g.alpha = d->alpha;
   g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
+  g.band = 0;
 #ifdef LT_GEMM_TIMING
   if (const char* e = getenv("LT_GEMM_STAGGER")) { int u = 0, gr = 2; sscanf(e, "%d,%d", &u, &gr); g.sc = (d->batch > 1) ? g.sc : (long)((gr << 8) | u); }
 #endif
@@ -1197,14 +1206,15 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
-  // ---- persistent 192 x 256 kernel with the epilogue under the next tile's K-loop (gemm_p.hip).  force_kernel 10, or LT_GEMM_1P=1
-  // (read per call: tools/ab_step.py flips it between steps) for every eligible forward / dgrad GEMM of >= 2048 rows
+  // ---- persistent 192 x 256 kernel with the epilogue under the next tile's K-loop (gemm_p.hip).  force_kernel 10, or LT_GEMM_1P (read
+  // per call: tools/ab_step.py flips it between steps), a bit mask over the eligible forward / dgrad GEMMs of >= 2048 rows: 1 = those
+  // with N >= 1024 (qkv, fc1, the GELU' dgrad), 2 = the narrower ones (proj, fc2 and their dgrads)
   {
     const char* env_1p = getenv("LT_GEMM_1P");
     const int use_1p = env_1p ? atoi(env_1p) : 0;
     const bool elig = batch == 1 && gemm1p_eligible(g, d->epilogue, d->trans_a != 0);
     if (d->force_kernel == 10) LT_CHECK_ARG(elig, "lt_gemm_bf16: shape / layout / epilogue not served by the persistent kernel (force_kernel 10)");
-    if (elig && (d->force_kernel == 10 || (use_1p && d->force_kernel == 0 && d->M >= 2048))) {
+    if (elig && (d->force_kernel == 10 || ((use_1p & (d->N >= 1024 ? 1 : 2)) && d->force_kernel == 0 && d->M >= 2048))) {
       rc = gemm1p_launch(g, d->epilogue, d->trans_b != 0, st);
       if (rc != LT_OK) return rc;
       LT_CHECK_LAUNCH("lt_gemm_bf16");
@@ -1261,6 +1271,13 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     g.k_per_split = lt_cdiv(ktiles2, sp) * BK;
     sp = lt_cdiv(d->K, g.k_per_split);
     if (slab) g.C2 = d->workspace;
+    {   // LT_GEMM_BAND (read per call): band width of the four-phase kernel's tile order.  Default: 4 where 4 divides a column-tile count
+      // >= 8 (N = 3072: fc1 + GELU reads 24 % less, the GELU' dgrad 13 % less through the L2's memory side; no change in time), none
+      // elsewhere (N = 2304 in bands of 3 read 7 % MORE: profiles/r03c_band_traffic.log)
+      const char* env_b = getenv("LT_GEMM_BAND");
+      const int nb = env_b ? atoi(env_b) : 4;
+      g.band = (!d->trans_a && g.tiles_n >= 8 && nb > 0 && (env_b || g.tiles_n % nb == 0)) ? nb : 0;
+    }
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
     static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
     if (bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || use_q)) {

@@ -24,6 +24,7 @@ struct GemmArgs {
   const float* rowscale; float branch_scale;
   float alpha;
   int tiles_m, tiles_n, k_per_split;
+  int band;         // four-phase kernel: column tiles per band of the tile order (0 / >= tiles_n: plain row-major order)
   long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
 };
 

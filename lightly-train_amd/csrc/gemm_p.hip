@@ -638,6 +638,9 @@ int gemm1p_launch(const GemmArgs& g0, int epi, bool trans_b, hipStream_t st) {
   int grid = nt < cus ? nt : cus;
   static const int env_grid = [] { const char* s = getenv("LT_GEMM_1P_GRID"); return s ? atoi(s) : 0; }();   // diagnostic: fewer workgroups = more tiles each
   if (env_grid > 0 && env_grid < grid) grid = env_grid;
+  // LT_GEMM_1P_TPW (read per call): tiles per workgroup -> more workgroups than CUs, each walking only a few tiles, so that workgroups
+  // of other streams' kernels get CUs at the granularity of a few tiles instead of a whole launch
+  if (const char* s = getenv("LT_GEMM_1P_TPW")) { const int tpw = atoi(s); if (tpw > 0) { const int gq = (nt + tpw - 1) / tpw; if (gq > grid) grid = gq; } }
   // column band: 4 tiles (or 3 where that divides and 4 does not), the whole width below 5
   int wb = g.tiles_n <= 4 ? g.tiles_n : (g.tiles_n % 4 == 0 ? 4 : (g.tiles_n % 3 == 0 ? 3 : 4));
   static const int env_wb = [] { const char* s = getenv("LT_GEMM_1P_BAND"); return s ? atoi(s) : 0; }();

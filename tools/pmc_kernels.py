@@ -15,7 +15,7 @@ for path in sys.argv[2:]:
             k = r["Kernel_Name"]
             if pat not in k:
                 continue
-            k = k.split("(")[0][-60:]
+            k = k.replace("(anonymous namespace)::", "").split("(")[0][-60:]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[k][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
     for k, cs in acc.items():
