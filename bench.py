@@ -62,15 +62,42 @@ def step_flops_per_image(D: int, depth: int, hidden: int, n_g: int, n_l: int, n_
     return teacher + 3 * student
 
 
-def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 3) -> dict:
+def host_cpu_info() -> dict:
+    """Physical cores (unique (physical id, core id) pairs of /proc/cpuinfo) and the CPU model of this box."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("processor"):
+                    logical += 1
+                elif ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    phys = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":", 1)[1].strip()
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or logical or (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": n, "logical_cpus": logical or (os.cpu_count() or 1)}
+
+
+def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 5, warmups: int = 2) -> dict:
     """CPU baseline (BASELINE.md section 3 / SURVEY 8(d)): a full training step (training_step_impl + backward + clip + AdamW + EMA)
-    in fp32 on the host cores, bounded sample: batch 4, 1 warm-up + `timed_steps` timed steps, MEDIAN step time.
+    in fp32 on the host cores, bounded sample: batch 2, `warmups` untimed + `timed_steps` timed steps, MEDIAN step time and spread,
+    one torch thread per PHYSICAL core (hyper-thread siblings only add contention to a GEMM-bound fp32 step; round 2 ran on
+    torch's default = every logical CPU and its first timed steps were still warming up: 28.9 -> 18.1 -> 15.6 s).
     kind "reference": the reference's own DINOv2 class driven through oracle/ref_harness.py -- only where /root/reference exists
-    (the build container; it cannot travel to the GPU box); kind "port": oracle/dinov2_oracle.py, the pinned restatement of that
-    step (bit-level equal losses, tests/test_oracle_pin.py).  Reported baseline only, never the measured path."""
+    (the build container; it cannot travel to the GPU box) and can run the configuration; kind "port": oracle/dinov2_oracle.py, the pinned
+    restatement of that step (bit-level equal losses, tests/test_oracle_pin.py).  Reported baseline only, never the measured path."""
     import statistics
 
-    b = 4
+    info = host_cpu_info()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, info["physical_cores"]))
+    b = 2
     g = torch.Generator().manual_seed(0)
     name = {768: "vit_base", 384: "vit_small", 1024: "vit_large", 192: "vit_tiny"}[arch["embed_dim"]]
     views = [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [
@@ -95,17 +122,21 @@ def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, tim
         o = O.OracleDINOv2(sb, sh, cfg, args=dict(output_dim=K), global_batch_size=b, total_steps=1000, teacher_head=th)
         step = lambda: o.train_step(views)   # noqa: E731
     random.seed(0)
-    step()
+    for _ in range(warmups):
+        step()
     times = []
     for _ in range(timed_steps):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
+    torch.set_num_threads(prev_threads)
     dt = statistics.median(times)
     what = "the reference's own DINOv2.training_step_impl via oracle/ref_harness.py" if kind == "reference" else "oracle/dinov2_oracle.py"
-    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": kind,
-            "sample": f"{what}, fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, 1 warm-up + {timed_steps} timed steps, median "
-                      f"(step times {', '.join(f'{t:.2f}' for t in times)} s)"}
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": info["physical_cores"], "kind": kind,
+            "cpu_model": info["model"], "logical_cpus": info["logical_cpus"],
+            "spread": round((max(times) - min(times)) / dt, 3),
+            "sample": f"{what}, fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, {warmups} warm-ups + {timed_steps} timed steps on "
+                      f"{info['physical_cores']} torch threads (one per physical core), median (step times {', '.join(f'{t:.2f}' for t in times)} s)"}
 
 
 def main() -> None:
@@ -295,6 +326,12 @@ def main() -> None:
             ops.gemm = orig
             method.overlap_streams = not args.single_stream
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+        # attention products of the step (4 T^2 D per block and image-crop forward; backward twice that): teacher forward on the
+        # global crops + 3 x the student's global and local passes
+        if args.method == "dinov2":
+            att_flops = float(arch["depth"] * 4 * arch["embed_dim"] * B * ((1 + 3) * 2 * n_g * n_g + 3 * args.n_local * n_l * n_l))
+        else:
+            att_flops = 0.0
         fl = sum(f for _, _, f, _ in recs)
         alg_bytes = sum(b_ for _, _, _, b_ in recs) / max(1, len(recs))
         achieved = fl / (t_ms * 1e-3) / 1e12
@@ -321,7 +358,12 @@ def main() -> None:
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": len(recs), "gemm_ms_per_step": round(t_ms, 2),
                     "gemm_flops_per_step": fl, "step_algorithmic_gflop_per_image": round(gf_img, 1),
-                    "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
+                    # two fractions of the bf16 MFMA peak for the WHOLE step: the reference's dense FLOP count (what a
+                    # dense implementation would execute for these images) and the FLOPs this step really executes (GEMM launches as
+                    # counted above + the attention products; the last block's MLP / projection run on the rows the losses read only)
+                    "step_frac_of_mfma_peak": round(gf_img * 1e9 * img_per_s / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+                    "step_executed_tflop": round((fl + att_flops) / 1e12, 2),
+                    "step_frac_of_mfma_peak_executed": round((fl + att_flops) / (ms_per_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.method == "dinov2":

@@ -149,7 +149,9 @@ int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma,
                       float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
 /* LayerScale gradient from the weight gradient instead of the saved branch output (layer_scale.py:27-28 backward):
  * dgamma[c] += (sum_k W[c,k] dW[c,k] + bias[c] dbias[c]) / gamma[c], W bf16 [N,K] = the Linear feeding the LayerScale,
- * dW/dbias = its accumulated gradients (computed from dD = dx*gamma).  Call once per step after all weight gradients. */
+ * dW/dbias = its accumulated gradients (computed from dD = dx*gamma).  Call once per step after all weight gradients.
+ * The identity divides by gamma: a channel with gamma == 0 exactly (|gamma| <= 1e-30) has no recoverable gradient and is left
+ * unchanged -- callers must not train a LayerScale initialised at 0 on this path (ViTEngine refuses init_values == 0). */
 int lt_layerscale_dgamma(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
                          float* dgamma, int N, int K, void* stream);
 /* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */

@@ -5,8 +5,8 @@ exchanges are:
   C1   gradient mean over ranks        -> GradSync (bucketed async all-reduce on the flat fp32 grad buffer)
   C3/4 DINO / iBOT center sums         -> async all-reduce, consumed at the next step (dinov2.py, _pending)
   C5/6 Sinkhorn-Knopp row sums         -> synchronous all-reduce inside the teacher path
-No parameter broadcast is needed after init: every rank builds identical weights from the same seed and the
-EMA teacher of identical students stays identical.
+Parameters: `DINOv2.__init__` broadcasts rank 0's flat student / teacher storage once at construction (what DDP does when it wraps a
+module); after that nothing but gradients is exchanged -- identical students give identical EMA teachers.
 """
 from __future__ import annotations
 

@@ -210,6 +210,9 @@ class ViTEngine:
             self.wpe_pad = torch.zeros(D, self.kpad, dtype=torch.bfloat16, device=self.dev)
             self.refresh_padded_weights()
         assert D % 8 == 0 and cfg.hidden % 8 == 0, "embed_dim and mlp hidden must be multiples of 8"
+        if cfg.init_values is not None and float(cfg.init_values) == 0.0:
+            # the LayerScale gradient is recovered from the weight gradient by dividing by gamma (lt_layerscale_dgamma): gamma == 0 has none
+            raise ValueError("LayerScale init_values == 0 is not supported (use None for no LayerScale): its gradient is formed as (W . dW) / gamma")
 
     def refresh_padded_weights(self) -> None:
         """Re-derive the zero-padded bf16 patch-embedding matrix after the fp32 weights changed (optimizer / EMA)."""
