@@ -1,0 +1,205 @@
+"""Executable drop-in at the reference's plugin point: `DINOv2AMD(Method)` -- the class INTEGRATION.md section 3 describes.
+
+The reference has no FFI; its boundary for this path is the `Method` protocol (LT/_methods/method.py:47-155: `training_step` ->
+`training_step_impl(batch, batch_idx) -> TrainingStepResult`, the optimizer / clipping / EMA hooks) and the module containers Lightning
+checkpoints (`teacher_embedding_model`, `student_embedding_model`, `teacher_head`, `student_head`, `dino_loss`, `ibot_loss`:
+LT/_methods/dinov2/dinov2.py:176-257).  `DINOv2AMD` keeps EXACTLY those containers -- built by the reference's own constructors, so
+`state_dict()` keys, `lightly_train.export()` and the pickled `CheckpointLightlyTrainModels{model, wrapped_model, embedding_model}`
+envelope (LT/_checkpoint.py:85-123, read by LT/_commands/export.py:94,165-169) are the reference's -- and runs the step on
+`lightly_train_amd.dinov2.DINOv2` (flat fp32 storage + HIP kernels, explicit backward, fused AdamW / EMA):
+
+  * `training_step_impl` hands the batch to the HIP step, which also does backward, clipping, the optimizer step and the EMA
+    (`automatic_optimization = False`: Lightning neither calls backward nor steps an optimizer; `configure_optimizers` returns None);
+  * `on_save_checkpoint` copies the flat storage back into the reference containers (`sync_to_containers`) and puts the reference-format
+    `state_dict` / `optimizer_states` / `lr_schedulers` into the checkpoint dict; the reference's ModelCheckpoint callback then pickles
+    the (now current) containers into the envelope -- a file written here is read by the reference's `Checkpoint.from_dict` and exported
+    by `lightly_train.export()` unchanged;
+  * `on_load_checkpoint` resumes the flat storage, moments and step counters from such a checkpoint (or one the reference wrote).
+
+The class is created lazily (`dinov2_amd_method_cls()`), because it subclasses the reference's `Method`, which needs `lightly_train`
+importable.  `install_as("dinov2")` maps a method name to it in `method_helpers` for `lightly_train.train(method="dinov2", ...)`;
+`get_method_cls` also accepts an instance (method_helpers.py:42-44).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Mapping, Optional
+
+import torch
+from torch import Tensor
+
+from .dinov2 import DINOv2 as _HipDINOv2
+from .dinov2 import DINOv2Args as _HipArgs
+from .checkpoint import vit_key_to_flat
+from .vit import ViTConfig
+
+_CLS: Optional[type] = None
+
+
+def vit_config_from_reference(model: Any, drop_path_rate: float = 0.0) -> ViTConfig:
+    """`ViTConfig` of a reference `DinoVisionTransformer` (LT/_models/dinov2_vit/dinov2_vit_src/models/vision_transformer.py:75-183),
+    read off the module's attributes and parameter shapes."""
+    sd = model.state_dict()
+    pre = "blocks.0.0." if getattr(model, "chunked_blocks", False) else "blocks.0."
+    D = int(model.embed_dim)
+    swiglu = pre + "mlp.w12.weight" in sd
+    if swiglu:
+        hidden = sd[pre + "mlp.w3.weight"].shape[1]
+        mlp_ratio, ffn = 4.0, "swiglufused"
+        assert (int(D * mlp_ratio * 2 / 3) + 7) // 8 * 8 == hidden, "SwiGLU width is not the fused default of mlp_ratio 4"
+    else:
+        mlp_ratio, ffn = sd[pre + "mlp.fc1.weight"].shape[0] / D, "mlp"
+    n_p = sd["pos_embed"].shape[1] - 1
+    img = int(round(n_p ** 0.5)) * int(model.patch_size)
+    chunks = len(model.blocks) if getattr(model, "chunked_blocks", False) else 0
+    ls = pre + "ls1.gamma"
+    return ViTConfig(embed_dim=D, depth=int(model.n_blocks), num_heads=int(model.num_heads), mlp_ratio=mlp_ratio, patch_size=int(model.patch_size),
+                     img_size=img, in_chans=int(sd["patch_embed.proj.weight"].shape[1]),
+                     init_values=(float(sd[ls].flatten()[0]) if ls in sd else None), interpolate_offset=float(model.interpolate_offset),
+                     interpolate_antialias=bool(model.interpolate_antialias), drop_path_rate=drop_path_rate,
+                     num_register_tokens=int(model.num_register_tokens), ffn_layer=ffn, block_chunks=chunks)
+
+
+def hip_args_from_reference(method_args: Any) -> _HipArgs:
+    """The reference's `DINOv2Args` (dinov2.py:70-153; "auto" values already resolved) -> the HIP step's dataclass of the same fields."""
+    import dataclasses
+
+    kw = {}
+    for f in dataclasses.fields(_HipArgs):
+        if hasattr(method_args, f.name):
+            v = getattr(method_args, f.name)
+            if v is not None and not (isinstance(v, str) and v == "auto"):
+                kw[f.name] = tuple(v) if isinstance(v, list) else v
+    return _HipArgs(**kw)
+
+
+def _strip(sd: Mapping[str, Tensor], prefix: str, backbone: bool = False) -> Dict[str, Tensor]:
+    """Sub-dict of a state_dict without its prefix; backbone keys of chunked models (`blocks.<chunk>.<i>.`) flattened to `blocks.<i>.`."""
+    return {(vit_key_to_flat(k[len(prefix):]) if backbone else k[len(prefix):]): v.detach().clone() for k, v in sd.items() if k.startswith(prefix)}
+
+
+def dinov2_amd_method_cls() -> type:
+    """The `Method` subclass (needs the reference package importable)."""
+    global _CLS
+    if _CLS is not None:
+        return _CLS
+    from lightly_train._methods.dinov2.dinov2 import DINOv2 as RefDINOv2
+    from lightly_train._methods.dinov2.dinov2 import DINOv2AdamWViTArgs, DINOv2Args
+    from lightly_train._methods.method import Method, TrainingStepResult
+
+    class DINOv2AMD(RefDINOv2):   # type: ignore[misc, valid-type]
+        """`method="dinov2"` on MI355X.  Subclasses the reference method for its constructor (the module containers, built by the
+        reference's own code), its static class hooks (`method_args_cls`, `optimizer_args_cls`, `transform_cls`) and `Method.training_step`
+        (logging with sync_dist); everything that computes is replaced."""
+
+        def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
+                     device: Optional[torch.device] = None) -> None:
+            super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
+                             global_batch_size=global_batch_size, num_input_channels=num_input_channels)
+            self.automatic_optimization = False     # the HIP step owns backward, clipping, AdamW and the EMA
+            self._impl: Optional[_HipDINOv2] = None
+            self._impl_device = device
+            self._pending_resume: Optional[Dict[str, Any]] = None
+
+        # ---- the HIP step, built on first use (Lightning moves the module to its device only after __init__)
+        def impl(self) -> _HipDINOv2:
+            if self._impl is None:
+                dev = self._impl_device or next(self.parameters()).device
+                sd = Method.state_dict(self)
+                t_model = self.teacher_embedding_model.wrapped_model.get_model()
+                a = self.method_args
+                cfg = vit_config_from_reference(t_model)
+                bb = "embedding_model.wrapped_model._model."
+                self._impl = _HipDINOv2(
+                    cfg, hip_args_from_reference(a), global_batch_size=self.global_batch_size,
+                    total_steps=int(self.trainer.estimated_stepping_batches), device=dev,
+                    backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
+                    student_head_state=_strip(sd, "student_head.dino_head."), teacher_head_state=_strip(sd, "teacher_head.dino_head."),
+                    student_ibot_head_state=_strip(sd, "student_head.ibot_head.") if a.ibot_separate_head else None,
+                    teacher_ibot_head_state=_strip(sd, "teacher_head.ibot_head.") if a.ibot_separate_head else None)
+                self._impl.load_state_dict(sd)   # centers, BatchNorm buffers, chunked-block key names
+                if self._pending_resume is not None:
+                    self._impl.load_checkpoint_dict(self._pending_resume)
+                    self._pending_resume = None
+            return self._impl
+
+        def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
+            m = self.impl()
+            if int(self.trainer.global_step) > m.trainer.global_step:   # (a resumed Trainer is ahead of a freshly built step object)
+                m.trainer.global_step = int(self.trainer.global_step)
+            res = m.training_step_impl(batch, batch_idx)     # forward + explicit backward in HIP: gradients in m.student.grad
+            m.optimizer_step()                               # WD / lr schedules + freezes, clip 3.0, AdamW; global_step += 1 (dinov2.py:550-639)
+            m.on_train_batch_end()                           # EMA teacher at the incremented step             (dinov2.py:641-660)
+            self._tick_lightning()
+            return TrainingStepResult(loss=res.loss, log_dict=res.log_dict)
+
+        def _tick_lightning(self) -> None:
+            """Manual optimization: Lightning advances `trainer.global_step` when a LightningOptimizer steps.  `configure_optimizers`
+            returns a no-op SGD over a tensor that is not part of the module, stepped here once per batch, so that max_steps, the
+            checkpoint callback's step counter and `checkpoint["global_step"]` keep their meaning."""
+            opts = getattr(self, "optimizers", None)
+            if callable(opts):
+                try:
+                    o = opts()
+                except Exception:
+                    return
+                for one in (o if isinstance(o, (list, tuple)) else [o]):
+                    if one is not None and hasattr(one, "step"):
+                        one.step()
+
+        def configure_optimizers(self) -> Any:   # manual optimization: a counter for Lightning's progress tracking only (_tick_lightning)
+            return torch.optim.SGD([torch.zeros((), requires_grad=True)], lr=0.0)
+
+        def configure_gradient_clipping(self, *a: Any, **k: Any) -> None:
+            return None
+
+        def on_before_optimizer_step(self, *a: Any, **k: Any) -> None:
+            return None
+
+        def on_train_batch_end(self, outputs: Any, batch: Any, batch_idx: int) -> None:
+            Method.on_train_batch_end(self, outputs=outputs, batch=batch, batch_idx=batch_idx)   # batch timing only: the EMA has run
+
+        # ---- checkpoints
+        def sync_to_containers(self) -> None:
+            """Flat HIP storage -> the reference module containers (what `state_dict()`, the export commands and the pickled envelope read)."""
+            if self._impl is not None:
+                sd = {k: v.detach().to("cpu") for k, v in self._impl.state_dict().items()}
+                Method.load_state_dict(self, sd, strict=True)
+
+        def state_dict(self, *a: Any, **k: Any) -> Any:
+            self.sync_to_containers()
+            return Method.state_dict(self, *a, **k)
+
+        def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+            self.sync_to_containers()
+            checkpoint["state_dict"] = Method.state_dict(self)
+            if self._impl is not None:
+                ck = self._impl.checkpoint_dict()
+                checkpoint["optimizer_states"] = ck["optimizer_states"]
+                checkpoint["lr_schedulers"] = ck["lr_schedulers"]
+
+        def on_load_checkpoint(self, checkpoint: Mapping[str, Any]) -> None:
+            ck = {k: checkpoint[k] for k in ("state_dict", "optimizer_states", "global_step") if k in checkpoint}
+            if self._impl is not None:
+                self._impl.load_checkpoint_dict(ck)
+            else:
+                self._pending_resume = ck
+
+    DINOv2AMD.__qualname__ = "DINOv2AMD"
+    _CLS = DINOv2AMD
+    return _CLS
+
+
+def install_as(name: str = "dinov2") -> type:
+    """Map a method name of `lightly_train.train(method=...)` to the MI355X class (method_helpers.py:54-69 builds its table per call)."""
+    from lightly_train._methods import method_helpers
+
+    cls = dinov2_amd_method_cls()
+    orig = method_helpers._method_name_to_cls
+
+    def patched() -> Dict[str, type]:
+        m = orig()
+        m[name] = cls
+        return m
+
+    method_helpers._method_name_to_cls = patched
+    return cls

@@ -215,8 +215,11 @@ def build_reference_method(
     global_batch_size: int = 16,
     total_steps: int = 100,
     seed: int = 0,
+    method_cls=None,
+    method_cls_kwargs: dict | None = None,
 ):
-    """Instantiate the reference DINOv2 Method (CPU, fp32) around a reference ViT."""
+    """Instantiate the reference DINOv2 Method (CPU, fp32) around a reference ViT.  `method_cls`: a subclass to instantiate instead
+    (lightly_train_amd.integration.DINOv2AMD), built by the same constructor calls from the same seed = identical initial weights."""
     install()
     import random
 
@@ -238,9 +241,9 @@ def build_reference_method(
     margs = DINOv2Args(**(method_kwargs or {}))
     oargs = DINOv2AdamWViTArgs()
     margs.resolve_auto(scaling_info=None, optimizer_args=oargs, wrapped_model=wrapped)  # type: ignore[arg-type]
-    method = DINOv2(
+    method = (method_cls or DINOv2)(
         method_args=margs, optimizer_args=oargs, embedding_model=emb,
-        global_batch_size=global_batch_size, num_input_channels=3,
+        global_batch_size=global_batch_size, num_input_channels=3, **(method_cls_kwargs or {}),
     )
     method.trainer = MockTrainer(total_steps)
     return method

@@ -1,0 +1,205 @@
+"""CPU, build container only (needs /root/reference): the executable drop-in `DINOv2AMD(Method)` of lightly_train_amd/integration.py at the
+reference's own plugin point -- BASELINE configs[0] (plumbing: `_vittest14`, batch 16, 2 steps, accelerator = cpu).
+
+The reference's `Method` base class, `method_helpers.get_method_cls`, its module containers, `Checkpoint` envelope and export path are the
+REAL reference code, imported from /root/reference through oracle/ref_harness.py's stub Lightning (pytorch_lightning / lightly / cv2 ... are
+not installable here); the HIP kernels are replaced by the plain-torch statements of their contracts (tests/tools/ops_emu.py, fp32), as in
+tests/test_dinov2_method_cpu.py.  Checked:
+  * the class is a `Method`, `get_method_cls(instance)` returns it, `install_as("dinov2")` maps the name to it;
+  * two training steps driven in Lightning's hook order equal the reference's own `DINOv2` class on identical weights, views and mask
+    draws: loss terms (3e-5; KoLeo, a nearest-neighbour distance of cls tokens that agree to 1e-6 at LayerScale 1e-5, at 2e-2),
+    and with the KoLeo weight at 0 every student / EMA-teacher tensor after the two steps (3e-5 absolute: 6 % of one AdamW step of
+    lr 5e-4 -- entries whose gradient is at round-off level take +-lr steps whose sign no two fp32 implementations share);
+  * a checkpoint assembled the way Lightning + the reference's ModelCheckpoint callback assemble it (dump -> `on_save_checkpoint` -> the
+    `lightly_train` envelope with the pickled containers) is read back by the reference's `Checkpoint.from_dict`, and
+    `_commands/export.py::_get_model` returns modules whose weights are the trained EMA teacher -- bit-identical to the flat storage;
+  * `on_load_checkpoint` resumes a fresh object from that file: its third step equals the original's third step.
+"""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+
+from oracle import ref_harness as H  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not H.reference_available(), reason="needs the reference tree at /root/reference (build container only)")
+
+import lightly_train_amd  # noqa: E402,F401
+import ops_emu  # noqa: E402
+from lightly_train_amd import ops  # noqa: E402
+from test_dinov2_method_cpu import F32Workspace, _NoStream  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _no_cuda_streams(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _NoStream())
+    monkeypatch.setattr(torch.cuda, "set_stream", lambda s: None)
+
+
+def views_for(step, b=16):
+    g = torch.Generator().manual_seed(500 + step)
+    return [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(8)]
+
+
+def exactify(m):
+    """fp32 everywhere (see tests/test_dinov2_method_cpu.py::build_exact)."""
+    m.ws = F32Workspace(torch.device("cpu"))
+    for fp in (m.student, m.teacher):
+        fp.bf16 = fp.data.clone()
+        fp.b = {n: fp.bf16[fp.offsets[n]:fp.offsets[n] + fp.p[n].numel()].view(fp.shapes[n]) for n in fp.names}
+    for h in {id(x): x for x in (m.s_head, m.t_head, m.s_ihead, m.t_ihead)}.values():
+        h.wn = h.wn.float()
+    for v in (m.s_vit, m.t_vit):
+        if v.wpe_pad is not None:
+            v.wpe_pad = v.wpe_pad.float()
+    m._refresh_derived()
+
+
+def build_pair(koleo, total_steps=2):
+    from lightly_train_amd import integration
+
+    H.install()
+    kw = dict(arch="_vit_test", patch_size=14, img_size=224, global_batch_size=16, total_steps=total_steps, seed=0,
+              method_kwargs=dict(koleo_loss_weight=koleo))
+    ref = H.build_reference_method(**kw)
+    cls = integration.dinov2_amd_method_cls()
+    amd = H.build_reference_method(method_cls=cls, method_cls_kwargs=dict(device=torch.device("cpu")), **kw)
+    return ref, amd, cls
+
+
+def drive(amd, views, step):
+    """What Lightning's loop does around a manual-optimization module for one batch."""
+    batch = {"views": views, "filename": []}
+    amd.trainer.global_step = step
+    res = amd.training_step_impl(batch, step)
+    amd.trainer.global_step = step + 1
+    try:
+        amd.on_train_batch_end(None, batch, step)
+    except Exception:      # batch-timing hooks of the base class need a real Trainer
+        pass
+    out = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    out["loss"] = float(res.loss)
+    return out
+
+
+def test_dinov2_amd_is_a_registered_reference_method():
+    from lightly_train_amd import integration
+
+    H.install()
+    from lightly_train._methods import method_helpers
+    from lightly_train._methods.dinov2.dinov2 import DINOv2Args
+    from lightly_train._methods.method import Method
+
+    _, amd, cls = build_pair(0.1)
+    assert issubclass(cls, Method) and isinstance(amd, Method)
+    assert method_helpers.get_method_cls(amd) is cls
+    assert cls.method_args_cls() is DINOv2Args and cls.transform_cls().__name__ == "DINOv2ViTTransform"
+    assert amd.automatic_optimization is False
+    orig = method_helpers._method_name_to_cls
+    try:
+        integration.install_as("dinov2")
+        assert method_helpers.get_method_cls("dinov2") is cls
+        assert method_helpers.get_method_cls("dino").__name__ == "DINO"
+    finally:
+        method_helpers._method_name_to_cls = orig
+    # identical containers: the state_dict keys of the drop-in are the reference's, in order
+    ref, _, _ = build_pair(0.1)
+    assert list(amd.state_dict()) == list(ref.state_dict())
+
+
+@pytest.mark.parametrize("koleo", [0.1, 0.0])
+def test_two_plumbing_steps_equal_the_reference_class(koleo):
+    ref, amd, _ = build_pair(koleo)
+    runner = H.ReferenceRunner(ref)
+    with ops_emu.emulate(ops):
+        exactify(amd.impl())
+        for step in range(2):
+            v = views_for(step)
+            random.seed(70 + step); torch.manual_seed(70 + step)
+            want = runner.train_step([x.clone() for x in v])
+            random.seed(70 + step); torch.manual_seed(70 + step)
+            got = drive(amd, v, step)
+            for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+                assert got[k] == pytest.approx(want[k], rel=3e-5, abs=3e-5), (step, k)
+            assert got["koleo_loss"] == pytest.approx(want["koleo_loss"], rel=2e-2), step
+            if koleo == 0.0:
+                assert got["loss"] == pytest.approx(want["loss"], rel=3e-5)
+        assert amd.impl().trainer.global_step == 2 and amd.impl().opt_step == 2
+        if koleo == 0.0:
+            sd, rsd = amd.state_dict(), ref.state_dict()
+            assert list(sd) == list(rsd)
+            for k in rsd:
+                assert torch.allclose(sd[k].float(), rsd[k].float(), atol=3e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+
+
+def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
+    H.install()
+    import lightly_train
+    if not hasattr(lightly_train, "__version__"):
+        lightly_train.__version__ = "0.17.0"
+    from lightly_train._checkpoint import CHECKPOINT_LIGHTLY_TRAIN_KEY, Checkpoint, CheckpointLightlyTrain, CheckpointLightlyTrainModels
+    from lightly_train._commands import export as E
+    from lightly_train._transforms.transform import NormalizeArgs
+
+    ref, amd, _ = build_pair(0.0, total_steps=4)
+    with ops_emu.emulate(ops):
+        exactify(amd.impl())
+        init_teacher = {k: v.clone() for k, v in amd.teacher_embedding_model.wrapped_model.get_model().state_dict().items()}
+        for step in range(2):
+            random.seed(80 + step); torch.manual_seed(80 + step)
+            drive(amd, views_for(step), step)
+        # --- what Trainer.save_checkpoint does: dump (stale module state), module hook, then the reference's ModelCheckpoint callback adds
+        # the envelope around the containers it was given at set-up (the embedding model passed to the method = the EMA teacher)
+        from lightly_train._methods.method import Method
+        ckpt = {"epoch": 0, "global_step": 2, "state_dict": Method.state_dict(amd), "optimizer_states": [], "lr_schedulers": []}
+        amd.on_save_checkpoint(ckpt)
+        emb = amd.teacher_embedding_model
+        env = CheckpointLightlyTrain.from_now(models=CheckpointLightlyTrainModels(model=emb.wrapped_model.get_model(), wrapped_model=emb.wrapped_model,
+                                                                                   embedding_model=emb), normalize_args=NormalizeArgs())
+        ckpt[CHECKPOINT_LIGHTLY_TRAIN_KEY] = env.to_dict()
+        path = tmp_path / "last.ckpt"
+        torch.save(ckpt, path)
+
+        loaded = torch.load(path, weights_only=False)
+        cp = Checkpoint.from_dict(loaded)                                   # the reference's reader
+        model = E._get_model(checkpoint=cp, part=E.ModelPart.MODEL)         # what `lightly_train.export(part="model")` exports
+        wrapped = E._get_model(checkpoint=cp, part=E.ModelPart.WRAPPED_MODEL)
+        embm = E._get_model(checkpoint=cp, part=E.ModelPart.EMBEDDING_MODEL)
+        want = amd.impl().export_backbone_state_dict()
+        got = model.state_dict()
+        assert list(got) == list(want)
+        moved = 0
+        for k in want:
+            assert torch.equal(got[k], want[k].cpu()), k                     # bit-identical to the flat EMA-teacher storage
+            moved += int(not torch.equal(got[k], init_teacher[k]))
+        assert moved > 10                                                    # ... and trained: not the initial weights
+        assert torch.equal(wrapped.get_model().state_dict()["cls_token"], want["cls_token"].cpu())
+        assert torch.equal(embm.wrapped_model.get_model().state_dict()["norm.weight"], want["norm.weight"].cpu())
+        # state_dict of the checkpoint = the module's keys with current values, optimizer state in torch.optim.AdamW's format
+        assert list(cp.state_dict) == list(ref.state_dict())
+        osd = loaded["optimizer_states"][0]
+        assert set(osd) == {"state", "param_groups"} and all(int(s["step"]) == 2 for s in osd["state"].values())
+
+        # --- resume: a fresh object loads the file, its third step equals the original's third step
+        _, amd2, _ = build_pair(0.0, total_steps=4)
+        amd2.on_load_checkpoint(loaded)
+        exactify(amd2.impl())
+        amd2.impl()._refresh_derived()
+        v = views_for(2)
+        # (the batch-center sums of the last step before the save are not part of a checkpoint -- `DINOLoss.async_batch_center` is a plain
+        # attribute in the reference too, dinov2_loss.py:139-160 -- so a resumed run applies no center update at its first step; the
+        # uninterrupted object is put into the same state for the comparison)
+        amd.impl()._pending.clear()
+        random.seed(90); torch.manual_seed(90)
+        a = drive(amd, v, 2)
+        random.seed(90); torch.manual_seed(90)
+        b = drive(amd2, v, 2)
+        assert b["loss"] == pytest.approx(a["loss"], rel=1e-6)
+        s1, s2 = amd.state_dict(), amd2.state_dict()
+        for k in s1:
+            assert torch.allclose(s1[k].float(), s2[k].float(), atol=1e-7), k
