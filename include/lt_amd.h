@@ -257,6 +257,13 @@ int lt_lars_norms(const float* p, const float* g, int64_t n, const int32_t* seg_
 int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
                  const uint8_t* seg_wd_on, const float* seg_norms, float lr_factor, float wd, float momentum, float dampening, int nesterov,
                  float trust, float eps, int first_step, const float* sumsq, float max_norm, void* stream);
+/* torch.optim.SGD as LT/_optim/sgd_args.py:19-31 builds it (the "auto" optimizer of DINO, LT/_methods/dino/dino.py:213-216,343-352):
+ * d = g + wd p on every tensor of a decayed segment (coupled weight decay, no trust ratio), then the momentum rule and the clipping of
+ * lt_lars_flat.  A segment with seg_lr 0 keeps its parameters but still moves its momentum buffer, as torch does for a group at lr 0
+ * (DINO's frozen last layer, dino.py:470-473). */
+int lt_sgd_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
+                const uint8_t* seg_wd_on, float lr_factor, float wd, float momentum, float dampening, int nesterov, int first_step,
+                const float* sumsq, float max_norm, void* stream);
 /* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow.  m is a double: 1 - m (~1e-6 at the end of the
  * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
 int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);

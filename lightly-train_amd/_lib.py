@@ -79,6 +79,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_ema_flat": [vp, vp, vp, i64, C.c_double, vp],
     "lt_lars_norms": [vp, vp, i64, vp, i32, vp, vp, vp],
     "lt_lars_flat": [vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, f32, f32, i32, vp, f32, vp],
+    "lt_sgd_flat": [vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, f32, vp],
     "lt_im2col_nhwc_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lt_col2im_nhwc_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lt_im2col_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -115,6 +115,9 @@ __global__ __launch_bounds__(64) void lars_seg_norms_kernel(const float* __restr
   for (int o = 32; o > 0; o >>= 1) { sp += __shfl_down(sp, o, 64); sg += __shfl_down(sg, o, 64); }
   if (threadIdx.x == 0) { seg_norms[2 * seg] = (float)sqrt(sp); seg_norms[2 * seg + 1] = (float)sqrt(sg); }
 }
+// ADAPT = false: torch.optim.SGD (LT/_optim/sgd_args.py:19-31) -- the same momentum rule without the trust ratio, coupled weight decay on
+// every tensor of a decayed group: d = g + wd * p.
+template <bool ADAPT>
 __global__ __launch_bounds__(256) void lars_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, bf16_t* __restrict__ pb,
                                                    const int32_t* __restrict__ seg_of_chunk, const float* __restrict__ seg_lr,
                                                    const uint8_t* __restrict__ seg_wd_on, const float* __restrict__ seg_norms, float lr_factor, float wd,
@@ -126,10 +129,13 @@ __global__ __launch_bounds__(256) void lars_kernel(float* __restrict__ p, const 
   float clip = 1.f;
   if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));   // the optimizer sees the clipped gradient
   const float wdv = seg_wd_on[seg] ? wd : 0.f;
-  const float p_norm = seg_norms[2 * seg], g_norm = seg_norms[2 * seg + 1] * clip;
-  const bool adapt = wdv != 0.f && p_norm != 0.f && g_norm != 0.f;
-  const float q = adapt ? p_norm / (g_norm + p_norm * wdv + eps) * trust : 1.f;
-  const float wadd = adapt ? wdv : 0.f;
+  float q = 1.f, wadd = wdv;
+  if constexpr (ADAPT) {
+    const float p_norm = seg_norms[2 * seg], g_norm = seg_norms[2 * seg + 1] * clip;
+    const bool adapt = wdv != 0.f && p_norm != 0.f && g_norm != 0.f;
+    q = adapt ? p_norm / (g_norm + p_norm * wdv + eps) * trust : 1.f;
+    wadd = adapt ? wdv : 0.f;
+  }
   const long i = chunk * 1024 + threadIdx.x * 4;
   float4 pp = *reinterpret_cast<float4*>(p + i);
   const float4 gg = *reinterpret_cast<const float4*>(g + i);
@@ -205,7 +211,20 @@ extern "C" int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, 
   LT_CHECK_ARG(max_norm <= 0.f || sumsq, "lt_lars_flat: sumsq must be given when clipping");
   LT_CHECK_ARG(!nesterov || (momentum > 0.f && dampening == 0.f), "lt_lars_flat: Nesterov momentum requires a momentum and zero dampening");
   if (n == 0) return LT_OK;
-  hipLaunchKernelGGL(lars_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, buf, (bf16_t*)p_bf16, seg_of_chunk, seg_lr, seg_wd_on, seg_norms,
+  hipLaunchKernelGGL(lars_kernel<true>, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, buf, (bf16_t*)p_bf16, seg_of_chunk, seg_lr, seg_wd_on, seg_norms,
                      lr_factor, wd, momentum, dampening, nesterov, trust, eps, first_step, sumsq, max_norm);
   LT_CHECK_LAUNCH("lt_lars_flat");
+}
+
+extern "C" int lt_sgd_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
+                           const uint8_t* seg_wd_on, float lr_factor, float wd, float momentum, float dampening, int nesterov, int first_step,
+                           const float* sumsq, float max_norm, void* stream) {
+  LT_CHECK_ARG(p && g && seg_of_chunk && seg_lr && seg_wd_on && (momentum == 0.f || buf), "lt_sgd_flat: null pointer");
+  LT_CHECK_ARG(n % 1024 == 0, "lt_sgd_flat: n must be a multiple of the 1024-element chunk (n=%ld)", (long)n);
+  LT_CHECK_ARG(max_norm <= 0.f || sumsq, "lt_sgd_flat: sumsq must be given when clipping");
+  LT_CHECK_ARG(!nesterov || (momentum > 0.f && dampening == 0.f), "lt_sgd_flat: Nesterov momentum requires a momentum and zero dampening");
+  if (n == 0) return LT_OK;
+  hipLaunchKernelGGL(lars_kernel<false>, dim3((unsigned)(n / 1024)), dim3(256), 0, ST, p, g, buf, (bf16_t*)p_bf16, seg_of_chunk, seg_lr, seg_wd_on,
+                     (const float*)nullptr, lr_factor, wd, momentum, dampening, nesterov, 0.f, 0.f, first_step, sumsq, max_norm);
+  LT_CHECK_LAUNCH("lt_sgd_flat");
 }

@@ -568,6 +568,65 @@ class DINOv2:
             self._static_idx[key] = {k: v.to(self.device) for k, v in d.items()}
         return self._static_idx[key]
 
+    def _backward_backbone(self, sg: Dict[str, Any], dxn_g: Tensor, sl: Optional[Dict[str, Any]], dxn_l: Optional[Tensor]) -> None:
+        """Backward of the student ViT from the gradients at its final-norm output: global crops (`sg`) and local crops (`sl`), with the
+        early gradient all-reduces of data-parallel runs.  The projection-head gradients are final when this is called."""
+        ws = self.ws
+        main = torch.cuda.current_stream()
+        side = self.side_stream if self.overlap_streams else None
+        sync = self._gradient_sync() if self.overlap_grad_reduce and self.reduce_stream is not None else None
+        done_blocks: List[int] = []
+
+        def reduce_block(i: int, after: Tuple[Any, ...]) -> None:
+            """Block i is through every backward pass: finish its LayerScale gradients and start its all-reduce, ordered
+            after the streams that wrote its gradients, on a stream of its own (nothing of backward waits for it)."""
+            if sync is None:
+                return
+            rs = self.reduce_stream
+            for st in after:
+                if st is not None:
+                    rs.wait_event(st.record_event())
+            with torch.cuda.stream(rs):
+                self.s_vit.finish_layerscale_grads(blocks=[i], last_call=False)
+                sync.start(*self._block_spans[i])
+            done_blocks.append(i)
+
+        if sync is not None:
+            sync.start(*self._head_span)   # the prototype heads are final: their all-reduce runs under the whole ViT backward
+        if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
+            # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
+            # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
+            lstream2 = self.local_bwd_stream
+            lstream2.wait_event(main.record_event())
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
+            live = [True, True]
+            blk = self.cfg.depth
+            while any(live):
+                for ci, (st, gen) in enumerate(chains):
+                    if live[ci]:
+                        with torch.cuda.stream(st):
+                            live[ci] = next(gen) != "tail"
+                blk -= 1
+                if blk >= 0:
+                    reduce_block(blk, (lstream2, main, side))
+            main.wait_stream(lstream2)
+            for _, gen in chains:   # tails: plain accumulations into cls/pos/patch-embedding gradients, one after the other
+                for _ in gen:
+                    pass
+        else:
+            if sl is not None:
+                self.s_vit.backward(ws, sl, dxn_l, side=side)
+            blk = self.cfg.depth
+            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side):
+                if ev == "block":
+                    blk -= 1
+                    reduce_block(blk, (main, side))
+        if side is not None:
+            main.wait_stream(side)
+        if sync is not None:
+            main.wait_stream(self.reduce_stream)
+        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
+
     # ------------------------------------------------------------------ the step
     def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:
         a, cfg, ws, dev = self.method_args, self.cfg, self.ws, self.device
@@ -743,24 +802,6 @@ class DINOv2:
                 ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
 
         # ---------------- backward
-        side = self.side_stream if self.overlap_streams else None
-        sync = self._gradient_sync() if self.overlap_grad_reduce and self.reduce_stream is not None else None
-        done_blocks: List[int] = []
-
-        def reduce_block(i: int, after: Tuple[Any, ...]) -> None:
-            """Block i is through every backward pass: finish its LayerScale gradients and start its all-reduce, ordered
-            after the streams that wrote its gradients, on a stream of its own (nothing of backward waits for it)."""
-            if sync is None:
-                return
-            rs = self.reduce_stream
-            for st in after:
-                if st is not None:
-                    rs.wait_event(st.record_event())
-            with torch.cuda.stream(rs):
-                self.s_vit.finish_layerscale_grads(blocks=[i], last_call=False)
-                sync.start(*self._block_spans[i])
-            done_blocks.append(i)
-
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
@@ -770,45 +811,12 @@ class DINOv2:
             dx_ihead = self.s_ihead.backward(ws, shi, dlogits_i)
             self.s_ihead.finish_weightnorm_grad()
             ops.scatter_add_rows(dx_ihead[:M], patch_rows, dxn_g, D, M, D)
-        if sync is not None:
-            sync.start(*self._head_span)   # the prototype heads are final: their all-reduce runs under the whole ViT backward
+        dxn_l = None
         if sl is not None:
             dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
             dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
-        if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
-            # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
-            # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
-            lstream2 = self.local_bwd_stream
-            lstream2.wait_event(main.record_event())
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
-            live = [True, True]
-            blk = self.cfg.depth
-            while any(live):
-                for ci, (st, gen) in enumerate(chains):
-                    if live[ci]:
-                        with torch.cuda.stream(st):
-                            live[ci] = next(gen) != "tail"
-                blk -= 1
-                if blk >= 0:
-                    reduce_block(blk, (lstream2, main, side))
-            main.wait_stream(lstream2)
-            for _, gen in chains:   # tails: plain accumulations into cls/pos/patch-embedding gradients, one after the other
-                for _ in gen:
-                    pass
-        else:
-            if sl is not None:
-                self.s_vit.backward(ws, sl, dxn_l, side=side)
-            blk = self.cfg.depth
-            for ev in self.s_vit.backward_iter(ws, sg, dxn_g, side=side):
-                if ev == "block":
-                    blk -= 1
-                    reduce_block(blk, (main, side))
-        if side is not None:
-            main.wait_stream(side)
-        if sync is not None:
-            main.wait_stream(self.reduce_stream)
-        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
+        self._backward_backbone(sg, dxn_g, sl, dxn_l)
 
         ls = self._loss_slots
         # slots hold weighted terms; report the unweighted terms like the reference's log_dict

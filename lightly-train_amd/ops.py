@@ -401,6 +401,14 @@ def lars_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tens
                            dampening, int(nesterov), trust, eps, int(first_step), _p(sumsq_t), max_norm, _stream()), "lt_lars_flat")
 
 
+def sgd_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tensor], seg_of_chunk: Tensor, seg_lr: Tensor, seg_wd_on: Tensor,
+             lr_factor: float, wd: float, momentum: float, dampening: float, nesterov: bool, first_step: bool, sumsq_t: Optional[Tensor],
+             max_norm: float) -> None:
+    """One torch.optim.SGD step on flat storage (lt_sgd_flat): coupled weight decay on the decayed segments, momentum buffer, clipping."""
+    check(_lib.load().lt_sgd_flat(_p(p), _p(g), _p(buf), _p(p_bf16), p.numel(), _p(seg_of_chunk), _p(seg_lr), _p(seg_wd_on), lr_factor, wd, momentum,
+                                  dampening, int(nesterov), int(first_step), _p(sumsq_t), max_norm, _stream()), "lt_sgd_flat")
+
+
 def ema_flat(teacher: Tensor, student: Tensor, teacher_bf16: Optional[Tensor], m: float) -> None:
     check(_lib.load().lt_ema_flat(_p(teacher), _p(student), _p(teacher_bf16), teacher.numel(), m, _stream()), "lt_ema_flat")
 

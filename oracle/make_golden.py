@@ -188,6 +188,11 @@ def main() -> None:
     if "--dinov3-only" in sys.argv:
         make_dinov3_vit()
         return
+    if "--dino-v1-only" in sys.argv:
+        make_dino_v1_kats()
+        make_dino_v1("sgd")
+        make_dino_v1("adamw")
+        return
     if "--lars-only" in sys.argv:
         make_distill12("v1", optimizer="lars")
         return
@@ -334,6 +339,133 @@ def make_distill12(kind: str, optimizer: str = "adamw") -> None:
                 "student_cfg": scfg, "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final,
                 "state_dict_keys": list(m.state_dict().keys())}, os.path.join(OUT, name + ".pt"))
     print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")
+
+
+def make_dino_v1_kats() -> None:
+    """Anchors for the restated LightlySSL pieces of DINO (oracle/dino_oracle.py), evaluated by the reference's VENDORED twins:
+    `dinov2_loss.DINOLoss` (softmax-center teacher, the cross-entropy summed over view pairs, the center update) and
+    `dinov2_head.DINOv2ProjectionHead` (same function as lightly's DINOProjectionHead under other attribute names)."""
+    H.install()
+    from lightly_train._methods.dinov2.dinov2_head import DINOv2ProjectionHead
+    from lightly_train._methods.dinov2.dinov2_loss import DINOLoss as VendoredDINOLoss
+
+    g = torch.Generator().manual_seed(515)
+    B, K, n_views, temp = 6, 32, 4, 0.05
+    teacher = [torch.randn(B, K, generator=g) for _ in range(2)]
+    student = [torch.randn(B, K, generator=g) for _ in range(n_views)]
+    center = 0.3 * torch.randn(1, K, generator=g)
+    L = VendoredDINOLoss(out_dim=K, student_temp=0.1, center_momentum=0.9)
+    L.center = center.clone()
+    tp = [L.softmax_center_teacher(t, temp) for t in teacher]
+    every_pair = L(student, tp)                                   # sum over all (s, t) of -mean_b sum_k t log_softmax(s / T_s)
+    same_view = L([student[0]], [tp[0]]) + L([student[1]], [tp[1]])
+    n_terms = 2 * n_views - 2
+    L.update_center(torch.cat(teacher))
+    L.apply_center_update()
+    torch.manual_seed(99)
+    head = DINOv2ProjectionHead(in_dim=16, out_dim=48, hidden_dim=24, bottleneck_dim=8)
+    for prm in head.parameters():
+        prm.data.add_(0.05 * torch.randn_like(prm))
+    x = torch.randn(5, 16, generator=g)
+    torch.save({"teacher": teacher, "student": student, "center": center, "teacher_temp": temp, "student_temp": 0.1, "center_momentum": 0.9,
+                "loss": float((every_pair - same_view) / n_terms), "center_after": L.center.detach().clone(),
+                "head_state": {k: v.detach().clone() for k, v in head.state_dict().items()}, "head_in": x, "head_out": head(x).detach().clone()},
+               os.path.join(OUT, "dino_v1_kats.pt"))
+    print("wrote dino_v1_kats")
+
+
+def make_dino_v1(optimizer: str) -> None:
+    """(g) DINO (LT/_methods/dino/dino.py:221-480): the reference's own `DINO` class around a DINOv2 ViT (D = 64, depth 2, /16; 96^2
+    global and 48^2 local views, 2 + 2 views, batch 8), 4 optimizer steps with the last layer frozen during the first two
+    (student_freeze_last_layer_steps=2) and the teacher temperature warming up over 3.  optimizer "sgd" = the method's "auto" arguments
+    (DINOSGDArgs: lr 0.03, momentum 0.9, weight decay 1e-4), "adamw" = DINOAdamWArgs (lr 5e-4) with the weight decay scheduled 0.04 ->
+    0.4.  The LightlySSL pieces (DINOLoss, DINOProjectionHead, get_weight_decay_parameters) are the restatements of oracle/dino_oracle.py
+    that ref_harness registers -- parity unpinned for those; everything else that runs is the reference's code."""
+    H.install()
+    from lightly_train._methods.dino.dino import DINO, DINOAdamWArgs, DINOArgs, DINOSGDArgs
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as v2
+    from lightly_train._models.embedding_model import EmbeddingModel
+    from lightly_train._scaling import ScalingInfo
+
+    b, g_size, l_size, n_local, total, n_steps = 8, 96, 48, 2, 50, 4
+    torch.manual_seed(4242)
+    model = v2.DinoVisionTransformer(img_size=g_size, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
+                                     drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    for n_, prm in model.named_parameters():   # constants at init (biases 0, norm weights 1, mask token 0): randomise for a real test
+        if n_.endswith(".bias") or "norm" in n_ or n_ == "mask_token":
+            prm.data.add_(0.1 * torch.randn_like(prm))
+    wrapped = DINOv2ViTModelWrapper(model)
+    margs = DINOArgs(hidden_dim=128, bottleneck_dim=64, output_dim=512, student_freeze_last_layer_steps=2, teacher_temp=0.07, warmup_teacher_temp=0.04,
+                     warmup_teacher_temp_steps=3, momentum_start=0.99)
+    if optimizer == "adamw":
+        oargs = DINOAdamWArgs()
+        margs.weight_decay_start, margs.weight_decay_end = 0.04, 0.4
+    else:
+        oargs = DINO.optimizer_args_cls("auto")()
+        assert isinstance(oargs, DINOSGDArgs)
+    margs.resolve_auto(scaling_info=ScalingInfo(dataset_size=1000, epochs=1), optimizer_args=oargs, wrapped_model=wrapped)
+    m = DINO(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=wrapped), global_batch_size=b, num_input_channels=3)
+    m.trainer = H.MockTrainer(total)
+    m.current_epoch = 0
+    [opt], [sched] = m.configure_optimizers()
+    sched = sched["scheduler"]
+    groups = {g["name"]: len(g["params"]) for g in opt.param_groups}
+
+    def split(sd):
+        out = {"student_backbone": {}, "teacher_backbone": {}, "student_head": {}, "teacher_head": {}, "other": {}}
+        for k, v in sd.items():
+            for role in ("student", "teacher"):
+                for pre, dst in ((f"{role}_embedding_model.wrapped_model._model.", f"{role}_backbone"), (f"{role}_projection_head.", f"{role}_head")):
+                    if k.startswith(pre):
+                        out[dst][k[len(pre):]] = v.detach().clone()
+                        break
+                else:
+                    continue
+                break
+            else:
+                out["other"][k] = v.detach().clone()
+        return out
+
+    init = split(m.state_dict())
+    steps = []
+    t_calls, s_calls = [], []
+    for mod, sink in ((m.teacher_projection_head, t_calls), (m.student_projection_head, s_calls)):
+        orig = mod.forward
+        mod.forward = (lambda orig, sink: lambda x: (sink.append(orig(x)), sink[-1])[1])(orig, sink)
+    for step in range(n_steps):
+        views = synth_views(3000 + step, b, g_size, l_size, n_local)
+        t_calls.clear(); s_calls.clear()
+        res = m.training_step_impl({"views": views, "filename": []}, 0)
+        res.loss.backward()
+        m.on_before_optimizer_step(opt)
+        hp = {g["name"]: {"lr": g["lr"], "weight_decay": g["weight_decay"]} for g in opt.param_groups}
+        params = [p for g in opt.param_groups for p in g["params"] if p.grad is not None]
+        gnorm = torch.nn.utils.clip_grad_norm_(params, 3.0)
+        rec = {"view_seed": 3000 + step, "logs": {"loss": float(res.loss.detach()), "grad_norm": float(gnorm), **{k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}},
+               "hparams": hp, "teacher_logits": t_calls[0].detach().clone(), "student_global_logits": s_calls[0].detach().clone(),
+               "student_local_logits": s_calls[1].detach().clone()}
+        if step == 0:   # clipped gradients of the first step, by state_dict name
+            names = {id(p): n for n, p in m.named_parameters()}
+            rec["grads"] = {names[id(p)]: p.grad.detach().clone() for p in params}
+            rec["no_grad"] = sorted(names[id(p)] for g in opt.param_groups for p in g["params"] if p.grad is None)
+        opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+        m.trainer.global_step += 1
+        rec["center"] = m.criterion.center.value.detach().clone()
+        steps.append(rec)
+        print("dino_v1", optimizer, step, {k: round(v, 6) for k, v in rec["logs"].items()}, hp["params_last_layer"])
+    final = split(m.state_dict())
+    osd = opt.state_dict()
+    name = "dino_v1_d64" + ("_adamw" if optimizer == "adamw" else "")
+    torch.save({"optimizer": optimizer, "b": b, "g_size": g_size, "l_size": l_size, "n_local": n_local, "total_steps": total,
+                "cfg": dict(patch_size=16, num_heads=1, depth=2, img_size=g_size, embed_dim=64, init_values=0.1),
+                "method_args": {k: getattr(margs, k) for k in ("hidden_dim", "bottleneck_dim", "output_dim", "student_freeze_last_layer_steps", "norm_last_layer",
+                                                                 "teacher_temp", "warmup_teacher_temp", "warmup_teacher_temp_steps", "student_temp", "center_momentum",
+                                                                 "momentum_start", "momentum_end", "weight_decay_start", "weight_decay_end", "warmup_steps",
+                                                                 "warmup_max_steps_fraction", "lr_scale_method", "reference_batch_size")},
+                "optimizer_args": oargs.model_dump(), "groups": groups, "init": init, "steps": steps, "final": final,
+                "optimizer_state": osd, "state_dict_keys": list(m.state_dict().keys())}, os.path.join(OUT, name + ".pt"))
+    print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB", groups)
 
 
 def make_distill_case(name: str, img: int, s_patch: int, b: int, s_kind: str = "dinov2") -> None:

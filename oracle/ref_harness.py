@@ -181,6 +181,16 @@ def install() -> None:
     lus.CosineWarmupScheduler = O.CosineWarmupScheduler  # type: ignore[attr-defined]
     luo = importlib.import_module("lightly.utils.optim")
     luo.update_param_groups = O.update_param_groups  # type: ignore[attr-defined]
+    # the LightlySSL pieces of the DINO method (LT/_methods/dino/dino.py:15-17), restated in oracle/dino_oracle.py (parity unpinned)
+    from oracle import dino_oracle as ODN
+
+    ll.DINOLoss = ODN.DINOLoss  # type: ignore[attr-defined]
+    lmh = importlib.import_module("lightly.models.modules.heads")
+    lmh.DINOProjectionHead = ODN.DINOProjectionHead  # type: ignore[attr-defined]
+    lmu = importlib.import_module("lightly.models.utils")
+    lmu.get_weight_decay_parameters = ODN.get_weight_decay_parameters  # type: ignore[attr-defined]
+    lu = importlib.import_module("lightly.utils")
+    lu.optim = luo  # type: ignore[attr-defined]
     from oracle import lars_oracle
 
     lul = importlib.import_module("lightly.utils.lars")

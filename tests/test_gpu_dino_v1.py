@@ -1,0 +1,135 @@
+"""-m gpu: DINO (v1) in HIP (lightly_train_amd/dino.py) against tests/golden/dino_v1_d64*.pt, written by the reference's
+own `DINO` class on CPU (oracle/make_golden.py::make_dino_v1: DINOv2 ViT D=64 /16, 2 x 96^2 + 2 x 48^2 views, batch 8, 4 steps, the last
+layer frozen during the first two; SGD = the method's "auto" optimizer, and AdamW with a scheduled weight decay).  Tolerances (bf16 MFMA
+operands vs fp32): loss 1e-2 relative, gradient norm 5e-2, first-step gradients 5e-2 of max|grad| per tensor, head outputs 2e-2 of their
+range; after 4 steps the parameter UPDATE of every tensor within 12 % of its own norm (SGD) / 95 % of the elements within 0.15 lr per
+step (AdamW), teacher (EMA) likewise; the center to 1e-2 of its range."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def build(fx):
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dino import DINO, DINOArgs
+    from lightly_train_amd.vit import ViTConfig
+
+    c, ma, oa = fx["cfg"], fx["method_args"], fx["optimizer_args"]
+    cfg = ViTConfig(embed_dim=c["embed_dim"], depth=c["depth"], num_heads=c["num_heads"], mlp_ratio=4.0, patch_size=c["patch_size"], img_size=c["img_size"],
+                    init_values=c["init_values"])
+    args = DINOArgs(hidden_dim=ma["hidden_dim"], bottleneck_dim=ma["bottleneck_dim"], output_dim=ma["output_dim"],
+                    student_freeze_last_layer_steps=ma["student_freeze_last_layer_steps"], norm_last_layer=ma["norm_last_layer"],
+                    teacher_temp=ma["teacher_temp"], warmup_teacher_temp=ma["warmup_teacher_temp"], warmup_teacher_temp_steps=ma["warmup_teacher_temp_steps"],
+                    student_temp=ma["student_temp"], center_momentum=ma["center_momentum"], momentum_start=ma["momentum_start"], momentum_end=ma["momentum_end"],
+                    weight_decay_start=ma["weight_decay_start"], weight_decay_end=ma["weight_decay_end"], warmup_steps=ma["warmup_steps"],
+                    optimizer=fx["optimizer"], lr=oa["lr"], weight_decay=oa["weight_decay"])
+    init = fx["init"]
+    return DINO(cfg, args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda", backbone_state=init["student_backbone"],
+                teacher_backbone_state=init["teacher_backbone"], student_head_state=init["student_head"], teacher_head_state=init["teacher_head"])
+
+
+def views_of(fx, rec):
+    g = torch.Generator().manual_seed(rec["view_seed"])
+    return [torch.randn(fx["b"], 3, fx["g_size"], fx["g_size"], generator=g) for _ in range(2)] + \
+           [torch.randn(fx["b"], 3, fx["l_size"], fx["l_size"], generator=g) for _ in range(fx["n_local"])]
+
+
+@pytest.mark.parametrize("name", ["dino_v1_d64", "dino_v1_d64_adamw"])
+def test_dino_v1_steps_match_reference_fixture(name):
+    from lightly_train_amd import _lib
+    assert _lib.load() is not None
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    m = build(fx)
+    B = fx["b"]
+    for si, rec in enumerate(fx["steps"]):
+        res = m.training_step_impl({"views": views_of(fx, rec)}, 0)
+        logs = rec["logs"]
+        assert float(res.loss) == pytest.approx(logs["loss"], rel=1e-2), si
+        sw = torch.cat([rec["teacher_logits"][B:], rec["teacher_logits"][:B]])
+        rng = float(sw.abs().max())
+        assert float((m._last["t_logits"][:2 * B].cpu() - sw).abs().max()) < 2e-2 * rng, si
+        assert float((m._last["s_global_logits"].cpu() - rec["student_global_logits"]).abs().max()) < 2e-2 * rng, si
+        assert float((m._last["s_local_logits"].cpu() - rec["student_local_logits"]).abs().max()) < 2e-2 * rng, si
+        if "grads" in rec:
+            clip = min(1.0, 3.0 / (logs["grad_norm"] + 1e-6))
+            worst = 0.0
+            for n in m.student.names:
+                key = m._ref_key("student", n)
+                if key in rec["no_grad"]:
+                    assert float(m.student.g[n].abs().max()) == 0.0, n
+                    continue
+                want = rec["grads"][key] / clip
+                err = float((m.student.g[n].cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-20)
+                worst = max(worst, err)
+                assert err < 5e-2, (n, err)
+            print(f"{name}: first-step gradients, worst tensor {worst:.3e} of max|grad|")
+        m.optimizer_step()
+        assert float(m.last_grad_norm.sqrt()) == pytest.approx(logs["grad_norm"], rel=5e-2), si
+        c = rec["center"].view(-1)
+        assert float((m.center.view(-1).cpu() - c).abs().max()) < 1e-2 * float(c.abs().max()), si
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    assert list(sd) == fx["state_dict_keys"]
+    fin, init = fx["final"], fx["init"]
+    n_steps = len(fx["steps"])
+    lr_last = fx["steps"][-1]["hparams"]["params"]["lr"]
+    for role in ("student", "teacher"):
+        num = den = 0.0
+        agree = tot = 0
+        for part, pre in (("backbone", f"{role}_embedding_model.wrapped_model._model."), ("head", f"{role}_projection_head.")):
+            for k, v in fin[f"{role}_{part}"].items():
+                v0 = init[f"{role}_{part}"][k]
+                upd = (v - v0).double()
+                got = sd[pre + k]
+                if float(upd.abs().max()) == 0:
+                    assert torch.equal(got, v), (role, k)     # the mask token and the normalised last layer's weight_g never move
+                    continue
+                err = float((got.double() - v.double()).norm())
+                num += err ** 2; den += float(upd.norm()) ** 2
+                if fx["optimizer"] == "sgd" or role == "teacher":
+                    assert err <= 0.12 * float(upd.norm()) + 1e-7, (role, k, err, float(upd.norm()))
+                else:
+                    agree += int(((got - v).abs() <= 0.15 * lr_last * n_steps).sum()); tot += v.numel()
+        assert (num / den) ** 0.5 < 0.06, (role, (num / den) ** 0.5)
+        if tot:
+            assert agree / tot > 0.95, (role, agree / tot)
+        print(f"{name}: {role} update error {100 * (num / den) ** 0.5:.2f} % of the update norm")
+
+
+def test_dino_v1_sgd_kernel_matches_torch_sgd():
+    """lt_sgd_flat against torch.optim.SGD (momentum 0.9, coupled weight decay) over three steps, with one segment at lr 0 (its
+    momentum buffer must keep moving) and clipping."""
+    from lightly_train_amd import ops
+    from lightly_train_amd.params import FlatParams
+
+    g = torch.Generator().manual_seed(5)
+    named = [("a", torch.randn(300, 7, generator=g)), ("b", torch.randn(2048, generator=g)), ("c", torch.randn(33, generator=g))]
+    fp = FlatParams(named, "cuda", True)
+    ref = [torch.nn.Parameter(t.clone().cuda()) for _, t in named]
+    opt = torch.optim.SGD([{"params": [ref[0]], "weight_decay": 1e-2}, {"params": [ref[1]], "weight_decay": 0.0}, {"params": [ref[2]], "weight_decay": 1e-2, "lr": 0.0}],
+                          lr=0.1, momentum=0.9)
+    seg_lr = torch.tensor([0.1, 0.1, 0.0], device="cuda")
+    seg_wd = torch.tensor([1, 0, 1], dtype=torch.uint8, device="cuda")
+    buf = torch.zeros_like(fp.data)
+    sumsq = torch.zeros(1, device="cuda")
+    for step in range(3):
+        fp.grad.zero_()
+        for (n, _), r in zip(named, ref):
+            gr = torch.randn(r.shape, generator=g).cuda()
+            fp.g[n].copy_(gr)
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 3.0)
+        opt.step()
+        sumsq.zero_()
+        ops.sumsq(fp.grad, sumsq)
+        ops.sgd_flat(fp.data, fp.grad, buf, fp.bf16, fp.seg_of_chunk, seg_lr, seg_wd, 1.0, 1e-2, 0.9, 0.0, False, step == 0, sumsq, 3.0)
+    for (n, _), r in zip(named, ref):
+        assert torch.allclose(fp.p[n], r.data, atol=2e-6), n
+        o, cnt = fp.offsets[n], r.numel()
+        assert torch.allclose(buf[o:o + cnt].view(r.shape), opt.state[r]["momentum_buffer"], atol=2e-6), n
+        assert torch.equal(fp.b[n].float(), fp.p[n].to(torch.bfloat16).float()), n
+    assert torch.equal(fp.p["c"].cpu(), named[2][1])     # lr 0: parameters untouched

@@ -295,3 +295,53 @@ def test_distillation_v1_v2_oracle_matches_reference_fixture(name):
         assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
     for k, v in fx["final"]["head"].items():
         assert (o.head[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+
+
+def test_restated_dino_v1_pieces_match_the_vendored_twins_and_hand_values():
+    """lightly's DINOLoss / DINOProjectionHead / get_weight_decay_parameters are un-vendored (oracle/dino_oracle.py: parity unpinned).
+    Anchors: (1) hand-computed values; (2) tests/golden/dino_v1_kats.pt, written by the reference's vendored twins
+    (_methods/dinov2/dinov2_loss.py:61-160, dinov2_head.py:32-71)."""
+    from oracle import dino_oracle as ODN
+
+    # (1) by hand.  T = S = 2, B = 1, K = 2, all logits 0: teacher softmax (1/2, 1/2), student log-softmax (ln 1/2, ln 1/2); each of the
+    # two off-diagonal pairs contributes ln 2; / (n_terms = 2) / (B = 1) -> ln 2.  Center: 0.9 * 0 + 0.1 * mean(teacher) with teacher
+    # rows (1, 3) and (3, 5) -> 0.1 * (2, 4) = (0.2, 0.4).
+    L = ODN.DINOLoss(output_dim=2, student_temp=0.1, center_momentum=0.9)
+    z = torch.zeros(1, 2)
+    assert float(L([z, z], [z, z], teacher_temp=0.04)) == pytest.approx(math.log(2), rel=1e-6)
+    L = ODN.DINOLoss(output_dim=2, student_temp=1.0, center_momentum=0.9)
+    t0, t1 = torch.tensor([[1.0, 3.0]]), torch.tensor([[3.0, 5.0]])
+    # teacher softmax((t - 0) / 2) = softmax(0.5, 1.5) = (1, e) / (1 + e) for both views; student rows (0, ln 3) -> log-softmax (ln 1/4, ln 3/4)
+    s = torch.tensor([[0.0, math.log(3.0)]])
+    e = math.e
+    want = -(1 / (1 + e)) * math.log(0.25) - (e / (1 + e)) * math.log(0.75)
+    assert float(L([t0, t1], [s, s], teacher_temp=2.0)) == pytest.approx(want, rel=1e-6)
+    assert torch.allclose(L.center.value.view(-1), torch.tensor([0.2, 0.4]))
+    # three views: T S - min(T, S) = 2 * 3 - 2 = 4 terms, all equal here
+    L = ODN.DINOLoss(output_dim=2, student_temp=1.0)
+    assert float(L([t0, t0], [s, s, s], teacher_temp=2.0)) == pytest.approx(want, rel=1e-6)
+    # weight-decay grouping: LayerNorm parameters and biases are not decayed, everything else (a bare token too) is
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.tok = torch.nn.Parameter(torch.zeros(1, 4))
+            self.lin = torch.nn.Linear(4, 4)
+            self.norm = torch.nn.LayerNorm(4)
+    toy = Toy()
+    wd, no_wd = ODN.get_weight_decay_parameters([toy])
+    assert [id(p) for p in wd] == [id(toy.tok), id(toy.lin.weight)] and [id(p) for p in no_wd] == [id(toy.lin.bias), id(toy.norm.weight), id(toy.norm.bias)]
+
+    # (2) the vendored twins
+    k = load("dino_v1_kats")
+    L = ODN.DINOLoss(output_dim=32, student_temp=k["student_temp"], center_momentum=k["center_momentum"])
+    L.center.center = k["center"].view(1, 1, -1).clone()
+    assert float(L(k["teacher"], k["student"], teacher_temp=k["teacher_temp"])) == pytest.approx(k["loss"], rel=1e-5)
+    assert torch.allclose(L.center.value.view(1, -1), k["center_after"], atol=1e-6)
+    head = ODN.DINOProjectionHead(16, 24, 8, 48)
+    hs = k["head_state"]
+    head.load_state_dict({"layers.0.weight": hs["mlp.0.weight"], "layers.0.bias": hs["mlp.0.bias"], "layers.2.weight": hs["mlp.2.weight"],
+                          "layers.2.bias": hs["mlp.2.bias"], "layers.4.weight": hs["mlp.4.weight"], "layers.4.bias": hs["mlp.4.bias"],
+                          "last_layer.weight_g": hs["last_layer.parametrizations.weight.original0"],
+                          "last_layer.weight_v": hs["last_layer.parametrizations.weight.original1"]})
+    assert torch.allclose(head(k["head_in"]), k["head_out"], atol=1e-6)
+    assert not head.last_layer.weight_g.requires_grad and head.last_layer.weight_v.requires_grad

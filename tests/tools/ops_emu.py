@@ -326,6 +326,23 @@ def emulate(ops):
         if p_bf16 is not None:
             p_bf16.copy_(p_.to(p_bf16.dtype))
 
+    def sgd_flat(p_, g, buf, p_bf16, seg_of_chunk, seg_lr, seg_wd_on, lr_factor, wd, momentum, dampening, nesterov, first_step, sumsq_t, max_norm):
+        clip = 1.0
+        if max_norm > 0:
+            clip = min(1.0, max_norm / (float(sumsq_t[0]) ** 0.5 + 1e-6))
+        seg = seg_of_chunk.long().repeat_interleave(1024)
+        lr = seg_lr[seg] * lr_factor
+        d = g * clip + (seg_wd_on[seg].float() * wd) * p_
+        if momentum != 0:
+            if first_step:
+                buf.copy_(d)
+            else:
+                buf.mul_(momentum).add_(d, alpha=1 - dampening)
+            d = d + momentum * buf if nesterov else buf
+        p_.sub_(lr * d)
+        if p_bf16 is not None:
+            p_bf16.copy_(p_.to(p_bf16.dtype))
+
     def rope_apply(qkv, sin_t, cos_t, B, N, Hh, dh, prefix, inverse=False):
         v = qkv.reshape(-1)[: B * N * 3 * Hh * dh].view(B, N, 3, Hh, dh)
         x = v[:, prefix:, :2].float()                                    # q and k of the patch tokens
@@ -497,7 +514,7 @@ def emulate(ops):
                      ("scale_f32", scale_f32), ("fill_f32", fill_f32), ("ce_fwd_bwd", ce_fwd_bwd), ("sk_exp", sk_exp), ("sk_iter", sk_iter),
                      ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat),
                      ("resample_tokens", resample_tokens), ("kl_fwd_bwd", kl_fwd_bwd), ("cast_bf16", cast_bf16), ("symmetrize_bf16", symmetrize_bf16),
-                     ("mixup", mixup), ("mse_fwd_bwd", mse_fwd_bwd), ("lars_flat", lars_flat), ("rope_apply", rope_apply),
+                     ("mixup", mixup), ("mse_fwd_bwd", mse_fwd_bwd), ("lars_flat", lars_flat), ("sgd_flat", sgd_flat), ("rope_apply", rope_apply),
                      ("require_device", lambda dev, who: None)):
         patch(name, fn)
     try:
