@@ -18,8 +18,8 @@ reference's DINO does differently:
     (lightly's `get_weight_decay_parameters`: tokens, positional embedding and LayerScale ARE decayed here, unlike DINOv2);
     linear lr scaling from batch 256; gradient clipping at 3.0; CosineWarmupScheduler with warmup min(12500, 10 % of the steps).
 
-The LightlySSL pieces are un-vendored in the reference tree: see oracle/dino_oracle.py for their restatement (parity unpinned for
-those).  Convolutional backbones (the method accepts any `EmbeddingModel`) and `batch_norm=True` heads are not built.
+The LightlySSL pieces are un-vendored in the reference tree (parity unpinned for those: DESIGN.md lists how the test-side restatement
+is anchored).  Convolutional backbones (the method accepts any `EmbeddingModel`) and `batch_norm=True` heads are not built.
 """
 from __future__ import annotations
 
