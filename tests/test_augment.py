@@ -69,6 +69,60 @@ def test_oracle_colour_ops_sanity():
     assert torch.allclose(ident, (img[5:37, 10:42].float() / 255).permute(2, 0, 1).flip(-1), atol=1e-6)
 
 
+def test_augmentation_op_definitions_by_hand():
+    """albumentations / OpenCV are un-vendored (parity unpinned): every op of the restated transform evaluated on paper."""
+    px = lambda *rgb: torch.tensor(rgb, dtype=torch.float32).view(3, 1, 1)   # noqa: E731
+    p1 = px(0.5, 0.8, 0.2)
+    lum1 = 0.299 * 0.5 + 0.587 * 0.8 + 0.114 * 0.2                          # 0.6419
+    # area resampling: row (0, 255, 51) / 255 = (0, 1, .2); crop x in [0.5, 2.5) to 2 pixels: (.5*0 + .5*1, .5*1 + .5*.2) = (.5, .6); flipped (.6, .5)
+    img = torch.tensor([[0, 255, 51], [0, 255, 51]], dtype=torch.uint8).unsqueeze(-1).expand(2, 3, 3).contiguous()
+    out = AO.crop_resize_area(img, 0.5, 0.0, 2.0, 2.0, 2, False)
+    assert torch.allclose(out[0], torch.tensor([[0.5, 0.6], [0.5, 0.6]]), atol=1e-6)
+    assert torch.allclose(AO.crop_resize_area(img, 0.5, 0.0, 2.0, 2.0, 2, True)[0], torch.tensor([[0.6, 0.5], [0.6, 0.5]]), atol=1e-6)
+    # a 2 x 2 crop of a 2 x 2 image to one pixel is the plain mean
+    chk = torch.tensor([[0, 255], [255, 0]], dtype=torch.uint8).unsqueeze(-1).expand(2, 2, 3).contiguous()
+    assert torch.allclose(AO.crop_resize_area(chk, 0, 0, 2, 2, 1, False), torch.full((3, 1, 1), 0.5), atol=1e-6)
+    # brightness 1.5: (.75, 1.2 -> 1, .3)
+    assert torch.allclose(AO.color_jitter(p1, (0,), 1.5, 1, 1, 0), px(0.75, 1.0, 0.3), atol=1e-6)
+    # contrast 0.5 on two pixels p1 and white: mean luminance (0.6419 + 1) / 2 = 0.82095; x -> .5 x + .5 * .82095
+    two = torch.cat([p1, px(1.0, 1.0, 1.0)], dim=2)
+    m = (lum1 + 1.0) / 2
+    want = torch.cat([px(0.25 + m / 2, 0.4 + m / 2, 0.1 + m / 2), px(0.5 + m / 2, 0.5 + m / 2, 0.5 + m / 2)], dim=2)
+    assert torch.allclose(AO.color_jitter(two, (1,), 1, 0.5, 1, 0), want, atol=1e-6)
+    # saturation 0: the pixel's own luminance; saturation 2: 2 x - lum, clamped: (.3581, .9581, -.2419 -> 0)
+    assert torch.allclose(AO.color_jitter(p1, (2,), 1, 1, 0.0, 0), px(lum1, lum1, lum1), atol=1e-6)
+    assert torch.allclose(AO.color_jitter(p1, (2,), 1, 1, 2.0, 0), px(1.0 - lum1, 1.6 - lum1, 0.0), atol=1e-6)
+    # hue: (.5, .8, .2) has V = .8, S = .75, H = (2 + (.2 - .5) / .6) / 6 = .25; + .25 -> H = .5 (cyan sector, f = 0): (V(1-S), V, V) = (.2, .8, .8)
+    assert torch.allclose(AO.color_jitter(p1, (3,), 1, 1, 1, 0.25), px(0.2, 0.8, 0.8), atol=1e-6)
+    assert torch.allclose(AO.color_jitter(px(1.0, 0.0, 0.0), (3,), 1, 1, 1, 0.5), px(0.0, 1.0, 1.0), atol=1e-6)
+    # the order matters: brightness 2 then saturation 0 -> lum(clamp(2 x)) = lum(1, 1, .4) = .9316; saturation 0 then brightness 2 -> clamp(2 * .6419) = 1
+    assert torch.allclose(AO.color_jitter(p1, (0, 2), 2.0, 1, 0.0, 0), px(0.9316, 0.9316, 0.9316), atol=1e-6)
+    assert torch.allclose(AO.color_jitter(p1, (2, 0), 2.0, 1, 0.0, 0), px(1.0, 1.0, 1.0), atol=1e-6)
+    assert torch.allclose(AO.to_gray(p1), px(lum1, lum1, lum1), atol=1e-6)
+    # Gaussian blur, sigma 0.5: radius ceil(1.5) = 2, taps exp(-2 d^2) = (1, e^-2, e^-8), normaliser Z = 1 + 2 (e^-2 + e^-8)
+    Z = 1 + 2 * (math.exp(-2) + math.exp(-8))
+    imp = torch.zeros(3, 7, 7); imp[:, 3, 3] = 1.0
+    b = AO.gaussian_blur(imp, 0.5)
+    assert b[0, 3, 3].item() == pytest.approx(1 / Z ** 2, rel=1e-5) and b[0, 3, 4].item() == pytest.approx(math.exp(-2) / Z ** 2, rel=1e-5)
+    assert b[0, 2, 2].item() == pytest.approx(math.exp(-4) / Z ** 2, rel=1e-5) and b[0, 3, 6].item() == 0.0
+    # reflect-101 border (column -1 mirrors to column +1, the edge pixel is not repeated): an impulse in the corner pixel (0, 0) reaches
+    # (0, 0) through the centre taps only and (0, 1) through tap -1 only; an impulse at (0, 1) reaches (0, 0) through tap +1 AND the
+    # mirrored tap -1: 2 e^-2 / Z in x (times 1 / Z in y)
+    corner = torch.zeros(3, 7, 7); corner[:, 0, 0] = 1.0
+    bc = AO.gaussian_blur(corner, 0.5)
+    assert bc[0, 0, 0].item() == pytest.approx(1 / Z ** 2, rel=1e-5)
+    assert bc[0, 0, 1].item() == pytest.approx(math.exp(-2) / Z ** 2, rel=1e-5)
+    c1 = torch.zeros(3, 7, 7); c1[:, 0, 1] = 1.0
+    assert AO.gaussian_blur(c1, 0.5)[0, 0, 0].item() == pytest.approx(2 * math.exp(-2) / Z ** 2, rel=1e-5)
+    assert torch.allclose(AO.gaussian_blur(torch.full((3, 9, 9), 0.37), 1.3), torch.full((3, 9, 9), 0.37), atol=1e-6)
+    # solarize at 0.5 (x >= t flips) and Normalize: ((.5, .3, .49) - mean) / std
+    x = px(0.5, 0.7, 0.49)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    want = px((0.5 - 0.485) / 0.229, (0.3 - 0.456) / 0.224, (0.49 - 0.406) / 0.225)
+    assert torch.allclose(AO.finish(x, 0.0, True, 0.5, mean, std), want, atol=1e-6)
+    assert torch.allclose(AO.finish(x, 0.0, False, 0.5, mean, std), px((0.5 - 0.485) / 0.229, (0.7 - 0.456) / 0.224, (0.49 - 0.406) / 0.225), atol=1e-6)
+
+
 @pytest.mark.gpu
 def test_augmentation_kernels_match_oracle_with_explicit_parameters():
     g = torch.Generator().manual_seed(3)

@@ -530,6 +530,26 @@ def test_koleo():
     assert rel_err(dx, xr.grad) < 1e-4
 
 
+def test_koleo_hand_computed_value():
+    """KoLeo is un-vendored LightlySSL code (parity unpinned): four points done on paper.  Rows (3,4), (4,3), (0,5), (5,0) normalise
+    to (.6,.8), (.8,.6), (0,1), (1,0); nearest neighbours by cosine: 0<->1 (cos .96), 2->0 (.8), 3->1 (.8); distances sqrt(.08), sqrt(.08),
+    sqrt(.4), sqrt(.4); loss = -(ln .08 + ln .4) / 4 = -ln(.032) / 4 = 0.8605048...  The gradient is tangent to the unit circle, so
+    dL/dx . x = 0 for every row (scale invariance of the normalisation)."""
+    o = ops()
+    n, D = 4, 64
+    x = torch.zeros(n, D, device=DEV)
+    x[:, :2] = torch.tensor([[3.0, 4.0], [4.0, 3.0], [0.0, 5.0], [5.0, 0.0]], device=DEV)
+    loss = torch.zeros(1, device=DEV); dx = torch.zeros(n, D, device=DEV)
+    ws = torch.empty(2 * n * D + 2 * n, device=DEV); nn = torch.empty(n, dtype=torch.int32, device=DEV)
+    o.koleo_fwd_bwd(x, D, loss, dx, D, n, D, 1.0, ws, nn)
+    assert nn.tolist() == [1, 0, 0, 1]
+    assert loss.item() == pytest.approx(-math.log(0.032) / 4, rel=1e-5)
+    assert float((dx * x).sum(1).abs().max()) < 1e-5 and float(dx[:, 2:].abs().max()) == 0.0
+    # row 2 = (0, 5): L_2 = -ln|z - x0| / 4 with z = (0,1), x0 = (.6,.8); dL/dz = -(z - x0) / (4 |z - x0|^2) = -(-.6, .2) / 1.6; projected on the tangent
+    # (1, 0) and divided by |row| = 5: dL/dx_2 = (.6 / 1.6 / 5, 0) = (0.075, 0) -- plus row 2's role as nobody's neighbour: none.
+    assert dx[2, 0].item() == pytest.approx(0.075, rel=1e-4) and abs(dx[2, 1].item()) < 1e-6
+
+
 def test_adamw_ema_match_torch():
     o = ops()
     sizes = [1024 * 3, 1024, 2048]

@@ -345,3 +345,17 @@ def test_restated_dino_v1_pieces_match_the_vendored_twins_and_hand_values():
                           "last_layer.weight_v": hs["last_layer.parametrizations.weight.original1"]})
     assert torch.allclose(head(k["head_in"]), k["head_out"], atol=1e-6)
     assert not head.last_layer.weight_g.requires_grad and head.last_layer.weight_v.requires_grad
+
+
+def test_koleo_hand_computed_value():
+    """lightly.loss.KoLeoLoss is un-vendored (parity unpinned): four points done on paper -- see tests/test_gpu_ops.py's twin for the
+    arithmetic: loss = -ln(0.032) / 4, gradient of row (0, 5) = (0.075, 0)."""
+    x = torch.tensor([[3.0, 4.0], [4.0, 3.0], [0.0, 5.0], [5.0, 0.0]], requires_grad=True)
+    loss = O.koleo_loss(x)
+    assert float(loss) == pytest.approx(-math.log(0.032) / 4, rel=1e-6)
+    loss.backward()
+    assert torch.allclose(x.grad[2], torch.tensor([0.075, 0.0]), atol=1e-6)
+    assert float((x.grad * x.detach()).sum(1).abs().max()) < 1e-6
+    # two identical rows: distance eps-floored, -log(|eps * sqrt(D)| + eps) -- the value the reference's eps conventions imply
+    y = torch.tensor([[1.0, 0.0], [1.0, 0.0]])
+    assert float(O.koleo_loss(y)) == pytest.approx(-math.log(1e-8 * math.sqrt(2) + 1e-8), rel=1e-6)
