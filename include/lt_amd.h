@@ -264,6 +264,17 @@ int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, 
 int lt_sgd_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
                 const uint8_t* seg_wd_on, float lr_factor, float wd, float momentum, float dampening, int nesterov, int first_step,
                 const float* sumsq, float max_norm, void* stream);
+/* Order-fixed reductions (bitwise reproducible steps).  Between lt_reduce_begin and lt_reduce_end the kernels that end in a sum over
+ * workgroups -- lt_layernorm_bwd(_fused) (dw, db, dbias_next), lt_layerscale_bwd (dgamma, dbias), lt_colsum_bf16, lt_assemble_tokens_bwd
+ * (mask-token gradient) -- store per-workgroup partial rows into `scratch` instead of issuing fp32 atomics; their destinations are
+ * complete only after the next lt_reduce_flush / lt_reduce_end, which adds each destination's partial rows in call order with a fixed
+ * summation tree (one launch for everything recorded).  Calls are recorded at enqueue time: flush on a stream that is ordered after
+ * every stream the producers ran on.  When `scratch` runs out the kernels fall back to atomics; lt_reduce_overflows counts that.
+ * (The loss scalars of lt_ce_fwd_bwd / lt_kl_fwd_bwd / lt_koleo_fwd_bwd, the KoLeo gradient and lt_colsum_f32 are order-fixed always.) */
+int lt_reduce_begin(float* scratch, int64_t floats);
+int lt_reduce_flush(void* stream);
+int lt_reduce_end(void* stream);
+int64_t lt_reduce_overflows(void);
 /* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow.  m is a double: 1 - m (~1e-6 at the end of the
  * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
 int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);

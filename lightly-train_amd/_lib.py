@@ -79,6 +79,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_ema_flat": [vp, vp, vp, i64, C.c_double, vp],
     "lt_lars_norms": [vp, vp, i64, vp, i32, vp, vp, vp],
     "lt_lars_flat": [vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, f32, f32, i32, vp, f32, vp],
+    "lt_reduce_begin": [vp, i64],
+    "lt_reduce_flush": [vp],
+    "lt_reduce_end": [vp],
     "lt_sgd_flat": [vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, f32, vp],
     "lt_im2col_nhwc_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lt_col2im_nhwc_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -125,6 +128,8 @@ def load() -> C.CDLL:
     lib.lt_attention_bwd_ws_floats.argtypes = [i32, i32, i32, i32]
     lib.lt_batchnorm_ws_floats.restype = C.c_int64
     lib.lt_batchnorm_ws_floats.argtypes = [i32]
+    lib.lt_reduce_overflows.restype = C.c_int64
+    lib.lt_reduce_overflows.argtypes = []
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, also loud
         fn.argtypes = argtypes

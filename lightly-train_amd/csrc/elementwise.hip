@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "lt_common.h"
+#include "reduce_ledger.h"
 
 namespace {
 
@@ -107,7 +108,7 @@ template <int V>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const uint8_t* __restrict__ masks,
                                                            bf16_t* __restrict__ dpatch, float* __restrict__ dcls, float* __restrict__ dpos,
                                                            float* __restrict__ dmask, float* __restrict__ dreg, int B, int n_p, int n_reg,
-                                                           int D) {
+                                                           int D, float* __restrict__ pmask) {
   __shared__ float red[2][4][64 * V];
   const int N = n_p + 1 + n_reg;
   const int t = blockIdx.x;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
       else if (i < 0) dreg[(long)(t - 1) * D + d + v] += s2;
       else {
         dpos[(long)(1 + i) * D + d + v] += s2;
-        if (masks && m2 != 0.f) atomicAdd(&dmask[d + v], m2);
+        if (pmask) pmask[(size_t)i * D + d + v] = m2;   // [n_p][D] partial rows (reduction ledger)
+        else if (masks && m2 != 0.f) atomicAdd(&dmask[d + v], m2);
       }
     }
   }
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const void* __restrict__ dyv, const float* __restrict__ dres,
                                                                 float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-                                                                float* __restrict__ partial, int rows, int D, LnbNext nx,
+                                                                float* __restrict__ partial, int prows, int rows, int D, LnbNext nx,
                                                                 const float* __restrict__ gamma_next, float* __restrict__ dbias_next) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -535,9 +537,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         const float4 b0 = red[1][0][lane], b1 = red[1][1][lane], b2 = red[1][2][lane], b3 = red[1][3][lane];
         const float4 sa = make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
         const float4 sb = make_float4(b0.x + b1.x + b2.x + b3.x, b0.y + b1.y + b2.y + b3.y, b0.z + b1.z + b2.z + b3.z, b0.w + b1.w + b2.w + b3.w);
-        if (partial) {  // per-block partial rows [gridDim.x][2][D], summed by ln_partial_reduce_kernel (deterministic, no atomics)
-          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2) * D + c) = sa;
-          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 1) * D + c) = sb;
+        if (partial) {  // per-block partial rows [gridDim.x][prows][D], summed in a fixed order later (deterministic, no atomics)
+          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * prows) * D + c) = sa;
+          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * prows + 1) * D + c) = sb;
         } else {
           atomicAdd(&dw[c], sa.x); atomicAdd(&dw[c + 1], sa.y); atomicAdd(&dw[c + 2], sa.z); atomicAdd(&dw[c + 3], sa.w);
           atomicAdd(&db[c], sb.x); atomicAdd(&db[c + 1], sb.y); atomicAdd(&db[c + 2], sb.z); atomicAdd(&db[c + 3], sb.w);
@@ -552,8 +554,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
           const float4 a0 = red[0][0][lane], a1 = red[0][1][lane], a2 = red[0][2][lane], a3 = red[0][3][lane];
-          atomicAdd(&dbias_next[c], a0.x + a1.x + a2.x + a3.x); atomicAdd(&dbias_next[c + 1], a0.y + a1.y + a2.y + a3.y);
-          atomicAdd(&dbias_next[c + 2], a0.z + a1.z + a2.z + a3.z); atomicAdd(&dbias_next[c + 3], a0.w + a1.w + a2.w + a3.w);
+          if (partial && prows == 3) {
+            *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 2) * D + c) =
+                make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
+          } else {
+            atomicAdd(&dbias_next[c], a0.x + a1.x + a2.x + a3.x); atomicAdd(&dbias_next[c + 1], a0.y + a1.y + a2.y + a3.y);
+            atomicAdd(&dbias_next[c + 2], a0.z + a1.z + a2.z + a3.z); atomicAdd(&dbias_next[c + 3], a0.w + a1.w + a2.w + a3.w);
+          }
         }
       }
     }
@@ -646,7 +653,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
                                                              const float* __restrict__ gamma, bf16_t* __restrict__ dy,
                                                              float* __restrict__ dgamma, float* __restrict__ dbias,
-                                                             const float* __restrict__ rowscale, float scale, int rows, int D) {
+                                                             const float* __restrict__ rowscale, float scale, int rows, int D,
+                                                             float* __restrict__ partial) {
   __shared__ float4 red[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cl) * 4;
@@ -678,8 +686,13 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
       a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
     }
-    if (gamma && y) { atomicAdd(&dgamma[c], a.x); atomicAdd(&dgamma[c + 1], a.y); atomicAdd(&dgamma[c + 2], a.z); atomicAdd(&dgamma[c + 3], a.w); }
-    if (dbias) { atomicAdd(&dbias[c], b.x); atomicAdd(&dbias[c + 1], b.y); atomicAdd(&dbias[c + 2], b.z); atomicAdd(&dbias[c + 3], b.w); }
+    if (partial) {   // [gridDim.y][2][D] partial rows for the ordered sum of the reduction ledger
+      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * 2) * D + c) = a;
+      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * 2 + 1) * D + c) = b;
+    } else {
+      if (gamma && y) { atomicAdd(&dgamma[c], a.x); atomicAdd(&dgamma[c + 1], a.y); atomicAdd(&dgamma[c + 2], a.z); atomicAdd(&dgamma[c + 3], a.w); }
+      if (dbias) { atomicAdd(&dbias[c], b.x); atomicAdd(&dbias[c + 1], b.y); atomicAdd(&dbias[c + 2], b.z); atomicAdd(&dbias[c + 3], b.w); }
+    }
   }
 }
 // scalar fallback for D % 4 != 0
@@ -709,7 +722,8 @@ __global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float*
 }
 
 // column sums: bf16 rows read as 16-byte vectors (8 columns per thread); block = 32 column-chunks x 8 row-lanes
-__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int N) {
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int N,
+                                                              float* __restrict__ partial) {
   __shared__ float red[8][32][9];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cl) * 8;
@@ -735,7 +749,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
     float s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s2 += red[i][cc][j];
-    atomicAdd(&out[col], s2);
+    if (partial) partial[(size_t)blockIdx.y * N + col] = s2;   // ordered sum at the reduction ledger's next flush
+    else atomicAdd(&out[col], s2);
   }
 }
 template <typename T>
@@ -757,7 +772,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 // fp32 column sums, 16 bytes per lane and four independent row loads in flight per thread (the teacher-logit center sums over
 // [rows, 65536]: the scalar form above ran at 3.7 TB/s)
-__global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int N) {
+__global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int N,
+                                                             float* __restrict__ partial) {
   __shared__ float4 red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cl) * 4;
@@ -784,9 +800,22 @@ __global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __rest
   __syncthreads();
   if (rl == 0 && c < N) {
     const float4 s0 = red[0][cl], s1 = red[1][cl], s2 = red[2][cl], s3 = red[3][cl];
-    atomicAdd(&out[c], s0.x + s1.x + s2.x + s3.x); atomicAdd(&out[c + 1], s0.y + s1.y + s2.y + s3.y);
-    atomicAdd(&out[c + 2], s0.z + s1.z + s2.z + s3.z); atomicAdd(&out[c + 3], s0.w + s1.w + s2.w + s3.w);
+    const float4 t = make_float4(s0.x + s1.x + s2.x + s3.x, s0.y + s1.y + s2.y + s3.y, s0.z + s1.z + s2.z + s3.z, s0.w + s1.w + s2.w + s3.w);
+    if (partial) *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + c) = t;   // row slabs added in order by colsum_slabs_kernel
+    else { float* o = out + c; o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }       // a single row slab: plain add
   }
+}
+// out[c] += partial[0][c] + partial[1][c] + ...  (fixed order: the sums feed the loss centers, which must not depend on scheduling)
+__global__ __launch_bounds__(256) void colsum_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  float4 a = *reinterpret_cast<const float4*>(partial + c);
+  for (int s = 1; s < slabs; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * N + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  float* o = out + c;
+  o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
 }
 
 // ------------------------------------------------------------------------------------ gather / scatter / cast
@@ -939,12 +968,14 @@ extern "C" int lt_assemble_tokens_bwd(const float* dx, const uint8_t* masks, voi
                                       float* dmask_token, float* dreg, int B, int n_p, int n_reg, int D, void* stream) {
   LT_CHECK_ARG(dx && dpatch_bf16 && dcls && dpos && (!masks || dmask_token) && n_reg >= 0 && (n_reg == 0 || dreg),
                "lt_assemble_tokens_bwd: bad arguments");
+  float* pmask = (masks && lt_ledger::active()) ? lt_ledger::reserve((size_t)n_p * D) : nullptr;
   if (D % 4 == 0 && (((uintptr_t)dx | (uintptr_t)dpatch_bf16) & 15) == 0)
     hipLaunchKernelGGL(assemble_bwd_kernel<4>, dim3(n_p + 1 + n_reg, lt_cdiv(D, 256)), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls,
-                       dpos, dmask_token, dreg, B, n_p, n_reg, D);
+                       dpos, dmask_token, dreg, B, n_p, n_reg, D, pmask);
   else
     hipLaunchKernelGGL(assemble_bwd_kernel<1>, dim3(n_p + 1 + n_reg, lt_cdiv(D, 64)), dim3(256), 0, ST, dx, masks, (bf16_t*)dpatch_bf16, dcls,
-                       dpos, dmask_token, dreg, B, n_p, n_reg, D);
+                       dpos, dmask_token, dreg, B, n_p, n_reg, D, pmask);
+  if (pmask) lt_ledger::record(dmask_token, pmask, n_p, (long)D, D);
   LT_CHECK_LAUNCH("lt_assemble_tokens_bwd");
 }
 extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
@@ -978,24 +1009,34 @@ extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const floa
   if (rows == 0) return LT_OK;
   static const int grid_cap = [] { const char* e = getenv("LT_LN_BWD_GRID"); return e ? atoi(e) : 256; }();  // one 4-wave block per CU: best measured (115 us vs 133 at 512)
   int grid = min(lt_cdiv(rows, 4), grid_cap);
-  const bool vec_ok = D % 4 == 0;
   float* partial = nullptr;
-  if (vec_ok && ws && ws_floats >= (int64_t)2 * D * 64) {  // workspace given: no same-address atomics
-    grid = (int)std::min<int64_t>(grid, ws_floats / (2 * D));
-    partial = ws;
-  }
+  int prows = 2;
+  bool ledger = false;
   const bool vec = D % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
                    (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)w % 16 == 0);
   LT_CHECK_ARG(!dnext_bf16 || (vec && (uintptr_t)dnext_bf16 % 8 == 0 && (!gamma_next || (uintptr_t)gamma_next % 16 == 0)),
                "lt_layernorm_bwd_fused: the fused next-branch output needs D %% 4 == 0 and 16-byte aligned rows");
-#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, rows, D, nx, gamma_next, dbias_next)
+  if (vec && ws && ws_floats >= (int64_t)2 * D * 64) {  // workspace given: no same-address atomics
+    grid = (int)std::min<int64_t>(grid, ws_floats / (2 * D));
+    partial = ws;
+  } else if (vec && lt_ledger::active()) {               // deferred: partial rows now, one ordered sum at the next lt_reduce_flush
+    prows = (dnext_bf16 && dbias_next) ? 3 : 2;
+    partial = lt_ledger::reserve((size_t)grid * prows * D);
+    ledger = partial != nullptr;
+    if (!ledger) prows = 2;
+  }
+#define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, prows, rows, D, nx, gamma_next, dbias_next)
   if (vec) {
     const int nv = (D + 255) / 256;
     if (dy_is_f32) { if (nv <= 2) LT_LNB(true, 2); else if (nv <= 3) LT_LNB(true, 3); else if (nv <= 4) LT_LNB(true, 4); else LT_LNB(true, 8); }
     else { if (nv <= 2) LT_LNB(false, 2); else if (nv <= 3) LT_LNB(false, 3); else if (nv <= 4) LT_LNB(false, 4); else LT_LNB(false, 8); }
   }
 #undef LT_LNB
-  if (vec && partial)
+  if (vec && ledger) {
+    lt_ledger::record(dw, partial, grid, (long)prows * D, D);
+    lt_ledger::record(db, partial + D, grid, (long)prows * D, D);
+    if (prows == 3) lt_ledger::record(dbias_next, partial + 2 * D, grid, (long)prows * D, D);
+  } else if (vec && partial)
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(lt_cdiv(D, 64), 2), dim3(256), 0, ST, partial, dw, db, grid, D);
   if (vec) { LT_CHECK_LAUNCH("lt_layernorm_bwd"); }
   if (dy_is_f32)
@@ -1010,9 +1051,16 @@ extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const fl
   if (rows == 0) return LT_OK;
   if (D % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dy_bf16 % 8 == 0 && (!y_bf16 || (uintptr_t)y_bf16 % 8 == 0) &&
       (!gamma || (uintptr_t)gamma % 16 == 0)) {
-    dim3 grid(lt_cdiv(D, 128), min(lt_cdiv(rows, 8), 256));
+    const bool want = (gamma && y_bf16) || dbias;
+    const bool defer = want && lt_ledger::active();
+    dim3 grid(lt_cdiv(D, 128), min(lt_cdiv(rows, 8), defer ? 64 : 256));
+    float* partial = defer ? lt_ledger::reserve((size_t)grid.y * 2 * D) : nullptr;
     hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16, dgamma,
-                       dbias, rowscale, scale, rows, D);
+                       dbias, rowscale, scale, rows, D, partial);
+    if (partial) {
+      if (gamma && y_bf16) lt_ledger::record(dgamma, partial, (int)grid.y, 2L * D, D);
+      if (dbias) lt_ledger::record(dbias, partial + D, (int)grid.y, 2L * D, D);
+    }
   } else {
     dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
     hipLaunchKernelGGL(layerscale_bwd_scalar_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
@@ -1048,8 +1096,11 @@ extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* 
   LT_CHECK_ARG(x && out, "lt_colsum_bf16: null pointer");
   if (rows == 0) return LT_OK;
   if (N % 8 == 0 && (uintptr_t)x % 16 == 0) {
-    dim3 grid(lt_cdiv(N, 256), min(lt_cdiv(rows, 8), 256));
-    hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
+    const bool defer = lt_ledger::active();
+    dim3 grid(lt_cdiv(N, 256), min(lt_cdiv(rows, 8), defer ? 64 : 256));
+    float* partial = defer ? lt_ledger::reserve((size_t)grid.y * N) : nullptr;
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N, partial);
+    if (partial) lt_ledger::record(out, partial, (int)grid.y, (long)N, N);
   } else {
     dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N);
@@ -1066,7 +1117,13 @@ extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int ac
   if (N % 4 == 0 && ((uintptr_t)x & 15) == 0) {
     const int gx = lt_cdiv(N / 4, 64);
     dim3 grid(gx, max(1, min(lt_cdiv(rows, 16), lt_cdiv(2048, gx))));   // ~2048 blocks, >= 4 rows per thread where possible
-    hipLaunchKernelGGL(colsum_f32_vec_kernel, grid, dim3(256), 0, ST, x, out, rows, N);
+    float* partial = nullptr;
+    if (grid.y > 1) {
+      partial = lt_scratch_ring((size_t)grid.y * N);
+      if (!partial) { lt_set_error("lt_colsum_f32: scratch allocation failed"); return LT_ERR_HIP; }
+    }
+    hipLaunchKernelGGL(colsum_f32_vec_kernel, grid, dim3(256), 0, ST, x, out, rows, N, partial);
+    if (partial) hipLaunchKernelGGL(colsum_slabs_kernel, dim3(lt_cdiv(N, 1024)), dim3(256), 0, ST, partial, out, (int)grid.y, N);
   } else {
     dim3 grid(lt_cdiv(N, 64), min(lt_cdiv(rows, 4), 128));
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, x, out, rows, N);

@@ -82,10 +82,38 @@ __global__ __launch_bounds__(1024) void softmax_center_reg_kernel(const float* _
   }
 }
 
+// Per-row loss terms are stored, then added by ONE workgroup in a fixed order (thread t takes rows t, t + 256, ...; LDS tree): the loss
+// scalars are bitwise reproducible (one atomicAdd per row was not).  Up to 8 slots.
+constexpr int LOSS_SLOTS = 8;
+__global__ __launch_bounds__(256) void rowloss_sum_kernel(const float* __restrict__ terms, const int32_t* __restrict__ slot, int rows,
+                                                          float* __restrict__ loss) {
+  __shared__ float red[LOSS_SLOTS][256];
+  float acc[LOSS_SLOTS];
+#pragma unroll
+  for (int k = 0; k < LOSS_SLOTS; ++k) acc[k] = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int sl = slot ? slot[r] : 0;
+    const float v = terms[r];
+#pragma unroll
+    for (int k = 0; k < LOSS_SLOTS; ++k) acc[k] += (sl == k) ? v : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < LOSS_SLOTS; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < LOSS_SLOTS; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < LOSS_SLOTS && red[threadIdx.x][0] != 0.f) loss[threadIdx.x] += red[threadIdx.x][0];
+}
+
 __global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ s, const float* __restrict__ teacher,
                                                       const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
                                                       const float* __restrict__ row_weight, const int32_t* __restrict__ slot,
-                                                      float scale, float inv_temp, float* __restrict__ loss,
+                                                      float scale, float inv_temp, float* __restrict__ terms,
                                                       bf16_t* __restrict__ dlogits, int K) {
   __shared__ float red[32];
   const long row = blockIdx.x;
@@ -114,7 +142,7 @@ __global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ 
   tsum = block_sum(tsum, red);
   const float lse = a.m + __logf(a.s);
   const float coef = scale * (row_weight ? row_weight[row] : 1.f);
-  if (threadIdx.x == 0) atomicAdd(loss + (slot ? slot[row] : 0), -coef * (dot - lse * tsum));
+  if (threadIdx.x == 0) terms[row] = -coef * (dot - lse * tsum);
   if (dlogits) {
     const float c2 = coef * inv_temp;
 #pragma unroll
@@ -141,7 +169,7 @@ __global__ void center_ema_kernel(float* center, const float* colsum, float scal
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, const float* __restrict__ teacher,
                                                  const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
                                                  const float* __restrict__ row_weight, const int32_t* __restrict__ slot,
-                                                 float scale, float inv_temp, float* __restrict__ loss,
+                                                 float scale, float inv_temp, float* __restrict__ terms,
                                                  bf16_t* __restrict__ dlogits, int K) {
   __shared__ float red[16];
   const long row = blockIdx.x;
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, co
   tsum = block_sum(tsum, red);
   const float lse = a.m + __logf(a.s);
   const float coef = scale * (row_weight ? row_weight[row] : 1.f);
-  if (threadIdx.x == 0) atomicAdd(loss + (slot ? slot[row] : 0), -coef * (dot - lse * tsum));
+  if (threadIdx.x == 0) terms[row] = -coef * (dot - lse * tsum);
   if (dlogits) {
     const float c2 = coef * inv_temp;
     for (int k = threadIdx.x; k < K; k += 256) {
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ s, co
 // (DistillationV3Loss, LT/_methods/distillationv3/distillationv3_loss.py:60-115: KLDivLoss(batchmean) of a log_softmax
 // student against a softmax teacher).  Rows are `ld` floats apart (>= K; the similarity matrices are padded to 8 columns).
 __global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ s, const float* __restrict__ t, int ld, float inv_temp,
-                                                 float coef, float* __restrict__ loss, bf16_t* __restrict__ dlogits, int ldd, int K) {
+                                                 float coef, float* __restrict__ terms, bf16_t* __restrict__ dlogits, int ldd, int K) {
   __shared__ float red[16];
   const long row = blockIdx.x;
   const float* zs = s + row * ld;
@@ -196,13 +224,16 @@ __global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ s, co
     if (dlogits) dlogits[row * ldd + k] = f2bf(coef * inv_temp * (__expf(ls) - tk));
   }
   kl = block_sum(kl, red);
-  if (threadIdx.x == 0) atomicAdd(loss, coef * kl);
+  if (threadIdx.x == 0) terms[row] = coef * kl;
 }
 extern "C" int lt_kl_fwd_bwd(const float* s_logits, const float* t_logits, int ld, float inv_temp, float coef, float* loss,
                              void* dlogits_bf16, int ldd, int rows, int K, void* stream) {
   LT_CHECK_ARG(s_logits && t_logits && loss && K > 0 && ld >= K && (!dlogits_bf16 || ldd >= K), "lt_kl_fwd_bwd: bad arguments");
   if (rows == 0) return LT_OK;
-  hipLaunchKernelGGL(kl_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s_logits, t_logits, ld, inv_temp, coef, loss, (bf16_t*)dlogits_bf16, ldd, K);
+  float* terms = lt_scratch_ring((size_t)rows);
+  if (!terms) { lt_set_error("lt_kl_fwd_bwd: scratch allocation failed"); return LT_ERR_HIP; }
+  hipLaunchKernelGGL(kl_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s_logits, t_logits, ld, inv_temp, coef, terms, (bf16_t*)dlogits_bf16, ldd, K);
+  hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, terms, (const int32_t*)nullptr, rows, loss);
   LT_CHECK_LAUNCH("lt_kl_fwd_bwd");
 }
 
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(256) void koleo_normalize_kernel(const float* __res
 }
 // one block per row i: nearest neighbour by max cosine (diag excluded), distance, loss, per-row coefficient
 __global__ __launch_bounds__(256) void koleo_nn_kernel(const float* __restrict__ xn, int32_t* __restrict__ nn, float* __restrict__ coef,
-                                                       float* __restrict__ loss, int n, int D, float eps, float weight) {
+                                                       float* __restrict__ term, int n, int D, float eps, float weight) {
   __shared__ float sval[256];
   __shared__ int sidx[256];
   __shared__ float red[16];
@@ -307,18 +338,29 @@ __global__ __launch_bounds__(256) void koleo_nn_kernel(const float* __restrict__
     nn[i] = j;
     // L = -(1/n) sum log(dist + eps);  dL/du = -(1/n) * 1/(dist+eps) * u/dist
     coef[i] = -weight / ((float)n * (dist + eps) * fmaxf(dist, 1e-30f));
-    atomicAdd(loss, -(weight == 0.f ? 1.f : weight) * __logf(dist + eps) / (float)n);   // weight 0: report the unweighted term
+    term[i] = -(weight == 0.f ? 1.f : weight) * __logf(dist + eps) / (float)n;   // weight 0: report the unweighted term
   }
 }
-// dxn[i] += c_i*u_i ; dxn[nn(i)] -= c_i*u_i  (atomics: several i may share a neighbour)
+// the n row terms added in row order by one thread (n = rows of one crop chunk: tens to a few hundred)
+__global__ void koleo_loss_kernel(const float* __restrict__ term, int n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += term[i];
+    *loss += s;
+  }
+}
+// dxn[r] = c_r u_r - sum_{i: nn(i) = r} c_i u_i, u_i = xn_i - xn_nn(i) + eps.  One block per row r gathers its contributions in
+// ascending i (several rows may share a neighbour: scattering them needed atomics and left the order to chance).
 __global__ __launch_bounds__(256) void koleo_dxn_kernel(const float* __restrict__ xn, const int32_t* __restrict__ nn,
-                                                        const float* __restrict__ coef, float* __restrict__ dxn, int D, float eps) {
-  const int i = blockIdx.x, j = nn[i];
-  const float c = coef[i];
+                                                        const float* __restrict__ coef, float* __restrict__ dxn, int n, int D, float eps) {
+  const int r = blockIdx.x, j = nn[r];
+  const float c = coef[r];
   for (int d = threadIdx.x; d < D; d += 256) {
-    const float g = c * (xn[(long)i * D + d] - xn[(long)j * D + d] + eps);
-    atomicAdd(&dxn[(long)i * D + d], g);
-    atomicAdd(&dxn[(long)j * D + d], -g);
+    const float xr = xn[(long)r * D + d];
+    float acc = c * (xr - xn[(long)j * D + d] + eps);
+    for (int i = 0; i < n; ++i)       // nn / coef: n small, broadcast reads out of L1
+      if (nn[i] == r) acc -= coef[i] * (xn[(long)i * D + d] - xr + eps);
+    dxn[(long)r * D + d] = acc;
   }
 }
 // through x/max(||x||,eps): dx += (dxn - xn*(xn.dxn)) * inv
@@ -379,6 +421,8 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, c
 extern "C" int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream) {
   LT_CHECK_ARG(logits && probs && K > 0, "lt_softmax_center: bad arguments");
   if (rows == 0) return LT_OK;
+  float* terms = lt_scratch_ring((size_t)rows);
+  if (!terms) { lt_set_error("lt_ce_fwd_bwd: scratch allocation failed"); return LT_ERR_HIP; }
   static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
   if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)probs % 16 == 0) &&
       (!center || (uintptr_t)center % 16 == 0))
@@ -397,14 +441,17 @@ extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t
                              void* stream) {
   LT_CHECK_ARG(s && teacher && ta && loss && K > 0, "lt_ce_fwd_bwd: bad arguments");
   if (rows == 0) return LT_OK;
+  float* terms = lt_scratch_ring((size_t)rows);
+  if (!terms) { lt_set_error("lt_ce_fwd_bwd: scratch allocation failed"); return LT_ERR_HIP; }
   static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
   if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)s % 16 == 0) && ((uintptr_t)teacher % 16 == 0) &&
       (!dlogits_bf16 || (uintptr_t)dlogits_bf16 % 8 == 0))
-    hipLaunchKernelGGL(ce_reg_kernel, dim3(rows), dim3(1024), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
+    hipLaunchKernelGGL(ce_reg_kernel, dim3(rows), dim3(1024), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, terms,
                        (bf16_t*)dlogits_bf16, K);
   else
-    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, loss,
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, ST, s, teacher, ta, tb, row_weight, slot, scale, inv_temp, terms,
                        (bf16_t*)dlogits_bf16, K);
+  hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, ST, terms, slot, rows, loss);
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
 }
 extern "C" int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream) {
@@ -426,14 +473,12 @@ extern "C" int lt_koleo_fwd_bwd(const float* x, int ld, float* loss, float* dx, 
   float* xn = ws;
   float* inv = ws + (size_t)n * D;
   float* coef = inv + n;
-  // dxn is accumulated in place of a second buffer: reuse dx? no -- separate scratch after coef
-  float* dxn = coef + n;
-  hipError_t e = hipMemsetAsync(dxn, 0, sizeof(float) * (size_t)n * D, ST);
-  if (e != hipSuccess) { lt_set_error("lt_koleo_fwd_bwd: memset failed"); return LT_ERR_HIP; }
+  float* dxn = coef + n;    // [n, D]; its first n floats hold the per-row loss terms until koleo_loss_kernel has added them
   hipLaunchKernelGGL(koleo_normalize_kernel, dim3(n), dim3(256), 0, ST, x, ld, xn, inv, D, eps);
-  hipLaunchKernelGGL(koleo_nn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, loss, n, D, eps, weight);
+  hipLaunchKernelGGL(koleo_nn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, n, D, eps, weight);
+  hipLaunchKernelGGL(koleo_loss_kernel, dim3(1), dim3(64), 0, ST, dxn, n, loss);
   if (weight == 0.f) { LT_CHECK_LAUNCH("lt_koleo_fwd_bwd"); }   // value only (the reference logs the term even when it is not trained on)
-  hipLaunchKernelGGL(koleo_dxn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, D, eps);
+  hipLaunchKernelGGL(koleo_dxn_kernel, dim3(n), dim3(256), 0, ST, xn, nn, coef, dxn, n, D, eps);
   hipLaunchKernelGGL(koleo_dx_kernel, dim3(n), dim3(256), 0, ST, xn, dxn, inv, dx, ld_dx, D);
   LT_CHECK_LAUNCH("lt_koleo_fwd_bwd");
 }

@@ -204,4 +204,8 @@ __device__ __forceinline__ void mul_gelu_grad2(float& a, float& b, float pa, flo
 #endif
 }
 
+// A region of `floats` device floats out of a ring of 8 library-owned buffers (reduce.hip): scratch for the ordered second stage of a
+// reduction, valid until 7 further calls have been made (kernels of one step never hold more than a few at a time).  nullptr on failure.
+float* lt_scratch_ring(size_t floats);
+
 static inline int lt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

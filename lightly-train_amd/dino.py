@@ -250,7 +250,7 @@ class DINO(DINOv2):
             sl = self.s_vit.forward(ws, "sl", lv, None, save=True, drop_plan=plan_l, checkpoint=self.activation_checkpointing, last_mlp_rows=rows_l)
         Rl = n_local * B
         Rs = 2 * B + Rl
-        s_in = ws.get("s.head_in", (Rs, D), torch.bfloat16)
+        s_in = ws.get("s.head_in", (Rs, D), torch.bfloat16, pad_rows=64)
         ops.gather_rows(sg["xn"].view(-1, D), D, ix["s_cls"], 2 * B, D, out_bf16=s_in[:2 * B])
         if sl is not None:
             ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B:Rs])
@@ -266,10 +266,11 @@ class DINO(DINOv2):
         slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32)])
         ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
         main.wait_event(teacher_done)
-        dlogits = ws.get("s.dlogits", (Rs, K), torch.bfloat16)
+        dlogits = ws.get("s.dlogits", (Rs, K), torch.bfloat16, pad_rows=64)
         ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, 1.0 / a.student_temp, self._loss_slots, dlogits, Rs, K, slot=slot)
 
         # ---------------- backward
+        self._reduce_begin()
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         if a.norm_last_layer:

@@ -27,7 +27,7 @@ from .masking import MaskingGenerator, MaskProducer, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, make_drop_plan, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, make_drop_plan, padded_rows, split_k_plan, vit_param_shapes
 
 
 @dataclass
@@ -243,6 +243,7 @@ class HeadEngine:
     def forward(self, ws: Workspace, tag: str, x: Tensor, R: int, cap: int, save: bool,
                 segs: Optional[Sequence[Tuple[int, int]]] = None, bn_training: bool = True) -> Dict[str, Any]:
         hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
+        cap = (cap + 63) // 64 * 64   # whole 64-row tiles for the weight-gradient contractions over the rows
         l0, l1, l2 = self.lin
         bnc: List[Dict[str, Tensor]] = []
         h1p = h2p = None
@@ -283,20 +284,22 @@ class HeadEngine:
             bit pattern) so that the contraction runs in whole K-tiles on the 256-row slab kernel with its deterministic split-K
             reduction -- ragged, these four GEMMs fell to the 128-row kernel and fp32 atomics (1.3 ms per step at 0.3 PF/s)."""
             kpad = (R + 63) // 64 * 64
-            if self.pad_wgrad_rows and kpad != R and kpad <= dy.shape[0] and kpad <= xin.shape[0]:
-                dy[R:kpad].zero_()
-                xin[R:kpad].zero_()
+            dyp, xp = padded_rows(dy, R), padded_rows(xin, R)
+            if self.pad_wgrad_rows and kpad != R and dyp is not None and xp is not None:
+                dyp[R:kpad].zero_()
+                xp[R:kpad].zero_()
+                dy, xin = dyp, xp
             else:
                 kpad = R
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
             ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                     split_k=_split_k(tiles, kpad), lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None)
+                     lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
 
         wgrad(dlogits, c["zn"], self.dwn, K, bn)
         dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
         # [R, bn] output = only ~35 tiles but a 65 536-long contraction: split-K into slabs, accumulate into zeros
         dzn.zero_()
-        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=2, workspace=slab)
+        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, workspace=slab, **split_k_plan(R, bn, K, False, 2))
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         l0, l1, l2 = self.lin
@@ -437,6 +440,9 @@ class DINOv2:
         self._static_idx: Dict[Tuple[int, ...], Dict[str, Tensor]] = {}
         self.last_grad_norm: Optional[Tensor] = None
         self.overlap_streams = True
+        # order-fixed reductions (csrc/reduce.hip): LayerNorm / bias / LayerScale / mask-token gradients without fp32 atomics, so that a
+        # step is bitwise reproducible; LT_DETERMINISTIC=0 goes back to atomics
+        self.deterministic = os.environ.get("LT_DETERMINISTIC", "1") != "0"
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
         # the last block's MLP branch, forward and backward, only at the token rows the losses read (cls + masked patches): vit.forward
         self.sparse_last_mlp = os.environ.get("LT_SPARSE_LAST_MLP", "1") != "0"
@@ -568,6 +574,17 @@ class DINOv2:
             self._static_idx[key] = {k: v.to(self.device) for k, v in d.items()}
         return self._static_idx[key]
 
+    def _reduce_begin(self) -> None:
+        """Open the reduction ledger for this step's backward (before the projection-head backward); `_backward_backbone` closes it."""
+        if not self.deterministic or self.device.type != "cuda":
+            return
+        cfg, a = self.cfg, self.method_args
+        D = cfg.embed_dim
+        H1 = int(D * cfg.mlp_ratio) * (2 if cfg.swiglu else 1)
+        per_pass = 2 * 256 * 3 * D + 64 * (3 * D + D + H1 + D) + 4 * 64 * D      # LayerNorm x 2, four bias sums, LayerScale x 2 of one block
+        floats = 2 * (cfg.depth * per_pass + 256 * 3 * D + 2 * 1024 * D) + 4 * 64 * (2 * a.hidden_dim + 2 * D + 4096)
+        ops.reduce_begin(self.ws.get("reduce.scratch", (int(floats * 1.25) // 4 * 4,), torch.float32))
+
     def _backward_backbone(self, sg: Dict[str, Any], dxn_g: Tensor, sl: Optional[Dict[str, Any]], dxn_l: Optional[Tensor]) -> None:
         """Backward of the student ViT from the gradients at its final-norm output: global crops (`sg`) and local crops (`sl`), with the
         early gradient all-reduces of data-parallel runs.  The projection-head gradients are final when this is called."""
@@ -587,11 +604,16 @@ class DINOv2:
                 if st is not None:
                     rs.wait_event(st.record_event())
             with torch.cuda.stream(rs):
+                if det:
+                    ops.reduce_flush()    # every producer enqueued so far is on a stream `rs` has just waited for
                 self.s_vit.finish_layerscale_grads(blocks=[i], last_call=False)
                 sync.start(*self._block_spans[i])
             done_blocks.append(i)
 
+        det = self.deterministic and self.device.type == "cuda"
         if sync is not None:
+            if det:
+                ops.reduce_flush()         # the head's bias sums
             sync.start(*self._head_span)   # the prototype heads are final: their all-reduce runs under the whole ViT backward
         if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
             # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
@@ -625,6 +647,8 @@ class DINOv2:
             main.wait_stream(side)
         if sync is not None:
             main.wait_stream(self.reduce_stream)
+        if det:
+            ops.reduce_end()               # one ordered sum for everything still recorded; back to immediate reductions
         self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
 
     # ------------------------------------------------------------------ the step
@@ -758,19 +782,22 @@ class DINOv2:
         Rl = n_local * B
         Rd = 2 * B + Rl                      # rows of the DINO head: global cls + local cls
         Rs, cap_s = Rd + M, Rd + cap_M       # student row layout [2B cls | Rl local cls | M masked patches]
-        s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16)
+        s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16, pad_rows=64)
         sxn = sg["xn"].view(-1, D)
         ops.gather_rows(sxn, D, ix["s_cls"], 2 * B, D, out_bf16=s_in[:2 * B])
         if sl is not None:
             ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B:Rd])
-        ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in[Rd:Rs])
+        # (two heads: the patch rows get a buffer of their own -- each head's weight-gradient GEMMs zero the rows up to the next multiple
+        # of 64 behind their input, which must not be the other head's rows)
+        s_in_i = ws.get("s.head_in_i", (cap_M, D), torch.bfloat16, pad_rows=64) if sep else s_in[Rd:Rs]
+        ops.gather_rows(sxn, D, patch_rows, M, D, out_bf16=s_in_i[:M])
         if not sep:
             # BatchNorm segments in the reference's call order: global cls, masked patches (dinov2.py:487-503), local cls (:515)
             sh = self.s_head.forward(ws, "sh", s_in, Rs, cap_s, save=True, segs=[(0, 2 * B), (Rd, M), (2 * B, Rl)])
             shi = None
         else:
             sh = self.s_head.forward(ws, "sh", s_in, Rd, Rd, save=True, segs=[(0, 2 * B), (2 * B, Rl)])
-            shi = self.s_ihead.forward(ws, "shi", s_in[Rd:], M, cap_M, save=True)
+            shi = self.s_ihead.forward(ws, "shi", s_in_i, M, cap_M, save=True)
 
         # ---------------- losses : dinov2.py:335-387, dinov2_loss.py:117-133,246-268
         r2 = torch.arange(2 * B, dtype=torch.int32)
@@ -784,11 +811,11 @@ class DINOv2:
         main.wait_event(teacher_done)
         inv_ts = 1.0 / a.student_temp
         if not sep:
-            dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16)
+            dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16, pad_rows=64)
             ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rs, K, slot=slot)
         else:
-            dlogits = ws.get("s.dlogits", (Rd, K), torch.bfloat16)
-            dlogits_i = ws.get("s.dlogits_i", (cap_M, K), torch.bfloat16)
+            dlogits = ws.get("s.dlogits", (Rd, K), torch.bfloat16, pad_rows=64)
+            dlogits_i = ws.get("s.dlogits_i", (cap_M, K), torch.bfloat16, pad_rows=64)
             ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rd, K, slot=slot)
             ops.ce_fwd_bwd(shi["logits"], t_probs, ta[Rd:], tb[Rd:], coef[Rd:], 1.0, inv_ts, self._loss_slots, dlogits_i, M, K, slot=slot[Rd:])
 
@@ -802,6 +829,7 @@ class DINOv2:
                 ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
 
         # ---------------- backward
+        self._reduce_begin()
         dx_head = self.s_head.backward(ws, sh, dlogits)
         self.s_head.finish_weightnorm_grad()
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)

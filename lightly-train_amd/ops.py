@@ -401,6 +401,25 @@ def lars_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tens
                            dampening, int(nesterov), trust, eps, int(first_step), _p(sumsq_t), max_norm, _stream()), "lt_lars_flat")
 
 
+def reduce_begin(scratch: Tensor) -> None:
+    """Start deferring the cross-workgroup sums of the backward kernels into `scratch` (lt_reduce_begin: order-fixed reductions)."""
+    _chk(scratch, torch.float32, "reduce_begin.scratch")
+    check(_lib.load().lt_reduce_begin(_p(scratch), scratch.numel()), "lt_reduce_begin")
+
+
+def reduce_flush() -> None:
+    """Add everything recorded since the last flush, on the current stream (which must be ordered after the producers' streams)."""
+    check(_lib.load().lt_reduce_flush(_stream()), "lt_reduce_flush")
+
+
+def reduce_end() -> None:
+    check(_lib.load().lt_reduce_end(_stream()), "lt_reduce_end")
+
+
+def reduce_overflows() -> int:
+    return int(_lib.load().lt_reduce_overflows())
+
+
 def sgd_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tensor], seg_of_chunk: Tensor, seg_lr: Tensor, seg_wd_on: Tensor,
              lr_factor: float, wd: float, momentum: float, dampening: float, nesterov: bool, first_step: bool, sumsq_t: Optional[Tensor],
              max_norm: float) -> None:

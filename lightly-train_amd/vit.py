@@ -162,16 +162,49 @@ class Workspace:
         self.device = device
         self.bufs: Dict[str, Tensor] = {}
 
-    def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype, zero: bool = False) -> Tensor:
-        """`zero`: zero-fill when the buffer is (re)allocated (padding that kernels never write must stay finite)."""
+    def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype, zero: bool = False, pad_rows: int = 0) -> Tensor:
+        """`zero`: zero-fill when the buffer is (re)allocated (padding that kernels never write must stay finite).
+        `pad_rows`: allocate the first dimension rounded up to this multiple and return the leading `shape[0]` rows -- operands of the
+        weight-gradient GEMMs, whose contraction over rows runs in whole 64-row tiles (`padded_rows`)."""
+        full = tuple(shape)
+        if pad_rows:
+            full = (-(-shape[0] // pad_rows) * pad_rows,) + tuple(shape[1:])
         t = self.bufs.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        if t is None or tuple(t.shape) != full or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(full, dtype=dtype, device=self.device)
             self.bufs[name] = t
-        return t
+        return t[:shape[0]] if pad_rows else t
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+def padded_rows(t: Tensor, rows: int, multiple: int = 64) -> Optional[Tensor]:
+    """`t` (row-major [>= rows, C], possibly the leading slice of a larger allocation) seen with its row count rounded up to `multiple`,
+    or None when the allocation ends before that.  A weight-gradient GEMM contracts over the rows: with the <= 63 pad rows zeroed in both
+    operands it runs in whole K-tiles on the 256-row slab kernel (deterministic split-K) instead of the 128-row kernel's fp32 atomics."""
+    kpad = -(-rows // multiple) * multiple
+    if kpad == rows:
+        return t[:rows]
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) != t.shape[1]:
+        return None
+    avail = (t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()) // t.shape[1]
+    return t.as_strided((kpad, t.shape[1]), (t.shape[1], 1)) if avail >= kpad else None
+
+
+DETERMINISTIC_SPLIT_K = os.environ.get("LT_DETERMINISTIC", "1") != "0"
+
+
+def split_k_plan(M: int, N: int, K: int, trans_a: bool, split: int) -> Dict[str, int]:
+    """`split_k` / `force_kernel` arguments of an accumulating GEMM with a split contraction.  The 256-row kernel reduces its K-slices
+    through fp32 slabs in a fixed order; the dispatcher sends short contractions (< 4096 rows) to the 128-row kernel, whose slices meet in
+    fp32 atomics -- arrival order, last bits differ from run to run.  For reproducible steps (LT_DETERMINISTIC, default on) every split
+    contraction the slab kernel can take is pinned to it (force_kernel 8), and the rest run unsplit."""
+    if split <= 1 or not DETERMINISTIC_SPLIT_K:
+        return dict(split_k=split)
+    if K % 64 == 0 and N % 8 == 0 and N >= 128 and M >= 64 and (not trans_a or M % 8 == 0):
+        return dict(split_k=split, force_kernel=8)
+    return dict(split_k=1)
 
 
 def _split_k(tiles: int, k: int, slots: int = 512) -> int:
@@ -399,12 +432,12 @@ class ViTEngine:
             # ---------------- attention branch
             a = branch_setup(e1, s, "a", x)
             R, nb = a["rows"], a["nb"]
-            ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16)
+            ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16, pad_rows=64)
             a["mean"], a["rstd"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
             ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"], eps=cfg.ln_eps)
             qkv = ws.get(s + "qkv", (T, 3 * D), torch.bfloat16)
             ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=R, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
-            att = ws.get(s + "att", (T, D), torch.bfloat16)
+            att = ws.get(s + "att", (T, D), torch.bfloat16, pad_rows=64)
             lse = ws.get(s + "lse", (B, Hh, N), torch.float32)
             if rope is not None:
                 ops.rope_apply(qkv, rope[i][0], rope[i][1], nb, N, Hh, dh, 1 + n_reg)
@@ -420,7 +453,7 @@ class ViTEngine:
                 # last block, output read at `ridx` only: the attention projection + LayerScale + residual are row-local too -- R rows of
                 # them, written into an otherwise ZERO block-middle tensor (finite everywhere: the final LayerNorm still runs densely)
                 ridx, Rr = e2[1]
-                att_r = ws.get(s + "att_r", (T, D), torch.bfloat16)
+                att_r = ws.get(s + "att_r", (T, D), torch.bfloat16, pad_rows=64)
                 words = att.element_size() * D // 4    # a row as 32-bit words (bf16: D / 2): the row gather moves words, whatever they hold
                 ops.gather_rows(att.view(torch.float32), words, ridx, Rr, words, out_f32=att_r.view(torch.float32))
                 x_r = ws.get(tag + ".x_r", (T, D), torch.float32)
@@ -439,10 +472,10 @@ class ViTEngine:
             # ---------------- MLP branch
             m = branch_setup(e2, s, "m", xm)
             R2 = m["rows"]
-            ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16)
+            ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16, pad_rows=64)
             m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
             ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"], eps=cfg.ln_eps)
-            act = ws.get(s + "act", (T, hid), torch.bfloat16)
+            act = ws.get(s + "act", (T, hid), torch.bfloat16, pad_rows=64)
             if cfg.swiglu:   # w12 -> silu(x1) * x2 -> w3
                 hpre = ws.get(s + "hpre", (T, 2 * hid), torch.bfloat16)
                 ops.gemm(ln2, self.wb(pre + "mlp.w12.weight"), hpre, M=R2, N=2 * hid, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "mlp.w12.bias"))
@@ -552,14 +585,14 @@ class ViTEngine:
         scale = dh ** -0.5
         dxa = ws.get(tag + ".dxa", (T, D), torch.float32)
         dxb = ws.get(tag + ".dxb", (T, D), torch.float32)
-        dDs = [ws.get(tag + ".dD", (T, D), torch.bfloat16), ws.get(tag + ".dDb", (T, D), torch.bfloat16)]  # upstream grads of
+        dDs = [ws.get(tag + ".dD", (T, D), torch.bfloat16, pad_rows=64), ws.get(tag + ".dDb", (T, D), torch.bfloat16, pad_rows=64)]  # upstream grads of
         # consecutive branches alternate between two buffers: the LayerNorm backward of one branch writes the next one's
-        dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16)
-        dH = ws.get(tag + ".dH", (T, 2 * hid if cfg.swiglu else hid), torch.bfloat16)
-        dAct = ws.get(tag + ".dAct", (T, hid), torch.bfloat16) if cfg.swiglu else None
+        dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16, pad_rows=64)
+        dH = ws.get(tag + ".dH", (T, 2 * hid if cfg.swiglu else hid), torch.bfloat16, pad_rows=64)
+        dAct = ws.get(tag + ".dAct", (T, hid), torch.bfloat16, pad_rows=64) if cfg.swiglu else None
         fc1, fc2 = ("mlp.w12", "mlp.w3") if cfg.swiglu else ("mlp.fc1", "mlp.fc2")
         hid1 = 2 * hid if cfg.swiglu else hid
-        dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16)
+        dQ = ws.get(tag + ".dQ", (T, 3 * D), torch.bfloat16, pad_rows=64)
         aws = ws.get(tag + ".attn_ws", (ops.attention_bwd_ws_floats(B, N, Hh, dh),), torch.float32)
 
         blocks_ctx = ctx["blocks"]
@@ -595,9 +628,11 @@ class ViTEngine:
         def wgrad(dy: Tensor, xin: Tensor, wname: str, n_out: int, k_in: int, rows: int, bias: Optional[str] = None) -> None:
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
             kpad = (rows + 63) // 64 * 64
-            if kpad != rows and kpad <= dy.shape[0] and kpad <= xin.shape[0]:
-                dy[rows:kpad].zero_()   # zero the <=63 pad rows so the contraction can run in whole 64-row k-tiles
-                xin[rows:kpad].zero_()  # (both operands: stale pad rows could hold NaN bit patterns)
+            dyp, xp = padded_rows(dy, rows), padded_rows(xin, rows)
+            if kpad != rows and dyp is not None and xp is not None:
+                dyp[rows:kpad].zero_()   # zero the <=63 pad rows so the contraction can run in whole 64-row k-tiles
+                xp[rows:kpad].zero_()    # (both operands: stale pad rows could hold NaN bit patterns)
+                dy, xin = dyp, xp
             else:
                 kpad = rows
 
@@ -605,7 +640,7 @@ class ViTEngine:
                 if bias is not None:
                     ops.colsum_bf16(dy, self.gw(bias), rows, n_out)
                 ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                         split_k=_split_k(tiles, kpad), lda=n_out, ldb=k_in, ldc=k_in, workspace=slab)
+                         lda=n_out, ldb=k_in, ldc=k_in, workspace=slab, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
 
             if side is None:
                 run()
@@ -677,7 +712,7 @@ class ViTEngine:
                 before_write(dD)
                 ops.layerscale_bwd(dxs, None, g1, dD, None, Rr, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=None, scale=1.0)
                 wgrad(dD, pr["att_r"], pre + "attn.proj.weight", D, D, Rr)
-                dAr = ws.get(tag + ".dAr", (T, D), torch.bfloat16)
+                dAr = ws.get(tag + ".dAr", (T, D), torch.bfloat16, pad_rows=64)
                 ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dAr, M=Rr, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
                 dD2.zero_()
                 dD2.index_copy_(0, ridx[:Rr], dAr[:Rr])
@@ -741,7 +776,8 @@ class ViTEngine:
                 target = ws.get(tag + ".dwpe_pad", (D, self.kpad), torch.float32)
                 target.zero_()
             ops.gemm(dpatch, ctx["cols"], target, M=D, N=self.kpad, K=B * n_p, trans_a=True,
-                     trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=max(2, _split_k(tiles, B * n_p)), lda=D, ldb=self.kpad,
+                     trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=D, ldb=self.kpad,
+                     **split_k_plan(D, self.kpad, B * n_p, True, max(2, _split_k(tiles, B * n_p))),
                      ldc=self.kpad, workspace=slab)
             if self.kpad != self.kreal:
                 ops.unpad_accumulate(target, gview, D, self.kreal, self.kpad)
