@@ -398,6 +398,73 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// R rows per wave, every load of all R rows (and of the affine parameters) issued before the first reduction: a wave that owns one row
+// holds 3 KB in flight and then idles through two dependent wave reductions; with R rows the reductions of one row run under the
+// loads of the others.  Rows past the end are clamped to the last row and not stored (branch-free loads keep the waitcnt counted).
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, bf16_t* __restrict__ yb,
+                                                                 float* __restrict__ yf, float* __restrict__ mean_o,
+                                                                 float* __restrict__ rstd_o, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float4 v[R][NV], ww[NV], bb[NV];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const long row = row0 + r < rows ? row0 + r : (long)rows - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      v[r][i] = *reinterpret_cast<const float4*>(x + row * D + (c < D ? c : 0));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    ww[i] = *reinterpret_cast<const float4*>(w + (c < D ? c : 0));
+    bb[i] = *reinterpret_cast<const float4*>(b + (c < D ? c : 0));
+  }
+  const float invD = 1.f / (float)D;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if ((i * 64 + lane) * 4 < D) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if ((i * 64 + lane) * 4 < D) {
+        const float a0 = v[r][i].x - mean, a1 = v[r][i].y - mean, a2 = v[r][i].z - mean, a3 = v[r][i].w - mean;
+        q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    const long row = row0 + r;
+    if (row < rows) {
+      if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+          float4 o;
+          o.x = (v[r][i].x - mean) * rstd * ww[i].x + bb[i].x;
+          o.y = (v[r][i].y - mean) * rstd * ww[i].y + bb[i].y;
+          o.z = (v[r][i].z - mean) * rstd * ww[i].z + bb[i].z;
+          o.w = (v[r][i].w - mean) * rstd * ww[i].w + bb[i].w;
+          if (yf) *reinterpret_cast<float4*>(yf + row * D + c) = o;
+          if (yb) *reinterpret_cast<uint2*>(yb + row * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+        }
+      }
+    }
+  }
+}
+
 // Vector backward for D % 4 == 0, D <= NV*256: lane owns float4 column groups c = (i*64 + lane)*4.  Each wave walks its rows
 // two at a time (both rows' loads are issued before either row's reductions, hiding the HBM latency a single dependent
 // row chain would expose); per-lane dw/db partials stay in registers, are reduced over the block's 4 waves in LDS, then
@@ -982,6 +1049,19 @@ extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, 
                                 float* rstd, int rows, int D, float eps, void* stream) {
   LT_CHECK_ARG(x && w && b && (y_bf16 || y_f32) && rows >= 0 && D > 0 && D <= MAXV * 256, "lt_layernorm_fwd: bad arguments (D=%d)", D);
   if (rows == 0) return LT_OK;
+  // rows per wave (read per call: tools/ln_bench.py sweeps it).  1, 2 and 4 rows per wave all run at the rate of a plain fp32 -> bf16 cast of
+  // the same size (profiles/r03f_ln_stream_limit.log: 3.1 TB/s from HBM, 5.5 from the Infinity Cache): the kernel is at the streaming limit
+  const char* env_r = getenv("LT_LN_FWD_ROWS");
+  const int R = env_r ? atoi(env_r) : 1;
+  const int nv = (D + 255) / 256;
+  const bool al = D % 4 == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y_f32) & 15) == 0 && ((uintptr_t)y_bf16 & 7) == 0;
+#define LT_LNF(NV, RR) hipLaunchKernelGGL((layernorm_fwd_rows_kernel<NV, RR>), dim3(lt_cdiv(rows, 4 * RR)), dim3(256), 0, ST, x, w, b, (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps)
+  if (al && R >= 1 && nv <= 4 && rows >= 1024) {
+    if (R >= 4 && nv <= 3) { if (nv <= 2) LT_LNF(2, 4); else LT_LNF(3, 4); }
+    else if (R >= 2) { if (nv <= 2) LT_LNF(2, 2); else if (nv == 3) LT_LNF(3, 2); else LT_LNF(4, 2); }
+    else { if (nv <= 2) LT_LNF(2, 1); else if (nv == 3) LT_LNF(3, 1); else LT_LNF(4, 1); }
+  } else
+#undef LT_LNF
   if (D % 4 == 0)
     hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(lt_cdiv(rows, 4)), dim3(256), 0, ST, x, w, b, (bf16_t*)y_bf16, y_f32,
                        mean, rstd, rows, D, eps);
