@@ -747,10 +747,9 @@ class DINOv2:
             self._pending["ibot"] = (cs_i, 1.0, hi)
         else:
             self._sinkhorn(t_logits[:2 * B], t_probs[:2 * B], 2 * B, K, teacher_temp, float(2 * B * self.world), "skd")
-            n_masked_total = torch.tensor([float(M)], device=dev)
-            if self.world > 1:
-                dist.all_reduce(n_masked_total)
-            self._sinkhorn(t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, K, teacher_temp, n_masked_total, "ski")
+            # n_masked_patches over all ranks (dinov2.py:441-449) only scales Q between iterations (see _sinkhorn): this rank's count
+            # times the world size stands in for it -- no collective and no host read-back of a device scalar in the step
+            self._sinkhorn(t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, K, teacher_temp, float(max(M, 1) * self.world), "ski")
 
         teacher_done = tstream.record_event()
         torch.cuda.set_stream(main)
@@ -872,7 +871,10 @@ class DINOv2:
 
     def _sinkhorn(self, logits: Tensor, out: Tensor, rows: int, K: int, temp: float, n_total: Any, tag: str) -> None:
         """dinov2_loss.py:84-115 / :188-224.  The initial Q /= sum(Q) is a global scalar that cancels in the first
-        row normalisation, so it is skipped (same value up to fp32 rounding)."""
+        row normalisation, so it is skipped (same value up to fp32 rounding).  So does the sample count `n_total` (B in the
+        reference): every iteration ends with Q /= B, a factor common to all of Q, which the next iteration's Q /= sum_of_rows
+        removes again, and the closing Q *= B undoes the last one -- the result does not depend on it beyond rounding, which is why the
+        iBOT call may pass an estimate instead of all-reducing the masked-patch count (tests/test_dinov2_method_cpu.py checks it)."""
         nt = float(n_total.item()) if isinstance(n_total, Tensor) else float(n_total)
         ops.sk_exp(logits, out, 1.0 / temp)
         cs = self.ws.get(tag + ".colsum", (K,), torch.float32)

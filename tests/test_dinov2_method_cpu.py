@@ -419,3 +419,25 @@ def test_drawn_configurations_equal_the_restatement(seed):
                     # take the other sign on the two sides -- bounded by 2 lr per step, and rare
                     d = (m.student.p[n_] - od[n_[len(pre):]].detach()).abs()
                     assert d.max().item() <= 2.2 * lr_eff * (s + 1) + 1e-7 and (d > 3e-6).float().mean().item() < 5e-3, (c, s, n_, d.max().item())
+
+
+def test_sinkhorn_result_does_not_depend_on_the_sample_count():
+    """`DINOv2._sinkhorn(..., n_total)`: the reference divides Q by the global sample count B at the end of every iteration
+    (dinov2_loss.py:106-113, 215-222) and multiplies by it once at the end.  A factor common to all of Q cancels in the next iteration's
+    row normalisation, so the assignment is the same for ANY positive n_total up to rounding -- which is what lets the iBOT call pass
+    `local count x world size` instead of all-reducing the number of masked patches."""
+    from oracle import dinov2_oracle as O
+
+    fx = torch.load(os.path.join(GOLD, "step_vittest_sinkhorn.pt"), weights_only=False)
+    with ops_emu.emulate(ops):
+        m = build_exact(fx)
+        g = torch.Generator().manual_seed(2)
+        logits = torch.randn(24, 512, generator=g) * 0.2
+        ref = O.sinkhorn_knopp(logits, 0.05, 24.0)
+        outs = []
+        for n_total in (24.0, 7.0, 4096.0):
+            out = torch.empty_like(logits)
+            m._sinkhorn(logits, out, 24, 512, 0.05, n_total, "t")
+            outs.append(out.clone())
+            assert torch.allclose(out, ref, rtol=2e-5, atol=1e-9), n_total
+        assert torch.allclose(outs[0], outs[1], rtol=2e-6, atol=1e-10) and torch.allclose(outs[0], outs[2], rtol=2e-6, atol=1e-10)

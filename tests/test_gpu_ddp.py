@@ -301,3 +301,64 @@ def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path)
             assert fro(r[0][2][k], buf_w[k]) < 2e-2, k
         elif k.endswith("running_mean"):
             assert (r[0][2][k] - buf_w[k]).abs().max().item() < 2e-2, k
+
+
+def _rccl_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """ONE rank on a real RCCL communicator (two ranks cannot share the box's single GPU: profiles/r03g_rccl_one_gpu.log), with the step
+    told that it is one of two: every collective of the data-parallel path (async center sums, Sinkhorn row sums, the head / per-block
+    gradient all-reduces started during backward) is issued as a real RCCL operation on RCCL's own stream -- identity in value, but with
+    the stream semantics gloo does not have."""
+    import random
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import lightly_train_amd  # noqa: F401
+        from lightly_train_amd import parallel
+        from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+        from lightly_train_amd.vit import ViTConfig
+
+        parallel.world_size = lambda: 2
+        DINOv2.world = property(lambda self: 2)
+        cfg = ViTConfig(embed_dim=384, depth=3, num_heads=6, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-2, drop_path_rate=0.1)
+        B = 8
+        g = torch.Generator().manual_seed(0)
+        views = [torch.randn(B, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(B, 3, 96, 96, generator=g) for _ in range(8)]
+        out = {}
+        for key, center, overlap in (("overlap", "softmax", True), ("overlap_again", "softmax", True), ("after", "softmax", False),
+                                     ("sk_overlap", "sinkhorn_knopp", True), ("sk_after", "sinkhorn_knopp", False)):
+            m = DINOv2(cfg, DINOv2Args(output_dim=8192, hidden_dim=512, dino_bottleneck_dim=256, center_method=center), global_batch_size=2 * B,
+                       total_steps=100, device="cuda", seed=3)
+            m.overlap_grad_reduce = overlap
+            early, losses = [], []
+            for s in range(3):
+                random.seed(50 + s)
+                res = m.training_step_impl({"views": views}, 0)
+                early.append(sum(b - a for a, b in m._grad_sync.covered) if m._grad_sync is not None else 0)
+                m.optimizer_step()
+                m.on_train_batch_end()
+                losses.append(float(res.loss))
+            torch.cuda.synchronize()
+            out[key] = (m.student.data.cpu().clone(), m.teacher.data.cpu().clone(), m.dino_center.cpu().clone(), early, m.student.numel, losses)
+        torch.save(out, os.path.join(out_dir, "rccl.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_over_rccl_overlapped_equal_sequential(tmp_path):
+    """The data-parallel code path over RCCL itself (one rank, told it is one of two).  With the order-fixed reductions a step is
+    bitwise reproducible, so the comparison is exact: all-reduces started during backward on RCCL's stream == one all-reduce after it
+    == the same run again, for both centering methods; and the early ranges cover most of the gradient buffer."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl.pt", weights_only=False)
+    for a, b in (("overlap", "overlap_again"), ("overlap", "after"), ("sk_overlap", "sk_after")):
+        for i, what in enumerate(("student", "teacher", "center")):
+            assert torch.equal(r[a][i], r[b][i]), (a, b, what, (r[a][i] - r[b][i]).abs().max().item())
+        assert r[a][5] == r[b][5], (a, b, "losses")
+    assert all(e > 0.5 * r["overlap"][4] for e in r["overlap"][3]) and all(e == 0 for e in r["after"][3])
+    assert all(x == x for x in r["overlap"][5])     # finite losses
