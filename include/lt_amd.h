@@ -222,7 +222,8 @@ int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* st
 /* Q[r,k] *= 1/(colsum[k]*K); then row-normalise: Q[r,:] /= (rowsum(r) * n_total); final: Q *= final_mul */
 int lt_sk_iter(float* Q, const float* colsum, int rows, int K, float n_total, float final_mul, void* stream);
 /* DistillationV2Loss (nn.MSELoss, LT/_methods/distillationv2/distillationv2_loss.py:14-44): *loss += scale * sum (s - t)^2 and
- * ds = 2 * scale * (s - t) (ds may be null); scale = 1 / numel for the mean.  Deterministic two-level sum; one launch in flight at a time. */
+ * ds = 2 * scale * (s - t) (ds may be null); scale = 1 / numel for the mean.  *loss is ACCUMULATED into: zero it before the first call of a
+ * step.  Deterministic two-level sum through library-owned scratch that rotates per call (launches on several streams may overlap). */
 int lt_mse_fwd_bwd(const float* s, const float* t, float* ds, int64_t n, float scale, float* loss, void* stream);
 /* KoLeo (lightly.loss.KoLeoLoss, call site dinov2.py:377-380): *loss += weight*L(x), dx += weight*dL/dx.
  * weight == 0: value only -- *loss += L(x) and dx is not touched (the reference logs the term at weight 0 too, dinov2.py:377-396).

@@ -100,10 +100,12 @@ def load_method_state_dict(sd: Mapping[str, Tensor], student: FlatParams, teache
                            strict: bool = True) -> Dict[str, Tensor]:
     """Copy a reference `method.state_dict()` into the flat storages (fp32 master copies AND their bf16 shadows).  Returns the
     non-parameter entries (`dino_loss.center`, `ibot_loss.center`) for the caller.  strict: every flat tensor must be present
-    with its shape, and every key must be understood."""
+    with its shape, and every key must be understood.  Everything is validated before the first copy: a load that raises leaves the
+    model as it was."""
     seen = {"student": set(), "teacher": set()}
     extra: Dict[str, Tensor] = {}
     fps = {"student": student, "teacher": teacher}
+    plan: List[Tuple[FlatParams, str, Tensor]] = []
     for k, v in sd.items():
         hit = method_key_to_flat(k, separate_ibot)
         if hit is None:
@@ -123,13 +125,15 @@ def load_method_state_dict(sd: Mapping[str, Tensor], student: FlatParams, teache
             continue
         if tuple(v.shape) != tuple(fp.shapes[name]):
             raise ValueError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(fp.shapes[name])}")
-        fp.p[name].copy_(v.to(fp.device, torch.float32))
+        plan.append((fp, name, v))
         seen[role].add(name)
     if strict:
         for role, fp in fps.items():
             missing = [n for n in fp.names if n not in seen[role]]
             if missing:
                 raise KeyError(f"missing keys for the {role}: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+    for fp, name, v in plan:
+        fp.p[name].copy_(v.to(fp.device, torch.float32))
     for fp in fps.values():
         fp.bf16.copy_(fp.data)
     return extra
@@ -183,6 +187,7 @@ def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_a
     if len(osd["param_groups"]) != len(fg):
         raise ValueError(f"optimizer state has {len(osd['param_groups'])} parameter groups, this model has {len(fg)}")
     steps = set()
+    plan: List[Tuple[Tensor, Tensor]] = []
     for g, og in zip(fg, osd["param_groups"]):
         if len(og["params"]) != len(g["members"]):
             raise ValueError(f"parameter group {og.get('name', '?')}: {len(og['params'])} parameters in the checkpoint vs {len(g['members'])}")
@@ -194,50 +199,77 @@ def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_a
                 v = _view(buf, student, n)
                 if tuple(st[key].shape) != tuple(v.shape):
                     raise ValueError(f"optimizer state of {n}: shape {tuple(st[key].shape)} vs {tuple(v.shape)}")
-                v.copy_(st[key].to(v.device, torch.float32))
+                plan.append((v, st[key]))
             steps.add(int(float(st["step"])))
     if len(steps) > 1:
         raise ValueError(f"parameters disagree on the optimizer step count: {sorted(steps)}")
+    # validated: now replace the state.  Parameters without an entry (a step-0 or partial checkpoint) get zero moments, as
+    # torch's load_state_dict drops their state -- not whatever this object had accumulated before.
+    exp_avg.zero_()
+    exp_avg_sq.zero_()
+    for v, src in plan:
+        v.copy_(src.to(v.device, torch.float32))
     return steps.pop() if steps else 0
 
 
 # ---- the distillation methods (Distillation, DistillationV2, DistillationV3): model state in the reference's key names, optimizer state
 # in this package's flat layout (their reference optimizer is LARS / AdamW over two unnamed groups: there is no per-parameter key to keep)
 def distill_load_state_dict(m: Any, sd: Mapping[str, Tensor], head_map: Mapping[str, str], strict: bool = True) -> None:
-    """Inverse of the methods' `state_dict()`: `student_embedding_model.wrapped_model._model.*` (ViT / DINOv3 students) or `._features.*`
-    (torchvision ResNet students), the projection heads (`head_map`: reference prefix -> flat prefix) and `teacher_queue`; keys of the
-    frozen teacher, which `on_save_checkpoint` drops anyway, are ignored."""
+    """Inverse of the methods' `state_dict()`: `student_embedding_model.wrapped_model._model.*` (ViT / DINOv3 students; chunked
+    `blocks.<chunk>.<i>.` names accepted) or `._features.*` (torchvision ResNet students), the projection heads (`head_map`: reference
+    prefix -> flat prefix) and `teacher_queue`; keys of the frozen teacher, which `on_save_checkpoint` drops anyway, are ignored.
+    Keys and shapes are validated before the first copy; `strict` applies to backbone, head and BatchNorm-buffer keys alike."""
     fp: FlatParams = m.student
     seen = set()
     net = getattr(m, "s_net", None) or getattr(getattr(m, "s", None), "net", None)
     conv = hasattr(net, "w_stem")
     pre_vit, pre_conv = "student_embedding_model.wrapped_model._model.", "student_embedding_model.wrapped_model._features."
     bb = {k[len(pre_conv if conv else pre_vit):]: v for k, v in sd.items() if k.startswith(pre_conv if conv else pre_vit)}
+    plan: List[Tuple[str, Tensor]] = []
+
+    def want(n: str, key: str, v: Tensor) -> None:
+        if n not in fp.p:
+            if strict:
+                raise KeyError(f"unexpected key in state_dict: {key}")
+            return
+        if tuple(v.shape) != tuple(fp.shapes[n]):
+            raise ValueError(f"size mismatch for {key}: checkpoint {tuple(v.shape)} vs model {tuple(fp.shapes[n])}")
+        plan.append((n, v)); seen.add(n)
+
     if conv:
-        net.load_state_dict(bb)
-        seen.update(n for n in fp.names if n.startswith("backbone."))
+        from .resnet import resnet_param_shapes, to_flat_layout
+
+        params = {n for n, _ in resnet_param_shapes(net.cfg)}
+        for k in net.buffers:                      # BatchNorm running estimates: required when strict
+            if strict and k not in bb:
+                raise KeyError(f"missing BatchNorm buffer in state_dict: {pre_conv}{k}")
+        for k, v in bb.items():
+            if k in params:
+                want("backbone." + k, pre_conv + k, to_flat_layout(k, v.float()))
+            elif k not in net.buffers and not k.startswith("fc.") and strict:
+                raise KeyError(f"unexpected key in state_dict: {pre_conv}{k}")
     else:
         scfg = getattr(m, "scfg")
+        bb = {vit_key_to_flat(k): v for k, v in bb.items()}
         if getattr(scfg, "rope_base", None) is not None:
             from .dinov3 import convert_dinov3_state
             bb = convert_dinov3_state(bb, scfg)
         for k, v in bb.items():
-            n = "backbone." + k
-            if n in fp.p:
-                if tuple(v.shape) != tuple(fp.shapes[n]):
-                    raise ValueError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(fp.shapes[n])}")
-                fp.p[n].copy_(v.to(fp.device, torch.float32)); seen.add(n)
-            elif strict:
-                raise KeyError(f"unexpected key in state_dict: {k}")
+            want("backbone." + k, pre_vit + k, v)
     for rp, fpre in head_map.items():
         for k, v in sd.items():
             if k.startswith(rp):
-                n = fpre + k[len(rp):]
-                fp.p[n].copy_(v.to(fp.device, torch.float32)); seen.add(n)
+                want(fpre + k[len(rp):], k, v)
     if strict:
         missing = [n for n in fp.names if n not in seen]
         if missing:
             raise KeyError(f"missing keys for the student: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+    if "teacher_queue" in sd and tuple(sd["teacher_queue"].shape) != tuple(m.teacher_queue.shape):
+        raise ValueError(f"size mismatch for teacher_queue: checkpoint {tuple(sd['teacher_queue'].shape)} vs model {tuple(m.teacher_queue.shape)}")
+    for n, v in plan:
+        fp.p[n].copy_(v.to(fp.device, torch.float32))
+    if conv:
+        net.load_buffers(bb)
     if "teacher_queue" in sd:
         m.teacher_queue.copy_(sd["teacher_queue"].to(m.teacher_queue.device, torch.float32))
     fp.bf16.copy_(fp.data)

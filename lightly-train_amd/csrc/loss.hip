@@ -379,12 +379,11 @@ __global__ __launch_bounds__(256) void koleo_dx_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------ MSE (DistillationV2Loss = nn.MSELoss(), mean over all elements)
 // loss += scale * sum (s - t)^2,  ds = 2 * scale * (s - t); two-level deterministic sum (per-block partials, last block adds them in order)
 constexpr int MSE_MAX_GRID = 1024;
-__device__ float mse_partials[MSE_MAX_GRID];
-__device__ unsigned mse_ticket;
+// per-block partial sums (already scaled) into caller-provided scratch; rowloss_sum_kernel adds them in a fixed order.  The scratch comes
+// from the library's ring, so launches in flight on different streams do not share it.
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ ds, long n, float scale,
-                                                  float* __restrict__ loss) {
+                                                  float* __restrict__ partials) {
   __shared__ float red[16];
-  __shared__ bool last;
   float acc = 0.f;
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
@@ -400,18 +399,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, c
     if (ds) ds[j] = 2.f * scale * d;
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    mse_partials[blockIdx.x] = acc;
-    __threadfence();
-    last = atomicAdd(&mse_ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  float tot = 0.f;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) tot += __builtin_nontemporal_load(&mse_partials[b]);
-  tot = block_sum(tot, red);
-  if (threadIdx.x == 0) { *loss += scale * tot; mse_ticket = 0; }
+  if (threadIdx.x == 0) partials[blockIdx.x] = scale * acc;
 }
 
 }  // namespace
@@ -421,8 +409,6 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ s, c
 extern "C" int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream) {
   LT_CHECK_ARG(logits && probs && K > 0, "lt_softmax_center: bad arguments");
   if (rows == 0) return LT_OK;
-  float* terms = lt_scratch_ring((size_t)rows);
-  if (!terms) { lt_set_error("lt_ce_fwd_bwd: scratch allocation failed"); return LT_ERR_HIP; }
   static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
   if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)probs % 16 == 0) &&
       (!center || (uintptr_t)center % 16 == 0))
@@ -487,6 +473,9 @@ extern "C" int lt_mse_fwd_bwd(const float* s, const float* t, float* ds, int64_t
                "lt_mse_fwd_bwd: bad arguments / alignment");
   if (n == 0) return LT_OK;
   const int grid = (int)min((long)MSE_MAX_GRID, (long)lt_cdiv(n, 1024));
-  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, ST, s, t, ds, (long)n, scale, loss);
+  float* partials = lt_scratch_ring((size_t)grid);
+  if (!partials) { lt_set_error("lt_mse_fwd_bwd: scratch allocation failed"); return LT_ERR_HIP; }
+  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, ST, s, t, ds, (long)n, scale, partials);
+  hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, ST, partials, (const int32_t*)nullptr, grid, loss);
   LT_CHECK_LAUNCH("lt_mse_fwd_bwd");
 }

@@ -415,13 +415,16 @@ class DINO(DINOv2):
                 step = max(step, int(st["step"]))
         self.opt_step = step
 
+    def _lr_end_value(self) -> float:
+        return 0.001       # CosineWarmupScheduler's default (dino.py:404-413 passes none)
+
+    def _opt_counts_steps(self) -> bool:
+        return self.optimizer != "sgd"     # torch's SGD keeps no step count
+
     def load_checkpoint_dict(self, ckpt: Mapping[str, Any], strict: bool = True) -> None:
-        self.load_state_dict(ckpt["state_dict"], strict=strict)
-        if ckpt.get("optimizer_states"):
-            self.load_optimizer_state_dict(ckpt["optimizer_states"][0])
-        self.trainer.global_step = int(ckpt.get("global_step", self.opt_step))
+        super().load_checkpoint_dict(ckpt, strict)
         if self.optimizer == "sgd" and self.trainer.global_step > 0:
-            self.opt_step = self.trainer.global_step      # SGD keeps no step count; the buffers exist from the first step on
+            self.opt_step = self.trainer.global_step      # the momentum buffers exist from the first step on
 
     def train_step(self, views: List[Tensor], masks: Any = None) -> TrainingStepResult:
         res = self.training_step_impl({"views": views}, 0)

@@ -527,20 +527,40 @@ class DINOv2:
     def load_optimizer_state_dict(self, osd: Mapping[str, Any]) -> None:
         self.opt_step = checkpoint.load_optimizer_state_dict(osd, self.student, self.exp_avg, self.exp_avg_sq, self._group_entries())
 
+    def lr_scheduler_state(self) -> Dict[str, Any]:
+        """`CosineWarmupScheduler.state_dict()` (a LambdaLR: every attribute but the optimizer; the lambda is stored as None) at the
+        current step, for the optimizer's parameter groups as `optimizer_state_dict()` lists them."""
+        k = self.trainer.global_step
+        groups = self.optimizer_state_dict()["param_groups"]
+        return {"warmup_epochs": self.warmup_steps, "max_epochs": int(self.trainer.estimated_stepping_batches), "start_value": 1.0,
+                "end_value": self._lr_end_value(), "period": None, "base_lrs": [g_.get("initial_lr", g_["lr"]) for g_ in groups], "last_epoch": k,
+                "verbose": False, "_step_count": k + 1, "_get_lr_called_within_step": False, "_last_lr": [g_["lr"] for g_ in groups],
+                "lr_lambdas": [None]}
+
+    def _lr_end_value(self) -> float:
+        return self.method_args.min_lr / self.base_lr       # configure_optimizers (dinov2.py:561-572)
+
     def checkpoint_dict(self) -> Dict[str, Any]:
         """The parts of a Lightning checkpoint this step owns (LT/_checkpoint.py:101-123; Lightning's `dump_checkpoint`):
-        module state, optimizer state, scheduler position, global step."""
-        return {"state_dict": self.state_dict(), "optimizer_states": [self.optimizer_state_dict()],
-                "lr_schedulers": [{"last_epoch": self.trainer.global_step, "warmup_epochs": self.warmup_steps,
-                                   "max_epochs": self.trainer.estimated_stepping_batches}],
-                "global_step": self.trainer.global_step, "epoch": 0}
+        module state, optimizer state, scheduler state, global step; `epoch` from `trainer.steps_per_epoch` when the caller set it
+        (Lightning writes its own when it drives the loop: integration.py)."""
+        spe = getattr(self.trainer, "steps_per_epoch", None)
+        return {"state_dict": self.state_dict(), "optimizer_states": [self.optimizer_state_dict()], "lr_schedulers": [self.lr_scheduler_state()],
+                "global_step": self.trainer.global_step, "epoch": (self.trainer.global_step // spe) if spe else 0}
 
     def load_checkpoint_dict(self, ckpt: Mapping[str, Any], strict: bool = True) -> None:
-        """Resume: inverse of `checkpoint_dict()`; also accepts a checkpoint written around the reference's own module."""
+        """Resume: inverse of `checkpoint_dict()`; also accepts a checkpoint written around the reference's own module.  The optimizer's
+        step count and the checkpoint's global_step must agree (one optimizer step per batch in this method)."""
         self.load_state_dict(ckpt["state_dict"], strict=strict)
         if ckpt.get("optimizer_states"):
             self.load_optimizer_state_dict(ckpt["optimizer_states"][0])
-        self.trainer.global_step = int(ckpt.get("global_step", self.opt_step))
+        gs = int(ckpt.get("global_step", self.opt_step))
+        if ckpt.get("optimizer_states") and self.opt_step not in (0, gs) and self._opt_counts_steps():
+            raise ValueError(f"checkpoint global_step {gs} does not match its optimizer step count {self.opt_step}")
+        self.trainer.global_step = gs
+
+    def _opt_counts_steps(self) -> bool:
+        return True
 
     def export_backbone_state_dict(self) -> Dict[str, Tensor]:
         """What the reference exports (EMA teacher backbone, dinov2_vit_package.py:146-162)."""

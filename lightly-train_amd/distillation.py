@@ -249,7 +249,10 @@ class _DistillBase:
     def _backbone_state(self) -> Dict[str, Tensor]:
         if self.s.conv:
             return {"student_embedding_model.wrapped_model._features." + k: v for k, v in self.s.net.state_dict().items()}
-        return {"student_embedding_model.wrapped_model._model." + n[9:]: self.student.p[n].detach().clone()
+        from .checkpoint import vit_key_from_flat
+
+        cfg = self.s.net.cfg     # chunked students (block_chunks > 0: vitl14 / vitg14) keep the reference's `blocks.<chunk>.<i>.` names
+        return {"student_embedding_model.wrapped_model._model." + vit_key_from_flat(n[9:], cfg.depth, cfg.block_chunks): self.student.p[n].detach().clone()
                 for n in self.student.names if n.startswith("backbone.")}
 
     def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:

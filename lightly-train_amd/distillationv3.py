@@ -452,6 +452,10 @@ class DistillationV3:
             from .dinov3 import export_dinov3_state
 
             bb = export_dinov3_state(bb, self.scfg)
+        if not self.conv_student and self.scfg.rope_base is None:
+            from .checkpoint import vit_key_from_flat
+
+            bb = {vit_key_from_flat(k, self.scfg.depth, self.scfg.block_chunks): v for k, v in bb.items()}   # chunked DINOv2 students
         for k, v in bb.items():
             out["student_embedding_model.wrapped_model._model." + k] = v
         for n in self.student.names:

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Mapping, Any, Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -393,7 +393,11 @@ class ResNetEngine:
         for n, _ in resnet_param_shapes(self.cfg):
             self.P.p[self.prefix + n].copy_(to_flat_layout(n, sd[n].float()).to(self.dev))
             self.P.b[self.prefix + n].copy_(self.P.p[self.prefix + n])
+        self.load_buffers(sd)
+        self.refresh_padded_weights()
+
+    def load_buffers(self, sd: Mapping[str, Tensor]) -> None:
+        """BatchNorm running estimates / batch counters present in `sd` (torchvision names)."""
         for k in self.buffers:
             if k in sd:
                 self.buffers[k].copy_(sd[k].to(self.dev))
-        self.refresh_padded_weights()

@@ -292,3 +292,58 @@ def test_drawn_distillationv3_configurations_equal_the_restatement(name, b, queu
         assert torch.allclose(m.teacher_queue, o.queue, atol=2e-6)
         assert torch.allclose(m.student.p["proj_global.weight"], o.pg["weight"].detach(), atol=3e-6)
         assert torch.allclose(m.student.p["proj_local.weight"], o.pl["weight"].detach(), atol=3e-6)
+
+
+def test_distillation_state_dict_chunked_names_and_validate_before_copy():
+    """A chunked student (block_chunks > 0, the reference's vitl14 / vitg14 layout) writes and reads `blocks.<chunk>.<i>.` names; a load
+    that fails -- unknown key, wrong shape, missing tensor -- leaves the model untouched; strict=False tolerates unknown / missing keys."""
+    from lightly_train_amd.distillation import Distillation, DistillationArgs
+
+    fx = torch.load(os.path.join(GOLD, "distill_v1_d64.pt"), weights_only=False)
+    scfg, tcfg = vit_cfg(fx["student_cfg"]), vit_cfg(fx["teacher_cfg"])
+    scfg.block_chunks = 2
+    with ops_emu.emulate(ops):
+        kw = dict(global_batch_size=fx["b"], total_steps=fx["total_steps"], max_epochs=1, device="cpu", teacher_state=fx["teacher_state"])
+        a = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw"), seed=1, **kw)
+        b = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw"), seed=2, **kw)
+        sd = a.state_dict()
+        pre = "student_embedding_model.wrapped_model._model."
+        assert pre + "blocks.0.0.attn.qkv.weight" in sd and pre + "blocks.1.1.mlp.fc2.bias" in sd and not any(k.startswith(pre + "blocks.0.attn") for k in sd)
+        before = b.student.data.clone()
+        assert not torch.equal(before, a.student.data)
+        bad_key = dict(sd, **{"student_projection_head.nonsense.weight": torch.zeros(3)})
+        with pytest.raises(KeyError):
+            b.load_state_dict(bad_key)
+        bad_shape = dict(sd)
+        last = [k for k in sd if k.startswith("student_projection_head.")][-1]
+        bad_shape[last] = torch.zeros(5, 7)
+        with pytest.raises(ValueError):
+            b.load_state_dict(bad_shape)
+        missing = {k: v for k, v in sd.items() if "blocks.1.1.mlp.fc2.bias" not in k}
+        with pytest.raises(KeyError):
+            b.load_state_dict(missing)
+        assert torch.equal(b.student.data, before), "a failed load must not have copied anything"
+        b.load_state_dict(bad_key, strict=False)          # unknown keys tolerated
+        assert torch.equal(b.student.data, a.student.data)
+        b.student.data.copy_(before)
+        b.load_state_dict(missing, strict=False)          # missing tensors keep their values
+        name = "backbone.blocks.1.mlp.fc2.bias"
+        o, n = b.student.offsets[name], b.student.p[name].numel()
+        assert torch.equal(b.student.data[o:o + n], before[o:o + n])
+        b.load_state_dict(sd)
+        assert torch.equal(b.student.data, a.student.data) and torch.equal(b.teacher_queue, a.teacher_queue)
+
+
+def test_optimizer_state_load_zeroes_moments_without_an_entry():
+    """checkpoint.load_optimizer_state_dict: a step-0 (empty-state) checkpoint loaded into an object that has trained resets the Adam
+    moments, as torch's Optimizer.load_state_dict drops state it is not given."""
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+
+    with ops_emu.emulate(ops):
+        cfg = ViTConfig(embed_dim=64, depth=1, num_heads=1, mlp_ratio=4.0, patch_size=16, img_size=32, init_values=0.1)
+        m = DINOv2(cfg, DINOv2Args(output_dim=64, hidden_dim=32, dino_bottleneck_dim=16), global_batch_size=2, total_steps=10, device="cpu")
+        fresh = m.optimizer_state_dict()
+        assert fresh["state"] == {}
+        m.exp_avg.fill_(3.0); m.exp_avg_sq.fill_(2.0); m.opt_step = 7
+        m.load_optimizer_state_dict(fresh)
+        assert m.opt_step == 0 and float(m.exp_avg.abs().max()) == 0.0 and float(m.exp_avg_sq.abs().max()) == 0.0

@@ -130,6 +130,13 @@ def test_two_plumbing_steps_equal_the_reference_class(koleo):
             if koleo == 0.0:
                 assert got["loss"] == pytest.approx(want["loss"], rel=3e-5)
         assert amd.impl().trainer.global_step == 2 and amd.impl().opt_step == 2
+        # the scheduler entry of a checkpoint: the reference scheduler's own state_dict() after the same two steps, field by field
+        want_s, got_s = runner.sched.state_dict(), amd.impl().lr_scheduler_state()
+        assert set(got_s) >= set(want_s) - {"_is_initial"}, set(want_s) - set(got_s)
+        for k in ("last_epoch", "_step_count", "warmup_epochs", "max_epochs"):
+            assert got_s[k] == want_s[k], k
+        assert got_s["end_value"] == pytest.approx(want_s["end_value"], rel=1e-12)
+        assert got_s["base_lrs"] == pytest.approx(want_s["base_lrs"], rel=1e-9) and got_s["_last_lr"] == pytest.approx(want_s["_last_lr"], rel=1e-9)
         if koleo == 0.0:
             sd, rsd = amd.state_dict(), ref.state_dict()
             assert list(sd) == list(rsd)
