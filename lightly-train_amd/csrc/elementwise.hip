@@ -1177,7 +1177,8 @@ extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* 
   if (rows == 0) return LT_OK;
   if (N % 8 == 0 && (uintptr_t)x % 16 == 0) {
     const bool defer = lt_ledger::active();
-    dim3 grid(lt_cdiv(N, 256), min(lt_cdiv(rows, 8), defer ? 64 : 256));
+    // deferred: fewer, longer row slabs keep the partial rows small (128 x N floats), still >= 1000 workgroups for N >= 2048
+    dim3 grid(lt_cdiv(N, 256), min(lt_cdiv(rows, 8), defer ? 128 : 256));
     float* partial = defer ? lt_ledger::reserve((size_t)grid.y * N) : nullptr;
     hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, ST, (const bf16_t*)x, out, rows, N, partial);
     if (partial) lt_ledger::record(out, partial, (int)grid.y, (long)N, N);

@@ -1249,7 +1249,9 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     auto eff = [&](int bn, int sp) { const long b = (long)lt_cdiv(d->M, 256) * lt_cdiv(d->N, bn) * sp; return (double)b / ((double)((b + cus - 1) / cus) * cus); };
     int sp = 1;
     const bool accum = d->epilogue == LT_EPI_F32_ACCUM;
-    int bn = d->N >= 256 ? 256 : 128;  // measured: the 4x2-wave 128-wide variant only pays when N < 256
+    // measured: the 4x2-wave 128-wide variant only pays when N < 256 (again in round 3 for N = 384, where a third of the 256-wide tiling is
+    // padding: ViT-S step 42.7 ms with it, 44.7 ms with 128-wide tiles for N <= 640)
+    int bn = d->N >= 256 ? 256 : 128;
     if (accum && d->split_k != 1) {
       // few output tiles, long contraction: choose the slice count that fills whole waves of 256 workgroups.
       // Slices are capped so the fp32 slabs fit the caller's workspace (without one: <= 4 slices of atomics).

@@ -601,8 +601,8 @@ class DINOv2:
         cfg, a = self.cfg, self.method_args
         D = cfg.embed_dim
         H1 = int(D * cfg.mlp_ratio) * (2 if cfg.swiglu else 1)
-        per_pass = 2 * 256 * 3 * D + 64 * (3 * D + D + H1 + D) + 4 * 64 * D      # LayerNorm x 2, four bias sums, LayerScale x 2 of one block
-        floats = 2 * (cfg.depth * per_pass + 256 * 3 * D + 2 * 1024 * D) + 4 * 64 * (2 * a.hidden_dim + 2 * D + 4096)
+        per_pass = 2 * 256 * 3 * D + 128 * (3 * D + D + H1 + D) + 4 * 64 * D     # LayerNorm x 2, four bias sums, LayerScale x 2 of one block
+        floats = 2 * (cfg.depth * per_pass + 256 * 3 * D + 2 * 1024 * D) + 4 * 128 * (2 * a.hidden_dim + 2 * D + 4096)
         ops.reduce_begin(self.ws.get("reduce.scratch", (int(floats * 1.25) // 4 * 4,), torch.float32))
 
     def _backward_backbone(self, sg: Dict[str, Any], dxn_g: Tensor, sl: Optional[Dict[str, Any]], dxn_l: Optional[Tensor]) -> None:

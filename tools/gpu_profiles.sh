@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 profile collection on the GPU box: default bench line, rocprofv3 kernel stats (single-stream reference and shipped multi-stream),
+# per-round profile collection on the GPU box (tag = first argument, e.g. r03): default bench line, rocprofv3 kernel stats (single-stream reference and shipped multi-stream),
 # the three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) over one default step, the per-workgroup GEMM timeline, cfg2 / cfg5 bench lines.
 set -x
 R=$GRAFT_REPO_ROOT
@@ -26,5 +26,9 @@ python tools/pmc_step_report.py $F $W $M $FL > $O/pmc_step_report.md 2>&1
 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 $B --steps 10 --warmup 3 --model vit_small > $O/bench_vits.log 2>&1
 python tools/run_cfg5.py 32 > $O/cfg5.log 2>&1
+$B --steps 10 --warmup 3 --method distillationv3 --student resnet50 > $O/bench_cfg4_resnet50.log 2>&1
+# the N > 1 code path on this 1-GPU box: two ranks folded onto cuda:0 over gloo (RCCL refuses two ranks per device); the line's `comm`
+# object carries the exposed all-reduce time per step -- a baseline to read the first real multi-GPU run against, not a scaling number
+LT_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --batch 32 > $O/bench_gloo2.log 2>&1
 rm -rf $O/ks_* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA
 ls -la $O; tail -3 $O/gemm_traffic.txt; tail -4 $O/pmc_step_report.md; tail -1 $O/bench_vits.log; tail -2 $O/cfg5.log; tail -1 $O/bench_default_full.log
