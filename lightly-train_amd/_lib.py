@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID, EPI_F32, EPI_BF16_GELUGRAD, EPI_F32_ACCUM = range(6)
-ABI_VERSION = 2   # lt_abi_version() of include/lt_amd.h this binding was written against
+ABI_VERSION = 3   # lt_abi_version() of include/lt_amd.h this binding was written against
 
 # name -> argtypes (every function returns int status except lt_last_error)
 SIGNATURES: dict[str, list[Any]] = {
