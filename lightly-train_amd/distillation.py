@@ -362,14 +362,74 @@ class DistillationV2(_DistillBase):
                  student_state: Optional[Dict[str, Tensor]] = None, teacher_state: Optional[Dict[str, Tensor]] = None,
                  head_state: Optional[Dict[str, Tensor]] = None, seed: int = 0) -> None:
         a = method_args or DistillationV2Args()
-        if a.n_projection_layers != 1:
-            raise NotImplementedError("DistillationV2Head with n_projection_layers > 1 (Linear-LayerNorm-GELU stacks) is not implemented; "
-                                      "the reference default is 1")
         Ds = student_cfg.feature_dim if isinstance(student_cfg, ResNetConfig) else student_cfg.embed_dim
         self.Dtt = a.n_teacher_blocks * teacher_cfg.embed_dim
-        super().__init__(student_cfg, teacher_cfg, a, [("mlp.weight", (self.Dtt, Ds)), ("mlp.bias", (self.Dtt,))], global_batch_size, total_steps,
-                         max_epochs, device, student_state, teacher_state, head_state, seed)
+        # DistillationV2Head (distillationv2.py:116-152): one Linear, or Linear-LayerNorm-GELU stacks of width `projection_hidden_dim`
+        # closed by a Linear; Sequential indices 3i (Linear), 3i + 1 (LayerNorm)
+        n, hid = max(a.n_projection_layers, 1), a.projection_hidden_dim
+        if n > 1 and hid > 2048:
+            raise NotImplementedError("projection_hidden_dim > 2048: the LayerNorm kernels hold a row in registers up to 2048 columns")
+        self._lin: List[Tuple[str, int, int]] = []   # (name prefix, out, in) of the Linear layers
+        self._ln: List[str] = []
+        shapes: List[Tuple[str, Tuple[int, ...]]] = []
+        d_in = Ds
+        for i in range(n - 1):
+            self._lin.append((f"mlp.{3 * i}.", hid, d_in))
+            self._ln.append(f"mlp.{3 * i + 1}.")
+            shapes += [(f"mlp.{3 * i}.weight", (hid, d_in)), (f"mlp.{3 * i}.bias", (hid,)), (f"mlp.{3 * i + 1}.weight", (hid,)), (f"mlp.{3 * i + 1}.bias", (hid,))]
+            d_in = hid
+        last = "mlp." if n == 1 else f"mlp.{3 * (n - 1)}."
+        self._lin.append((last, self.Dtt, d_in))
+        shapes += [(last + "weight", (self.Dtt, d_in)), (last + "bias", (self.Dtt,))]
+        super().__init__(student_cfg, teacher_cfg, a, shapes, global_batch_size, total_steps, max_epochs, device, student_state, teacher_state,
+                         head_state, seed)
+        if head_state is None:      # nn.LayerNorm starts at weight 1 (the base class zero-fills 1-D head tensors: biases)
+            for ln in self._ln:
+                self.student.p["head." + ln + "weight"].fill_(1.0)
+            self.student.bf16.copy_(self.student.data)
         self._tabs: Dict[Tuple[int, int, int, int], Any] = {}
+
+    def _head_forward(self, x: Tensor, R: int) -> Tuple[Tensor, List[Dict[str, Tensor]]]:
+        """tokens bf16 [R, Ds] -> projected fp32 [R, Dtt]; the saved activations of the hidden layers for the backward."""
+        ws, P = self.ws, self.student
+        saved: List[Dict[str, Tensor]] = []
+        for i, ((lin, n_out, k_in), ln) in enumerate(zip(self._lin[:-1], self._ln)):
+            y = ws.get(f"s.hy{i}", (R, n_out), torch.float32)
+            ops.gemm(x, P.b["head." + lin + "weight"], y, M=R, N=n_out, K=k_in, epilogue=ops.EPI_F32, bias=P.p["head." + lin + "bias"])
+            u = ws.get(f"s.hu{i}", (R, n_out), torch.bfloat16)
+            mean, rstd = ws.get(f"s.hmean{i}", (R,), torch.float32), ws.get(f"s.hrstd{i}", (R,), torch.float32)
+            ops.layernorm_fwd(y, P.p["head." + ln + "weight"], P.p["head." + ln + "bias"], R, n_out, y_bf16=u, mean=mean, rstd=rstd, eps=1e-5)
+            h = ws.get(f"s.hh{i}", (R, n_out), torch.bfloat16, pad_rows=64)
+            ops.gelu_fwd(u, h, R * n_out)
+            saved.append(dict(x=x, y=y, u=u, mean=mean, rstd=rstd))
+            x = h
+        lin, n_out, k_in = self._lin[-1]
+        s_proj = ws.get("s.proj", (R, n_out), torch.float32)
+        ops.gemm(x, P.b["head." + lin + "weight"], s_proj, M=R, N=n_out, K=k_in, epilogue=ops.EPI_F32, bias=P.p["head." + lin + "bias"])
+        saved.append(dict(x=x))
+        return s_proj, saved
+
+    def _head_backward(self, dsb: Tensor, saved: List[Dict[str, Tensor]], R: int) -> Tensor:
+        """d(projected) bf16 [R, Dtt] -> d(tokens) fp32 [R, Ds]; parameter gradients accumulated."""
+        ws, P = self.ws, self.student
+        d = dsb
+        for i in range(len(self._lin) - 1, -1, -1):
+            lin, n_out, k_in = self._lin[i]
+            self._head_wgrad(lin, d, saved[i]["x"], n_out, k_in, R)
+            if i == 0:
+                dtok = ws.get("s.dtok", (R, k_in), torch.float32)
+                ops.gemm(d, P.b["head." + lin + "weight"], dtok, M=R, N=k_in, K=n_out, trans_b=True, epilogue=ops.EPI_F32)
+                return dtok
+            dh = ws.get(f"s.hdh{i}", (R, k_in), torch.bfloat16)
+            ops.gemm(d, P.b["head." + lin + "weight"], dh, M=R, N=k_in, K=n_out, trans_b=True, epilogue=ops.EPI_BF16)
+            sv, ln = saved[i - 1], self._ln[i - 1]
+            ops.gelu_bwd(dh, sv["u"], dh, R * k_in)
+            dy32 = ws.get(f"s.hdy32_{i}", (R, k_in), torch.float32)
+            ops.layernorm_bwd(sv["y"], P.p["head." + ln + "weight"], sv["mean"], sv["rstd"], dh, None, dy32, P.g["head." + ln + "weight"],
+                              P.g["head." + ln + "bias"], R, k_in)
+            d = ws.get(f"s.hdy{i}", (R, k_in), torch.bfloat16, pad_rows=64)
+            ops.cast_bf16(dy32, d)
+        raise AssertionError("unreachable")
 
     def _resample(self, hs: int, ws_: int, ht: int, wt: int):
         key = (hs, ws_, ht, wt)
@@ -408,8 +468,7 @@ class DistillationV2(_DistillBase):
         f = self.s.forward(ws, x, want_pooled=False, want_tokens=True)
         n_ps = f["n"]
         resize = (f["gh"], f["gw"]) != (tc["gh"], tc["gw"])
-        s_proj = ws.get("s.proj", (B * n_ps, Dtt), torch.float32)
-        ops.gemm(f["tokens"], P.b["head.mlp.weight"], s_proj, M=B * n_ps, N=Dtt, K=Ds, epilogue=ops.EPI_F32, bias=P.p["head.mlp.bias"])
+        s_proj, head_saved = self._head_forward(f["tokens"], B * n_ps)
         if resize:
             (fi, fw, ft), (bi, bw, bt) = self._resample(f["gh"], f["gw"], tc["gh"], tc["gw"])
             s_feat = ws.get("s.feat", (B * n_pt, Dtt), torch.float32)
@@ -427,15 +486,14 @@ class DistillationV2(_DistillBase):
             ds_proj = ds_feat
         dsb = ws.get("s.dproj", (B * n_ps, Dtt), torch.bfloat16)
         ops.cast_bf16(ds_proj, dsb)
-        self._head_wgrad("mlp.", dsb, f["tokens"], Dtt, Ds, B * n_ps)
-        dtok = ws.get("s.dtok", (B * n_ps, Ds), torch.float32)
-        ops.gemm(dsb, P.b["head.mlp.weight"], dtok, M=B * n_ps, N=Ds, K=Dtt, trans_b=True, epilogue=ops.EPI_F32)
+        dtok = self._head_backward(dsb, head_saved, B * n_ps)
         self.s.backward(ws, f, B, None, dtok, self.side_stream)
         self._last = dict(lam=lam, index=index, t_feat=t_feat, s_feat=s_feat)
         return TrainingStepResult(loss=self._loss[0], log_dict={})
 
     def state_dict(self) -> Dict[str, Tensor]:
         out = self._backbone_state()
-        out["student_projection_head.mlp.weight"] = self.student.p["head.mlp.weight"].detach().clone()
-        out["student_projection_head.mlp.bias"] = self.student.p["head.mlp.bias"].detach().clone()
+        for n in self.student.names:
+            if n.startswith("head."):
+                out["student_projection_head." + n[5:]] = self.student.p[n].detach().clone()
         return out

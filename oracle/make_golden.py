@@ -196,6 +196,9 @@ def main() -> None:
     if "--lars-only" in sys.argv:
         make_distill12("v1", optimizer="lars")
         return
+    if "--distill-v2-mlp-only" in sys.argv:
+        make_distill12("v2", n_layers=3)
+        return
     if "--distill12-only" in sys.argv:
         make_distill12("v1")
         make_distill12("v2")
@@ -254,7 +257,7 @@ def make_distill() -> None:
     make_distill_case("distill_v3_resnet", img=64, s_patch=16, b=8, s_kind="resnet")
 
 
-def make_distill12(kind: str, optimizer: str = "adamw") -> None:
+def make_distill12(kind: str, optimizer: str = "adamw", n_layers: int = 1) -> None:
     """(f) Distillation (v1: pooled feature vs a queue, KL) and DistillationV2 (patch features of the last 2 teacher blocks, MSE): the
     reference's own classes with a frozen DINOv2 ViT teacher (D = 64, /14: 4x4 tokens at 56^2 ... here 8x8 at 112^2) and a DINOv2 ViT
     student (/16: 7x7 tokens, resized onto the teacher grid in v2), AdamW (the reference's "auto" LARS lives in un-vendored LightlySSL),
@@ -291,7 +294,8 @@ def make_distill12(kind: str, optimizer: str = "adamw") -> None:
         cls = mod.Distillation
     else:
         mod = importlib.import_module("lightly_train._methods.distillationv2.distillationv2")
-        margs = mod.DistillationV2Args(teacher="local")
+        # n_layers > 1: the Linear-LayerNorm-GELU projection stack of DistillationV2Head (distillationv2.py:116-152), hidden width 48
+        margs = mod.DistillationV2Args(teacher="local", n_projection_layers=n_layers, projection_hidden_dim=48)
         oargs = AdamWArgs()
         cls = mod.DistillationV2
     mod.get_teacher = lambda *a, **k: t      # the registry lookup by name is outside this path
@@ -305,9 +309,11 @@ def make_distill12(kind: str, optimizer: str = "adamw") -> None:
     teacher_state = {k: v.detach().clone() for k, v in t.state_dict().items()}
     scfg = dict(patch_size=16, num_heads=1, depth=2, img_size=img, embed_dim=64, init_values=0.1)
     tcfg = dict(patch_size=14, num_heads=1, depth=3, img_size=img, embed_dim=64, init_values=0.5)
-    o = OD.OracleDistillation12(kind, init["student_backbone"], scfg, teacher_state, tcfg, init["head"], qsz, b, total, lr=float(oargs.lr),
-                                weight_decay=float(oargs.weight_decay), optimizer=optimizer)
-    assert (o.n_decay, o.n_no_decay) == tuple(len(g["params"]) for g in opt.param_groups), ((o.n_decay, o.n_no_decay), [len(g["params"]) for g in opt.param_groups])
+    o = None
+    if n_layers == 1:   # (the restated twin covers the single-Linear head; the deeper stacks are pinned by this fixture alone)
+        o = OD.OracleDistillation12(kind, init["student_backbone"], scfg, teacher_state, tcfg, init["head"], qsz, b, total, lr=float(oargs.lr),
+                                    weight_decay=float(oargs.weight_decay), optimizer=optimizer)
+        assert (o.n_decay, o.n_no_decay) == tuple(len(g["params"]) for g in opt.param_groups), ((o.n_decay, o.n_no_decay), [len(g["params"]) for g in opt.param_groups])
     steps = []
     for step in range(3):
         x = torch.randn(b, 3, img, img, generator=torch.Generator().manual_seed(2100 + step))
@@ -322,9 +328,10 @@ def make_distill12(kind: str, optimizer: str = "adamw") -> None:
         opt.step(); opt.zero_grad(set_to_none=True); sched.step()
         m.trainer.global_step += 1
         logs = {"loss": float(res.loss.detach()), "grad_norm": float(gnorm), "lr": lr_now}
-        ol = o.train_step(x, lam, index)
-        for k in ("loss", "grad_norm"):
-            assert abs(ol[k] - logs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (kind, step, k, ol[k], logs[k])
+        if o is not None:
+            ol = o.train_step(x, lam, index)
+            for k in ("loss", "grad_norm"):
+                assert abs(ol[k] - logs[k]) <= 2e-5 * max(1.0, abs(logs[k])), (kind, step, k, ol[k], logs[k])
         steps.append({"x_seed": 2100 + step, "lam": lam, "index": index.clone(), "logs": logs})
         print("distill", kind, step, {k: round(v, 6) for k, v in logs.items()})
     final = {"student_backbone": {k: v.detach().clone() for k, v in s_model.state_dict().items()},
@@ -332,11 +339,13 @@ def make_distill12(kind: str, optimizer: str = "adamw") -> None:
     if kind == "v1":
         final["queue"] = m.teacher_queue.detach().clone()
         assert (o.queue - final["queue"]).abs().max().item() < 1e-6
-    for k, v in final["student_backbone"].items():
-        assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
-    name = "distill_" + kind + "_d64" + ("_lars" if optimizer == "lars" else "")
+    if o is not None:
+        for k, v in final["student_backbone"].items():
+            assert (o.sb[k].detach() - v).abs().max().item() <= 2e-6 + 2e-5 * v.abs().max().item(), k
+    name = "distill_" + kind + "_d64" + ("_lars" if optimizer == "lars" else "") + (f"_mlp{n_layers}" if n_layers > 1 else "")
     torch.save({"kind": kind, "optimizer": optimizer, "b": b, "img": img, "total_steps": total, "queue_size": qsz, "lr": float(oargs.lr), "weight_decay": float(oargs.weight_decay),
                 "student_cfg": scfg, "teacher_cfg": tcfg, "teacher_state": teacher_state, "init": init, "steps": steps, "final": final,
+                "n_projection_layers": n_layers, "projection_hidden_dim": 48,
                 "state_dict_keys": list(m.state_dict().keys())}, os.path.join(OUT, name + ".pt"))
     print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".pt")) // 1024, "KiB")
 

@@ -84,7 +84,7 @@ def check_final(sd, fx, key, atol=3e-6):
         assert torch.allclose(sd[key + k], v, atol=atol), (k, (sd[key + k] - v).abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64", "distill_v1_d64_lars"])
+@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64", "distill_v1_d64_lars", "distill_v2_d64_mlp3"])
 def test_distillation_v1_v2_reproduce_the_reference_fixture(name):
     from lightly_train_amd.distillation import Distillation, DistillationArgs, DistillationV2, DistillationV2Args
     from lightly_train_amd.lars import LARSArgs
@@ -100,7 +100,8 @@ def test_distillation_v1_v2_reproduce_the_reference_fixture(name):
         elif fx["kind"] == "v1":
             m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         else:
-            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"], n_projection_layers=fx.get("n_projection_layers", 1),
+                                                          projection_hidden_dim=fx.get("projection_hidden_dim", 2048)), **kw)
         exactify(m)
         for si, rec in enumerate(fx["steps"]):
             x = torch.randn(fx["b"], 3, fx["img"], fx["img"], generator=torch.Generator().manual_seed(rec["x_seed"]))
@@ -182,7 +183,8 @@ def _build_any(name, fresh=False):
         elif fx["kind"] == "v1":
             m = Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
         else:
-            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+            m = DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"], n_projection_layers=fx.get("n_projection_layers", 1),
+                                                          projection_hidden_dim=fx.get("projection_hidden_dim", 2048)), **kw)
         return fx, exactify(m), 400
     sc, tc = fx["student_cfg"], fx["teacher_cfg"]
     student_state = fx["init"]["student_backbone"]

@@ -36,10 +36,11 @@ def build(fx):
                                                          lars=LARSArgs(lr=fx["lr"], weight_decay=fx["weight_decay"])), **kw)
     if fx["kind"] == "v1":
         return Distillation(scfg, tcfg, DistillationArgs(queue_size=fx["queue_size"], optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
-    return DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]), **kw)
+    return DistillationV2(scfg, tcfg, DistillationV2Args(optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"], n_projection_layers=fx.get("n_projection_layers", 1),
+                                                          projection_hidden_dim=fx.get("projection_hidden_dim", 2048)), **kw)
 
 
-@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64"])
+@pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64", "distill_v2_d64_mlp3"])
 def test_distillation_v1_v2_steps_match_reference_fixture(name):
     fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     m = build(fx)
