@@ -70,8 +70,13 @@ def convert_dinov3_state(state: Dict[str, Tensor], cfg: ViTConfig) -> Dict[str, 
             if mask is not None:
                 b = b * mask.to(b.dtype).nan_to_num(nan=0.0)
             out[k] = b
-        elif k.startswith(("cls_norm.", "local_cls_norm.", "head.")):
-            raise NotImplementedError(f"untied cls norms / heads are not supported by the engine ({k})")
+        elif k.startswith("local_cls_norm."):
+            # untie_global_and_local_cls_norm (the SAT-493M ViT-L and the ViT-7B recipes, hub/backbones.py:476-487,615): a LayerNorm applied to
+            # the class / storage tokens of the LOCAL crops of a TRAINING forward only (vision_transformer.py:286-292).  The frozen teacher
+            # of the distillation methods runs in eval(): the parameters are never read there, so they are dropped on load.
+            continue
+        elif k.startswith(("cls_norm.", "head.")):
+            raise NotImplementedError(f"untie_cls_and_patch_norms / classification heads are not supported by the engine ({k})")
         else:
             out[k] = v.detach().clone().float()
     n_p = (cfg.img_size // cfg.patch_size) ** 2

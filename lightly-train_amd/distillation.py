@@ -285,8 +285,6 @@ class Distillation(_DistillBase):
         super().__init__(student_cfg, teacher_cfg, a, [("weight", (Dt, Ds)), ("bias", (Dt,))], global_batch_size, total_steps, max_epochs, device,
                          student_state, teacher_state, head_state, seed)
         self.teacher_queue = torch.zeros(a.queue_size, Dt, device=self.device)
-        if a.queue_size % 8:
-            raise NotImplementedError("queue sizes must be multiples of 8")
 
     @staticmethod
     def _init_bias(shape: Tuple[int, ...], fan_in: int, g: torch.Generator) -> Tensor:
@@ -303,6 +301,7 @@ class Distillation(_DistillBase):
         P.grad.zero_()
         self._loss.zero_()
         Q = self.teacher_queue.shape[0]
+        Qp = (Q + 7) // 8 * 8
         ts = self.teacher_stream
         ts.wait_event(main.record_event())
         with torch.cuda.stream(ts):   # _forward_teacher (distillation.py:243-251) + _update_queue (:225-241)
@@ -320,10 +319,12 @@ class Distillation(_DistillBase):
             else:
                 self.teacher_queue[B:] = self.teacher_queue[:-B].clone()
                 self.teacher_queue[:B] = tgn
-            qb = ws.get("queue.bf16", (Q, Dt), torch.bfloat16)
-            ops.cast_bf16(self.teacher_queue, qb)
-            t_logits = ws.get("g.t_logits", (B, Q), torch.float32)
-            ops.gemm(tg, qb, t_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
+            # similarity matrices [B, Q] are held with rows of Qp = Q rounded up to 8 columns (16-byte rows for the GEMMs); the pad rows of
+            # the bf16 queue copy stay zero, the pad columns of the logits are never read (lt_kl_fwd_bwd takes the row stride)
+            qb = ws.get("queue.bf16", (Qp, Dt), torch.bfloat16, zero=True)
+            ops.cast_bf16(self.teacher_queue, qb[:Q])
+            t_logits = ws.get("g.t_logits", (B, Qp), torch.float32)
+            ops.gemm(tg, qb, t_logits, M=B, N=Qp, K=Dt, epilogue=ops.EPI_F32)
             teacher_done = ts.record_event()
         # _forward_student (:253-266): pooled feature -> Linear -> normalize
         f = self.s.forward(ws, x, want_pooled=True, want_tokens=False)
@@ -333,19 +334,19 @@ class Distillation(_DistillBase):
         sinv = ws.get("s.inv", (B,), torch.float32)
         ops.l2norm_fwd(sg_raw, sg, sinv, B, Dt, 1e-12)
         main.wait_event(teacher_done)
-        s_logits = ws.get("g.s_logits", (B, Q), torch.float32)
-        ops.gemm(sg, qb, s_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
-        dlg = ws.get("g.dlogits", (B, Q), torch.bfloat16)
-        ops.kl_fwd_bwd(s_logits, t_logits, Q, 1.0 / a.temperature, 1.0 / B, self._loss, dlg, Q, B, Q)
+        s_logits = ws.get("g.s_logits", (B, Qp), torch.float32)
+        ops.gemm(sg, qb, s_logits, M=B, N=Qp, K=Dt, epilogue=ops.EPI_F32)
+        dlg = ws.get("g.dlogits", (B, Qp), torch.bfloat16, zero=True)     # pad columns: zero, never written
+        ops.kl_fwd_bwd(s_logits, t_logits, Qp, 1.0 / a.temperature, 1.0 / B, self._loss, dlg, Qp, B, Q)
         dsg_n = ws.get("g.dsg_n", (B, Dt), torch.float32)
-        ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Q, trans_b=True, epilogue=ops.EPI_F32)
+        ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Qp, trans_b=True, epilogue=ops.EPI_F32)
         dsg = ws.get("g.dsg", (B, Dt), torch.bfloat16)
         ops.l2norm_bwd(dsg_n, sg_raw, sinv, dsg, B, Dt)
         self._head_wgrad("", dsg, f["pooled"], Dt, Ds, B)
         dpool = ws.get("s.dpool", (B, Ds), torch.float32)
         ops.gemm(dsg, P.b["head.weight"], dpool, M=B, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
         self.s.backward(ws, f, B, dpool, None, self.side_stream)
-        self._last = dict(lam=lam, index=index, t_logits=t_logits, s_logits=s_logits)
+        self._last = dict(lam=lam, index=index, t_logits=t_logits[:, :Q], s_logits=s_logits[:, :Q])
         return TrainingStepResult(loss=self._loss[0], log_dict={})
 
     def state_dict(self) -> Dict[str, Tensor]:

@@ -245,10 +245,13 @@ class DistillationV3:
             else:
                 self.teacher_queue[B:] = self.teacher_queue[:-B].clone()
                 self.teacher_queue[:B] = tgn
-            qb = ws.get("queue.bf16", (Q, Dt), torch.bfloat16)
-            ops.cast_bf16(self.teacher_queue, qb)
-            t_logits = ws.get("g.t_logits", (B, Q), torch.float32)
-            ops.gemm(tg, qb, t_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
+            # [B, Q] similarity rows are Qp = Q rounded up to 8 columns apart (16-byte rows for the GEMMs); pad rows of the bf16 queue copy
+            # stay zero, pad columns of the logits are never read (lt_kl_fwd_bwd takes the row stride)
+            Qp = (Q + 7) // 8 * 8
+            qb = ws.get("queue.bf16", (Qp, Dt), torch.bfloat16, zero=True)
+            ops.cast_bf16(self.teacher_queue, qb[:Q])
+            t_logits = ws.get("g.t_logits", (B, Qp), torch.float32)
+            ops.gemm(tg, qb, t_logits, M=B, N=Qp, K=Dt, epilogue=ops.EPI_F32)
             n_pad = (n_pt + 7) // 8 * 8
             St = ws.get("l.St", (B * n_pt, n_pad), torch.float32)
             ops.gemm(tl, tl, St, M=n_pt, N=n_pt, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_pt * Dt, stride_b=n_pt * Dt,
@@ -300,11 +303,10 @@ class DistillationV3:
         # ---- losses (distillationv3_loss.py:60-115) and their gradients w.r.t. the similarity logits
         main.wait_event(teacher_done)
         Q = self.teacher_queue.shape[0]
-        s_logits = ws.get("g.s_logits", (B, Q), torch.float32)
-        ops.gemm(sg, qb, s_logits, M=B, N=Q, K=Dt, epilogue=ops.EPI_F32)
-        Qp = (Q + 7) // 8 * 8
-        dlg = ws.get("g.dlogits", (B, Qp), torch.bfloat16)
-        ops.kl_fwd_bwd(s_logits, t_logits, Q, 1.0 / a.temperature_global, 1.0 / B, self._loss_slots[0:], dlg, Qp, B, Q)
+        s_logits = ws.get("g.s_logits", (B, Qp), torch.float32)
+        ops.gemm(sg, qb, s_logits, M=B, N=Qp, K=Dt, epilogue=ops.EPI_F32)
+        dlg = ws.get("g.dlogits", (B, Qp), torch.bfloat16, zero=True)     # pad columns: zero, never written
+        ops.kl_fwd_bwd(s_logits, t_logits, Qp, 1.0 / a.temperature_global, 1.0 / B, self._loss_slots[0:], dlg, Qp, B, Q)
         Ss = ws.get("l.Ss", (B * n_pl, n_pad), torch.float32)
         ops.gemm(sl, sl, Ss, M=n_pl, N=n_pl, K=Dt, epilogue=ops.EPI_F32, ldc=n_pad, batch=B, stride_a=n_pl * Dt, stride_b=n_pl * Dt,
                  stride_c=n_pl * n_pad)
@@ -314,9 +316,7 @@ class DistillationV3:
 
         # ---- backward: similarity logits -> normalised features -> projection heads -> student tokens
         dsg_n = ws.get("g.dsg_n", (B, Dt), torch.float32)
-        if Qp != Q:
-            raise NotImplementedError("queue sizes must be multiples of 8")
-        ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Q, trans_b=True, epilogue=ops.EPI_F32)
+        ops.gemm(dlg, qb, dsg_n, M=B, N=Dt, K=Qp, trans_b=True, epilogue=ops.EPI_F32)
         G = ws.get("l.G", (B * n_pl, n_pad), torch.bfloat16, zero=True)
         ops.symmetrize_bf16(dS, G, B, n_pl, n_pad)
         dsl_n = ws.get("l.dsl_n", (B * n_pl, Dt), torch.float32)
@@ -381,7 +381,7 @@ class DistillationV3:
         ls = self._loss_slots
         w = a.loss_local_weight
         logs = {"train_loss/global_loss": ls[0], "train_loss/local_loss": ls[1] / w if w else ls[1]}
-        self._last = dict(B=B, lam=lam, index=index, t_logits=t_logits, s_logits=s_logits, tg=tg, tl=tl, sg=sg, sl=sl)
+        self._last = dict(B=B, lam=lam, index=index, t_logits=t_logits[:, :Q], s_logits=s_logits[:, :Q], tg=tg, tl=tl, sg=sg, sl=sl)
         return TrainingStepResult(loss=ls[0] + ls[1], log_dict=logs)
 
     def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:

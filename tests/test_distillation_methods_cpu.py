@@ -349,3 +349,76 @@ def test_optimizer_state_load_zeroes_moments_without_an_entry():
         m.exp_avg.fill_(3.0); m.exp_avg_sq.fill_(2.0); m.opt_step = 7
         m.load_optimizer_state_dict(fresh)
         assert m.opt_step == 0 and float(m.exp_avg.abs().max()) == 0.0 and float(m.exp_avg_sq.abs().max()) == 0.0
+
+
+def test_dinov3_teacher_state_with_untied_local_cls_norm_loads_and_matches_the_reference_in_eval():
+    """`untie_global_and_local_cls_norm=True` (the SAT-493M ViT-L / ViT-7B recipes): `local_cls_norm` is read by training-mode
+    local-crop forwards only (vision_transformer.py:286-292), never by a frozen eval() teacher -- the converted state drops it and the
+    engine's eval forward equals the reference model's."""
+    from oracle import ref_harness as H
+
+    if not H.reference_available():
+        pytest.skip("/root/reference not present (GPU box)")
+    H.install()
+    from lightly_train._models.dinov3.dinov3_src.models.vision_transformer import DinoVisionTransformer as V3
+    from lightly_train_amd.dinov3 import convert_dinov3_state, dinov3_vit_config
+    from lightly_train_amd.params import FlatParams
+    from lightly_train_amd.vit import ViTEngine, vit_param_shapes
+
+    torch.manual_seed(5)
+    ref = V3(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4, qkv_bias=True, layerscale_init=0.1, norm_layer="layernormbf16",
+             ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True, pos_embed_rope_base=100, pos_embed_rope_normalize_coords="separate",
+             pos_embed_rope_rescale_coords=None, pos_embed_rope_dtype="fp32", untie_global_and_local_cls_norm=True)
+    ref.init_weights()
+    with torch.no_grad():
+        for n_, p_ in ref.named_parameters():
+            if "norm" in n_ or n_.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    ref.eval()
+    sd = ref.state_dict()
+    assert any(k.startswith("local_cls_norm.") for k in sd)
+    cfg = dinov3_vit_config(64, 2, 1, patch_size=16, img_size=64)
+    conv = convert_dinov3_state(sd, cfg)
+    assert not any(k.startswith("local_cls_norm.") for k in conv)
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    with ops_emu.emulate(ops):
+        fp = FlatParams([(n, conv[n]) for n, _ in vit_param_shapes(cfg)], "cpu", False)
+        fp.bf16 = fp.data.clone()
+        fp.b = {n: fp.bf16[fp.offsets[n]:fp.offsets[n] + fp.p[n].numel()].view(fp.shapes[n]) for n in fp.names}
+        eng = ViTEngine(cfg, fp, "")
+        if eng.wpe_pad is not None:
+            eng.wpe_pad = eng.wpe_pad.float()
+        eng.refresh_padded_weights()
+        ctx = eng.forward(F32Workspace(torch.device("cpu")), "t", x, None, save=False)
+    with torch.no_grad():
+        out = ref.forward_features(x)
+    xn = ctx["xn"].view(3, -1, 64)
+    assert torch.allclose(xn[:, 0], out["x_norm_clstoken"], atol=2e-5) and torch.allclose(xn[:, 5:], out["x_norm_patchtokens"], atol=2e-5)
+
+
+def test_distillation_v1_queue_size_off_the_8_grid():
+    """A queue size that is not a multiple of 8 (the similarity rows are padded to 8 columns inside, lt_kl_fwd_bwd reads the real ones):
+    three steps against the restated method (oracle/distill_oracle.py, itself pinned on the reference's fixture at queue 32), through the
+    queue filling up and rolling (37 entries, batch 8)."""
+    from lightly_train_amd.distillation import Distillation, DistillationArgs
+    from oracle import distill_oracle as OD
+
+    fx = torch.load(os.path.join(GOLD, "distill_v1_d64.pt"), weights_only=False)
+    Q = 37
+    o = OD.OracleDistillation12("v1", fx["init"]["student_backbone"], fx["student_cfg"], fx["teacher_state"], fx["teacher_cfg"], fx["init"]["head"], Q,
+                                fx["b"], fx["total_steps"], lr=fx["lr"], weight_decay=fx["weight_decay"])
+    with ops_emu.emulate(ops):
+        m = exactify(Distillation(vit_cfg(fx["student_cfg"]), vit_cfg(fx["teacher_cfg"]),
+                                  DistillationArgs(queue_size=Q, optimizer="adamw", lr=fx["lr"], weight_decay=fx["weight_decay"]),
+                                  global_batch_size=fx["b"], total_steps=fx["total_steps"], max_epochs=1, device="cpu",
+                                  student_state=fx["init"]["student_backbone"], teacher_state=fx["teacher_state"], head_state=fx["init"]["head"]))
+        for s in range(6):
+            x = torch.randn(fx["b"], 3, fx["img"], fx["img"], generator=torch.Generator().manual_seed(900 + s))
+            lam, index = 0.3 + 0.1 * s, torch.randperm(fx["b"], generator=torch.Generator().manual_seed(s))
+            want = o.train_step(x, lam, index)
+            res = m.train_step(x, mix=(lam, index))
+            assert float(res.loss) == pytest.approx(want["loss"], rel=2e-5, abs=1e-7), s
+            assert m._last["t_logits"].shape == (fx["b"], Q)
+        assert torch.allclose(m.teacher_queue, o.queue, atol=1e-6)
+        for k, v in o.sb.items():
+            assert torch.allclose(m.student.p["backbone." + k], v.detach(), atol=3e-6), k
