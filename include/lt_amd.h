@@ -276,6 +276,18 @@ int lt_reduce_begin(float* scratch, int64_t floats);
 int lt_reduce_flush(void* stream);
 int lt_reduce_end(void* stream);
 int64_t lt_reduce_overflows(void);
+/* RCCL communicator handle of this process -- the library's only process-wide state besides scratch.  Rank 0 draws
+ * a 128-byte unique id (lt_comm_unique_id) and hands it to the other ranks by any out-of-band means; every rank calls lt_comm_init once.
+ * lt_comm_allreduce_f32 sums buf over the ranks in place on the communicator's own stream, ordered after what `after_stream` holds at the
+ * call; lt_comm_wait makes `stream` wait for every collective enqueued so far (no host synchronisation in either).  The reference does
+ * the same through DDP's bucket hooks and torch.distributed (LT/_commands/train.py: strategy "ddp"); the Python driver here can use either
+ * (parallel.GradSync, LT_GRAD_COMM=abi).  librccl.so is loaded at lt_comm_init, not at library load. */
+int lt_comm_unique_id(void* id_out, int bytes);
+int lt_comm_init(int rank, int world, const void* unique_id, int bytes);
+int lt_comm_allreduce_f32(float* buf, int64_t n, void* after_stream);
+int lt_comm_wait(void* stream);
+int lt_comm_size(void);
+int lt_comm_destroy(void);
 /* teacher = m*teacher + (1-m)*student ; also refresh the teacher's bf16 shadow.  m is a double: 1 - m (~1e-6 at the end of the
  * cosine momentum schedule) is formed in double before the cast, as update_momentum does (_torch_helpers.py:75-96). */
 int lt_ema_flat(float* teacher, const float* student, void* teacher_bf16, int64_t n, double m, void* stream);

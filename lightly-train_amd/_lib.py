@@ -79,6 +79,12 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_ema_flat": [vp, vp, vp, i64, C.c_double, vp],
     "lt_lars_norms": [vp, vp, i64, vp, i32, vp, vp, vp],
     "lt_lars_flat": [vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, f32, f32, i32, vp, f32, vp],
+    "lt_comm_unique_id": [vp, i32],
+    "lt_comm_init": [i32, i32, vp, i32],
+    "lt_comm_allreduce_f32": [vp, i64, vp],
+    "lt_comm_wait": [vp],
+    "lt_comm_size": [],
+    "lt_comm_destroy": [],
     "lt_reduce_begin": [vp, i64],
     "lt_reduce_flush": [vp],
     "lt_reduce_end": [vp],

@@ -32,6 +32,59 @@ def per_rank_batch(global_batch: int, world: int) -> int:
     return global_batch // world
 
 
+class AbiComm:
+    """The library's own RCCL communicator (include/lt_amd.h: lt_comm_*) as the gradient all-reduce transport instead of
+    torch.distributed's.  `from_torch_group()` bootstraps it from an initialised torch process group: rank 0 draws the unique id, a
+    byte-tensor broadcast hands it out.  One communicator per process."""
+    _instance: Optional["AbiComm"] = None
+
+    def __init__(self, rank_: int, world: int, unique_id: bytes) -> None:
+        from . import _lib
+
+        self.lib = _lib.load()
+        _lib.check(self.lib.lt_comm_init(rank_, world, unique_id, len(unique_id)), "lt_comm_init")
+        self.world = world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from . import _lib
+
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().lt_comm_unique_id(buf, 128), "lt_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, device: torch.device) -> "AbiComm":
+        if cls._instance is None:
+            r, w = rank(), world_size()
+            t = torch.zeros(128, dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+            if r == 0:
+                t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+            if w > 1:
+                dist.broadcast(t, src=0)
+            cls._instance = cls(r, w, bytes(t.cpu().tolist()))
+        return cls._instance
+
+    def all_reduce(self, t: Tensor) -> None:
+        """In-place sum on the communicator's stream, ordered after the current stream's work (no host wait)."""
+        from . import _lib, ops
+
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.lt_comm_allreduce_f32(t.data_ptr(), t.numel(), ops._stream()), "lt_comm_allreduce_f32")
+
+    def wait(self) -> None:
+        """The current stream waits for every collective enqueued so far."""
+        from . import _lib, ops
+
+        _lib.check(self.lib.lt_comm_wait(ops._stream()), "lt_comm_wait")
+
+    def destroy(self) -> None:
+        self.lib.lt_comm_destroy()
+        AbiComm._instance = None
+
+
 def bucket_ranges(numel: int, bucket_elems: int) -> List[Tuple[int, int]]:
     return [(o, min(o + bucket_elems, numel)) for o in range(0, numel, bucket_elems)]
 
@@ -45,8 +98,13 @@ class GradSync:
     the collective is ordered after it); `finish()` reduces whatever no `start` has covered, waits for everything on the
     current stream and applies the 1/world scale.  Every rank must issue the same ranges in the same order."""
 
-    def __init__(self, flat_grad: Tensor, bucket_bytes: int = 64 << 20) -> None:
+    def __init__(self, flat_grad: Tensor, bucket_bytes: int = 64 << 20, comm: Optional[AbiComm] = None) -> None:
         self.g = flat_grad
+        # LT_GRAD_COMM=abi: the all-reduces go through the library's own RCCL communicator (lt_comm_*) instead of torch.distributed
+        import os
+        if comm is None and os.environ.get("LT_GRAD_COMM") == "abi" and flat_grad.is_cuda and world_size() > 1:
+            comm = AbiComm.from_torch_group(flat_grad.device)
+        self.comm = comm
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.ranges = bucket_ranges(flat_grad.numel(), self.bucket_elems)
         self.handles: List = []
@@ -72,13 +130,18 @@ class GradSync:
         hi = self.g.numel() if hi is None else hi
         for a, b in self.uncovered(lo, hi):
             for c, d in bucket_ranges(b - a, self.bucket_elems):
-                self.handles.append(dist.all_reduce(self.g[a + c:a + d], op=dist.ReduceOp.SUM, async_op=True))
+                if self.comm is not None:
+                    self.comm.all_reduce(self.g[a + c:a + d])
+                else:
+                    self.handles.append(dist.all_reduce(self.g[a + c:a + d], op=dist.ReduceOp.SUM, async_op=True))
             self.covered.append((a, b))
 
     def reset(self) -> None:
         """Drop the bookkeeping of an unfinished step (waits for its collectives first)."""
         for h in self.handles:
             h.wait()
+        if self.comm is not None:
+            self.comm.wait()
         self.handles.clear()
         self.covered.clear()
 
@@ -89,6 +152,8 @@ class GradSync:
         self.start()
         for h in self.handles:
             h.wait()
+        if self.comm is not None:
+            self.comm.wait()
         self.handles.clear()
         self.covered.clear()
         if self.g.is_cuda:

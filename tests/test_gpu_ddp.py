@@ -331,7 +331,12 @@ def _rccl_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         views = [torch.randn(B, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(B, 3, 96, 96, generator=g) for _ in range(8)]
         out = {}
         for key, center, overlap in (("overlap", "softmax", True), ("overlap_again", "softmax", True), ("after", "softmax", False),
-                                     ("sk_overlap", "sinkhorn_knopp", True), ("sk_after", "sinkhorn_knopp", False)):
+                                     ("sk_overlap", "sinkhorn_knopp", True), ("sk_after", "sinkhorn_knopp", False), ("abi", "softmax", True)):
+            # "abi": the gradient all-reduces through the library's own communicator handle (lt_comm_*, include/lt_amd.h) instead of
+            # torch.distributed's -- a second RCCL communicator of this process on the same device
+            os.environ["LT_GRAD_COMM"] = "abi" if key == "abi" else ""
+            if key == "abi":      # (a one-rank communicator: the step merely believes it is one of two)
+                parallel.AbiComm._instance = parallel.AbiComm(0, 1, parallel.AbiComm.unique_id())
             m = DINOv2(cfg, DINOv2Args(output_dim=8192, hidden_dim=512, dino_bottleneck_dim=256, center_method=center), global_batch_size=2 * B,
                        total_steps=100, device="cuda", seed=3)
             m.overlap_grad_reduce = overlap
@@ -356,7 +361,7 @@ def test_collectives_over_rccl_overlapped_equal_sequential(tmp_path):
     == the same run again, for both centering methods; and the early ranges cover most of the gradient buffer."""
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "rccl.pt", weights_only=False)
-    for a, b in (("overlap", "overlap_again"), ("overlap", "after"), ("sk_overlap", "sk_after")):
+    for a, b in (("overlap", "overlap_again"), ("overlap", "after"), ("sk_overlap", "sk_after"), ("overlap", "abi")):
         for i, what in enumerate(("student", "teacher", "center")):
             assert torch.equal(r[a][i], r[b][i]), (a, b, what, (r[a][i] - r[b][i]).abs().max().item())
         assert r[a][5] == r[b][5], (a, b, "losses")

@@ -888,3 +888,28 @@ def test_persistent_gemm_race_screen():
     for env in ({}, {"LT_GEMM_1P_GRID": "24"}, {"LT_GEMM_1P_DBG": "2"}):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm1p_stress.py"), "6"], env={**os.environ, **env}, capture_output=True, text=True)
         assert r.returncode == 0 and "FAILURES 0" in r.stdout, (env, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_comm_handle_single_rank_allreduce_is_ordered_with_the_streams():
+    """lt_comm_* (the C ABI's RCCL communicator handle) with one rank: the all-reduce is the identity in value; what is checked is the
+    fencing -- it runs on the communicator's stream AFTER the producer enqueued on the caller's stream, and a consumer that called
+    lt_comm_wait sees its result."""
+    from lightly_train_amd.parallel import AbiComm
+
+    comm = AbiComm(0, 1, AbiComm.unique_id())
+    try:
+        assert comm.lib.lt_comm_size() == 1
+        n = 64 * 1024 * 1024
+        buf = torch.zeros(n, device=DEV)
+        side = torch.cuda.Stream()
+        for it in range(3):
+            with torch.cuda.stream(side):
+                buf.fill_(float(it + 1))          # producer on `side`
+                comm.all_reduce(buf)              # ordered after it, on the communicator's stream
+            comm.wait()                           # the current (default) stream waits for the collective
+            out = buf * 2.0                       # consumer
+            assert float(out[0]) == 2.0 * (it + 1) and float(out[-1]) == 2.0 * (it + 1)
+            side.wait_stream(torch.cuda.current_stream())
+    finally:
+        comm.destroy()
+    assert comm.lib.lt_comm_size() == 0
