@@ -189,11 +189,84 @@ def dinov2_amd_method_cls() -> type:
     return _CLS
 
 
+_DINO_CLS: Optional[type] = None
+
+
+def dino_amd_method_cls() -> type:
+    """`DINOAMD(Method)`: the same binding for `method="dino"` (LT/_methods/dino/dino.py:221-480) on `lightly_train_amd.dino.DINO`.
+    ViT backbones (the DINOv2 ViT wrapper); the reference's containers are `teacher_embedding_model`, `teacher_projection_head`,
+    `student_embedding_model`, `student_projection_head`, `criterion.center`."""
+    global _DINO_CLS
+    if _DINO_CLS is not None:
+        return _DINO_CLS
+    from lightly_train._methods.dino.dino import DINO as RefDINO
+    from lightly_train._methods.method import Method, TrainingStepResult
+    from lightly_train._optim.optimizer_type import OptimizerType
+
+    from .dino import DINO as HipDINO
+    from .dino import DINOArgs as HipDINOArgs
+
+    base = dinov2_amd_method_cls()
+
+    class DINOAMD(RefDINO):   # type: ignore[misc, valid-type]
+        def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
+                     device: Optional[torch.device] = None) -> None:
+            super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
+                             global_batch_size=global_batch_size, num_input_channels=num_input_channels)
+            self.automatic_optimization = False
+            self._impl: Optional[HipDINO] = None
+            self._impl_device = device
+            self._pending_resume: Optional[Dict[str, Any]] = None
+
+        def impl(self) -> HipDINO:
+            if self._impl is None:
+                import dataclasses
+
+                dev = self._impl_device or next(self.parameters()).device
+                sd = Method.state_dict(self)
+                a, oa = self.method_args, self.optimizer_args
+                kw = {f.name: getattr(a, f.name) for f in dataclasses.fields(HipDINOArgs)
+                      if hasattr(a, f.name) and getattr(a, f.name) is not None and getattr(a, f.name) != "auto"}
+                is_sgd = oa.type() == OptimizerType.SGD
+                kw.update(optimizer="sgd" if is_sgd else "adamw", lr=float(oa.lr), weight_decay=float(oa.weight_decay))
+                if is_sgd:
+                    kw["momentum"] = float(oa.momentum)
+                else:
+                    kw.update(betas=tuple(oa.betas), eps=float(oa.eps))
+                cfg = vit_config_from_reference(self.teacher_embedding_model.wrapped_model.get_model())
+                bb = "embedding_model.wrapped_model._model."
+                self._impl = HipDINO(cfg, HipDINOArgs(**kw), global_batch_size=self.global_batch_size,
+                                     total_steps=int(self.trainer.estimated_stepping_batches), device=dev,
+                                     backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
+                                     student_head_state=_strip(sd, "student_projection_head."), teacher_head_state=_strip(sd, "teacher_projection_head."))
+                self._impl.load_state_dict(sd)
+                if self._pending_resume is not None:
+                    self._impl.load_checkpoint_dict(self._pending_resume)
+                    self._pending_resume = None
+            return self._impl
+
+        def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
+            m = self.impl()
+            if int(self.trainer.global_step) > m.trainer.global_step:
+                m.trainer.global_step = int(self.trainer.global_step)
+            res = m.training_step_impl(batch, batch_idx)     # EMA first, then forward + explicit backward (dino.py:273-316)
+            m.optimizer_step()                               # WD schedule, last-layer freeze, clip 3.0, SGD / AdamW (dino.py:330-477)
+            self._tick_lightning()
+            return TrainingStepResult(loss=res.loss, log_dict=res.log_dict)
+
+    for name in ("_tick_lightning", "configure_optimizers", "configure_gradient_clipping", "on_before_optimizer_step", "on_train_batch_end",
+                 "sync_to_containers", "state_dict", "on_save_checkpoint", "on_load_checkpoint"):
+        setattr(DINOAMD, name, getattr(base, name))
+    DINOAMD.__qualname__ = "DINOAMD"
+    _DINO_CLS = DINOAMD
+    return _DINO_CLS
+
+
 def install_as(name: str = "dinov2") -> type:
     """Map a method name of `lightly_train.train(method=...)` to the MI355X class (method_helpers.py:54-69 builds its table per call)."""
     from lightly_train._methods import method_helpers
 
-    cls = dinov2_amd_method_cls()
+    cls = dino_amd_method_cls() if name == "dino" else dinov2_amd_method_cls()
     orig = method_helpers._method_name_to_cls
 
     def patched() -> Dict[str, type]:

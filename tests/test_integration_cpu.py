@@ -210,3 +210,61 @@ def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
         s1, s2 = amd.state_dict(), amd2.state_dict()
         for k in s1:
             assert torch.allclose(s1[k].float(), s2[k].float(), atol=1e-7), k
+
+
+def _build_dino(cls, seed=0):
+    """The reference's DINO constructor calls (as in oracle/make_golden.py::make_dino_v1) around `cls`."""
+    H.install()
+    from lightly_train._methods.dino.dino import DINO, DINOArgs
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as v2
+    from lightly_train._models.embedding_model import EmbeddingModel
+    from lightly_train._scaling import ScalingInfo
+
+    torch.manual_seed(seed)
+    model = v2.DinoVisionTransformer(img_size=96, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1, drop_path_rate=0.0,
+                                     ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    wrapped = DINOv2ViTModelWrapper(model)
+    margs = DINOArgs(hidden_dim=128, bottleneck_dim=64, output_dim=512, student_freeze_last_layer_steps=1, teacher_temp=0.07, warmup_teacher_temp=0.04,
+                     warmup_teacher_temp_steps=3, momentum_start=0.99)
+    oargs = DINO.optimizer_args_cls("auto")()
+    margs.resolve_auto(scaling_info=ScalingInfo(dataset_size=1000, epochs=1), optimizer_args=oargs, wrapped_model=wrapped)
+    kw = dict(device=torch.device("cpu")) if cls is not DINO else {}
+    m = cls(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=wrapped), global_batch_size=8, num_input_channels=3, **kw)
+    m.trainer = H.MockTrainer(20)
+    m.current_epoch = 0
+    return m
+
+
+def test_dino_v1_binding_two_steps_equal_the_reference_class():
+    """`DINOAMD(Method)` (integration.dino_amd_method_cls) behind the reference's own DINO constructor: two steps with the method's "auto"
+    optimizer (SGD), across the last-layer unfreeze, equal the reference class driven through Lightning's hook order -- loss and every
+    student / teacher tensor; state_dict keys in the reference's order."""
+    H.install()
+    from lightly_train._methods.dino.dino import DINO
+    from lightly_train_amd import integration
+
+    ref = _build_dino(DINO)
+    amd = _build_dino(integration.dino_amd_method_cls())
+    assert list(amd.state_dict()) == list(ref.state_dict())
+    [opt], [sched] = ref.configure_optimizers()
+    sched = sched["scheduler"]
+    g = torch.Generator().manual_seed(3)
+    with ops_emu.emulate(ops):
+        m = amd.impl()
+        exactify(m)
+        for step in range(2):
+            views = [torch.randn(8, 3, 96, 96, generator=g) for _ in range(2)] + [torch.randn(8, 3, 48, 48, generator=g) for _ in range(2)]
+            res = ref.training_step_impl({"views": [v.clone() for v in views], "filename": []}, 0)
+            res.loss.backward()
+            ref.on_before_optimizer_step(opt)
+            torch.nn.utils.clip_grad_norm_([p for g_ in opt.param_groups for p in g_["params"] if p.grad is not None], 3.0)
+            opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+            ref.trainer.global_step += 1
+            got = drive(amd, views, step)
+            assert got["loss"] == pytest.approx(float(res.loss), rel=3e-5), step
+        sd, rsd = amd.state_dict(), ref.state_dict()
+        assert list(sd) == list(rsd)
+        for k in rsd:
+            assert torch.allclose(sd[k].float(), rsd[k].float(), atol=3e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+    assert integration.install_as("dino") is integration.dino_amd_method_cls()
