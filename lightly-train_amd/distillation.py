@@ -32,7 +32,7 @@ from .parallel import GradSync
 from .params import FlatParams
 from .resnet import ResNetConfig, ResNetEngine, flat_named, init_resnet_state
 from .schedules import warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, split_k_plan, vit_param_shapes
 
 
 @dataclass
@@ -217,7 +217,7 @@ class _DistillBase:
         ops.colsum_bf16(dy, P.g["head." + name + "bias"], rows, n_out)
         tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
         ops.gemm(dy, xin, P.g["head." + name + "weight"], M=n_out, N=k_in, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                 lda=n_out, ldb=k_in, split_k=_split_k(tiles, rows), workspace=slab)
+                 lda=n_out, ldb=k_in, workspace=slab, **split_k_plan(n_out, k_in, rows, True, _split_k(tiles, rows)))
 
     def optimizer_step(self) -> None:
         a = self.method_args

@@ -32,7 +32,7 @@ from .lars import FlatLARS, LARSArgs
 from .params import FlatParams
 from .schedules import warmup_cosine_lr_factor
 from .resnet import ResNetConfig, ResNetEngine, flat_named, init_resnet_state
-from .vit import ViTConfig, ViTEngine, Workspace, _split_k, vit_param_shapes
+from .vit import ViTConfig, ViTEngine, Workspace, _split_k, split_k_plan, vit_param_shapes
 
 NO_DECAY_KEYS = ("cls_token", "mask_token", "storage_token", "register_token", "pos_embed")
 
@@ -341,7 +341,7 @@ class DistillationV3:
             ops.colsum_bf16(dy, P.g[tagp + ".bias"], rows, Dt)
             tiles = ((Dt + 127) // 128) * ((Ds + 127) // 128)   # few output tiles, long contraction: split-K into slabs
             ops.gemm(dy, xin, P.g[tagp + ".weight"], M=Dt, N=Ds, K=rows, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=Dt, ldb=Ds,
-                     split_k=_split_k(tiles, rows), workspace=slab)
+                     workspace=slab, **split_k_plan(Dt, Ds, rows, True, _split_k(tiles, rows)))
         dcls = ws.get("s.dcls", (B, Ds), torch.float32)
         dpat = ws.get("s.dpat", (B * n_ps, Ds), torch.float32)
         ops.gemm(dsg, P.b["proj_global.weight"], dcls, M=B, N=Ds, K=Dt, trans_b=True, epilogue=ops.EPI_F32)
