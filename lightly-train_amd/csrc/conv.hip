@@ -164,28 +164,30 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_t* __restric
     partial[((long)(j >> 3) * G + blockIdx.y) * C + vg * 8 + (j & 7)] = s;
   }
 }
-// pass 2: block = 32 channels x 8 partial-lanes.  Every thread adds its share of the G per-block partials (g = lane, lane + 8, ...)
-// in double, the 8 lanes of a channel are then combined in lane order: a fixed summation tree (deterministic), ~G/8 pipelined
-// loads per thread instead of one thread walking all G partials of a channel (that serial walk took 140-170 us per layer).
+// pass 2: block = BN_FC channels x BN_FL partial-lanes.  Every thread adds its share of the G per-block partials (g = lane, lane + BN_FL, ...)
+// in double, the lanes of a channel are then combined in lane order: a fixed summation tree (deterministic).  8 channels x 32 lanes: a
+// thread walks G / 32 partials (32 dependent double adds at G = 1024) -- with 32 channels x 8 lanes it was 128, and the kernel took 29 us
+// per layer for a few KB of data (one thread walking all G: 140-170 us).
+constexpr int BN_FC = 8, BN_FL = 32;
 __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ partial, int G, int C, int c, int lane, double& s0, double& s1,
-                                                double (*red)[32][2]) {
+                                                double (*red)[BN_FC][2]) {
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int g = lane; g < G; g += 8) { a += (double)partial[(long)g * C + c]; b += (double)partial[((long)G + g) * C + c]; }
+    for (int g = lane; g < G; g += BN_FL) { a += (double)partial[(long)g * C + c]; b += (double)partial[((long)G + g) * C + c]; }
   }
-  red[lane][threadIdx.x & 31][0] = a;
-  red[lane][threadIdx.x & 31][1] = b;
+  red[lane][threadIdx.x % BN_FC][0] = a;
+  red[lane][threadIdx.x % BN_FC][1] = b;
   __syncthreads();
   s0 = 0.0; s1 = 0.0;
 #pragma unroll
-  for (int l = 0; l < 8; ++l) { s0 += red[l][threadIdx.x & 31][0]; s1 += red[l][threadIdx.x & 31][1]; }
+  for (int l = 0; l < BN_FL; ++l) { s0 += red[l][threadIdx.x % BN_FC][0]; s1 += red[l][threadIdx.x % BN_FC][1]; }
 }
 // forward: batch statistics (biased variance for normalisation, unbiased for the running estimate, torch semantics)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int G, long rows, int C, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  __shared__ double red[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  __shared__ double red[BN_FL][BN_FC][2];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC), lane = threadIdx.x / BN_FC;
   double s, ss;
   bn_sum_partials(partial, G, C, c, lane, s, ss, red);
   if (lane != 0 || c >= C) return;
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 // backward: dgamma += sum dz*xhat, dbeta += sum dz, and the two means the input gradient needs
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, long rows, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2) {
-  __shared__ double red[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  __shared__ double red[BN_FL][BN_FC][2];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC), lane = threadIdx.x / BN_FC;
   double s, sx;
   bn_sum_partials(partial, G, C, c, lane, s, sx, red);
   if (lane != 0 || c >= C) return;
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // ---- SyncBatchNorm pieces: the per-rank raw sums leave the device-side reduction as doubles (one all-reduce over [2C + 1]: the last
 // element carries the row count), the statistics / input-gradient coefficients are then formed from the global sums.
 __global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ partial, int G, long rows, int C, double* __restrict__ sums) {
-  __shared__ double red[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  __shared__ double red[BN_FL][BN_FC][2];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC), lane = threadIdx.x / BN_FC;
   double s, ss;
   bn_sum_partials(partial, G, C, c, lane, s, ss, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) sums[2L * C] = (double)rows;
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double* __r
 }
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int G, long rows, int C, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, double* __restrict__ sums) {
-  __shared__ double red[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  __shared__ double red[BN_FL][BN_FC][2];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC), lane = threadIdx.x / BN_FC;
   double s, sx;
   bn_sum_partials(partial, G, C, c, lane, s, sx, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) sums[2L * C] = (double)rows;
@@ -482,7 +484,7 @@ extern "C" int lt_batchnorm_fwd(const void* x, const float* gamma, const float* 
   const BnGeom g = bn_geom(rows, C);
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, eps, momentum, mean, rstd, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lt_cdiv(C, BN_FC)), dim3(256), 0, ST, ws, g.G, (long)rows, C, eps, momentum, mean, rstd, running_mean,
                      running_var);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)resid,
                      (bf16_t*)y, (long)rows, C, relu);
@@ -509,7 +511,7 @@ extern "C" int lt_batchnorm_bwd(const void* dy, const void* y, const void* x, co
   float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd,
                      (bf16_t*)dz, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(lt_cdiv(C, BN_FC)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, c1, c2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)(dz ? dz : dy), (const bf16_t*)x, mean, rstd,
                      gamma, c1, c2, (bf16_t*)dx, (long)rows, C);
   LT_CHECK_LAUNCH("lt_batchnorm_bwd");
@@ -522,7 +524,7 @@ extern "C" int lt_batchnorm_stats(const void* x, int64_t rows, int C, float* ws,
   const BnGeom g = bn_geom(rows, C);
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_sums_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, sums);
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(lt_cdiv(C, BN_FC)), dim3(256), 0, ST, ws, g.G, (long)rows, C, sums);
   LT_CHECK_LAUNCH("lt_batchnorm_stats");
 }
 extern "C" int lt_batchnorm_fwd_from_sums(const void* x, const double* sums, const float* gamma, const float* beta, const void* resid, void* y,
@@ -543,7 +545,7 @@ extern "C" int lt_batchnorm_bwd_sums(const void* dy, const void* y, const void* 
   const BnGeom g = bn_geom(rows, C);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.gx, g.G), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd,
                      (bf16_t*)dz, ws, (long)rows, C, g.vpb);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(lt_cdiv(C, 32)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(lt_cdiv(C, BN_FC)), dim3(256), 0, ST, ws, g.G, (long)rows, C, dgamma, dbeta, sums);
   LT_CHECK_LAUNCH("lt_batchnorm_bwd_sums");
 }
 extern "C" int lt_batchnorm_bwd_from_sums(const void* dz, const void* x, const float* gamma, const float* mean, const float* rstd, const double* sums,

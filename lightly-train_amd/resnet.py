@@ -161,7 +161,8 @@ class ResNetEngine:
         for bn, c in bn_names(cfg):
             for k, init in ((".running_mean", torch.zeros(c)), (".running_var", torch.ones(c)), (".num_batches_tracked", torch.zeros((), dtype=torch.long))):
                 src = buffers[bn + k] if buffers is not None and (bn + k) in buffers else init
-                self.buffers[bn + k] = src.detach().clone().to(self.dev)
+                # the batch counters live on the host: `+= 1` per layer per step is then not a kernel launch (53 of them per ResNet-50 step)
+                self.buffers[bn + k] = src.detach().clone().to("cpu" if k == ".num_batches_tracked" else self.dev)
         self.act_dtype = torch.bfloat16   # storage type of activations / activation gradients (the HIP ops only accept bf16)
         # SyncBatchNorm: Lightning replaces every BatchNorm layer when sync_batchnorm=True, which the reference sets whenever the accelerator is a
         # GPU (LT/_commands/train_helpers.py:223,335-342).  None = per-process statistics (one rank); else a callable that adds a device tensor
@@ -400,4 +401,4 @@ class ResNetEngine:
         """BatchNorm running estimates / batch counters present in `sd` (torchvision names)."""
         for k in self.buffers:
             if k in sd:
-                self.buffers[k].copy_(sd[k].to(self.dev))
+                self.buffers[k].copy_(sd[k].to(self.buffers[k].device))
