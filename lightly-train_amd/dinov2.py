@@ -669,6 +669,11 @@ class DINOv2:
             main.wait_stream(self.reduce_stream)
         if det:
             ops.reduce_end()               # one ordered sum for everything still recorded; back to immediate reductions
+            n_ovf = ops.reduce_overflows()
+            if n_ovf != getattr(self, "_ledger_overflows", 0):   # scratch too small for this shape: those sums fell back to atomics
+                import warnings
+                warnings.warn(f"reduction ledger scratch exhausted ({n_ovf} fallbacks to atomic sums so far): the step is not bitwise reproducible")
+                self._ledger_overflows = n_ovf
         self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
 
     # ------------------------------------------------------------------ the step
