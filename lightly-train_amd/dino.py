@@ -430,3 +430,255 @@ class DINO(DINOv2):
         res = self.training_step_impl({"views": views}, 0)
         self.optimizer_step()
         return res
+
+
+class DINOResNet(DINO):
+    """DINO on a torchvision ResNet (the reference's `ResNetModelWrapper`: `_features` = conv1 .. layer4, pooled by `_pool`; BASELINE's
+    classic `model="torchvision/resnet50"` pairing).  Same step as `DINO`; what the backbone changes:
+
+      * student AND teacher run BatchNorm in training mode (the reference never puts the teacher in eval()): batch statistics per forward
+        call -- the student's global and local views are two calls -- and every call moves that network's running estimates; the EMA walks
+        parameters only, so the teacher's BatchNorm buffers are its own;
+      * `EmbeddingModel(x)` is the average-pooled layer4 map (`lt_token_mean_bf16` / `lt_pool_bwd_add`);
+      * weight decay: everything that is not a BatchNorm parameter or a bias, i.e. the convolution and Linear weights.
+
+    Kernels: `resnet.ResNetEngine` (NHWC, every convolution an MFMA GEMM, `csrc/conv.hip`) + the projection-head / loss / optimizer kernels
+    of the ViT path.  Convolutional weight gradients keep the dispatcher's split-K choice: reproducible to the last bits."""
+
+    def __init__(self, cfg: Any, method_args: Optional[DINOArgs] = None, global_batch_size: int = 256, total_steps: int = 125_000,
+                 device: "str | torch.device" = "cuda", backbone_state: Optional[Dict[str, Tensor]] = None,
+                 student_head_state: Optional[Dict[str, Tensor]] = None, teacher_head_state: Optional[Dict[str, Tensor]] = None,
+                 teacher_backbone_state: Optional[Dict[str, Tensor]] = None, seed: int = 0) -> None:
+        from .dinov2 import HeadEngine, MockTrainerState, head_param_shapes, init_head_state
+        from .params import FlatParams
+        from .resnet import ResNetEngine, flat_named, init_resnet_state
+        from .vit import Workspace
+
+        a = method_args or DINOArgs()
+        if a.batch_norm:
+            raise NotImplementedError("DINO(batch_norm=True): lightly's shared-BatchNorm1d head is not built")
+        if a.optimizer not in ("auto", "sgd", "adamw"):
+            raise ValueError(f"Invalid optimizer type: '{a.optimizer}'")
+        self.method_args, self.cfg = a, cfg     # type: ignore[assignment]
+        self.device = torch.device(device)
+        self.global_batch_size = global_batch_size
+        self.trainer = MockTrainerState(total_steps)
+        g = torch.Generator().manual_seed(seed)
+        D = cfg.feature_dim
+        bsd = backbone_state if backbone_state is not None else init_resnet_state(cfg, g)
+        tbs = teacher_backbone_state if teacher_backbone_state is not None else bsd
+        conv = (lambda s_: None if s_ is None else head_state_from_ref(s_) if any(k.startswith("layers.") for k in s_) else s_)
+        shs = conv(student_head_state) or init_head_state(D, a.hidden_dim, a.bottleneck_dim, a.output_dim, g)
+        ths = conv(teacher_head_state) or init_head_state(D, a.hidden_dim, a.bottleneck_dim, a.output_dim, g)
+        order_h = [n for n, _ in head_param_shapes(D, a.hidden_dim, a.bottleneck_dim, a.output_dim)]
+        self.student = FlatParams(flat_named(cfg, bsd, "backbone.") + [("head." + n, shs[n]) for n in order_h], self.device, True)
+        self.teacher = FlatParams(flat_named(cfg, tbs, "backbone.") + [("head." + n, ths[n]) for n in order_h], self.device, False)
+        if self.world > 1:
+            for fp in (self.student, self.teacher):
+                dist.broadcast(fp.data, src=0)
+                fp.bf16.copy_(fp.data)
+        self.s_net = ResNetEngine(cfg, self.student, "backbone.", buffers=bsd)
+        self.t_net = ResNetEngine(cfg, self.teacher, "backbone.", buffers=tbs)
+        self.s_vit = self.s_net            # (the inherited optimizer step refreshes the derived weight copies through this name)
+        shim = DINOv2Args(hidden_dim=a.hidden_dim, dino_bottleneck_dim=a.bottleneck_dim, output_dim=a.output_dim, batch_norm=False)
+        self.s_head = HeadEngine(self.student, "head.", D, shim)
+        self.t_head = HeadEngine(self.teacher, "head.", D, shim)
+        self.s_head.refresh_weightnorm()
+        self.t_head.refresh_weightnorm()
+        self.center = self.dino_center = torch.zeros(1, a.output_dim, device=self.device)
+        self.ws = Workspace(self.device)
+        self.optimizer = "sgd" if a.optimizer == "auto" else a.optimizer
+        lr = a.lr if a.lr is not None else (0.03 if self.optimizer == "sgd" else 0.0005)
+        self.weight_decay = a.weight_decay if a.weight_decay is not None else (1e-4 if self.optimizer == "sgd" else 0.04)
+        self.wd_start = a.weight_decay_start if a.weight_decay_start is not None else self.weight_decay
+        self.wd_end = a.weight_decay_end if a.weight_decay_end is not None else self.weight_decay
+        scale = global_batch_size / a.reference_batch_size
+        self.base_lr = lr * (math.sqrt(scale) if a.lr_scale_method == "sqrt" else scale)
+        self.warmup_steps = min(a.warmup_steps, int(total_steps * a.warmup_max_steps_fraction))
+        dev, names = self.device, self.student.names
+        self._untrained = {"head." + WN_G} if a.norm_last_layer else set()
+        last = {"head." + WN_G, "head." + WN_V}
+        self.groups = ["params_last_layer" if n in last else ("params" if (len(self.student.shapes[n]) > 1 and not n.endswith("bias")) else "params_no_weight_decay")
+                       for n in names]
+        lr_live = [0.0 if n in self._untrained else self.base_lr for n in names]
+        wd_live = [0 if (n in self._untrained or g_ == "params_no_weight_decay") else 1 for n, g_ in zip(names, self.groups)]
+        mk = lambda v, dt: torch.tensor(v, dtype=dt, device=dev)
+        self.seg_lr, self.seg_wd_on = mk(lr_live, torch.float32), mk(wd_live, torch.uint8)
+        self.seg_lr_frozen = mk([0.0 if g_ == "params_last_layer" else v for v, g_ in zip(lr_live, self.groups)], torch.float32)
+        self.seg_wd_on_frozen = mk([0 if g_ == "params_last_layer" else v for v, g_ in zip(wd_live, self.groups)], torch.uint8)
+        self.seg_frozen = mk([1 if g_ == "params_last_layer" else 0 for g_ in self.groups], torch.uint8)
+        self.param_groups = []
+        self.momentum_buffer = torch.zeros_like(self.student.data) if self.optimizer == "sgd" else None
+        self.exp_avg = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None
+        self.exp_avg_sq = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None
+        self.opt_step = 0
+        self._sumsq = torch.zeros(1, device=dev)
+        self._loss_slots = torch.zeros(5, device=dev)
+        self._gwn = self.student.g["head." + WN_G]
+        self._pending = {}
+        self._grad_sync = None
+        self.comm_events = None
+        self.last_grad_norm = None
+        self.overlap_streams = True
+        use_streams = self.device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(device=self.device) if use_streams else None
+        self.teacher_stream = torch.cuda.Stream(device=self.device) if use_streams else None
+
+    # ------------------------------------------------------------------ the step
+    def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Any = None) -> TrainingStepResult:
+        a, ws, dev = self.method_args, self.ws, self.device
+        k, total = self.trainer.global_step, self.trainer.estimated_stepping_batches
+        momentum = cosine_schedule(k, total, a.momentum_start, a.momentum_end)
+        ops.ema_flat(self.teacher.data, self.student.data, self.teacher.bf16, momentum)
+        self.t_head.refresh_weightnorm()
+        self.t_net.refresh_padded_weights()
+        teacher_temp = teacher_temp_schedule(a.teacher_temp, a.warmup_teacher_temp, a.warmup_teacher_temp_steps, k)
+        views: List[Tensor] = [v.to(dev, torch.float32, non_blocking=True) for v in batch["views"]]
+        n_views, n_local = len(views), len(views) - 2
+        gv = torch.cat(views[:2])
+        B = gv.shape[0] // 2
+        lv = torch.cat(views[2:]) if n_local > 0 else None
+        D, K = self.cfg.feature_dim, a.output_dim
+        Rl = n_local * B
+        Rs = 2 * B + Rl
+        if self._grad_sync is not None:
+            self._grad_sync.reset()
+        self.student.grad.zero_()
+        self._loss_slots.zero_()
+
+        # ---------------- teacher (no grad; BatchNorm in training mode) on its own stream
+        main = torch.cuda.current_stream()
+        tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
+        tstream.wait_event(main.record_event())
+        torch.cuda.set_stream(tstream)
+        tc = self.t_net.forward(ws, "t", gv, save=False, train=True)
+        t_in = ws.get("t.head_in", (2 * B, D), torch.bfloat16)
+        ops.token_mean(tc["feat"], t_in, 2 * B, tc["h"] * tc["w"], D)
+        t_logits = self.t_head.forward(ws, "th", t_in, 2 * B, 2 * B, save=False)["logits"]
+        t_probs = ws.get("t.probs", (2 * B, K), torch.float32)
+        ops.softmax_center(t_logits, self.center.view(-1), t_probs, 2 * B, K, 1.0 / teacher_temp)
+        cs = ws.get("t.colsum", (K,), torch.float32)
+        ops.colsum_f32(t_logits, cs, 2 * B, K)
+        if self.world > 1:
+            dist.all_reduce(cs)
+        ops.center_ema(self.center.view(-1), cs, 1.0 / (2 * B * self.world), a.center_momentum, K)
+        teacher_done = tstream.record_event()
+        torch.cuda.set_stream(main)
+
+        # ---------------- student: two forward calls (global, local), pooled, one projection-head batch
+        s_in = ws.get("s.head_in", (Rs, D), torch.bfloat16, pad_rows=64)
+        sg = self.s_net.forward(ws, "sg", gv, save=True, train=True)
+        ops.token_mean(sg["feat"], s_in[:2 * B], 2 * B, sg["h"] * sg["w"], D)
+        sl = None
+        if lv is not None:
+            sl = self.s_net.forward(ws, "sl", lv, save=True, train=True)
+            ops.token_mean(sl["feat"], s_in[2 * B:Rs], Rl, sl["h"] * sl["w"], D)
+        sh = self.s_head.forward(ws, "sh", s_in, Rs, Rs, save=True)
+
+        # ---------------- DINOLoss: student global row r against the teacher's other view (r + B) mod 2B, local rows against both
+        n_terms = 2 * n_views - 2
+        r2 = torch.arange(2 * B, dtype=torch.int32)
+        bb = torch.arange(B, dtype=torch.int32)
+        ta = torch.cat([(r2 + B) % (2 * B), bb.repeat(n_local)])
+        tb = torch.cat([torch.full((2 * B,), -1, dtype=torch.int32), (B + bb).repeat(n_local)])
+        coef = torch.full((Rs,), 1.0 / (n_terms * B))
+        slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32)])
+        ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
+        main.wait_event(teacher_done)
+        dlogits = ws.get("s.dlogits", (Rs, K), torch.bfloat16, pad_rows=64)
+        ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, 1.0 / a.student_temp, self._loss_slots, dlogits, Rs, K, slot=slot)
+
+        # ---------------- backward: head, then the two convolutional passes (weight gradients on the side stream)
+        dx_head = self.s_head.backward(ws, sh, dlogits)
+        self.s_head.finish_weightnorm_grad()
+        if a.norm_last_layer:
+            self._gwn.zero_()
+        side = self.side_stream if self.overlap_streams else None
+        for tag, ctx, lo, hi in (("sg", sg, 0, 2 * B), ("sl", sl, 2 * B, Rs)):
+            if ctx is None:
+                continue
+            n = ctx["h"] * ctx["w"]
+            dfeat = ws.get(tag + ".dfeat", (ctx["feat"].shape[0], D), torch.bfloat16, zero=True)
+            ops.pool_bwd_add(None, dx_head[lo:hi], dfeat, hi - lo, n, D)
+            self.s_net.backward(ws, ctx, dfeat, side=side)
+        if side is not None:
+            main.wait_stream(side)
+        ls = self._loss_slots
+        self._last = dict(t_logits=t_logits, t_probs=t_probs, s_global_logits=sh["logits"][:2 * B], s_local_logits=sh["logits"][2 * B:Rs], B=B, Rl=Rl)
+        return TrainingStepResult(loss=ls[0] + ls[1], log_dict={"schedule/momentum": momentum, "schedule/teacher_temp": teacher_temp})
+
+    def _refresh_derived(self) -> None:
+        self.s_head.refresh_weightnorm()
+        self.t_head.refresh_weightnorm()
+        self.s_net.refresh_padded_weights()
+        self.t_net.refresh_padded_weights()
+
+    # ------------------------------------------------------------------ reference-compatible views
+    def state_dict(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for role, fp, net in (("teacher", self.teacher, self.t_net), ("student", self.student, self.s_net)):
+            for k_, v in net.state_dict().items():
+                out[f"{role}_embedding_model.wrapped_model._features.{k_}"] = v
+            for n in fp.names:
+                if n.startswith("head."):
+                    out[f"{role}_projection_head." + head_key_to_ref(n[5:])] = fp.p[n].detach().clone()
+        out["criterion.center.center"] = self.center.detach().clone().view(1, 1, -1)
+        return out
+
+    def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
+        from .resnet import resnet_param_shapes, to_flat_layout
+
+        plan: List[Tuple[Tensor, Tensor]] = []
+        bufs: List[Tuple[Any, Dict[str, Tensor]]] = []
+        seen = set()
+        for role, fp, net in (("teacher", self.teacher, self.t_net), ("student", self.student, self.s_net)):
+            pre = f"{role}_embedding_model.wrapped_model._features."
+            bb = {k_[len(pre):]: v for k_, v in sd.items() if k_.startswith(pre)}
+            for n, shape in resnet_param_shapes(self.cfg):
+                if n in bb:
+                    if tuple(bb[n].shape) != tuple(shape):
+                        raise ValueError(f"load_state_dict: {pre}{n} has shape {tuple(bb[n].shape)}, expected {tuple(shape)}")
+                    plan.append((fp.p["backbone." + n], to_flat_layout(n, bb[n].float())))
+                    seen.add(pre + n)
+                elif strict:
+                    raise KeyError(f"load_state_dict: missing {pre}{n}")
+            for k_ in net.buffers:
+                if k_ in bb:
+                    seen.add(pre + k_)
+                elif strict:
+                    raise KeyError(f"load_state_dict: missing BatchNorm buffer {pre}{k_}")
+            bufs.append((net, bb))
+            hp = f"{role}_projection_head."
+            for n in fp.names:
+                if n.startswith("head."):
+                    key = hp + head_key_to_ref(n[5:])
+                    if key in sd:
+                        if tuple(sd[key].shape) != tuple(fp.shapes[n]):
+                            raise ValueError(f"load_state_dict: {key} has shape {tuple(sd[key].shape)}, expected {tuple(fp.shapes[n])}")
+                        plan.append((fp.p[n], sd[key]))
+                        seen.add(key)
+                    elif strict:
+                        raise KeyError(f"load_state_dict: missing {key}")
+        centers = ("criterion.center.center", "criterion.center")
+        extra = [k_ for k_ in sd if k_ not in seen and k_ not in centers and not (".fc." in k_)]
+        if strict and (extra or not any(c in sd for c in centers)):
+            raise KeyError(f"load_state_dict: unexpected {extra[:5]} / no center")
+        for dst, src in plan:
+            dst.copy_(src.to(self.device, torch.float32))
+        for net, bb in bufs:
+            net.load_buffers(bb)
+        for fp in (self.student, self.teacher):
+            fp.bf16.copy_(fp.data)
+        for c in centers:
+            if c in sd:
+                self.center.copy_(sd[c].to(self.device, torch.float32).view_as(self.center))
+                break
+        self._refresh_derived()
+
+    def _ref_key(self, role: str, flat: str) -> str:
+        if flat.startswith("backbone."):
+            return f"{role}_embedding_model.wrapped_model._features." + flat[9:]
+        return f"{role}_projection_head." + head_key_to_ref(flat[len("head."):])
+
+    def export_backbone_state_dict(self) -> Dict[str, Tensor]:
+        return self.t_net.state_dict()

@@ -192,6 +192,7 @@ def main() -> None:
         make_dino_v1_kats()
         make_dino_v1("sgd")
         make_dino_v1("adamw")
+        make_dino_v1("sgd", backbone="resnet")
         return
     if "--lars-only" in sys.argv:
         make_distill12("v1", optimizer="lars")
@@ -383,7 +384,7 @@ def make_dino_v1_kats() -> None:
     print("wrote dino_v1_kats")
 
 
-def make_dino_v1(optimizer: str) -> None:
+def make_dino_v1(optimizer: str, backbone: str = "vit") -> None:
     """(g) DINO (LT/_methods/dino/dino.py:221-480): the reference's own `DINO` class around a DINOv2 ViT (D = 64, depth 2, /16; 96^2
     global and 48^2 local views, 2 + 2 views, batch 8), 4 optimizer steps with the last layer frozen during the first two
     (student_freeze_last_layer_steps=2) and the teacher temperature warming up over 3.  optimizer "sgd" = the method's "auto" arguments
@@ -398,25 +399,43 @@ def make_dino_v1(optimizer: str) -> None:
     from lightly_train._scaling import ScalingInfo
 
     b, g_size, l_size, n_local, total, n_steps = 8, 96, 48, 2, 50, 4
-    torch.manual_seed(4242)
-    model = v2.DinoVisionTransformer(img_size=g_size, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
-                                     drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
-    for n_, prm in model.named_parameters():   # constants at init (biases 0, norm weights 1, mask token 0): randomise for a real test
-        if n_.endswith(".bias") or "norm" in n_ or n_ == "mask_token":
-            prm.data.add_(0.1 * torch.randn_like(prm))
-    wrapped = DINOv2ViTModelWrapper(model)
-    margs = DINOArgs(hidden_dim=128, bottleneck_dim=64, output_dim=512, student_freeze_last_layer_steps=2, teacher_temp=0.07, warmup_teacher_temp=0.04,
-                     warmup_teacher_temp_steps=3, momentum_start=0.99)
-    if optimizer == "adamw":
-        oargs = DINOAdamWArgs()
-        margs.weight_decay_start, margs.weight_decay_end = 0.04, 0.4
-    else:
-        oargs = DINO.optimizer_args_cls("auto")()
-        assert isinstance(oargs, DINOSGDArgs)
-    margs.resolve_auto(scaling_info=ScalingInfo(dataset_size=1000, epochs=1), optimizer_args=oargs, wrapped_model=wrapped)
-    m = DINO(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=wrapped), global_batch_size=b, num_input_channels=3)
-    m.trainer = H.MockTrainer(total)
-    m.current_epoch = 0
+
+    def construct():
+        torch.manual_seed(4242)
+        if backbone == "resnet":
+            # backbone "resnet": the reference's ResNetModelWrapper around the restated torchvision bottleneck ResNet (oracle/resnet_oracle.py:
+            # layers (1, 1, 1, 1), width 8 -> 256 features), train-mode BatchNorm in student AND teacher (batch statistics per forward call,
+            # running estimates moved by each); the EMA walks parameters only
+            from lightly_train._models.torchvision.resnet import ResNetModelWrapper
+            from oracle import resnet_oracle as OR
+
+            model = OR.ResNet((1, 1, 1, 1), width=8)
+            for n_, prm in model.named_parameters():
+                if "bn" in n_ or "downsample.1" in n_:
+                    prm.data.add_(0.2 * torch.randn_like(prm))
+            wrapped = ResNetModelWrapper(model)
+        else:
+            model = v2.DinoVisionTransformer(img_size=g_size, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1,
+                                             drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+            for n_, prm in model.named_parameters():   # constants at init (biases 0, norm weights 1, mask token 0): randomise for a real test
+                if n_.endswith(".bias") or "norm" in n_ or n_ == "mask_token":
+                    prm.data.add_(0.1 * torch.randn_like(prm))
+            wrapped = DINOv2ViTModelWrapper(model)
+        margs = DINOArgs(hidden_dim=128, bottleneck_dim=64, output_dim=512, student_freeze_last_layer_steps=2, teacher_temp=0.07, warmup_teacher_temp=0.04,
+                         warmup_teacher_temp_steps=3, momentum_start=0.99)
+        if optimizer == "adamw":
+            oargs = DINOAdamWArgs()
+            margs.weight_decay_start, margs.weight_decay_end = 0.04, 0.4
+        else:
+            oargs = DINO.optimizer_args_cls("auto")()
+            assert isinstance(oargs, DINOSGDArgs)
+        margs.resolve_auto(scaling_info=ScalingInfo(dataset_size=1000, epochs=1), optimizer_args=oargs, wrapped_model=wrapped)
+        m = DINO(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=wrapped), global_batch_size=b, num_input_channels=3)
+        m.trainer = H.MockTrainer(total)
+        m.current_epoch = 0
+        return m, margs, oargs
+
+    m, margs, oargs = construct()
     [opt], [sched] = m.configure_optimizers()
     sched = sched["scheduler"]
     groups = {g["name"]: len(g["params"]) for g in opt.param_groups}
@@ -425,7 +444,8 @@ def make_dino_v1(optimizer: str) -> None:
         out = {"student_backbone": {}, "teacher_backbone": {}, "student_head": {}, "teacher_head": {}, "other": {}}
         for k, v in sd.items():
             for role in ("student", "teacher"):
-                for pre, dst in ((f"{role}_embedding_model.wrapped_model._model.", f"{role}_backbone"), (f"{role}_projection_head.", f"{role}_head")):
+                for pre, dst in ((f"{role}_embedding_model.wrapped_model._model.", f"{role}_backbone"),
+                                 (f"{role}_embedding_model.wrapped_model._features.", f"{role}_backbone"), (f"{role}_projection_head.", f"{role}_head")):
                     if k.startswith(pre):
                         out[dst][k[len(pre):]] = v.detach().clone()
                         break
@@ -437,6 +457,15 @@ def make_dino_v1(optimizer: str) -> None:
         return out
 
     init = split(m.state_dict())
+    # yardstick for the bf16 kernels: the reference's own first step under torch.autocast("cpu", bfloat16) (= precision "bf16-mixed") from the
+    # same state -- how far ITS mixed-precision gradients are from its fp32 ones, tensor by tensor
+    my, _, _ = construct()     # (same seed, same constructor calls: the same initial state; deepcopy trips over nn.utils.weight_norm)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ry = my.training_step_impl({"views": synth_views(3000, b, g_size, l_size, n_local), "filename": []}, 0)
+    ry.loss.float().backward()
+    yard = {n: p.grad.detach().float().clone() for n, p in my.named_parameters() if p.grad is not None}
+    yard_loss = float(ry.loss.detach())
+    del my
     steps = []
     t_calls, s_calls = [], []
     for mod, sink in ((m.teacher_projection_head, t_calls), (m.student_projection_head, s_calls)):
@@ -457,6 +486,12 @@ def make_dino_v1(optimizer: str) -> None:
         if step == 0:   # clipped gradients of the first step, by state_dict name
             names = {id(p): n for n, p in m.named_parameters()}
             rec["grads"] = {names[id(p)]: p.grad.detach().clone() for p in params}
+            # (both sets of gradients unclipped for the comparison: clipping happened in place just above)
+            cl = min(1.0, 3.0 / (float(gnorm) + 1e-6))
+            errs = {k_: float((yard[k_] - g_ / cl).abs().max() / (g_ / cl).abs().max().clamp_min(1e-20)) for k_, g_ in rec["grads"].items() if k_ in yard}
+            rec["bf16_autocast"] = {"loss": yard_loss, "grad_err": errs}
+            ev = sorted(errs.values())
+            print("  reference bf16 autocast vs its fp32: loss", round(yard_loss, 5), "grad err median", round(ev[len(ev) // 2], 4), "max", round(ev[-1], 4))
             rec["no_grad"] = sorted(names[id(p)] for g in opt.param_groups for p in g["params"] if p.grad is None)
         opt.step(); opt.zero_grad(set_to_none=True); sched.step()
         m.trainer.global_step += 1
@@ -465,9 +500,10 @@ def make_dino_v1(optimizer: str) -> None:
         print("dino_v1", optimizer, step, {k: round(v, 6) for k, v in rec["logs"].items()}, hp["params_last_layer"])
     final = split(m.state_dict())
     osd = opt.state_dict()
-    name = "dino_v1_d64" + ("_adamw" if optimizer == "adamw" else "")
-    torch.save({"optimizer": optimizer, "b": b, "g_size": g_size, "l_size": l_size, "n_local": n_local, "total_steps": total,
-                "cfg": dict(patch_size=16, num_heads=1, depth=2, img_size=g_size, embed_dim=64, init_values=0.1),
+    name = ("dino_v1_resnet" if backbone == "resnet" else "dino_v1_d64") + ("_adamw" if optimizer == "adamw" else "")
+    torch.save({"optimizer": optimizer, "backbone": backbone, "b": b, "g_size": g_size, "l_size": l_size, "n_local": n_local, "total_steps": total,
+                "cfg": (dict(kind="resnet", layers=(1, 1, 1, 1), width=8) if backbone == "resnet" else
+                        dict(patch_size=16, num_heads=1, depth=2, img_size=g_size, embed_dim=64, init_values=0.1)),
                 "method_args": {k: getattr(margs, k) for k in ("hidden_dim", "bottleneck_dim", "output_dim", "student_freeze_last_layer_steps", "norm_last_layer",
                                                                  "teacher_temp", "warmup_teacher_temp", "warmup_teacher_temp_steps", "student_temp", "center_momentum",
                                                                  "momentum_start", "momentum_end", "weight_decay_start", "weight_decay_end", "warmup_steps",

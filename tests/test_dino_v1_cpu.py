@@ -134,3 +134,89 @@ def test_dino_v1_host_rules():
     assert (big.output_dim, big.teacher_temp, big.warmup_teacher_temp, big.momentum_start) == (65536, 0.07, 0.04, 0.996)
     with pytest.raises(ValueError):
         DINO(vit_cfg(dict(embed_dim=64, depth=1, num_heads=1, patch_size=16, img_size=32, init_values=0.1)), DINOArgs(optimizer="lamb"), device="cpu")
+
+
+def build_resnet(fx, device="cpu"):
+    from lightly_train_amd.dino import DINOResNet
+    from lightly_train_amd.resnet import ResNetConfig
+
+    ma, oa, c = fx["method_args"], fx["optimizer_args"], fx["cfg"]
+    args = DINOArgs(hidden_dim=ma["hidden_dim"], bottleneck_dim=ma["bottleneck_dim"], output_dim=ma["output_dim"],
+                    student_freeze_last_layer_steps=ma["student_freeze_last_layer_steps"], norm_last_layer=ma["norm_last_layer"],
+                    teacher_temp=ma["teacher_temp"], warmup_teacher_temp=ma["warmup_teacher_temp"], warmup_teacher_temp_steps=ma["warmup_teacher_temp_steps"],
+                    student_temp=ma["student_temp"], center_momentum=ma["center_momentum"], momentum_start=ma["momentum_start"], momentum_end=ma["momentum_end"],
+                    weight_decay_start=ma["weight_decay_start"], weight_decay_end=ma["weight_decay_end"], warmup_steps=ma["warmup_steps"],
+                    optimizer=fx["optimizer"], lr=oa["lr"], weight_decay=oa["weight_decay"])
+    init = fx["init"]
+    return DINOResNet(ResNetConfig(layers=tuple(c["layers"]), width=c["width"]), args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device=device,
+                      backbone_state=init["student_backbone"], teacher_backbone_state=init["teacher_backbone"], student_head_state=init["student_head"],
+                      teacher_head_state=init["teacher_head"])
+
+
+def exact_resnet(m):
+    from test_distillation_methods_cpu import F32Workspace
+
+    m.ws = F32Workspace(torch.device("cpu"))
+    for fp in (m.student, m.teacher):
+        fp.bf16 = fp.data.clone()
+        fp.b = {n: fp.bf16[fp.offsets[n]:fp.offsets[n] + fp.p[n].numel()].view(fp.shapes[n]) for n in fp.names}
+    for e in (m.s_net, m.t_net):
+        e.act_dtype = torch.float32
+        e.w_stem = e.w_stem.float()
+        e.refresh_padded_weights()
+    for h in (m.s_head, m.t_head):
+        h.wn = h.wn.float()
+        h.refresh_weightnorm()
+    return m
+
+
+def test_dino_v1_on_a_resnet_reproduces_the_reference_fixture():
+    """`DINOResNet` (convolutional backbone: train-mode BatchNorm in student and teacher, two student forward calls, average-pooled
+    features) in exact arithmetic against tests/golden/dino_v1_resnet.pt, written by the reference's `DINO` class around its
+    `ResNetModelWrapper` (on the restated torchvision ResNet): per step loss, schedules, gradient norm, head outputs, center; the first
+    step's gradients tensor by tensor; after four steps every parameter and BatchNorm buffer of student and teacher."""
+    from lightly_train_amd.resnet import from_flat_layout
+
+    fx = torch.load(os.path.join(GOLD, "dino_v1_resnet.pt"), weights_only=False)
+    with ops_emu.emulate(ops):
+        m = exact_resnet(build_resnet(fx))
+        assert {g: m.groups.count(g) for g in set(m.groups)} == fx["groups"]
+        B = fx["b"]
+        for si, rec in enumerate(fx["steps"]):
+            res = m.training_step_impl({"views": views_of(fx, rec)}, 0)
+            logs = rec["logs"]
+            assert float(res.loss) == pytest.approx(logs["loss"], rel=5e-6), si
+            assert torch.allclose(m._last["t_logits"][:2 * B], rec["teacher_logits"], atol=5e-5)
+            assert torch.allclose(m._last["s_global_logits"], rec["student_global_logits"], atol=5e-5)
+            assert torch.allclose(m._last["s_local_logits"], rec["student_local_logits"], atol=5e-5)
+            gn = float(torch.sqrt((m.student.grad.double() ** 2).sum()))
+            assert gn == pytest.approx(logs["grad_norm"], rel=5e-5), si
+            if "grads" in rec:
+                clip = min(1.0, 3.0 / (logs["grad_norm"] + 1e-6))
+                for n in m.student.names:
+                    key = m._ref_key("student", n)
+                    if key in rec["no_grad"]:
+                        assert float(m.student.g[n].abs().max()) == 0.0, n
+                        continue
+                    want = rec["grads"][key] / clip
+                    got = from_flat_layout(n[9:], m.student.g[n]) if n.startswith("backbone.") else m.student.g[n]
+                    assert torch.allclose(got, want, atol=2e-6 + 1e-4 * float(want.abs().max())), (n, (got - want).abs().max())
+            m.optimizer_step()
+            assert torch.allclose(m.center.view(-1), rec["center"].view(-1), atol=1e-6)
+        sd = m.state_dict()
+        assert list(sd.keys()) == fx["state_dict_keys"]
+        fin = fx["final"]
+        for role in ("student", "teacher"):
+            for k, v in fin[role + "_backbone"].items():
+                got = sd[f"{role}_embedding_model.wrapped_model._features.{k}"]
+                if k.endswith("num_batches_tracked"):
+                    assert int(got) == int(v), (role, k)
+                else:
+                    assert torch.allclose(got, v, atol=5e-6), (role, k, (got - v).abs().max())
+            for k, v in fin[role + "_head"].items():
+                assert torch.allclose(sd[f"{role}_projection_head.{k}"], v, atol=5e-6), (role, k)
+        # round trip through load_state_dict into an object built from another seed
+        other = exact_resnet(build_resnet(dict(fx, init=dict(fx["init"], student_head=None, teacher_head=None))))
+        other.load_state_dict(sd)
+        assert torch.equal(other.student.data, m.student.data) and torch.equal(other.teacher.data, m.teacher.data)
+        assert all(torch.equal(other.t_net.buffers[k], m.t_net.buffers[k]) for k in m.t_net.buffers)

@@ -134,3 +134,79 @@ def test_dino_v1_sgd_kernel_matches_torch_sgd():
         assert torch.allclose(buf[o:o + cnt].view(r.shape), opt.state[r]["momentum_buffer"], atol=2e-6), n
         assert torch.equal(fp.b[n].float(), fp.p[n].to(torch.bfloat16).float()), n
     assert torch.equal(fp.p["c"].cpu(), named[2][1])     # lr 0: parameters untouched
+
+
+def test_dino_v1_on_a_resnet_steps_match_reference_fixture():
+    """`DINOResNet` in HIP against tests/golden/dino_v1_resnet.pt (the reference's DINO class around its ResNetModelWrapper; width-8
+    bottleneck ResNet, 96^2 / 48^2 views, batch 8).  The conv path at this size is the noisy regime DESIGN 3 measures (BatchNorm over
+    16 x 3 x 3 positions in layer4 amplifies bf16 rounding): the fixture carries the reference's OWN first step under torch.autocast(bf16)
+    against its fp32 step -- per-tensor gradient error median 0.30, max 0.62 -- and the HIP step is held to that yardstick (median <= 1.25 x,
+    max <= 1.5 x), next to the loss per step (3e-2), the gradient norm (10 %), the head outputs (5 % of their range) and the 4-step update
+    in the norm; exact arithmetic is checked on the CPU (tests/test_dino_v1_cpu.py)."""
+    import json
+
+    from lightly_train_amd.dino import DINOArgs, DINOResNet
+    from lightly_train_amd.resnet import ResNetConfig, from_flat_layout
+
+    fx = torch.load(os.path.join(GOLD, "dino_v1_resnet.pt"), weights_only=False)
+    ma, oa, c, init = fx["method_args"], fx["optimizer_args"], fx["cfg"], fx["init"]
+    args = DINOArgs(hidden_dim=ma["hidden_dim"], bottleneck_dim=ma["bottleneck_dim"], output_dim=ma["output_dim"],
+                    student_freeze_last_layer_steps=ma["student_freeze_last_layer_steps"], teacher_temp=ma["teacher_temp"],
+                    warmup_teacher_temp=ma["warmup_teacher_temp"], warmup_teacher_temp_steps=ma["warmup_teacher_temp_steps"], momentum_start=ma["momentum_start"],
+                    weight_decay_start=ma["weight_decay_start"], weight_decay_end=ma["weight_decay_end"], optimizer=fx["optimizer"], lr=oa["lr"],
+                    weight_decay=oa["weight_decay"])
+    m = DINOResNet(ResNetConfig(layers=tuple(c["layers"]), width=c["width"]), args, global_batch_size=fx["b"], total_steps=fx["total_steps"], device="cuda",
+                   backbone_state=init["student_backbone"], teacher_backbone_state=init["teacher_backbone"], student_head_state=init["student_head"],
+                   teacher_head_state=init["teacher_head"])
+    B = fx["b"]
+    report = {"steps": []}
+    for si, rec in enumerate(fx["steps"]):
+        res = m.training_step_impl({"views": views_of(fx, rec)}, 0)
+        logs = rec["logs"]
+        rng = float(rec["teacher_logits"].abs().max())
+        e_t = float((m._last["t_logits"][:2 * B].cpu() - rec["teacher_logits"]).abs().max()) / rng
+        e_s = float((m._last["s_global_logits"].cpu() - rec["student_global_logits"]).abs().max()) / rng
+        entry = {"loss": float(res.loss), "ref_loss": logs["loss"], "teacher_logits_err": e_t, "student_logits_err": e_s}
+        assert float(res.loss) == pytest.approx(logs["loss"], rel=3e-2), si
+        assert e_t < 5e-2 and e_s < 5e-2, (si, e_t, e_s)
+        if "grads" in rec:
+            clip = min(1.0, 3.0 / (logs["grad_norm"] + 1e-6))
+            errs = []
+            for n in m.student.names:
+                key = m._ref_key("student", n)
+                if key in rec["no_grad"]:
+                    continue
+                want = rec["grads"][key] / clip
+                got = (from_flat_layout(n[9:], m.student.g[n]) if n.startswith("backbone.") else m.student.g[n]).cpu()
+                errs.append(float((got - want).abs().max()) / (float(want.abs().max()) + 1e-20))
+            errs.sort()
+            yard = sorted(rec["bf16_autocast"]["grad_err"].values())      # the reference's own bf16-autocast step against its fp32 step
+            entry["grad_err_median"], entry["grad_err_max"] = errs[len(errs) // 2], errs[-1]
+            entry["reference_autocast_grad_err_median"], entry["reference_autocast_grad_err_max"] = yard[len(yard) // 2], yard[-1]
+            assert errs[len(errs) // 2] <= 1.25 * yard[len(yard) // 2] + 0.02 and errs[-1] <= 1.5 * yard[-1] + 0.05, (entry)
+        m.optimizer_step()
+        entry["grad_norm"], entry["ref_grad_norm"] = float(m.last_grad_norm.sqrt()), logs["grad_norm"]
+        assert entry["grad_norm"] == pytest.approx(logs["grad_norm"], rel=0.10), si
+        report["steps"].append(entry)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    assert list(sd) == fx["state_dict_keys"]
+    num = den = 0.0
+    worst = 0.0
+    for k, v in fx["final"]["student_backbone"].items():
+        v0 = init["student_backbone"][k]
+        if not v.is_floating_point() or float((v - v0).abs().max()) == 0:
+            continue
+        got = sd["student_embedding_model.wrapped_model._features." + k]
+        upd = float((v - v0).double().norm())
+        err = float((got.double() - v.double()).norm())
+        num += err ** 2; den += upd ** 2
+        if "running" not in k:
+            worst = max(worst, err / upd)
+    report["update_err_total"], report["update_err_worst_tensor"] = (num / den) ** 0.5, worst
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "dino_v1_resnet_report.json"), "w"), indent=1)
+    print(json.dumps(report))
+    # the whole-model update (dominated by the BatchNorm running estimates) to 1 %; a single tensor's update no worse than the yardstick's
+    # per-tensor gradient error allows (observed: 0.2 % in total, 0.48 for the worst 4-step update against 0.62 for the worst autocast gradient)
+    yard_max = max(fx["steps"][0]["bf16_autocast"]["grad_err"].values())
+    assert report["update_err_total"] < 0.01 and worst <= 1.25 * yard_max, report

@@ -496,7 +496,10 @@ def emulate(ops):
         return out
 
     def pool_bwd_add(d_tok, d_pool, out, B, n, C):
-        out[: B * n] = (d_tok[: B * n].view(B, n, C) + d_pool[:, None] / n).reshape(B * n, C).to(out.dtype)
+        t = d_tok[: B * n].view(B, n, C) if d_tok is not None else torch.zeros(B, n, C)     # either operand may be absent (lt_pool_bwd_add)
+        if d_pool is not None:
+            t = t + d_pool[:B, None] / n
+        out[: B * n] = t.reshape(B * n, C).to(out.dtype)
         return out
 
     for name, fn in (("gemm", gemm), ("im2col_nhwc", im2col_nhwc), ("col2im_nhwc", col2im_nhwc), ("im2col_nchw_f32", im2col_nchw_f32),
