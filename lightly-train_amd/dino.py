@@ -19,7 +19,7 @@ reference's DINO does differently:
     linear lr scaling from batch 256; gradient clipping at 3.0; CosineWarmupScheduler with warmup min(12500, 10 % of the steps).
 
 The LightlySSL pieces are un-vendored in the reference tree (parity unpinned for those: DESIGN.md lists how the test-side restatement
-is anchored).  Convolutional backbones (the method accepts any `EmbeddingModel`) and `batch_norm=True` heads are not built.
+is anchored).  `DINOResNet` below runs the same method on a torchvision ResNet; `batch_norm=True` heads are not built.
 """
 from __future__ import annotations
 
