@@ -148,6 +148,17 @@ class DINO(DINOv2):
                          student_head_state=conv(student_head_state), teacher_head_state=conv(teacher_head_state),
                          teacher_backbone_state=teacher_backbone_state, seed=seed)
         self.method_args = a     # type: ignore[assignment]
+        # parameters that never receive a gradient in the reference: the mask token (no masking here) and, with norm_last_layer, weight_g
+        self._setup_optimizer(global_batch_size, total_steps, untrained={"backbone.mask_token"} | ({"head." + WN_G} if a.norm_last_layer else set()),
+                              decayed=decays)
+        self.center = self.dino_center            # [1, K]; `criterion.center.center` [1, 1, K] in the state_dict
+        self._gwn = self.student.g["head." + WN_G]
+
+    def _setup_optimizer(self, global_batch_size: int, total_steps: int, untrained: set, decayed: Any) -> None:
+        """Learning rate, schedules and the per-tensor group tables of the reference's optimizer (dino.py:343-413): groups `params`
+        (decayed), `params_last_layer`, `params_no_weight_decay`; `decayed(flat_name)` says which tensors lightly's
+        get_weight_decay_parameters decays for this backbone."""
+        a = self.method_args
         self.optimizer = "sgd" if a.optimizer == "auto" else a.optimizer
         lr = a.lr if a.lr is not None else (0.03 if self.optimizer == "sgd" else 0.0005)
         self.weight_decay = a.weight_decay if a.weight_decay is not None else (1e-4 if self.optimizer == "sgd" else 0.04)
@@ -157,10 +168,9 @@ class DINO(DINOv2):
         self.base_lr = lr * (math.sqrt(scale) if a.lr_scale_method == "sqrt" else scale)
         self.warmup_steps = min(a.warmup_steps, int(total_steps * a.warmup_max_steps_fraction))
         dev, names = self.device, self.student.names
-        # parameters that never receive a gradient in the reference: the mask token (no masking here) and, with norm_last_layer, weight_g
-        self._untrained = {"backbone.mask_token"} | ({"head." + WN_G} if a.norm_last_layer else set())
+        self._untrained = untrained
         last = {"head." + WN_G, "head." + WN_V}
-        self.groups = ["params_last_layer" if n in last else ("params" if decays(n) else "params_no_weight_decay") for n in names]
+        self.groups = ["params_last_layer" if n in last else ("params" if decayed(n) else "params_no_weight_decay") for n in names]
         lr_live = [0.0 if n in self._untrained else self.base_lr for n in names]
         wd_live = [0 if (n in self._untrained or g_ == "params_no_weight_decay") else 1 for n, g_ in zip(names, self.groups)]
         mk = lambda v, dt: torch.tensor(v, dtype=dt, device=dev)
@@ -171,13 +181,10 @@ class DINO(DINOv2):
         self.seg_wd_on_frozen = mk([0 if g_ == "params_last_layer" else v for v, g_ in zip(wd_live, self.groups)], torch.uint8)
         self.seg_frozen = mk([1 if g_ == "params_last_layer" else 0 for g_ in self.groups], torch.uint8)
         self.param_groups = []   # (DINOv2's per-tensor AdamW groups do not apply)
-        if self.optimizer == "sgd":
-            self.momentum_buffer: Optional[Tensor] = torch.zeros_like(self.student.data)
-            self.exp_avg = self.exp_avg_sq = None   # type: ignore[assignment]
-        else:
-            self.momentum_buffer = None
-        self.center = self.dino_center            # [1, K]; `criterion.center.center` [1, 1, K] in the state_dict
-        self._gwn = self.student.g["head." + WN_G]
+        self.momentum_buffer = torch.zeros_like(self.student.data) if self.optimizer == "sgd" else None
+        self.exp_avg = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None     # type: ignore[assignment]
+        self.exp_avg_sq = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None  # type: ignore[assignment]
+        self.opt_step = 0
 
     # ------------------------------------------------------------------ the step
     def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Any = None) -> TrainingStepResult:
@@ -487,31 +494,10 @@ class DINOResNet(DINO):
         self.t_head.refresh_weightnorm()
         self.center = self.dino_center = torch.zeros(1, a.output_dim, device=self.device)
         self.ws = Workspace(self.device)
-        self.optimizer = "sgd" if a.optimizer == "auto" else a.optimizer
-        lr = a.lr if a.lr is not None else (0.03 if self.optimizer == "sgd" else 0.0005)
-        self.weight_decay = a.weight_decay if a.weight_decay is not None else (1e-4 if self.optimizer == "sgd" else 0.04)
-        self.wd_start = a.weight_decay_start if a.weight_decay_start is not None else self.weight_decay
-        self.wd_end = a.weight_decay_end if a.weight_decay_end is not None else self.weight_decay
-        scale = global_batch_size / a.reference_batch_size
-        self.base_lr = lr * (math.sqrt(scale) if a.lr_scale_method == "sqrt" else scale)
-        self.warmup_steps = min(a.warmup_steps, int(total_steps * a.warmup_max_steps_fraction))
-        dev, names = self.device, self.student.names
-        self._untrained = {"head." + WN_G} if a.norm_last_layer else set()
-        last = {"head." + WN_G, "head." + WN_V}
-        self.groups = ["params_last_layer" if n in last else ("params" if (len(self.student.shapes[n]) > 1 and not n.endswith("bias")) else "params_no_weight_decay")
-                       for n in names]
-        lr_live = [0.0 if n in self._untrained else self.base_lr for n in names]
-        wd_live = [0 if (n in self._untrained or g_ == "params_no_weight_decay") else 1 for n, g_ in zip(names, self.groups)]
-        mk = lambda v, dt: torch.tensor(v, dtype=dt, device=dev)
-        self.seg_lr, self.seg_wd_on = mk(lr_live, torch.float32), mk(wd_live, torch.uint8)
-        self.seg_lr_frozen = mk([0.0 if g_ == "params_last_layer" else v for v, g_ in zip(lr_live, self.groups)], torch.float32)
-        self.seg_wd_on_frozen = mk([0 if g_ == "params_last_layer" else v for v, g_ in zip(wd_live, self.groups)], torch.uint8)
-        self.seg_frozen = mk([1 if g_ == "params_last_layer" else 0 for g_ in self.groups], torch.uint8)
-        self.param_groups = []
-        self.momentum_buffer = torch.zeros_like(self.student.data) if self.optimizer == "sgd" else None
-        self.exp_avg = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None
-        self.exp_avg_sq = torch.zeros_like(self.student.data) if self.optimizer != "sgd" else None
-        self.opt_step = 0
+        dev = self.device
+        shapes = self.student.shapes
+        self._setup_optimizer(global_batch_size, total_steps, untrained=({"head." + WN_G} if a.norm_last_layer else set()),
+                              decayed=lambda n: len(shapes[n]) > 1 and not n.endswith("bias"))    # convolution / Linear weights
         self._sumsq = torch.zeros(1, device=dev)
         self._loss_slots = torch.zeros(5, device=dev)
         self._gwn = self.student.g["head." + WN_G]
