@@ -233,12 +233,19 @@ def dino_amd_method_cls() -> type:
                     kw["momentum"] = float(oa.momentum)
                 else:
                     kw.update(betas=tuple(oa.betas), eps=float(oa.eps))
-                cfg = vit_config_from_reference(self.teacher_embedding_model.wrapped_model.get_model())
-                bb = "embedding_model.wrapped_model._model."
-                self._impl = HipDINO(cfg, HipDINOArgs(**kw), global_batch_size=self.global_batch_size,
-                                     total_steps=int(self.trainer.estimated_stepping_batches), device=dev,
-                                     backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
-                                     student_head_state=_strip(sd, "student_projection_head."), teacher_head_state=_strip(sd, "teacher_projection_head."))
+                wrapped = self.teacher_embedding_model.wrapped_model
+                common = dict(global_batch_size=self.global_batch_size, total_steps=int(self.trainer.estimated_stepping_batches), device=dev,
+                              student_head_state=_strip(sd, "student_projection_head."), teacher_head_state=_strip(sd, "teacher_projection_head."))
+                if hasattr(wrapped, "_features"):       # ResNetModelWrapper: convolutional backbone
+                    from .dino import DINOResNet
+
+                    bb = "embedding_model.wrapped_model._features."
+                    self._impl = DINOResNet(resnet_config_from_reference(wrapped._features), HipDINOArgs(**kw),
+                                            backbone_state=_strip(sd, "student_" + bb), teacher_backbone_state=_strip(sd, "teacher_" + bb), **common)
+                else:
+                    bb = "embedding_model.wrapped_model._model."
+                    self._impl = HipDINO(vit_config_from_reference(wrapped.get_model()), HipDINOArgs(**kw),
+                                         backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True), **common)
                 self._impl.load_state_dict(sd)
                 if self._pending_resume is not None:
                     self._impl.load_checkpoint_dict(self._pending_resume)
@@ -260,6 +267,21 @@ def dino_amd_method_cls() -> type:
     DINOAMD.__qualname__ = "DINOAMD"
     _DINO_CLS = DINOAMD
     return _DINO_CLS
+
+
+def resnet_config_from_reference(features: Any) -> Any:
+    """`ResNetConfig` of the `_features` container of a reference `ResNetModelWrapper` (LT/_models/torchvision/resnet.py): stage depths and
+    the stem width read off the state_dict."""
+    from .resnet import ResNetConfig
+
+    sd = features.state_dict()
+    layers = []
+    for li in range(1, 5):
+        n = 0
+        while f"layer{li}.{n}.conv1.weight" in sd:
+            n += 1
+        layers.append(n)
+    return ResNetConfig(layers=tuple(layers), width=int(sd["conv1.weight"].shape[0]), in_chans=int(sd["conv1.weight"].shape[1]))
 
 
 def install_as(name: str = "dinov2") -> type:

@@ -212,7 +212,7 @@ def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
             assert torch.allclose(s1[k].float(), s2[k].float(), atol=1e-7), k
 
 
-def _build_dino(cls, seed=0):
+def _build_dino(cls, seed=0, backbone="vit"):
     """The reference's DINO constructor calls (as in oracle/make_golden.py::make_dino_v1) around `cls`."""
     H.install()
     from lightly_train._methods.dino.dino import DINO, DINOArgs
@@ -222,9 +222,20 @@ def _build_dino(cls, seed=0):
     from lightly_train._scaling import ScalingInfo
 
     torch.manual_seed(seed)
-    model = v2.DinoVisionTransformer(img_size=96, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1, drop_path_rate=0.0,
-                                     ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
-    wrapped = DINOv2ViTModelWrapper(model)
+    if backbone == "resnet":
+        from lightly_train._models.torchvision.resnet import ResNetModelWrapper
+        from oracle import resnet_oracle as OR
+
+        model = OR.ResNet((1, 1, 1, 1), width=8)
+        with torch.no_grad():
+            for n_, prm in model.named_parameters():
+                if "bn" in n_ or "downsample.1" in n_:
+                    prm.add_(0.2 * torch.randn_like(prm))
+        wrapped = ResNetModelWrapper(model)
+    else:
+        model = v2.DinoVisionTransformer(img_size=96, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1, drop_path_rate=0.0,
+                                         ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+        wrapped = DINOv2ViTModelWrapper(model)
     margs = DINOArgs(hidden_dim=128, bottleneck_dim=64, output_dim=512, student_freeze_last_layer_steps=1, teacher_temp=0.07, warmup_teacher_temp=0.04,
                      warmup_teacher_temp_steps=3, momentum_start=0.99)
     oargs = DINO.optimizer_args_cls("auto")()
@@ -236,7 +247,21 @@ def _build_dino(cls, seed=0):
     return m
 
 
-def test_dino_v1_binding_two_steps_equal_the_reference_class():
+def _exactify_conv(m):
+    m.ws = F32Workspace(torch.device("cpu"))
+    for fp in (m.student, m.teacher):
+        fp.bf16 = fp.data.clone()
+        fp.b = {n: fp.bf16[fp.offsets[n]:fp.offsets[n] + fp.p[n].numel()].view(fp.shapes[n]) for n in fp.names}
+    for e in (m.s_net, m.t_net):
+        e.act_dtype = torch.float32
+        e.w_stem = e.w_stem.float()
+    for h in (m.s_head, m.t_head):
+        h.wn = h.wn.float()
+    m._refresh_derived()
+
+
+@pytest.mark.parametrize("backbone", ["vit", "resnet"])
+def test_dino_v1_binding_two_steps_equal_the_reference_class(backbone):
     """`DINOAMD(Method)` (integration.dino_amd_method_cls) behind the reference's own DINO constructor: two steps with the method's "auto"
     optimizer (SGD), across the last-layer unfreeze, equal the reference class driven through Lightning's hook order -- loss and every
     student / teacher tensor; state_dict keys in the reference's order."""
@@ -244,15 +269,15 @@ def test_dino_v1_binding_two_steps_equal_the_reference_class():
     from lightly_train._methods.dino.dino import DINO
     from lightly_train_amd import integration
 
-    ref = _build_dino(DINO)
-    amd = _build_dino(integration.dino_amd_method_cls())
+    ref = _build_dino(DINO, backbone=backbone)
+    amd = _build_dino(integration.dino_amd_method_cls(), backbone=backbone)
     assert list(amd.state_dict()) == list(ref.state_dict())
     [opt], [sched] = ref.configure_optimizers()
     sched = sched["scheduler"]
     g = torch.Generator().manual_seed(3)
     with ops_emu.emulate(ops):
         m = amd.impl()
-        exactify(m)
+        (_exactify_conv if backbone == "resnet" else exactify)(m)
         for step in range(2):
             views = [torch.randn(8, 3, 96, 96, generator=g) for _ in range(2)] + [torch.randn(8, 3, 48, 48, generator=g) for _ in range(2)]
             res = ref.training_step_impl({"views": [v.clone() for v in views], "filename": []}, 0)
@@ -267,4 +292,5 @@ def test_dino_v1_binding_two_steps_equal_the_reference_class():
         assert list(sd) == list(rsd)
         for k in rsd:
             assert torch.allclose(sd[k].float(), rsd[k].float(), atol=3e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+        assert type(m).__name__ == ("DINOResNet" if backbone == "resnet" else "DINO")
     assert integration.install_as("dino") is integration.dino_amd_method_cls()
