@@ -119,3 +119,58 @@ def test_two_ranks_with_their_own_data_equal_one_process_on_all_of_it(tmp_path, 
         for k, v in one[which].items():
             assert torch.equal(r[0][which][k], r[1][which][k]), k
             assert torch.allclose(r[0][which][k].float(), v.float(), atol=5e-5 if k.endswith("running_mean") else 2e-6), (which, k)
+
+
+def _run_dino_v1(ranks, world: int, n_steps: int = 3):
+    """DINO v1 (lightly_train_amd/dino.py): the EMA-first step with the center all-reduce of lightly's `Center.update` and the gradient
+    mean, per-rank views; concatenated crop-major for the single process."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import ops_emu
+    import test_dino_v1_cpu as TD
+    import test_dinov2_method_cpu as T
+    from lightly_train_amd import ops
+
+    torch.cuda.current_stream = lambda *a, **k: T._NoStream()
+    torch.cuda.set_stream = lambda s: None
+    torch.cuda.Stream = T._NoStream
+    fx = torch.load(os.path.join(GOLD, "dino_v1_d64.pt"), weights_only=False)
+    b = fx["b"]
+    fx = dict(fx, b=2 * b)          # global batch (LR scale) = two ranks' worth in every variant
+    with ops_emu.emulate(ops):
+        m = TD.exact(TD.build(fx))
+        assert m.world == world
+        losses = []
+        for s in range(n_steps):
+            vs = [_views(700 + 10 * s + r, b, fx["g_size"], fx["l_size"], fx["n_local"]) for r in ranks]
+            views = vs[0] if len(ranks) == 1 else [torch.cat([v[i] for v in vs]) for i in range(len(vs[0]))]
+            losses.append(float(m.train_step(views).loss))
+        return dict(loss=losses, student=m.student.data.clone(), teacher=m.teacher.data.clone(), center=m.center.clone())
+
+
+def _worker_dino_v1(rank: int, world: int, port: int, out_dir: str) -> None:
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.save(_run_dino_v1([rank], world), os.path.join(out_dir, f"d{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dino_v1_two_ranks_with_their_own_data_equal_one_process_on_all_of_it(tmp_path):
+    """Three steps (the last layer unfreezes after two): per-rank mean losses average to the global mean (every (t, s) pair term is a mean
+    over the batch), the center moves by the mean over views, batch AND ranks, the SGD step sees the rank-averaged gradient."""
+    mp.spawn(_worker_dino_v1, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"d{i}.pt", weights_only=False) for i in range(2)]
+    one = _run_dino_v1([0, 1], 1)
+    for s in range(len(one["loss"])):
+        assert 0.5 * (r[0]["loss"][s] + r[1]["loss"][s]) == pytest.approx(one["loss"][s], rel=3e-5), s
+    assert torch.equal(r[0]["student"], r[1]["student"]) and torch.equal(r[0]["teacher"], r[1]["teacher"])
+    for key in ("student", "teacher"):
+        assert (r[0][key] - one[key]).abs().max().item() < 5e-6, key
+    assert torch.allclose(r[0]["center"], one["center"], atol=1e-6)
