@@ -220,3 +220,25 @@ def test_dino_v1_on_a_resnet_reproduces_the_reference_fixture():
         other.load_state_dict(sd)
         assert torch.equal(other.student.data, m.student.data) and torch.equal(other.teacher.data, m.teacher.data)
         assert all(torch.equal(other.t_net.buffers[k], m.t_net.buffers[k]) for k in m.t_net.buffers)
+
+
+def test_dino_v1_resnet_resume_continues_the_same_trajectory():
+    """checkpoint_dict() / load_checkpoint_dict() of the convolutional class: parameters, both networks' BatchNorm buffers (the teacher's are
+    its own: the EMA walks parameters only), the momentum buffers, the center and the step counters -- a second object built from another
+    random state continues bit for bit."""
+    fx = torch.load(os.path.join(GOLD, "dino_v1_resnet.pt"), weights_only=False)
+    with ops_emu.emulate(ops):
+        a = exact_resnet(build_resnet(fx))
+        b = exact_resnet(build_resnet(dict(fx, init=dict(fx["init"], student_head=None, teacher_head=None))))
+        for rec in fx["steps"][:2]:
+            a.train_step(views_of(fx, rec))
+        ck = a.checkpoint_dict()
+        assert ck["global_step"] == 2 and len(ck["optimizer_states"][0]["state"]) == sum(1 for n in a.student.names if n not in a._untrained)
+        b.load_checkpoint_dict(ck)
+        for rec in fx["steps"][2:]:
+            ra, rb = a.train_step(views_of(fx, rec)), b.train_step(views_of(fx, rec))
+            assert float(ra.loss) == float(rb.loss)
+        assert torch.equal(a.student.data, b.student.data) and torch.equal(a.teacher.data, b.teacher.data)
+        assert torch.equal(a.momentum_buffer, b.momentum_buffer) and torch.equal(a.center, b.center)
+        for net_a, net_b in ((a.s_net, b.s_net), (a.t_net, b.t_net)):
+            assert all(torch.equal(net_a.buffers[k], net_b.buffers[k]) for k in net_a.buffers)
