@@ -187,6 +187,25 @@ def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
         assert moved > 10                                                    # ... and trained: not the initial weights
         assert torch.equal(wrapped.get_model().state_dict()["cls_token"], want["cls_token"].cpu())
         assert torch.equal(embm.wrapped_model.get_model().state_dict()["norm.weight"], want["norm.weight"].cpu())
+        # --- downstream: the file `lightly_train.export(format="package_default")` writes (DINOv2ViTPackage.export_model, dinov2_vit_package.py:
+        # 146-162) loads strictly into a freshly built reference ViT of the same architecture -- what fine-tuning / inference start from -- and
+        # that model's features equal the HIP engine's on the trained EMA-teacher weights
+        from lightly_train._models import package_helpers
+        from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as vits
+
+        package = package_helpers.get_package_from_model(model=model, include_custom=True, fallback_custom=True)
+        out = tmp_path / "exported_model.pt"
+        package.export_model(model=wrapped, out=out, log_example=False)
+        fresh = getattr(vits, "_vit_test")(img_size=224, patch_size=14, init_values=1e-5, drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0,
+                                            interpolate_offset=0.1)
+        fresh.load_state_dict(torch.load(out, weights_only=True), strict=True)
+        fresh.eval()
+        x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(4))
+        with torch.no_grad():
+            ref_out = fresh(x, None, is_training=True)
+        tctx = amd.impl().t_vit.forward(amd.impl().ws, "export_check", x, None, save=False)
+        xn = tctx["xn"].view(2, -1, fresh.embed_dim)
+        assert torch.allclose(xn[:, 0], ref_out["x_norm_clstoken"], atol=2e-5) and torch.allclose(xn[:, 1:], ref_out["x_norm_patchtokens"], atol=5e-5)
         # state_dict of the checkpoint = the module's keys with current values, optimizer state in torch.optim.AdamW's format
         assert list(cp.state_dict) == list(ref.state_dict())
         osd = loaded["optimizer_states"][0]
