@@ -83,7 +83,6 @@ def dinov2_amd_method_cls() -> type:
     if _CLS is not None:
         return _CLS
     from lightly_train._methods.dinov2.dinov2 import DINOv2 as RefDINOv2
-    from lightly_train._methods.dinov2.dinov2 import DINOv2AdamWViTArgs, DINOv2Args
     from lightly_train._methods.method import Method, TrainingStepResult
 
     class DINOv2AMD(RefDINOv2):   # type: ignore[misc, valid-type]
