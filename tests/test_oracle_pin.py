@@ -271,6 +271,30 @@ def test_restated_resnet50_anchors():
     w = sd["layer3.2.conv2.weight"]
     assert torch.equal(E.from_flat_layout("layer3.2.conv2.weight", E.to_flat_layout("layer3.2.conv2.weight", w)), w)
     assert E.to_flat_layout("layer3.2.conv2.weight", w).shape == (256, 3, 3, 256) and E.to_flat_layout("conv1.weight", sd["conv1.weight"]).shape == (64, 3, 7, 7)
+    # more published anchors of the same family (torchvision's model table): the deeper bottleneck nets and the shape of the feature map
+    for layers, n_params in (((3, 4, 23, 3), 44_549_160), ((3, 8, 36, 3), 60_192_808)):
+        assert sum(p.numel() for p in OR.ResNet(layers).parameters()) == n_params, layers
+    m.eval()
+    with torch.no_grad():
+        x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+        f = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        assert tuple(f.shape) == (1, 64, 56, 56)                       # 7x7/2 stem + 3x3/2 max-pool: 224 -> 56
+        for layer, shape in ((m.layer1, (1, 256, 56, 56)), (m.layer2, (1, 512, 28, 28)), (m.layer3, (1, 1024, 14, 14)), (m.layer4, (1, 2048, 7, 7))):
+            f = layer(f)
+            assert tuple(f.shape) == shape
+    # a hand-checked bottleneck: all-ones 1x1 / centre-tap 3x3 weights and identity BatchNorm make the block y = relu(x_sum-based value + x)
+    blk = OR.ResNet((1, 1, 1, 1), width=2).layer1[0]      # inplanes 2 -> planes 2 -> 8 channels, with a downsample path
+    blk.eval()
+    with torch.no_grad():
+        for mod in blk.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.zero_()
+                mod.weight[:, :, mod.kernel_size[0] // 2, mod.kernel_size[1] // 2] = 1.0      # every output channel = sum of the input channels
+            elif isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.fill_(1.0); mod.bias.zero_(); mod.running_mean.zero_(); mod.running_var.fill_(1.0 - mod.eps)   # identity in eval()
+        xin = torch.tensor([1.0, 2.0]).view(1, 2, 1, 1).expand(1, 2, 3, 3).contiguous()
+        # conv1: 1 + 2 = 3 on both planes; conv2 (centre tap): 3 + 3 = 6; conv3: 6 + 6 = 12 on all 8 channels; downsample: 3; out = relu(12 + 3) = 15
+        assert torch.allclose(blk(xin), torch.full((1, 8, 3, 3), 15.0), atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["distill_v1_d64", "distill_v2_d64", "distill_v1_d64_lars"])
