@@ -268,6 +268,146 @@ def dino_amd_method_cls() -> type:
     return _DINO_CLS
 
 
+def dinov3_config_from_reference(model: Any, student: bool = False) -> ViTConfig:
+    """`ViTConfig` of a reference DINOv3 `DinoVisionTransformer` (LT/_models/dinov3/dinov3_src/models/vision_transformer.py:75-230) from its
+    attributes and state_dict.  `student`: keep the training-mode RoPE coordinate rescaling (a frozen teacher runs in eval())."""
+    from .dinov3 import dinov3_vit_config
+
+    sd = model.state_dict()
+    D = int(model.embed_dim)
+    swiglu = "blocks.0.mlp.w1.weight" in sd
+    if swiglu:
+        raise NotImplementedError("DINOv3 SwiGLU feed-forward blocks are not bound (the hub's ViT-S/B/L recipes use the MLP)")
+    rope = model.rope_embed
+    ls = "blocks.0.ls1.gamma"
+    return dinov3_vit_config(D, int(model.n_blocks), int(model.num_heads), patch_size=int(model.patch_size), img_size=224,
+                             ffn_ratio=sd["blocks.0.mlp.fc1.weight"].shape[0] / D, n_storage_tokens=int(model.n_storage_tokens),
+                             layerscale_init=(float(sd[ls].flatten()[0]) if ls in sd else None), rope_base=float(rope.base),
+                             ln_eps=float(model.norm.eps), rope_rescale=(float(rope.rescale_coords) if (student and rope.rescale_coords) else None),
+                             mask_k_bias=any(k.endswith("qkv.bias_mask") for k in sd))
+
+
+_DV3_CLS: Optional[type] = None
+
+
+def distillationv3_amd_method_cls() -> type:
+    """`DistillationV3AMD(Method)`: the binding for `method="distillation"` (LT/_methods/distillationv3/distillationv3.py:171-440, BASELINE
+    configs[3]) on `lightly_train_amd.distillationv3.DistillationV3`: frozen DINOv3 / DINOv2 ViT teacher, DINOv2-ViT / DINOv3-ViT / torchvision
+    ResNet student, the two Linear projection heads, the teacher queue.  Same hooks as `DINOv2AMD`; the teacher's weights stay out of
+    checkpoints exactly as in the reference (`on_save_checkpoint` / `on_load_checkpoint` of the base class still run)."""
+    global _DV3_CLS
+    if _DV3_CLS is not None:
+        return _DV3_CLS
+    from lightly_train._methods.distillationv3.distillationv3 import DistillationV3 as RefDV3
+    from lightly_train._methods.method import Method, TrainingStepResult
+    from lightly_train._optim.optimizer_type import OptimizerType
+
+    from .dinov3 import convert_dinov3_state
+    from .distillationv3 import DistillationV3 as HipDV3
+    from .distillationv3 import DistillationV3Args as HipDV3Args
+    from .lars import LARSArgs
+
+    base = dinov2_amd_method_cls()
+
+    class DistillationV3AMD(RefDV3):   # type: ignore[misc, valid-type]
+        def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
+                     device: Optional[torch.device] = None) -> None:
+            super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
+                             global_batch_size=global_batch_size, num_input_channels=num_input_channels)
+            self.automatic_optimization = False
+            self._impl: Optional[HipDV3] = None
+            self._impl_device = device
+            self._pending_resume: Optional[Dict[str, Any]] = None
+
+        def impl(self) -> HipDV3:
+            if self._impl is None:
+                dev = self._impl_device or next(self.parameters()).device
+                a, oa = self.method_args, self.optimizer_args
+                kw: Dict[str, Any] = dict(queue_size=int(a.queue_size), temperature_global=float(a.temperature_global), temperature_local=float(a.temperature_local),
+                                          lr_scale_method=a.lr_scale_method, reference_batch_size=int(a.reference_batch_size),
+                                          loss_local_weight=float(a.loss_local_weight))
+                if oa.type() == OptimizerType.LARS:
+                    kw.update(optimizer="lars", lars=LARSArgs(lr=float(oa.lr), momentum=float(oa.momentum), dampening=float(oa.dampening),
+                                                              weight_decay=float(oa.weight_decay), nesterov=bool(oa.nesterov),
+                                                              trust_coefficient=float(oa.trust_coefficient), eps=float(oa.eps)))
+                else:
+                    kw.update(optimizer="adamw", lr=float(oa.lr), betas=tuple(oa.betas), eps=float(oa.eps), weight_decay=float(oa.weight_decay))
+                t_model = self.teacher_embedding_model.get_model()
+                t_sd = {k: v.detach().clone() for k, v in t_model.state_dict().items()}
+                if hasattr(t_model, "rope_embed"):
+                    tcfg = dinov3_config_from_reference(t_model)
+                    t_state = convert_dinov3_state(t_sd, tcfg)
+                else:
+                    tcfg = vit_config_from_reference(t_model)
+                    t_state = {vit_key_to_flat(k): v for k, v in t_sd.items()}
+                wrapped = self.student_embedding_model.wrapped_model
+                if hasattr(wrapped, "_features"):
+                    scfg: Any = resnet_config_from_reference(wrapped._features)
+                    s_state = {k: v.detach().clone() for k, v in wrapped._features.state_dict().items()}
+                else:
+                    s_model = wrapped.get_model()
+                    s_sd = {k: v.detach().clone() for k, v in s_model.state_dict().items()}
+                    if hasattr(s_model, "rope_embed"):
+                        scfg = dinov3_config_from_reference(s_model, student=True)
+                        s_state = convert_dinov3_state(s_sd, scfg)
+                    else:
+                        scfg = vit_config_from_reference(s_model)
+                        s_state = {vit_key_to_flat(k): v for k, v in s_sd.items()}
+                lin = lambda m_: {k: v.detach().clone() for k, v in m_.state_dict().items()}    # noqa: E731
+                self._impl = HipDV3(scfg, tcfg, HipDV3Args(**kw), global_batch_size=self.global_batch_size,
+                                    total_steps=int(self.trainer.estimated_stepping_batches), max_epochs=int(self.trainer.max_epochs or 1), device=dev,
+                                    student_state=s_state, teacher_state=t_state, proj_global_state=lin(self.student_projection_head_global),
+                                    proj_local_state=lin(self.student_projection_head_local))
+                self._impl.teacher_queue.copy_(self.teacher_queue.to(dev))
+                if self._pending_resume is not None:
+                    self._impl.load_state_dict(self._pending_resume["state_dict"], strict=False)
+                    if self._pending_resume.get("amd_optimizer_state") is not None:
+                        self._impl.load_optimizer_state(self._pending_resume["amd_optimizer_state"])
+                    self._pending_resume = None
+            return self._impl
+
+        def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
+            m = self.impl()
+            if int(self.trainer.global_step) > m.trainer.global_step:
+                m.trainer.global_step = int(self.trainer.global_step)
+            res = m.training_step_impl(batch, batch_idx)     # frozen teacher, mixup, student forward + explicit backward (:245-374)
+            m.optimizer_step()                               # clip 1.0, AdamW / LARS, generic warmup-cosine schedule
+            self._tick_lightning()
+            return TrainingStepResult(loss=res.loss, log_dict=dict(res.log_dict))
+
+        def sync_to_containers(self) -> None:
+            if self._impl is not None:
+                sd = {k: v.detach().to("cpu") for k, v in self._impl.state_dict().items()}
+                Method.load_state_dict(self, sd, strict=False)      # (the frozen teacher is not part of the step's state_dict)
+
+        def state_dict(self, *a: Any, **k: Any) -> Any:
+            self.sync_to_containers()
+            return Method.state_dict(self, *a, **k)
+
+        def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+            self.sync_to_containers()
+            checkpoint["state_dict"] = Method.state_dict(self)
+            if self._impl is not None:
+                checkpoint["amd_optimizer_state"] = self._impl.optimizer_state()   # flat moments / LARS buffer + counters (package layout)
+            RefDV3.on_save_checkpoint(self, checkpoint)                            # drops the teacher's keys, as the reference does
+
+        def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+            ck = {"state_dict": dict(checkpoint["state_dict"]), "amd_optimizer_state": checkpoint.get("amd_optimizer_state")}
+            RefDV3.on_load_checkpoint(self, checkpoint)                            # re-adds the teacher's keys for Lightning's strict load
+            if self._impl is not None:
+                self._impl.load_state_dict(ck["state_dict"], strict=False)
+                if ck["amd_optimizer_state"] is not None:
+                    self._impl.load_optimizer_state(ck["amd_optimizer_state"])
+            else:
+                self._pending_resume = ck
+
+    for name in ("_tick_lightning", "configure_optimizers", "configure_gradient_clipping", "on_before_optimizer_step", "on_train_batch_end"):
+        setattr(DistillationV3AMD, name, getattr(base, name))
+    DistillationV3AMD.__qualname__ = "DistillationV3AMD"
+    _DV3_CLS = DistillationV3AMD
+    return _DV3_CLS
+
+
 def resnet_config_from_reference(features: Any) -> Any:
     """`ResNetConfig` of the `_features` container of a reference `ResNetModelWrapper` (LT/_models/torchvision/resnet.py): stage depths and
     the stem width read off the state_dict."""
@@ -287,7 +427,8 @@ def install_as(name: str = "dinov2") -> type:
     """Map a method name of `lightly_train.train(method=...)` to the MI355X class (method_helpers.py:54-69 builds its table per call)."""
     from lightly_train._methods import method_helpers
 
-    cls = dino_amd_method_cls() if name == "dino" else dinov2_amd_method_cls()
+    cls = {"dino": dino_amd_method_cls, "distillation": distillationv3_amd_method_cls, "distillationv3": distillationv3_amd_method_cls}.get(
+        name, dinov2_amd_method_cls)()
     orig = method_helpers._method_name_to_cls
 
     def patched() -> Dict[str, type]:

@@ -32,13 +32,18 @@ pytestmark = pytest.mark.skipif(not H.reference_available(), reason="needs the r
 import lightly_train_amd  # noqa: E402,F401
 import ops_emu  # noqa: E402
 from lightly_train_amd import ops  # noqa: E402
-from test_dinov2_method_cpu import F32Workspace, _NoStream  # noqa: E402
+from test_dinov2_method_cpu import F32Workspace  # noqa: E402
+from test_distillation_methods_cpu import _NoStream  # noqa: E402  (accepts the device= argument of torch.cuda.Stream)
 
 
 @pytest.fixture(autouse=True)
 def _no_cuda_streams(monkeypatch):
+    import contextlib
+
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _NoStream())
     monkeypatch.setattr(torch.cuda, "set_stream", lambda s: None)
+    monkeypatch.setattr(torch.cuda, "Stream", _NoStream)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
 
 
 def views_for(step, b=16):
@@ -313,3 +318,100 @@ def test_dino_v1_binding_two_steps_equal_the_reference_class(backbone):
             assert torch.allclose(sd[k].float(), rsd[k].float(), atol=3e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
         assert type(m).__name__ == ("DINOResNet" if backbone == "resnet" else "DINO")
     assert integration.install_as("dino") is integration.dino_amd_method_cls()
+
+
+def _build_dv3(cls, s_kind, seed=11):
+    """The reference's DistillationV3 constructor calls (oracle/make_golden.py::make_distill_case) around `cls`: frozen DINOv3 ViT teacher
+    (D = 64), student of kind `s_kind`."""
+    H.install()
+    from lightly_train._methods.distillationv3.distillationv3 import DistillationV3AdamWArgs, DistillationV3Args
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as v2
+    from lightly_train._models.dinov3.dinov3_src.models import vision_transformer as v3
+    from lightly_train._models.dinov3.dinov3_vit import DINOv3ViTModelWrapper
+    from lightly_train._models.embedding_model import EmbeddingModel
+
+    torch.manual_seed(seed)
+    t = v3.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True, layerscale_init=0.5,
+                                 norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True, pos_embed_rope_base=100.0,
+                                 pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
+    t.init_weights()
+    if s_kind == "resnet":
+        from lightly_train._models.torchvision.resnet import ResNetModelWrapper
+        from oracle import resnet_oracle as OR
+
+        s_model = OR.ResNet((1, 1, 1, 1), width=8)
+        with torch.no_grad():
+            for n_, prm in s_model.named_parameters():
+                if "bn" in n_ or "downsample.1" in n_:
+                    prm.add_(0.2 * torch.randn_like(prm))
+        sw = ResNetModelWrapper(s_model)
+    elif s_kind == "dinov3":
+        s_model = v3.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, ffn_ratio=4.0, qkv_bias=True, layerscale_init=0.1,
+                                           norm_layer="layernormbf16", ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True, pos_embed_rope_base=100.0,
+                                           pos_embed_rope_dtype="fp32", pos_embed_rope_rescale_coords=2)
+        s_model.init_weights()
+        sw = DINOv3ViTModelWrapper(s_model)
+    else:
+        s_model = v2.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1, drop_path_rate=0.0,
+                                           ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+        sw = DINOv2ViTModelWrapper(s_model)
+    margs = DistillationV3Args(queue_size=32, teacher=DINOv3ViTModelWrapper(t))
+    oargs = DistillationV3AdamWArgs()
+    oargs.resolve_auto(wrapped_model=sw)
+    kw = dict(device=torch.device("cpu")) if cls.__name__.endswith("AMD") else {}
+    m = cls(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=sw), global_batch_size=8, num_input_channels=3, **kw)
+    m.trainer = H.MockTrainer(20)
+    return m
+
+
+@pytest.mark.parametrize("s_kind", ["dinov2", "dinov3", "resnet"])
+def test_distillationv3_binding_two_steps_equal_the_reference_class(s_kind):
+    """`DistillationV3AMD(Method)` (BASELINE configs[3]'s method) behind the reference's own constructor, for the three student families:
+    two steps with identical mixup draws equal the reference class driven through Lightning's hook order -- loss terms, student, heads and
+    queue; the teacher's keys are absent from a saved checkpoint and restored on load, as in the reference."""
+    H.install()
+    from lightly_train._methods.distillationv3.distillationv3 import DistillationV3
+    from lightly_train_amd import integration
+    from test_distillation_methods_cpu import exactify as exactify_distill
+
+    ref = _build_dv3(DistillationV3, s_kind)
+    amd = _build_dv3(integration.distillationv3_amd_method_cls(), s_kind)
+    assert list(amd.state_dict()) == list(ref.state_dict())
+    [opt], [sched] = ref.configure_optimizers()
+    sched = sched["scheduler"]
+    g = torch.Generator().manual_seed(9)
+    with ops_emu.emulate(ops):
+        exactify_distill(amd.impl())
+        for step in range(2):
+            x = torch.randn(8, 3, 64, 64, generator=g)
+            torch.manual_seed(600 + step)
+            res = ref.training_step_impl({"views": [x.clone()], "filename": []}, 0)
+            res.loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for g_ in opt.param_groups for p in g_["params"] if p.grad is not None], 1.0)
+            opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+            ref.trainer.global_step += 1
+            torch.manual_seed(600 + step)
+            batch = {"views": [x], "filename": []}
+            amd.trainer.global_step = step
+            got = amd.training_step_impl(batch, step)
+            amd.trainer.global_step = step + 1
+            assert float(got.loss) == pytest.approx(float(res.loss), rel=5e-5), (s_kind, step)
+            for k in ("train_loss/local_loss", "train_loss/global_loss"):
+                assert float(got.log_dict[k]) == pytest.approx(float(res.log_dict[k]), rel=5e-5, abs=1e-6), (s_kind, step, k)
+        sd, rsd = amd.state_dict(), ref.state_dict()
+        assert list(sd) == list(rsd)
+        for k in rsd:
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k]) == int(rsd[k]), k
+            else:
+                assert torch.allclose(sd[k].float(), rsd[k].float(), atol=3e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+        ckpt = {"state_dict": dict(sd)}
+        amd.on_save_checkpoint(ckpt)
+        assert not any(k.startswith("teacher_embedding_model.") for k in ckpt["state_dict"]) and "amd_optimizer_state" in ckpt
+        amd2 = _build_dv3(integration.distillationv3_amd_method_cls(), s_kind, seed=12)
+        amd2.on_load_checkpoint(ckpt)
+        assert any(k.startswith("teacher_embedding_model.") for k in ckpt["state_dict"])
+        exactify_distill(amd2.impl())
+        assert torch.equal(amd2.impl().student.data, amd.impl().student.data) and amd2.impl().opt_step == 2
+    assert integration.install_as("distillation") is integration.distillationv3_amd_method_cls()
