@@ -16,7 +16,10 @@ envelope (LT/_checkpoint.py:85-123, read by LT/_commands/export.py:94,165-169) a
     by `lightly_train.export()` unchanged;
   * `on_load_checkpoint` resumes the flat storage, moments and step counters from such a checkpoint (or one the reference wrote).
 
-The class is created lazily (`dinov2_amd_method_cls()`), because it subclasses the reference's `Method`, which needs `lightly_train`
+`DINOAMD` (`method="dino"`, ViT and ResNet wrappers) and `DistillationV3AMD` (`method="distillation"`, BASELINE configs[3]) bind their
+methods the same way (`dino_amd_method_cls()`, `distillationv3_amd_method_cls()`).
+
+The classes are created lazily (`dinov2_amd_method_cls()` ...), because they subclass the reference's `Method`, which needs `lightly_train`
 importable.  `install_as("dinov2")` maps a method name to it in `method_helpers` for `lightly_train.train(method="dinov2", ...)`;
 `get_method_cls` also accepts an instance (method_helpers.py:42-44).
 """
