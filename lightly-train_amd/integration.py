@@ -411,6 +411,132 @@ def distillationv3_amd_method_cls() -> type:
     return _DV3_CLS
 
 
+_D12_CLS: Dict[str, type] = {}
+
+
+def distillation12_amd_method_cls(kind: str) -> type:
+    """`DistillationAMD` (kind "v1": LT/_methods/distillation/distillation.py:155-360, pooled feature against a queue, KL) and
+    `DistillationV2AMD` (kind "v2": LT/_methods/distillationv2/distillationv2.py:155-377, patch features of the last teacher blocks, MSE)
+    on `lightly_train_amd.distillation`.  In both the reference keeps the teacher as the bare ViT (`teacher_embedding_model`), the
+    student as the `EmbeddingModel`, one `student_projection_head`; "auto" optimizer = LARS."""
+    if kind in _D12_CLS:
+        return _D12_CLS[kind]
+    import importlib
+
+    from lightly_train._methods.method import Method, TrainingStepResult
+    from lightly_train._optim.optimizer_type import OptimizerType
+
+    from . import distillation as HD
+    from .dinov3 import convert_dinov3_state
+    from .lars import LARSArgs
+
+    if kind == "v1":
+        Ref = importlib.import_module("lightly_train._methods.distillation.distillation").Distillation
+        Hip, HipArgs = HD.Distillation, HD.DistillationArgs
+    else:
+        Ref = importlib.import_module("lightly_train._methods.distillationv2.distillationv2").DistillationV2
+        Hip, HipArgs = HD.DistillationV2, HD.DistillationV2Args
+    base = dinov2_amd_method_cls()
+
+    class DistillationAMD(Ref):   # type: ignore[misc, valid-type]
+        def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
+                     device: Optional[torch.device] = None) -> None:
+            super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
+                             global_batch_size=global_batch_size, num_input_channels=num_input_channels)
+            self.automatic_optimization = False
+            self._impl: Optional[Any] = None
+            self._impl_device = device
+            self._pending_resume: Optional[Dict[str, Any]] = None
+
+        def impl(self) -> Any:
+            if self._impl is None:
+                dev = self._impl_device or next(self.parameters()).device
+                a, oa = self.method_args, self.optimizer_args
+                kw: Dict[str, Any] = dict(lr_scale_method=a.lr_scale_method, reference_batch_size=int(a.reference_batch_size))
+                if kind == "v1":
+                    kw.update(queue_size=int(a.queue_size), temperature=float(a.temperature))
+                else:
+                    kw.update(n_teacher_blocks=int(a.n_teacher_blocks), n_projection_layers=int(a.n_projection_layers),
+                              projection_hidden_dim=int(a.projection_hidden_dim))
+                if oa.type() == OptimizerType.LARS:
+                    kw.update(optimizer="lars", lars=LARSArgs(lr=float(oa.lr), momentum=float(oa.momentum), dampening=float(oa.dampening),
+                                                              weight_decay=float(oa.weight_decay), nesterov=bool(oa.nesterov),
+                                                              trust_coefficient=float(oa.trust_coefficient), eps=float(oa.eps)))
+                else:
+                    kw.update(optimizer="adamw", lr=float(oa.lr), betas=tuple(oa.betas), eps=float(oa.eps), weight_decay=float(oa.weight_decay))
+                t_model = self.teacher_embedding_model
+                t_sd = {k: v.detach().clone() for k, v in t_model.state_dict().items()}
+                if hasattr(t_model, "rope_embed"):
+                    tcfg = dinov3_config_from_reference(t_model)
+                    t_state = convert_dinov3_state(t_sd, tcfg)
+                else:
+                    tcfg = vit_config_from_reference(t_model)
+                    t_state = {vit_key_to_flat(k): v for k, v in t_sd.items()}
+                wrapped = self.student_embedding_model.wrapped_model
+                if hasattr(wrapped, "_features"):
+                    scfg: Any = resnet_config_from_reference(wrapped._features)
+                    s_state = {k: v.detach().clone() for k, v in wrapped._features.state_dict().items()}
+                else:
+                    s_model = wrapped.get_model()
+                    if hasattr(s_model, "rope_embed"):
+                        raise NotImplementedError("DINOv3 students are bound for DistillationV3 only")
+                    scfg = vit_config_from_reference(s_model)
+                    s_state = {vit_key_to_flat(k): v.detach().clone() for k, v in s_model.state_dict().items()}
+                head = {k: v.detach().clone() for k, v in self.student_projection_head.state_dict().items()}
+                self._impl = Hip(scfg, tcfg, HipArgs(**kw), global_batch_size=self.global_batch_size,
+                                 total_steps=int(self.trainer.estimated_stepping_batches), max_epochs=int(self.trainer.max_epochs or 1), device=dev,
+                                 student_state=s_state, teacher_state=t_state, head_state=head)
+                if kind == "v1":
+                    self._impl.teacher_queue.copy_(self.teacher_queue.to(dev))
+                if self._pending_resume is not None:
+                    self._impl.load_state_dict(self._pending_resume["state_dict"], strict=False)
+                    if self._pending_resume.get("amd_optimizer_state") is not None:
+                        self._impl.load_optimizer_state(self._pending_resume["amd_optimizer_state"])
+                    self._pending_resume = None
+            return self._impl
+
+        def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
+            m = self.impl()
+            if int(self.trainer.global_step) > m.trainer.global_step:
+                m.trainer.global_step = int(self.trainer.global_step)
+            res = m.training_step_impl(batch, batch_idx)
+            m.optimizer_step()
+            self._tick_lightning()
+            return TrainingStepResult(loss=res.loss, log_dict=dict(res.log_dict))
+
+        def sync_to_containers(self) -> None:
+            if self._impl is not None:
+                sd = {k: v.detach().to("cpu") for k, v in self._impl.state_dict().items()}
+                Method.load_state_dict(self, sd, strict=False)
+
+        def state_dict(self, *a: Any, **k: Any) -> Any:
+            self.sync_to_containers()
+            return Method.state_dict(self, *a, **k)
+
+        def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+            self.sync_to_containers()
+            checkpoint["state_dict"] = Method.state_dict(self)
+            if self._impl is not None:
+                checkpoint["amd_optimizer_state"] = self._impl.optimizer_state()
+            Ref.on_save_checkpoint(self, checkpoint)
+
+        def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+            ck = {"state_dict": dict(checkpoint["state_dict"]), "amd_optimizer_state": checkpoint.get("amd_optimizer_state")}
+            Ref.on_load_checkpoint(self, checkpoint)
+            if self._impl is not None:
+                self._impl.load_state_dict(ck["state_dict"], strict=False)
+                if ck["amd_optimizer_state"] is not None:
+                    self._impl.load_optimizer_state(ck["amd_optimizer_state"])
+            else:
+                self._pending_resume = ck
+
+    for name in ("_tick_lightning", "configure_optimizers", "configure_gradient_clipping", "on_before_optimizer_step", "on_train_batch_end"):
+        setattr(DistillationAMD, name, getattr(base, name))
+    DistillationAMD.__qualname__ = DistillationAMD.__name__ = "DistillationAMD" if kind == "v1" else "DistillationV2AMD"
+    _D12_CLS[kind] = DistillationAMD
+    return DistillationAMD
+
+
 def resnet_config_from_reference(features: Any) -> Any:
     """`ResNetConfig` of the `_features` container of a reference `ResNetModelWrapper` (LT/_models/torchvision/resnet.py): stage depths and
     the stem width read off the state_dict."""
@@ -430,7 +556,8 @@ def install_as(name: str = "dinov2") -> type:
     """Map a method name of `lightly_train.train(method=...)` to the MI355X class (method_helpers.py:54-69 builds its table per call)."""
     from lightly_train._methods import method_helpers
 
-    cls = {"dino": dino_amd_method_cls, "distillation": distillationv3_amd_method_cls, "distillationv3": distillationv3_amd_method_cls}.get(
+    cls = {"dino": dino_amd_method_cls, "distillation": distillationv3_amd_method_cls, "distillationv3": distillationv3_amd_method_cls,
+           "distillationv1": lambda: distillation12_amd_method_cls("v1"), "distillationv2": lambda: distillation12_amd_method_cls("v2")}.get(
         name, dinov2_amd_method_cls)()
     orig = method_helpers._method_name_to_cls
 

@@ -415,3 +415,74 @@ def test_distillationv3_binding_two_steps_equal_the_reference_class(s_kind):
         exactify_distill(amd2.impl())
         assert torch.equal(amd2.impl().student.data, amd.impl().student.data) and amd2.impl().opt_step == 2
     assert integration.install_as("distillation") is integration.distillationv3_amd_method_cls()
+
+
+def _build_d12(kind, amd, seed=21, optimizer="auto"):
+    """The reference's Distillation / DistillationV2 constructor calls (oracle/make_golden.py::make_distill12) around the reference class
+    or its MI355X binding; `get_teacher` (a registry lookup by model NAME) is replaced by a function returning a locally built teacher."""
+    import importlib
+
+    H.install()
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as v2
+    from lightly_train._models.embedding_model import EmbeddingModel
+    from lightly_train_amd import integration
+
+    torch.manual_seed(seed)
+    t = v2.DinoVisionTransformer(img_size=112, patch_size=14, embed_dim=64, depth=3, num_heads=1, mlp_ratio=4.0, init_values=0.5, drop_path_rate=0.0,
+                                 ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    t.eval()
+    for prm in t.parameters():
+        prm.requires_grad_(False)
+    s_model = v2.DinoVisionTransformer(img_size=112, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=0.1, drop_path_rate=0.0,
+                                       ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+    sw = DINOv2ViTModelWrapper(s_model)
+    if kind == "v1":
+        mod = importlib.import_module("lightly_train._methods.distillation.distillation")
+        margs, ref_cls = mod.DistillationArgs(queue_size=32, teacher="local"), mod.Distillation
+    else:
+        mod = importlib.import_module("lightly_train._methods.distillationv2.distillationv2")
+        margs, ref_cls = mod.DistillationV2Args(teacher="local"), mod.DistillationV2
+    oargs = ref_cls.optimizer_args_cls(optimizer)()          # "auto" = the method's LARS arguments
+    mod.get_teacher = lambda *a, **k: t
+    cls = integration.distillation12_amd_method_cls(kind) if amd else ref_cls
+    kw = dict(device=torch.device("cpu")) if amd else {}
+    m = cls(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=sw), global_batch_size=8, num_input_channels=3, **kw)
+    m.trainer = H.MockTrainer(20)
+    return m
+
+
+@pytest.mark.parametrize("kind", ["v1", "v2"])
+def test_distillation_v1_v2_bindings_two_steps_equal_the_reference_class(kind):
+    """`DistillationAMD` / `DistillationV2AMD` with the methods' "auto" optimizer (LARS, around the restated lightly.utils.lars.LARS):
+    two steps equal the reference classes -- loss, student, head, queue."""
+    from test_distillation_methods_cpu import exactify as exactify_distill
+
+    ref, amd = _build_d12(kind, False), _build_d12(kind, True)
+    assert list(amd.state_dict()) == list(ref.state_dict()) and type(amd).__name__ == ("DistillationAMD" if kind == "v1" else "DistillationV2AMD")
+    [opt], [sched] = ref.configure_optimizers()
+    sched = sched["scheduler"]
+    g = torch.Generator().manual_seed(13)
+    with ops_emu.emulate(ops):
+        exactify_distill(amd.impl())
+        assert amd.impl().optimizer == "lars"
+        for step in range(2):
+            x = torch.randn(8, 3, 112, 112, generator=g)
+            torch.manual_seed(700 + step)
+            res = ref.training_step_impl({"views": [x.clone()], "filename": []}, 0)
+            res.loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for g_ in opt.param_groups for p in g_["params"] if p.grad is not None], 1.0)
+            opt.step(); opt.zero_grad(set_to_none=True); sched.step()
+            ref.trainer.global_step += 1
+            torch.manual_seed(700 + step)
+            amd.trainer.global_step = step
+            got = amd.training_step_impl({"views": [x], "filename": []}, step)
+            amd.trainer.global_step = step + 1
+            assert float(got.loss) == pytest.approx(float(res.loss), rel=5e-5), (kind, step)
+        sd, rsd = amd.state_dict(), ref.state_dict()
+        assert list(sd) == list(rsd)
+        for k in rsd:
+            assert torch.allclose(sd[k].float(), rsd[k].float(), atol=5e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+        ckpt = {"state_dict": dict(sd)}
+        amd.on_save_checkpoint(ckpt)
+        assert not any(k.startswith("teacher_embedding_model.") for k in ckpt["state_dict"])
