@@ -154,6 +154,10 @@ int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma,
  * unchanged -- callers must not train a LayerScale initialised at 0 on this path (ViTEngine refuses init_values == 0). */
 int lt_layerscale_dgamma(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
                          float* dgamma, int N, int K, void* stream);
+/* the same for `batch` identically shaped layers in ONE launch: layer i's six tensors start `stride` elements behind layer i - 1's (the
+ * blocks of a ViT in the flat parameter / gradient / bf16-shadow storages, which share their offsets) */
+int lt_layerscale_dgamma_batched(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
+                                 float* dgamma, int N, int K, int batch, int64_t stride, void* stream);
 /* out[N] += column sums of a bf16 [rows,N] matrix (bias gradients) */
 int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream);
 /* out[N] (+)= column sums of an f32 [rows,N] matrix (teacher center, dinov2_loss.py:139-145,274-282) */

@@ -51,6 +51,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_layernorm_bwd": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "lt_layernorm_bwd_fused": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, vp, i32, i32, vp],
     "lt_layerscale_dgamma": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "lt_layerscale_dgamma_batched": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, vp],
     "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],
     "lt_colsum_bf16": [vp, vp, i32, i32, vp],
     "lt_colsum_f32": [vp, vp, i32, i32, i32, vp],

@@ -1151,11 +1151,17 @@ extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const fl
 // LayerScale gradient without the saved branch output y:  sum_r dD[r,c] * y[r,c]  with y = A W^T + b and dW = dD^T A is
 // sum_k W[c,k] dW[c,k] + b[c] db[c];  dD = dx * gamma  =>  dgamma[c] += (rowdot(W, dW)[c] + b[c] db[c]) / gamma[c].
 // One wave per output channel c.
+// blockIdx.y: one of `batch` identically shaped layers whose tensors lie `stride` elements apart in the flat parameter / gradient storage
 __global__ __launch_bounds__(256) void layerscale_dgamma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ dW,
                                                                 const float* __restrict__ bias, const float* __restrict__ dbias,
-                                                                const float* __restrict__ gamma, float* __restrict__ dgamma, int N, int K) {
+                                                                const float* __restrict__ gamma, float* __restrict__ dgamma, int N, int K,
+                                                                long stride) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= N) return;
+  const long o = (long)blockIdx.y * stride;
+  W += o; dW += o; gamma += o; dgamma += o;
+  if (bias) bias += o;
+  if (dbias) dbias += o;
   float acc = 0.f;
   for (int k = lane; k < K; k += 64) acc += bf2f(W[(size_t)c * K + k]) * dW[(size_t)c * K + k];
   acc = wave_sum(acc);
@@ -1169,8 +1175,15 @@ extern "C" int lt_layerscale_dgamma(const void* W_bf16, const float* dW, const f
                                     float* dgamma, int N, int K, void* stream) {
   LT_CHECK_ARG(W_bf16 && dW && gamma && dgamma && N > 0 && K > 0, "lt_layerscale_dgamma: bad arguments");
   hipLaunchKernelGGL(layerscale_dgamma_kernel, dim3(lt_cdiv(N, 4)), dim3(256), 0, ST, (const bf16_t*)W_bf16, dW, bias, dbias, gamma,
-                     dgamma, N, K);
+                     dgamma, N, K, 0L);
   LT_CHECK_LAUNCH("lt_layerscale_dgamma");
+}
+extern "C" int lt_layerscale_dgamma_batched(const void* W_bf16, const float* dW, const float* bias, const float* dbias, const float* gamma,
+                                            float* dgamma, int N, int K, int batch, int64_t stride, void* stream) {
+  LT_CHECK_ARG(W_bf16 && dW && gamma && dgamma && N > 0 && K > 0 && batch > 0 && stride >= 0, "lt_layerscale_dgamma_batched: bad arguments");
+  hipLaunchKernelGGL(layerscale_dgamma_kernel, dim3(lt_cdiv(N, 4), batch), dim3(256), 0, ST, (const bf16_t*)W_bf16, dW, bias, dbias, gamma,
+                     dgamma, N, K, (long)stride);
+  LT_CHECK_LAUNCH("lt_layerscale_dgamma_batched");
 }
 extern "C" int lt_colsum_bf16(const void* x, float* out, int rows, int N, void* stream) {
   LT_CHECK_ARG(x && out, "lt_colsum_bf16: null pointer");

@@ -182,6 +182,14 @@ def layerscale_dgamma(w_bf16: Tensor, dw: Tensor, bias: Optional[Tensor], dbias:
           "lt_layerscale_dgamma")
 
 
+def layerscale_dgamma_batched(w_bf16: Tensor, dw: Tensor, bias: Optional[Tensor], dbias: Optional[Tensor], gamma: Tensor, dgamma: Tensor,
+                              N: int, K: int, batch: int, stride: int) -> None:
+    """`layerscale_dgamma` for `batch` layers in one launch; the arguments are layer 0's tensors, layer i's lie i * stride elements on."""
+    _chk(w_bf16, torch.bfloat16, "layerscale_dgamma.w")
+    check(_lib.load().lt_layerscale_dgamma_batched(_p(w_bf16), _p(dw), _p(bias), _p(dbias), _p(gamma), _p(dgamma), N, K, batch, stride, _stream()),
+          "lt_layerscale_dgamma_batched")
+
+
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,
                    D: int, dbias: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, scale: float = 1.0) -> None:
     check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), _p(rowscale), scale, rows, D,

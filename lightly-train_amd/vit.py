@@ -558,7 +558,21 @@ class ViTEngine:
         fc2 = "mlp.w3" if cfg.swiglu else "mlp.fc2"
         if cfg.rope_base is not None and last_call:
             self.gw("pos_embed").zero_()            # no positional embedding in a RoPE model: the zero table stays zero
-        for i in (range(cfg.depth) if blocks is None else blocks):
+        todo = list(range(cfg.depth) if blocks is None else blocks)
+        if len(todo) == cfg.depth and cfg.depth > 1 and not cfg.mask_k_bias and self.has("blocks.0.ls1.gamma"):
+            # every block at once: the blocks are laid out one after the other with equal tensor sizes, so layer i's tensors start a
+            # constant number of elements behind layer i - 1's in the parameter, gradient and bf16-shadow storages alike -- two launches
+            # instead of 2 x depth at the tail of the step, where nothing else is running
+            off = self.P.offsets
+            names = [t + s_ for t in ("attn.proj", fc2) for s_ in (".weight", ".bias")] + ["ls1.gamma", "ls2.gamma"]
+            strides = [{off[self.prefix + f"blocks.{i + 1}." + n] - off[self.prefix + f"blocks.{i}." + n] for n in names} for i in range(cfg.depth - 1)]
+            if all(len(s_) == 1 for s_ in strides) and len({next(iter(s_)) for s_ in strides}) == 1:
+                stride = next(iter(strides[0]))
+                for gname, lin, k_in in (("blocks.0.ls1.gamma", "blocks.0.attn.proj", D), ("blocks.0.ls2.gamma", "blocks.0." + fc2, hid)):
+                    ops.layerscale_dgamma_batched(self.wb(lin + ".weight"), self.gw(lin + ".weight"), self.w(lin + ".bias"), self.gw(lin + ".bias"),
+                                                  self.w(gname), self.gw(gname), D, k_in, cfg.depth, stride)
+                return
+        for i in todo:
             pre = f"blocks.{i}."
             if cfg.mask_k_bias:
                 self.gw(pre + "attn.qkv.bias")[D:2 * D].zero_()   # LinearKMaskedBias: bias * mask => no gradient for the K third

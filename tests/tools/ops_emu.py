@@ -164,6 +164,11 @@ def emulate(ops):
             acc = acc + bias * dbias
         dgamma += torch.where(gamma.abs() > 1e-30, acc / gamma, torch.zeros_like(acc))
 
+    def layerscale_dgamma_batched(w, dw, bias, dbias, gamma, dgamma, N, K, batch, stride):
+        for i in range(batch):
+            at = lambda t, n: None if t is None else torch.as_strided(t, (n,), (1,), t.storage_offset() + i * stride)   # noqa: E731
+            layerscale_dgamma(at(w, N * K), at(dw, N * K), at(bias, N), at(dbias, N), at(gamma, N), at(dgamma, N), N, K)
+
     def gather_rows(src, ld, idx, M, D, out_bf16=None, out_f32=None):
         r = src.reshape(-1, ld)[idx[:M], :D]
         if out_bf16 is not None:
@@ -510,7 +515,7 @@ def emulate(ops):
                      ("weightnorm_fwd", weightnorm_fwd), ("weightnorm_bwd", weightnorm_bwd), ("colsum_bf16", colsum_bf16), ("gelu_fwd", gelu_fwd),
                      ("gelu_bwd", gelu_bwd), ("matmul_f32", matmul_f32), ("resize_4tap", resize_4tap), ("im2col", im2col),
                      ("assemble_tokens", assemble_tokens), ("assemble_tokens_bwd", assemble_tokens_bwd), ("layernorm_fwd", layernorm_fwd),
-                     ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma),
+                     ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma), ("layerscale_dgamma_batched", layerscale_dgamma_batched),
                      ("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("attention_fwd", attention_fwd),
                      ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
                      ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
