@@ -74,6 +74,10 @@ typedef struct lt_gemm_desc {
   int batch;                      /* > 1: `batch` independent problems of this shape, operands `stride_*` elements apart (plain
                                      epilogues only; 0 / 1 = single problem) */
   int64_t stride_a, stride_b, stride_c;
+  float* colsum;                  /* trans_a only (weight gradients dW = dY^T X, A = dY stored [K][M]): colsum[m] += sum_k A[k][m], m < M -- the bias
+                                     gradient of the same Linear (the column sums of dY), formed from the A fragments the kernel holds anyway
+                                     instead of a second pass over dY.  Fused into the four-phase slab kernel when the reduction ledger
+                                     (lt_reduce_begin) is open; otherwise a separate column-sum launch precedes the GEMM.  NULL = none */
 } lt_gemm_desc;
 
 int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);

@@ -20,12 +20,12 @@ class GemmDesc(C.Structure):
         ("trans_a", i32), ("trans_b", i32), ("epilogue", i32), ("C", vp), ("ldc", i32), ("C2", vp), ("ldc2", i32),
         ("bias", vp), ("gamma", vp), ("resid", vp), ("ldr", i32), ("aux", vp), ("ldaux", i32),
         ("alpha", f32), ("split_k", i32), ("force_kernel", i32), ("rowscale", vp), ("branch_scale", f32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
-        ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64),
+        ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("colsum", vp),
     ]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID, EPI_F32, EPI_BF16_GELUGRAD, EPI_F32_ACCUM = range(6)
-ABI_VERSION = 3   # lt_abi_version() of include/lt_amd.h this binding was written against
+ABI_VERSION = 4   # lt_abi_version() of include/lt_amd.h this binding was written against
 
 # name -> argtypes (every function returns int status except lt_last_error)
 SIGNATURES: dict[str, list[Any]] = {

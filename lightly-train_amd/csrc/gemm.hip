@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "gemm_args.h"
+#include "reduce_ledger.h"
 #include <cstdlib>
 
 using lt_gemm::GemmArgs;
@@ -617,7 +618,13 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const GemmArgs g) {
 // KT: K % 64 != 0 (K % 8 == 0): forward / dgrad layouts only (A K-contiguous).  The last K-tile is loaded with clamped k indices and
 // the A halves' tail pieces are zeroed by the waves that loaded them, right after the vmcnt wait that retires the tile and before
 // the barrier that publishes it (SwiGLU widths: 2736 = 42.75 tiles, 5472).
-template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false>
+// CS (weight gradients, TA: A = dY stored [K][M]): the kernel also leaves the column sums of dY -- the bias gradient of the same Linear
+// (LT .. layers/attention.py:44, mlp.py:36: nn.Linear(bias=True) backward) -- as partial rows g.cs[(slice * tiles_n + tn) * 4 + wn][M].
+// The four waves of a wave row read the same A fragments and the tiles_n workgroups of a tile row the same A tiles, so K-tile t of a
+// slice is summed by exactly one of them: wave column t % 4 of column tile (t / 4) % tiles_n.  A lane's fragment holds 8 consecutive
+// k of ONE output row m, i.e. the sum over k is lane-local (v_dot2c_f32_bf16 against (1, 1): 4 instructions per fragment, 32 per phase
+// of the one K-tile in 4 * tiles_n that is this wave's) -- the separate column-sum pass re-read dY from HBM (3.1 ms per step).
+template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false, bool CS = false>
 __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HB = 128 * 128, BUF = 4 * HB;
@@ -726,6 +733,25 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 
   bf16x8 fa[2][4], fb0[4], fb1[4];
   const int bcol = (wn & 1) * 2;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};                 // CS: per 32-row block of the wave's 128 A rows, this lane's k half
+  const int cs_period = 4 * g.tiles_n, cs_mine = tn * 4 + wn;
+  int cs_cnt = 0;
+#define LT_CS_ADD(I0)                                                                                             \
+  do {                                                                                                            \
+    if (CS && cs_cnt == cs_mine) {                                                                                \
+      const bf16x2_t one_ = {(__bf16)1.0f, (__bf16)1.0f};                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                            \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                       \
+        const bf16x8 f_ = fa[i_][ks_];                                                                            \
+        float c_ = csum[(I0) + i_];                                                                               \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 0, 1), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 2, 3), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 4, 5), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 6, 7), one_, c_, false);             \
+        csum[(I0) + i_] = c_;                                                                                     \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
   for (int t = 0; t < nk; ++t) {
     const char* buf = smem + (t & 1) * BUF;
     const char* la = buf + wm * HB;
@@ -752,6 +778,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[i][1], 0, 0, 0);
+    LT_CS_ADD(0);   // A rows 0-63 of the wave's half (read in P1, last used here)
     LT_PHASE_SYNC_OUT();
     // ---- P3
 #pragma unroll
@@ -776,8 +803,11 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[2 + i][0], 0, 0, 0);
+    LT_CS_ADD(2);   // A rows 64-127 (read in P3)
+    if (CS) cs_cnt = (cs_cnt + 1 == cs_period) ? 0 : cs_cnt + 1;
     LT_PHASE_SYNC_OUT();
   }
+#undef LT_CS_ADD
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
 #undef LT_DMA_HALF
 #undef LT_ZERO_TAIL
@@ -785,6 +815,15 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 #undef LT_PHASE_SYNC_OUT
   __syncthreads();
   LT_TSTAMP(2);
+  if (CS) {   // lanes l and l + 32 hold the two k halves of row l & 31: combine, then one 128-byte store per 32-row block
+    float* dst = g.cs + (size_t)((slice * g.tiles_n + tn) * 4 + wn) * g.M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+      const int row = m0 + wm * 128 + i * 32 + (l & 31);
+      if (l < 32 && row < g.M) dst[row] = v;
+    }
+  }
   GemmArgs ge = g;
   if (SLAB) {
     ge.C = (float*)g.C2 + (size_t)slice * g.M * g.N;
@@ -1013,16 +1052,16 @@ int launch_1w(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
   }
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false>
+template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false, bool CS = false>
 int launch_q_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<TA, TB, EPI, SLAB, KT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256q_kernel<TA, TB, EPI, SLAB, KT, CS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm256q_kernel<TA, TB, EPI, SLAB, KT>), grid, dim3(NT2), LDS_BYTES, st, g);
+  hipLaunchKernelGGL((gemm256q_kernel<TA, TB, EPI, SLAB, KT, CS>), grid, dim3(NT2), LDS_BYTES, st, g);
   return LT_OK;
 }
 // partial last K-tile (forward / dgrad layouts)
@@ -1046,6 +1085,7 @@ int launch_q(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
     case EPI_F32: return launch_q_one<TA, TB, EPI_F32, false>(g, grid, st);
     case EPI_BF16_GELUGRAD: return launch_q_one<TA, TB, EPI_BF16_GELUGRAD, false>(g, grid, st);
     case EPI_F32_ACCUM:
+      if (TA && slab && g.cs) return launch_q_one<TA, TB, EPI_F32_ACCUM, true, false, TA>(g, grid, st);   // + column sums of A (bias gradient)
       return slab ? launch_q_one<TA, TB, EPI_F32_ACCUM, true>(g, grid, st) : launch_q_one<TA, TB, EPI_F32_ACCUM, false>(g, grid, st);
     default: lt_set_error("lt_gemm_bf16: unknown epilogue %d", epi); return LT_ERR_INVALID;
   }
@@ -1168,6 +1208,17 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   g.alpha = d->alpha;
   g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
   g.band = 0;
+  g.cs = nullptr;
+  // column sums of the transposed A operand (bias gradient beside a weight gradient): fused into the four-phase slab kernel below when
+  // it is the kernel that runs and the reduction ledger is open; every other path starts with the stand-alone column-sum launch
+  LT_CHECK_ARG(!d->colsum || (d->trans_a && d->lda == d->M && d->epilogue == LT_EPI_F32_ACCUM && d->batch <= 1),
+               "lt_gemm_bf16: colsum needs a weight-gradient GEMM (trans_a, lda == M, accumulating epilogue)");
+  bool cs_pending = d->colsum != nullptr;
+  auto cs_standalone = [&]() -> int {
+    if (!cs_pending) return LT_OK;
+    cs_pending = false;
+    return lt_colsum_bf16(d->A, d->colsum, d->K, d->M, stream);
+  };
 #ifdef LT_GEMM_TIMING
   if (const char* e = getenv("LT_GEMM_STAGGER")) { int u = 0, gr = 2; sscanf(e, "%d,%d", &u, &gr); g.sc = (d->batch > 1) ? g.sc : (long)((gr << 8) | u); }
 #endif
@@ -1282,7 +1333,21 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
     static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
-    if (bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || use_q)) {
+    const bool q_kernel = bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || use_q);
+    if (cs_pending && q_kernel && slab && d->trans_a && d->trans_b) {
+      // LT_GEMM_CS=0 (read per call: tools/ab_step.py): keep the separate column-sum pass
+      const char* env_cs = getenv("LT_GEMM_CS");
+      const int nparts = sp * g.tiles_n * 4;
+      float* part = (env_cs && atoi(env_cs) == 0) ? nullptr : lt_ledger::reserve((size_t)nparts * d->M);
+      if (part) {
+        g.cs = part;
+        lt_ledger::record(d->colsum, part, nparts, d->M, d->M);
+        cs_pending = false;
+      }
+    }
+    rc = cs_standalone();
+    if (rc != LT_OK) return rc;
+    if (q_kernel) {
       if (!d->trans_a && !d->trans_b) rc = g256::launch_q<false, false>(g, d->epilogue, slab, grid2, st);
       else if (!d->trans_a) rc = g256::launch_q<false, true>(g, d->epilogue, slab, grid2, st);
       else rc = g256::launch_q<true, true>(g, d->epilogue, slab, grid2, st);
@@ -1298,6 +1363,8 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     LT_CHECK_LAUNCH("lt_gemm_bf16");
   }
+  rc = cs_standalone();
+  if (rc != LT_OK) return rc;
   if (!d->trans_a && !d->trans_b) rc = launch_epi<false, false>(g, d->epilogue, vec, grid, st);
   else if (!d->trans_a && d->trans_b) rc = launch_epi<false, true>(g, d->epilogue, vec, grid, st);
   else if (d->trans_a && d->trans_b) rc = launch_epi<true, true>(g, d->epilogue, vec, grid, st);

@@ -278,8 +278,8 @@ class HeadEngine:
 
         slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
 
-        def wgrad(dy: Tensor, xin: Tensor, out: Tensor, n_out: int, k_in: int) -> None:
-            """dW[n_out, k_in] += dy[:R]^T xin[:R].  The row count of a step (2B + local + masked rows) is data dependent and rarely a
+        def wgrad(dy: Tensor, xin: Tensor, out: Tensor, n_out: int, k_in: int, dbias: Optional[Tensor] = None) -> None:
+            """dW[n_out, k_in] += dy[:R]^T xin[:R]; dbias[n_out] += column sums of dy[:R] (taken from the same GEMM's operand fragments).  The row count of a step (2B + local + masked rows) is data dependent and rarely a
             multiple of 64; the <= 63 rows up to the next multiple are zeroed in both operands (both: a stale pad row could hold a NaN
             bit pattern) so that the contraction runs in whole K-tiles on the 256-row slab kernel with its deterministic split-K
             reduction -- ragged, these four GEMMs fell to the 128-row kernel and fp32 atomics (1.3 ms per step at 0.3 PF/s)."""
@@ -292,7 +292,7 @@ class HeadEngine:
             else:
                 kpad = R
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-            ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+            ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, colsum=dbias,
                      lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
 
         wgrad(dlogits, c["zn"], self.dwn, K, bn)
@@ -303,8 +303,7 @@ class HeadEngine:
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         l0, l1, l2 = self.lin
-        ops.colsum_bf16(dz, self.gw(l2 + ".bias"), R, bn)
-        wgrad(dz, c["h2"], self.gw(l2 + ".weight"), bn, hid)
+        wgrad(dz, c["h2"], self.gw(l2 + ".weight"), bn, hid, self.gw(l2 + ".bias"))
         dh2 = ws.get(tag + ".dh2", (cap, hid), torch.bfloat16)
         dh1 = ws.get(tag + ".dh1", (cap, hid), torch.bfloat16)
         if self.use_bn:
@@ -321,17 +320,14 @@ class HeadEngine:
 
             ops.gemm(dz, self.wb(l2 + ".weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16)
             dy1 = bn_bwd(1, dh2)
-            ops.colsum_bf16(dy1, self.gw(l1 + ".bias"), R, hid)
-            wgrad(dy1, c["h1"], self.gw(l1 + ".weight"), hid, hid)
+            wgrad(dy1, c["h1"], self.gw(l1 + ".weight"), hid, hid, self.gw(l1 + ".bias"))
             ops.gemm(dy1, self.wb(l1 + ".weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16)
             dh1 = bn_bwd(0, dh1)
         else:
             ops.gemm(dz, self.wb(l2 + ".weight"), dh2, M=R, N=hid, K=bn, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
-            ops.colsum_bf16(dh2, self.gw(l1 + ".bias"), R, hid)
-            wgrad(dh2, c["h1"], self.gw(l1 + ".weight"), hid, hid)
+            wgrad(dh2, c["h1"], self.gw(l1 + ".weight"), hid, hid, self.gw(l1 + ".bias"))
             ops.gemm(dh2, self.wb(l1 + ".weight"), dh1, M=R, N=hid, K=hid, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
-        ops.colsum_bf16(dh1, self.gw(l0 + ".bias"), R, hid)
-        wgrad(dh1, c["x"], self.gw(l0 + ".weight"), hid, D)
+        wgrad(dh1, c["x"], self.gw(l0 + ".weight"), hid, D, self.gw(l0 + ".bias"))
         dx = ws.get(tag + ".dx", (cap, D), torch.float32)
         ops.gemm(dh1, self.wb(l0 + ".weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
         return dx

@@ -56,9 +56,10 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
          alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
          ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, branch_scale: float = 1.0, batch: int = 1, stride_a: int = 0, stride_b: int = 0,
-         stride_c: int = 0) -> Tensor:
+         stride_c: int = 0, colsum: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h.  batch > 1: that many independent
-    problems, operands `stride_*` elements apart (plain epilogues of the 128x128 kernel)."""
+    problems, operands `stride_*` elements apart (plain epilogues of the 128x128 kernel).  colsum (weight gradients, trans_a): f32 [M]
+    += the column sums of the stored A = dY, i.e. the bias gradient of the same Linear, taken from the fragments the kernel holds."""
     _chk(a, torch.bfloat16, "gemm.a")
     _chk(b, torch.bfloat16, "gemm.b")
     d = GemmDesc()
@@ -84,6 +85,9 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
     d.workspace = _p(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
     d.batch, d.stride_a, d.stride_b, d.stride_c = batch, stride_a, stride_b, stride_c
+    if colsum is not None:
+        _chk(colsum, torch.float32, "gemm.colsum")
+    d.colsum = _p(colsum)
     check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
     return out
 

@@ -651,10 +651,10 @@ class ViTEngine:
                 kpad = rows
 
             def run() -> None:
-                if bias is not None:
-                    ops.colsum_bf16(dy, self.gw(bias), rows, n_out)
+                # the bias gradient (column sums of dy) rides the weight-gradient GEMM, which holds dy's fragments anyway (pad rows are zero)
                 ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
-                         lda=n_out, ldb=k_in, ldc=k_in, workspace=slab, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
+                         lda=n_out, ldb=k_in, ldc=k_in, workspace=slab, colsum=self.gw(bias) if bias is not None else None,
+                         **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
 
             if side is None:
                 run()
@@ -783,7 +783,6 @@ class ViTEngine:
         tiles = ((D + 127) // 128) * ((self.kpad + 127) // 128)
 
         def patch_wgrad() -> None:
-            ops.colsum_bf16(dpatch, self.gw("patch_embed.proj.bias"), B * n_p, D)
             gview = self.gw("patch_embed.proj.weight").view(D, -1)
             target = gview
             if self.kpad != self.kreal:  # accumulate into a padded scratch, then fold the real columns into the gradient
@@ -792,7 +791,7 @@ class ViTEngine:
             ops.gemm(dpatch, ctx["cols"], target, M=D, N=self.kpad, K=B * n_p, trans_a=True,
                      trans_b=True, epilogue=ops.EPI_F32_ACCUM, lda=D, ldb=self.kpad,
                      **split_k_plan(D, self.kpad, B * n_p, True, max(2, _split_k(tiles, B * n_p))),
-                     ldc=self.kpad, workspace=slab)
+                     ldc=self.kpad, workspace=slab, colsum=self.gw("patch_embed.proj.bias"))
             if self.kpad != self.kreal:
                 ops.unpad_accumulate(target, gview, D, self.kreal, self.kpad)
 

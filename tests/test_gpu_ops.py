@@ -109,6 +109,41 @@ def test_gemm_256_wgrad_slab_and_atomic(M, N, K, fk):
     assert torch.equal(outs[0], outs[2]), "slab split-K must be bit-reproducible"
 
 
+@pytest.mark.parametrize("M,N,K,fk", [(2304, 768, 50432, 0), (3072, 768, 51200, 8), (768, 768, 50176, 0), (256, 2048, 8832, 8), (2048, 768, 8832, 0),
+                                      (2000, 776, 8192, 8), (64, 576, 16384, 0), (768, 768, 1000, 0)])
+def test_gemm_wgrad_fused_bias_column_sums(M, N, K, fk):
+    """`colsum=`: db[M] += column sums of dY[K,M] beside dW += dY^T X -- fused into the four-phase slab kernel while the reduction ledger
+    is open (partial rows per (slice, column tile, wave column), order-fixed flush), stand-alone launch on every other path.  Checked
+    against torch in fp64, bitwise against a second run, and equal (to rounding) to the stand-alone column sum."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + K)
+    dY = bf(torch.randn(K, M, generator=g) + 0.25).to(DEV)     # non-zero mean: the sums do not cancel
+    X = bf(torch.randn(K, N, generator=g)).to(DEV)
+    ref_w = dY.double().t() @ X.double()
+    ref_b = 3.0 + dY.double().sum(0)
+    slab = torch.empty(64 * 1024 * 1024, device=DEV)
+    scratch = torch.empty(8 * 1024 * 1024, device=DEV)
+    outs = []
+    for ledger in (True, True, False):
+        dW = torch.zeros(M, N, device=DEV)
+        db = torch.full((M,), 3.0, device=DEV)
+        ovf = o.reduce_overflows()
+        if ledger:
+            o.reduce_begin(scratch)
+        o.gemm(dY, X, dW, M=M, N=N, K=K, trans_a=True, trans_b=True, epilogue=o.EPI_F32_ACCUM, split_k=2, lda=M, ldb=N, force_kernel=fk,
+               workspace=slab, colsum=db)
+        if ledger:
+            o.reduce_end()
+        assert o.reduce_overflows() == ovf
+        assert rel_err(dW, ref_w) < 2e-5
+        assert rel_err(db, ref_b) < 2e-5, (ledger, rel_err(db, ref_b))
+        outs.append((dW, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "fused column sums must be bit-reproducible"
+    db2 = torch.full((M,), 3.0, device=DEV)
+    o.colsum_bf16(dY, db2, K, M)
+    assert rel_err(outs[0][1], db2) < 1e-5
+
+
 def test_gemm_asymmetric_identity():
     """A = I with asymmetric B catches row/col swaps in the C write (guide G9)."""
     o = ops()

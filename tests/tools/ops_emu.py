@@ -37,6 +37,9 @@ def emulate(ops):
         for k_ in ("stride_a", "stride_b", "stride_c"):
             kw.pop(k_, None)
         A = (a.float().reshape(-1, lda or (M if trans_a else K))[:K, :M].t() if trans_a else a.float().reshape(-1, lda or K)[:M, :K])
+        if kw.get("colsum") is not None:               # bias gradient beside the weight gradient: column sums of dY = row sums of A^T
+            assert trans_a and epilogue == ops.EPI_F32_ACCUM
+            kw["colsum"].view(-1)[:M] += A.sum(1)
         Bm = (b.float().reshape(-1, ldb or (N if trans_b else K))[:K, :N] if trans_b else b.float().reshape(-1, ldb or K)[:N, :K].t())
         r = A @ Bm
         if bias is not None:
