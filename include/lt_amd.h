@@ -207,6 +207,12 @@ int lt_weightnorm_bwd(const float* dw, const float* v, const float* g, float* dv
  * ------------------------------------------------------------------------------------------ */
 /* probs = softmax((logits - center) * inv_temp) per row (:76-82, :178-186); center may be NULL */
 int lt_softmax_center(const float* logits, const float* center, float* probs, int rows, int K, float inv_temp, void* stream);
+/* the same centering without the probability matrix: stats f32 [rows][2] = (max_k z, 1 / sum_k exp(z - max)) of z = (logits - center) *
+ * inv_temp per row, and colsum f32 [K] = column sums of the raw logits (overwritten; the center update of :139-145 / :274-282) -- one
+ * pass over the teacher logits instead of three (probabilities written, column sums, cross-entropy).  lt_ce_fwd_bwd_logits rebuilds the
+ * probabilities from (logits, stats, center) */
+int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
+                            void* stream);
 /* center = center*momentum + colsum*scale*(1-momentum) (:147-160, :284-297) */
 int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream);
 /* student CE against 1 or 2 teacher rows (:117-133, :246-268):
@@ -216,6 +222,12 @@ int lt_center_ema(float* center, const float* colsum, float scale, float momentu
 int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const int32_t* tb, const float* row_weight,
                   const int32_t* slot, float scale, float inv_temp, float* loss, void* dlogits_bf16, int rows, int K,
                   void* stream);
+/* lt_ce_fwd_bwd with t_x = softmax((t_logits[x] - center(x)) * inv_temp_t) rebuilt per element from the teacher logits, their row
+ * statistics t_stats [rows_t][2] (lt_softmax_stats_colsum) and the center the statistics were formed with: center_a for teacher rows
+ * < split_row (the DINO cls rows), center_b for the others (the iBOT patch rows); either may be NULL (= 0) */
+int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const float* t_stats, const float* center_a, const float* center_b,
+                         int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot, float scale,
+                         float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K, void* stream);
 /* Distillation v3 (reference _methods/distillationv3/distillationv3_loss.py:60-115): per row KL(softmax(t/T) || softmax(s/T));
  * loss[0] += coef * KL, dlogits bf16 = coef/T * (softmax(s/T) - softmax(t/T)); rows `ld` (dlogits: `ldd`) elements apart */
 int lt_kl_fwd_bwd(const float* s_logits, const float* t_logits, int ld, float inv_temp, float coef, float* loss,

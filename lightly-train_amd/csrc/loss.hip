@@ -160,6 +160,214 @@ __global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ 
   }
 }
 
+// ---- softmax centering without the probability matrix ------------------------------------------------------------------------------
+// The teacher side of DINOLoss / IBOTPatchLoss with center_method="softmax" (dinov2_loss.py:76-82,139-160 / :178-186,274-297) needs, per
+// teacher row, softmax((x - center) / temp) inside the student's cross-entropy, and the column sums of the raw logits for the center
+// update.  Written as three passes (probabilities out, column sums, CE in) that is 2 GB of fp32 written and read twice more for
+// [7.8 k, 65 536] rows; here ONE pass over the teacher logits leaves the row statistics (max, 1 / sum-exp) and the column sums, and the
+// cross-entropy kernel below rebuilds the probabilities from the logits it reads anyway.
+//
+// 1024 threads own the 65 536 columns (thread t: columns (i * 1024 + t) * 4, i < 16) and walk rows blockIdx.x, + gridDim.x, ...: the
+// column sums stay in registers over the block's rows (partial[blockIdx.x][K] at the end, added in block order by colsum_slabs_kernel),
+// the row statistics take one wave reduction + one barrier per row (combined by wave 0 from a double-buffered LDS slot).
+constexpr int SC_CHUNK = 4;   // float4 loads in flight per thread and chunk
+__global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+                                                                    float* __restrict__ stats, float* __restrict__ partial, int rows, int K,
+                                                                    float inv_temp) {
+  __shared__ float red[2][32];
+  float4 cs[ROW_NV];
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int par = 0;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+    const float* x = logits + row * K;
+    MaxSum a; a.m = -INFINITY; a.s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ROW_NV; j += SC_CHUNK) {
+      float4 u[SC_CHUNK], c[SC_CHUNK];
+#pragma unroll
+      for (int i = 0; i < SC_CHUNK; ++i) {
+        const int k = ((j + i) * 1024 + threadIdx.x) * 4;
+        u[i] = make_float4(0.f, 0.f, 0.f, 0.f); c[i] = u[i];
+        if (k < K) {
+          u[i] = *reinterpret_cast<const float4*>(x + k);
+          if (center) c[i] = *reinterpret_cast<const float4*>(center + k);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SC_CHUNK; ++i) {
+        const int k = ((j + i) * 1024 + threadIdx.x) * 4;
+        if (k < K) {
+          cs[j + i].x += u[i].x; cs[j + i].y += u[i].y; cs[j + i].z += u[i].z; cs[j + i].w += u[i].w;
+          ms_push(a, (u[i].x - c[i].x) * inv_temp); ms_push(a, (u[i].y - c[i].y) * inv_temp);
+          ms_push(a, (u[i].z - c[i].z) * inv_temp); ms_push(a, (u[i].w - c[i].w) * inv_temp);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      MaxSum other;
+      other.m = __shfl_xor(a.m, o, 64);
+      other.s = __shfl_xor(a.s, o, 64);
+      a = ms_combine(a, other);
+    }
+    if (l == 0) { red[par][2 * w] = a.m; red[par][2 * w + 1] = a.s; }
+    __syncthreads();   // also orders this slot's reuse two rows on: every wave passes the NEXT row's barrier only after wave 0 has read it
+    if (w == 0) {
+      MaxSum r; r.m = (l < 16) ? red[par][2 * l] : -INFINITY; r.s = (l < 16) ? red[par][2 * l + 1] : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        MaxSum other;
+        other.m = __shfl_xor(r.m, o, 64);
+        other.s = __shfl_xor(r.s, o, 64);
+        r = ms_combine(r, other);
+      }
+      if (l == 0) { stats[2 * row] = r.m; stats[2 * row + 1] = 1.f / r.s; }
+    }
+  }
+  float* p = partial + (size_t)blockIdx.x * K;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K) *reinterpret_cast<float4*>(p + k) = cs[i];
+  }
+}
+// out[c] = partial[0][c] + partial[1][c] + ...  (fixed order: the sums feed the loss centers, which must not depend on scheduling)
+__global__ __launch_bounds__(256) void colsum_slabs_f32_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  float4 a = *reinterpret_cast<const float4*>(partial + c);
+  for (int s = 1; s < slabs; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * N + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + c) = a;
+}
+// generic widths: one 256-thread block per row (statistics only; the column sums come from lt_colsum_f32)
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+                                                            float* __restrict__ stats, int K, float inv_temp) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* x = logits + row * K;
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) ms_push(a, (x[k] - (center ? center[k] : 0.f)) * inv_temp);
+  a = block_ms(a, red);
+  if (threadIdx.x == 0) { stats[2 * row] = a.m; stats[2 * row + 1] = 1.f / a.s; }
+}
+
+// teacher probability of column k of teacher row `tr`, rebuilt from its logits: exp((x - center) * inv_temp_t - max) / sum-exp
+struct TRow { const float* x; const float* c; float m, is; };
+__device__ __forceinline__ TRow trow(const float* __restrict__ t_logits, const float* __restrict__ stats, const float* ca, const float* cb,
+                                     int split, int tr, int K) {
+  TRow r;
+  r.x = t_logits + (long)tr * K;
+  r.c = tr < split ? ca : cb;
+  r.m = stats[2 * tr];
+  r.is = stats[2 * tr + 1];
+  return r;
+}
+__device__ __forceinline__ float4 tprob4(const TRow& r, int k, float itt) {
+  const float4 x = *reinterpret_cast<const float4*>(r.x + k);
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r.c) c = *reinterpret_cast<const float4*>(r.c + k);
+  return make_float4(__expf((x.x - c.x) * itt - r.m) * r.is, __expf((x.y - c.y) * itt - r.m) * r.is,
+                     __expf((x.z - c.z) * itt - r.m) * r.is, __expf((x.w - c.w) * itt - r.m) * r.is);
+}
+__device__ __forceinline__ float tprob1(const TRow& r, int k, float itt) {
+  return __expf((r.x[k] - (r.c ? r.c[k] : 0.f)) * itt - r.m) * r.is;
+}
+
+// ce_reg_kernel with the teacher probabilities rebuilt from (teacher logits, row statistics, center): same arithmetic per element as
+// softmax_center_reg_kernel followed by ce_reg_kernel, without the probability matrix in between
+__global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __restrict__ s, const float* __restrict__ t_logits,
+                                                             const float* __restrict__ t_stats, const float* __restrict__ center_a,
+                                                             const float* __restrict__ center_b, int split, const int32_t* __restrict__ ta,
+                                                             const int32_t* __restrict__ tb, const float* __restrict__ row_weight,
+                                                             float scale, float inv_temp, float inv_temp_t, float* __restrict__ terms,
+                                                             bf16_t* __restrict__ dlogits, int K) {
+  __shared__ float red[32];
+  const long row = blockIdx.x;
+  const float* z = s + row * K;
+  const TRow r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
+  const bool two = tb && tb[row] >= 0;
+  const TRow r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
+  float4 v[ROW_NV];
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  float dot = 0.f, tsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K) {
+      float4 u = *reinterpret_cast<const float4*>(z + k);
+      u.x *= inv_temp; u.y *= inv_temp; u.z *= inv_temp; u.w *= inv_temp;
+      v[i] = u;
+      float4 t = tprob4(r0, k, inv_temp_t);
+      if (two) { const float4 t2 = tprob4(r1, k, inv_temp_t); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
+      ms_push(a, u.x); ms_push(a, u.y); ms_push(a, u.z); ms_push(a, u.w);
+      dot += t.x * u.x + t.y * u.y + t.z * u.z + t.w * u.w;
+      tsum += t.x + t.y + t.z + t.w;
+    }
+  }
+  a = block_ms(a, red);
+  dot = block_sum(dot, red);
+  tsum = block_sum(tsum, red);
+  const float lse = a.m + __logf(a.s);
+  const float coef = scale * (row_weight ? row_weight[row] : 1.f);
+  if (threadIdx.x == 0) terms[row] = -coef * (dot - lse * tsum);
+  if (dlogits) {
+    const float c2 = coef * inv_temp;
+#pragma unroll
+    for (int i = 0; i < ROW_NV; ++i) {
+      const int k = (i * 1024 + threadIdx.x) * 4;
+      if (k < K) {
+        float4 t = tprob4(r0, k, inv_temp_t);   // second read of the teacher row(s): L2 / Infinity Cache
+        if (two) { const float4 t2 = tprob4(r1, k, inv_temp_t); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
+        const float4 u = v[i];
+        *reinterpret_cast<uint2*>(dlogits + row * K + k) =
+            make_uint2(pack_bf2(c2 * (__expf(u.x - lse) * tsum - t.x), c2 * (__expf(u.y - lse) * tsum - t.y)),
+                       pack_bf2(c2 * (__expf(u.z - lse) * tsum - t.z), c2 * (__expf(u.w - lse) * tsum - t.w)));
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ce_logits_kernel(const float* __restrict__ s, const float* __restrict__ t_logits,
+                                                        const float* __restrict__ t_stats, const float* __restrict__ center_a,
+                                                        const float* __restrict__ center_b, int split, const int32_t* __restrict__ ta,
+                                                        const int32_t* __restrict__ tb, const float* __restrict__ row_weight, float scale,
+                                                        float inv_temp, float inv_temp_t, float* __restrict__ terms,
+                                                        bf16_t* __restrict__ dlogits, int K) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* z = s + row * K;
+  const TRow r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
+  const bool two = tb && tb[row] >= 0;
+  const TRow r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
+  MaxSum a; a.m = -INFINITY; a.s = 0.f;
+  float dot = 0.f, tsum = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float zk = z[k] * inv_temp;
+    const float tk = tprob1(r0, k, inv_temp_t) + (two ? tprob1(r1, k, inv_temp_t) : 0.f);
+    ms_push(a, zk);
+    dot += tk * zk;
+    tsum += tk;
+  }
+  a = block_ms(a, red);
+  dot = block_sum(dot, red);
+  tsum = block_sum(tsum, red);
+  const float lse = a.m + __logf(a.s);
+  const float coef = scale * (row_weight ? row_weight[row] : 1.f);
+  if (threadIdx.x == 0) terms[row] = -coef * (dot - lse * tsum);
+  if (dlogits) {
+    const float c2 = coef * inv_temp;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float zk = z[k] * inv_temp;
+      const float tk = tprob1(r0, k, inv_temp_t) + (two ? tprob1(r1, k, inv_temp_t) : 0.f);
+      dlogits[row * K + k] = f2bf(c2 * (__expf(zk - lse) * tsum - tk));
+    }
+  }
+}
+
 __global__ void center_ema_kernel(float* center, const float* colsum, float scale, float momentum, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < K) center[k] = center[k] * momentum + colsum[k] * scale * (1.f - momentum);
@@ -439,6 +647,47 @@ extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t
                        (bf16_t*)dlogits_bf16, K);
   hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, ST, terms, slot, rows, loss);
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
+}
+extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream);
+extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
+                                       void* stream) {
+  LT_CHECK_ARG(logits && stats && colsum && K > 0, "lt_softmax_stats_colsum: bad arguments");
+  if (rows == 0) {
+    if (hipMemsetAsync(colsum, 0, sizeof(float) * K, ST) != hipSuccess) { lt_set_error("lt_softmax_stats_colsum: memset failed"); return LT_ERR_HIP; }
+    return LT_OK;
+  }
+  static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
+  if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)logits % 16 == 0) && (!center || (uintptr_t)center % 16 == 0) &&
+      ((uintptr_t)colsum % 16 == 0)) {
+    const int grid = rows < 256 ? rows : 256;     // one workgroup per CU; each keeps its rows' column sums in registers
+    float* partial = lt_scratch_ring((size_t)grid * K);
+    if (!partial) { lt_set_error("lt_softmax_stats_colsum: scratch allocation failed"); return LT_ERR_HIP; }
+    hipLaunchKernelGGL(softmax_stats_colsum_kernel, dim3(grid), dim3(1024), 0, ST, logits, center, stats, partial, rows, K, inv_temp);
+    hipLaunchKernelGGL(colsum_slabs_f32_kernel, dim3(lt_cdiv(K, 1024)), dim3(256), 0, ST, partial, colsum, grid, K);
+    LT_CHECK_LAUNCH("lt_softmax_stats_colsum");
+  }
+  hipLaunchKernelGGL(softmax_stats_kernel, dim3(rows), dim3(256), 0, ST, logits, center, stats, K, inv_temp);
+  return lt_colsum_f32(logits, colsum, rows, K, 0, stream);
+}
+extern "C" int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const float* t_stats, const float* center_a, const float* center_b,
+                                    int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot,
+                                    float scale, float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K,
+                                    void* stream) {
+  LT_CHECK_ARG(s && t_logits && t_stats && ta && loss && K > 0, "lt_ce_fwd_bwd_logits: bad arguments");
+  if (rows == 0) return LT_OK;
+  float* terms = lt_scratch_ring((size_t)rows);
+  if (!terms) { lt_set_error("lt_ce_fwd_bwd_logits: scratch allocation failed"); return LT_ERR_HIP; }
+  static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
+  auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
+  if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && al16(s) && al16(t_logits) && al16(center_a) && al16(center_b) &&
+      (!dlogits_bf16 || (uintptr_t)dlogits_bf16 % 8 == 0))
+    hipLaunchKernelGGL(ce_logits_reg_kernel, dim3(rows), dim3(1024), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb,
+                       row_weight, scale, inv_temp, inv_temp_t, terms, (bf16_t*)dlogits_bf16, K);
+  else
+    hipLaunchKernelGGL(ce_logits_kernel, dim3(rows), dim3(256), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb, row_weight,
+                       scale, inv_temp, inv_temp_t, terms, (bf16_t*)dlogits_bf16, K);
+  hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, ST, terms, slot, rows, loss);
+  LT_CHECK_LAUNCH("lt_ce_fwd_bwd_logits");
 }
 extern "C" int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream) {
   LT_CHECK_ARG(logits && Q, "lt_sk_exp: null pointer");

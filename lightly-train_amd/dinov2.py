@@ -442,6 +442,9 @@ class DINOv2:
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
         # the last block's MLP branch, forward and backward, only at the token rows the losses read (cls + masked patches): vit.forward
         self.sparse_last_mlp = os.environ.get("LT_SPARSE_LAST_MLP", "1") != "0"
+        # softmax centering without the [rows, K] probability matrix (training_step_impl); LT_FUSED_CENTERING=0: softmax, column sums and
+        # cross-entropy as three passes
+        self.fused_centering = os.environ.get("LT_FUSED_CENTERING", "1") != "0"
         # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
         # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
         self.activation_checkpointing = False
@@ -750,14 +753,23 @@ class DINOv2:
                                                        bn_training=self.teacher_head_training)["logits"][:2 * B])
             t_logits[2 * B:Rt].copy_(self.t_ihead.forward(ws, "thi", t_in[2 * B:], M, cap_M, save=False,
                                                           bn_training=self.teacher_head_training)["logits"][:M])
-        t_probs = ws.get("t.probs", (cap_t, K), torch.float32)
+        # softmax centering (the default): one pass over the teacher logits leaves the row statistics and the column sums of the center
+        # update; the cross-entropy rebuilds the probabilities from the logits (no [rows, K] probability matrix: `teacher_probs()` forms
+        # it on demand).  Sinkhorn-Knopp iterates on the matrix and keeps it.  LT_FUSED_CENTERING=0: the three-pass form.
+        fused_center = a.center_method == "softmax" and self.fused_centering
+        t_probs = None if fused_center else ws.get("t.probs", (cap_t, K), torch.float32)
+        t_stats = ws.get("t.stats", (cap_t, 2), torch.float32) if fused_center else None
         if a.center_method == "softmax":
-            ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
-            ops.softmax_center(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_probs[2 * B:Rt], M, K, 1.0 / teacher_temp)
             cs_d = ws.get("t.colsum_dino", (K,), torch.float32)
             cs_i = ws.get("t.colsum_ibot", (K,), torch.float32)
-            ops.colsum_f32(t_logits[:2 * B], cs_d, 2 * B, K)
-            ops.colsum_f32(t_logits[2 * B:Rt], cs_i, M, K)
+            if fused_center:
+                ops.softmax_stats_colsum(t_logits[:2 * B], self.dino_center.view(-1), t_stats[:2 * B], cs_d, 2 * B, K, 1.0 / teacher_temp)
+                ops.softmax_stats_colsum(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_stats[2 * B:Rt], cs_i, M, K, 1.0 / teacher_temp)
+            else:
+                ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
+                ops.softmax_center(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_probs[2 * B:Rt], M, K, 1.0 / teacher_temp)
+                ops.colsum_f32(t_logits[:2 * B], cs_d, 2 * B, K)
+                ops.colsum_f32(t_logits[2 * B:Rt], cs_i, M, K)
             # dinov2_loss.py:139-145 / :274-282 -- DINO: sum over 2B rows / (2B*world); iBOT: per-rank mean over M / world
             ops.scale_f32(cs_i, 1.0 / max(M, 1))
             hd = hi = None
@@ -830,14 +842,21 @@ class DINOv2:
         ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
         main.wait_event(teacher_done)
         inv_ts = 1.0 / a.student_temp
+        def ce(logits: Tensor, ta_: Tensor, tb_: Tensor, coef_: Tensor, out: Tensor, rows: int, slot_: Tensor) -> None:
+            if fused_center:
+                ops.ce_fwd_bwd_logits(logits, t_logits, t_stats, self.dino_center.view(-1), self.ibot_center.view(-1), 2 * B, ta_, tb_, coef_, 1.0,
+                                      inv_ts, 1.0 / teacher_temp, self._loss_slots, out, rows, K, slot=slot_)
+            else:
+                ops.ce_fwd_bwd(logits, t_probs, ta_, tb_, coef_, 1.0, inv_ts, self._loss_slots, out, rows, K, slot=slot_)
+
         if not sep:
             dlogits = ws.get("s.dlogits", (cap_s, K), torch.bfloat16, pad_rows=64)
-            ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rs, K, slot=slot)
+            ce(sh["logits"], ta, tb, coef, dlogits, Rs, slot)
         else:
             dlogits = ws.get("s.dlogits", (Rd, K), torch.bfloat16, pad_rows=64)
             dlogits_i = ws.get("s.dlogits_i", (cap_M, K), torch.bfloat16, pad_rows=64)
-            ops.ce_fwd_bwd(sh["logits"], t_probs, ta, tb, coef, 1.0, inv_ts, self._loss_slots, dlogits, Rd, K, slot=slot)
-            ops.ce_fwd_bwd(shi["logits"], t_probs, ta[Rd:], tb[Rd:], coef[Rd:], 1.0, inv_ts, self._loss_slots, dlogits_i, M, K, slot=slot[Rd:])
+            ce(sh["logits"], ta, tb, coef, dlogits, Rd, slot)
+            ce(shi["logits"], ta[Rd:], tb[Rd:], coef[Rd:], dlogits_i, M, slot[Rd:])
 
         dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
         dxn_g.zero_()
@@ -876,10 +895,23 @@ class DINOv2:
         }
         self._last_masks = masks
         s_patch_logits = sh["logits"][Rd:Rs] if not sep else shi["logits"][:M]
-        self._last = dict(t_cls_logits=t_logits[:2 * B], t_patch_logits=t_logits[2 * B:Rt], t_probs=t_probs[:Rt],
+        self._last = dict(t_cls_logits=t_logits[:2 * B], t_patch_logits=t_logits[2 * B:Rt], t_probs=t_probs[:Rt] if t_probs is not None else None,
+                          t_stats=t_stats, teacher_temp=teacher_temp, Rt=Rt,
                           s_cls_logits=sh["logits"][:2 * B], s_local_logits=sh["logits"][2 * B:Rd], s_patch_logits=s_patch_logits,
                           B=B, M=M, Rl=Rl)
         return TrainingStepResult(loss=ls[:4].sum(), log_dict=logs)
+
+    def teacher_probs(self) -> Tensor:
+        """Teacher probabilities f32 [2B + M, K] of the last step ([cls rows, halves swapped | masked patch rows]): the matrix the fused
+        centering path never writes, formed on demand with the centers the step used (call before the next step moves them)."""
+        L = self._last
+        if L.get("t_probs") is not None:
+            return L["t_probs"]
+        B, M, Rt, K = L["B"], L["M"], L["Rt"], self.method_args.output_dim
+        out = torch.empty(Rt, K, dtype=torch.float32, device=self.device)
+        ops.softmax_center(L["t_cls_logits"], self.dino_center.view(-1), out[:2 * B], 2 * B, K, 1.0 / L["teacher_temp"])
+        ops.softmax_center(L["t_patch_logits"], self.ibot_center.view(-1), out[2 * B:], M, K, 1.0 / L["teacher_temp"])
+        return out
 
     def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:
         """`train_loss` + `log_dict` averaged over ranks in one coalesced all-reduce (what `Method.training_step` logs with

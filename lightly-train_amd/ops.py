@@ -367,6 +367,23 @@ def ce_fwd_bwd(s: Tensor, teacher: Tensor, ta: Tensor, tb: Optional[Tensor], row
                                     _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd")
 
 
+def softmax_stats_colsum(logits: Tensor, center: Optional[Tensor], stats: Tensor, colsum: Tensor, rows: int, K: int, inv_temp: float) -> None:
+    """stats[rows, 2] = (max, 1 / sum-exp) of (logits - center) * inv_temp per row, colsum[K] = column sums of the raw logits: the softmax
+    centering of the teacher logits in one pass, without the probability matrix (lt_softmax_stats_colsum)."""
+    _chk(stats, torch.float32, "softmax_stats.stats")
+    check(_lib.load().lt_softmax_stats_colsum(_p(logits), _p(center), _p(stats), _p(colsum), rows, K, inv_temp, _stream()), "lt_softmax_stats_colsum")
+
+
+def ce_fwd_bwd_logits(s: Tensor, t_logits: Tensor, t_stats: Tensor, center_a: Optional[Tensor], center_b: Optional[Tensor], split_row: int,
+                      ta: Tensor, tb: Optional[Tensor], row_weight: Optional[Tensor], scale: float, inv_temp: float, inv_temp_t: float,
+                      loss: Tensor, dlogits: Optional[Tensor], rows: int, K: int, slot: Optional[Tensor] = None) -> None:
+    """`ce_fwd_bwd` against teacher probabilities rebuilt from the teacher logits, their row statistics and the centers
+    (lt_ce_fwd_bwd_logits): teacher rows < split_row use center_a, the others center_b."""
+    _chk(ta, torch.int32, "ce.ta")
+    check(_lib.load().lt_ce_fwd_bwd_logits(_p(s), _p(t_logits), _p(t_stats), _p(center_a), _p(center_b), split_row, _p(ta), _p(tb), _p(row_weight),
+                                           _p(slot), scale, inv_temp, inv_temp_t, _p(loss), _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd_logits")
+
+
 def sk_exp(logits: Tensor, Q: Tensor, inv_temp: float) -> None:
     check(_lib.load().lt_sk_exp(_p(logits), _p(Q), logits.numel(), inv_temp, _stream()), "lt_sk_exp")
 

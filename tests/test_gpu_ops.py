@@ -504,6 +504,59 @@ def test_head_pieces():
     assert rel_err(dv, vr.grad) < 1e-5 and rel_err(dg, gr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("K,rows_a,rows_b", [(65536, 24, 300), (65536, 256, 700), (20484, 8, 40), (4096, 6, 20), (520, 5, 0)])
+def test_centering_without_the_probability_matrix(K, rows_a, rows_b):
+    """lt_softmax_stats_colsum + lt_ce_fwd_bwd_logits (the softmax-centering path of the step: row statistics and column sums in one pass,
+    probabilities rebuilt inside the cross-entropy) against torch and against the three-pass form (lt_softmax_center, lt_colsum_f32,
+    lt_ce_fwd_bwd): two centers (DINO cls rows / iBOT patch rows), one- and two-target student rows, slots and row weights."""
+    o = ops()
+    g = torch.Generator().manual_seed(K + rows_a)
+    Rt = rows_a + rows_b
+    tl = (torch.randn(Rt, K, generator=g) * 0.3).to(DEV)
+    ca = (torch.randn(K, generator=g) * 0.05).to(DEV)
+    cb = (torch.randn(K, generator=g) * 0.05).to(DEV)
+    itt = 1 / 0.05
+    stats = torch.zeros(Rt, 2, device=DEV)
+    cs_a, cs_b = torch.full((K,), 7.0, device=DEV), torch.full((K,), 7.0, device=DEV)
+    o.softmax_stats_colsum(tl[:rows_a], ca, stats[:rows_a], cs_a, rows_a, K, itt)
+    o.softmax_stats_colsum(tl[rows_a:], cb, stats[rows_a:], cs_b, rows_b, K, itt)
+    z = torch.cat([(tl[:rows_a] - ca) * itt, (tl[rows_a:] - cb) * itt]).double()
+    assert torch.allclose(stats[:, 0].double(), z.max(-1).values, atol=1e-5)
+    assert rel_err(1.0 / stats[:, 1], torch.exp(z - z.max(-1, keepdim=True).values).sum(-1)) < 1e-5
+    assert rel_err(cs_a, tl[:rows_a].double().sum(0)) < 1e-5 and rel_err(cs_b, tl[rows_a:].double().sum(0)) < 2e-5
+    ref_a, ref_b = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
+    o.colsum_f32(tl[:rows_a], ref_a, rows_a, K)
+    o.colsum_f32(tl[rows_a:], ref_b, rows_b, K)
+    assert rel_err(cs_a, ref_a) < 1e-5 and (rows_b == 0 or rel_err(cs_b, ref_b) < 1e-5)
+    cs2 = torch.empty(K, device=DEV)
+    o.softmax_stats_colsum(tl[:rows_a], ca, torch.zeros(rows_a, 2, device=DEV), cs2, rows_a, K, itt)
+    assert torch.equal(cs2, cs_a), "column sums must be bit-reproducible"
+    # student rows: one target (cls / patch rows) and two targets (local crops against both global teachers)
+    R = 40
+    s = torch.randn(R, K, generator=g).to(DEV)
+    ta = torch.randint(0, Rt, (R,), generator=g, dtype=torch.int32).to(DEV)
+    tb = torch.where(torch.rand(R, generator=g) < 0.5, torch.randint(0, rows_a, (R,), generator=g, dtype=torch.int32), torch.full((R,), -1, dtype=torch.int32)).to(DEV)
+    w = torch.rand(R, generator=g).to(DEV)
+    slot = torch.randint(0, 3, (R,), generator=g, dtype=torch.int32).to(DEV)
+    loss = torch.zeros(5, device=DEV); dl = torch.empty(R, K, device=DEV, dtype=torch.bfloat16)
+    o.ce_fwd_bwd_logits(s, tl, stats, ca, cb, rows_a, ta, tb, w, 0.37, 10.0, itt, loss, dl, R, K, slot=slot)
+    probs = torch.empty(Rt, K, device=DEV)
+    o.softmax_center(tl[:rows_a], ca, probs[:rows_a], rows_a, K, itt)
+    o.softmax_center(tl[rows_a:], cb, probs[rows_a:], rows_b, K, itt)
+    loss3 = torch.zeros(5, device=DEV); dl3 = torch.empty(R, K, device=DEV, dtype=torch.bfloat16)
+    o.ce_fwd_bwd(s, probs, ta, tb, w, 0.37, 10.0, loss3, dl3, R, K, slot=slot)
+    assert torch.allclose(loss, loss3, rtol=2e-6, atol=1e-6), (loss, loss3)
+    assert rel_err(dl, dl3) < 8e-3      # both rounded to bf16 from values that differ in the last fp32 bits
+    sr = s.double().requires_grad_(True)
+    pr = torch.softmax(z, -1)
+    t = pr[ta.long()] + pr[tb.clamp_min(0).long()] * (tb >= 0)[:, None]
+    rows_loss = -(0.37 * w.double() * (t * F.log_softmax(sr * 10.0, -1)).sum(-1))
+    rows_loss.sum().backward()
+    ref_slots = torch.zeros(5, dtype=torch.float64, device=DEV).index_add_(0, slot.long(), rows_loss.detach())
+    assert torch.allclose(loss.double(), ref_slots, rtol=2e-5, atol=1e-6)
+    assert rel_err(dl, sr.grad) < 8e-3
+
+
 @pytest.mark.parametrize("K", [4096, 65536, 20484])   # 256-thread kernels / register-resident rows (full and ragged)
 def test_losses(K):
     o = ops()

@@ -96,6 +96,25 @@ def test_cross_entropy_with_two_targets_slots_and_row_weights():
     _close(r["loss"], atol=1e-4); _close(r["d"])
 
 
+def test_fused_centering_contract():
+    """tests/tools/ops_emu.py's statements of lt_softmax_stats_colsum / lt_ce_fwd_bwd_logits against the kernels (two centers, two targets)."""
+    g = torch.Generator().manual_seed(14)
+    R, K, Ta, Tb = 40, 256, 10, 14
+    Tn = Ta + Tb
+    T = dict(s=torch.randn(R, K, generator=g), tl=torch.randn(Tn, K, generator=g) * 0.3, ca=torch.randn(K, generator=g) * 0.1, cb=torch.randn(K, generator=g) * 0.1,
+             st=torch.zeros(Tn, 2), csa=torch.zeros(K), csb=torch.zeros(K), ta=torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32),
+             tb=torch.where(torch.rand(R, generator=g) < 0.5, torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32), torch.full((R,), -1, dtype=torch.int32)),
+             w=torch.rand(R, generator=g), slot=torch.randint(0, 3, (R,), generator=g, dtype=torch.int32), loss=torch.zeros(5), d=torch.zeros(R, K).bfloat16())
+
+    def call(ops, t):
+        ops.softmax_stats_colsum(t["tl"][:Ta], t["ca"], t["st"][:Ta], t["csa"], Ta, K, 1.0 / 0.05)
+        ops.softmax_stats_colsum(t["tl"][Ta:], t["cb"], t["st"][Ta:], t["csb"], Tb, K, 1.0 / 0.05)
+        ops.ce_fwd_bwd_logits(t["s"], t["tl"], t["st"], t["ca"], t["cb"], Ta, t["ta"], t["tb"], t["w"], 0.7, 10.0, 1.0 / 0.05, t["loss"], t["d"], R, K, slot=t["slot"])
+
+    r = _both(call, T, ["st", "csa", "csb", "loss", "d"])
+    _close(r["st"], atol=1e-5); _close(r["csa"], atol=1e-5); _close(r["csb"], atol=1e-5); _close(r["loss"], atol=1e-4); _close(r["d"])
+
+
 def test_softmax_center_sinkhorn_and_center_ema():
     g = torch.Generator().manual_seed(5)
     R, K = 48, 128

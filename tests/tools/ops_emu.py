@@ -236,6 +236,30 @@ def emulate(ops):
         if dlogits is not None:
             dlogits.reshape(-1, K)[:rows] = ((coef * inv_temp)[:, None] * (lsm.exp() * t.sum(-1, keepdim=True) - t)).to(dlogits.dtype)
 
+    def softmax_stats_colsum(logits, center, stats, colsum, rows, K, inv_temp):
+        x = logits.reshape(-1, K)[:rows]
+        z = (x - center.view(1, K) if center is not None else x) * inv_temp
+        m = z.max(-1).values if rows else z.new_zeros(0)
+        st = stats.reshape(-1, 2)
+        st[:rows, 0] = m
+        st[:rows, 1] = 1.0 / torch.exp(z - m[:, None]).sum(-1)
+        colsum.view(-1).copy_(x.sum(0))
+
+    def ce_fwd_bwd_logits(s_, t_logits, t_stats, center_a, center_b, split_row, ta, tb, row_weight, scale, inv_temp, inv_temp_t, loss, dlogits,
+                          rows, K, slot=None):
+        tl = t_logits.reshape(-1, K)
+        nt = tl.shape[0]
+        cen = torch.zeros(nt, K)
+        if center_a is not None:
+            cen[:split_row] = center_a.view(1, K)
+        if center_b is not None:
+            cen[split_row:] = center_b.view(1, K)
+        st = t_stats.reshape(-1, 2)
+        used = torch.unique(torch.cat([ta[:rows].long(), tb[:rows].clamp_min(0).long()] if tb is not None else [ta[:rows].long()]))
+        probs = torch.zeros(nt, K)       # only the rows that are referenced have statistics
+        probs[used] = torch.exp((tl[used] - cen[used]) * inv_temp_t - st[used, 0:1]) * st[used, 1:2]
+        ce_fwd_bwd(s_, probs, ta, tb, row_weight, scale, inv_temp, loss, dlogits, rows, K, slot=slot)
+
     def sk_exp(logits, Q, inv_temp):
         Q.reshape(-1)[: logits.numel()] = torch.exp(logits.reshape(-1) * inv_temp)
 
@@ -521,7 +545,7 @@ def emulate(ops):
                      ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma), ("layerscale_dgamma_batched", layerscale_dgamma_batched),
                      ("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("attention_fwd", attention_fwd),
                      ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
-                     ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
+                     ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("softmax_stats_colsum", softmax_stats_colsum), ("ce_fwd_bwd_logits", ce_fwd_bwd_logits), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
                      ("scale_f32", scale_f32), ("fill_f32", fill_f32), ("ce_fwd_bwd", ce_fwd_bwd), ("sk_exp", sk_exp), ("sk_iter", sk_iter),
                      ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat),
                      ("resample_tokens", resample_tokens), ("kl_fwd_bwd", kl_fwd_bwd), ("cast_bf16", cast_bf16), ("symmetrize_bf16", symmetrize_bf16),
