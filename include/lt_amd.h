@@ -210,9 +210,10 @@ int lt_softmax_center(const float* logits, const float* center, float* probs, in
 /* the same centering without the probability matrix: stats f32 [rows][2] = (max_k z, 1 / sum_k exp(z - max)) of z = (logits - center) *
  * inv_temp per row, and colsum f32 [K] = column sums of the raw logits (overwritten; the center update of :139-145 / :274-282) -- one
  * pass over the teacher logits instead of three (probabilities written, column sums, cross-entropy).  lt_ce_fwd_bwd_logits rebuilds the
- * probabilities from (logits, stats, center) */
+ * probabilities from (logits, stats, center).  scratch: caller-owned, >= K floats (256 * K for one workgroup per CU): per-workgroup
+ * column sums, added in workgroup order (the library allocates nothing) */
 int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
-                            void* stream);
+                            float* scratch, int64_t scratch_floats, void* stream);
 /* center = center*momentum + colsum*scale*(1-momentum) (:147-160, :284-297) */
 int lt_center_ema(float* center, const float* colsum, float scale, float momentum, int K, void* stream);
 /* student CE against 1 or 2 teacher rows (:117-133, :246-268):

@@ -195,14 +195,28 @@ __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float*
           if (center) c[i] = *reinterpret_cast<const float4*>(center + k);
         }
       }
+      // chunk maximum first, then ONE exponential per element against it (ms_push would run both of its branches -- an exponential each --
+      // for nearly every element: with 64 elements per thread some lane of the wave meets a new maximum almost every time)
+      float cm = -INFINITY;
 #pragma unroll
       for (int i = 0; i < SC_CHUNK; ++i) {
         const int k = ((j + i) * 1024 + threadIdx.x) * 4;
         if (k < K) {
           cs[j + i].x += u[i].x; cs[j + i].y += u[i].y; cs[j + i].z += u[i].z; cs[j + i].w += u[i].w;
-          ms_push(a, (u[i].x - c[i].x) * inv_temp); ms_push(a, (u[i].y - c[i].y) * inv_temp);
-          ms_push(a, (u[i].z - c[i].z) * inv_temp); ms_push(a, (u[i].w - c[i].w) * inv_temp);
+          u[i].x = (u[i].x - c[i].x) * inv_temp; u[i].y = (u[i].y - c[i].y) * inv_temp;
+          u[i].z = (u[i].z - c[i].z) * inv_temp; u[i].w = (u[i].w - c[i].w) * inv_temp;
+          cm = fmaxf(cm, fmaxf(fmaxf(u[i].x, u[i].y), fmaxf(u[i].z, u[i].w)));
         }
+      }
+      if (cm > -INFINITY) {
+        float csum_e = 0.f;
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i) {
+          const int k = ((j + i) * 1024 + threadIdx.x) * 4;
+          if (k < K) csum_e += (__expf(u[i].x - cm) + __expf(u[i].y - cm)) + (__expf(u[i].z - cm) + __expf(u[i].w - cm));
+        }
+        MaxSum b; b.m = cm; b.s = csum_e;
+        a = ms_combine(a, b);
       }
     }
 #pragma unroll
@@ -650,8 +664,8 @@ extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t
 }
 extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream);
 extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
-                                       void* stream) {
-  LT_CHECK_ARG(logits && stats && colsum && K > 0, "lt_softmax_stats_colsum: bad arguments");
+                                       float* scratch, int64_t scratch_floats, void* stream) {
+  LT_CHECK_ARG(colsum && K > 0 && rows >= 0 && (rows == 0 || (logits && stats)), "lt_softmax_stats_colsum: bad arguments");
   if (rows == 0) {
     if (hipMemsetAsync(colsum, 0, sizeof(float) * K, ST) != hipSuccess) { lt_set_error("lt_softmax_stats_colsum: memset failed"); return LT_ERR_HIP; }
     return LT_OK;
@@ -659,9 +673,10 @@ extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center,
   static const int reg_rows = [] { const char* e = getenv("LT_LOSS_REG"); return e ? atoi(e) : 1; }();
   if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && ((uintptr_t)logits % 16 == 0) && (!center || (uintptr_t)center % 16 == 0) &&
       ((uintptr_t)colsum % 16 == 0)) {
-    const int grid = rows < 256 ? rows : 256;     // one workgroup per CU; each keeps its rows' column sums in registers
-    float* partial = lt_scratch_ring((size_t)grid * K);
-    if (!partial) { lt_set_error("lt_softmax_stats_colsum: scratch allocation failed"); return LT_ERR_HIP; }
+    int grid = rows < 256 ? rows : 256;           // one workgroup per CU; each keeps its rows' column sums in registers
+    LT_CHECK_ARG(scratch && scratch_floats >= K && ((uintptr_t)scratch & 15) == 0, "lt_softmax_stats_colsum: needs >= K floats of 16-byte aligned scratch");
+    if ((int64_t)grid * K > scratch_floats) grid = (int)(scratch_floats / K);   // fewer, longer row walks when the caller's scratch is small
+    float* partial = scratch;
     hipLaunchKernelGGL(softmax_stats_colsum_kernel, dim3(grid), dim3(1024), 0, ST, logits, center, stats, partial, rows, K, inv_temp);
     hipLaunchKernelGGL(colsum_slabs_f32_kernel, dim3(lt_cdiv(K, 1024)), dim3(256), 0, ST, partial, colsum, grid, K);
     LT_CHECK_LAUNCH("lt_softmax_stats_colsum");

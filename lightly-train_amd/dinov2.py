@@ -763,8 +763,9 @@ class DINOv2:
             cs_d = ws.get("t.colsum_dino", (K,), torch.float32)
             cs_i = ws.get("t.colsum_ibot", (K,), torch.float32)
             if fused_center:
-                ops.softmax_stats_colsum(t_logits[:2 * B], self.dino_center.view(-1), t_stats[:2 * B], cs_d, 2 * B, K, 1.0 / teacher_temp)
-                ops.softmax_stats_colsum(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_stats[2 * B:Rt], cs_i, M, K, 1.0 / teacher_temp)
+                cs_ws = ws.get("t.colsum_ws", (256 * K,), torch.float32)   # per-workgroup column sums (both calls run on this stream)
+                ops.softmax_stats_colsum(t_logits[:2 * B], self.dino_center.view(-1), t_stats[:2 * B], cs_d, 2 * B, K, 1.0 / teacher_temp, cs_ws)
+                ops.softmax_stats_colsum(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_stats[2 * B:Rt], cs_i, M, K, 1.0 / teacher_temp, cs_ws)
             else:
                 ops.softmax_center(t_logits[:2 * B], self.dino_center.view(-1), t_probs[:2 * B], 2 * B, K, 1.0 / teacher_temp)
                 ops.softmax_center(t_logits[2 * B:Rt], self.ibot_center.view(-1), t_probs[2 * B:Rt], M, K, 1.0 / teacher_temp)

@@ -367,11 +367,15 @@ def ce_fwd_bwd(s: Tensor, teacher: Tensor, ta: Tensor, tb: Optional[Tensor], row
                                     _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd")
 
 
-def softmax_stats_colsum(logits: Tensor, center: Optional[Tensor], stats: Tensor, colsum: Tensor, rows: int, K: int, inv_temp: float) -> None:
+def softmax_stats_colsum(logits: Tensor, center: Optional[Tensor], stats: Tensor, colsum: Tensor, rows: int, K: int, inv_temp: float,
+                         scratch: Tensor) -> None:
     """stats[rows, 2] = (max, 1 / sum-exp) of (logits - center) * inv_temp per row, colsum[K] = column sums of the raw logits: the softmax
-    centering of the teacher logits in one pass, without the probability matrix (lt_softmax_stats_colsum)."""
+    centering of the teacher logits in one pass, without the probability matrix (lt_softmax_stats_colsum).  scratch: f32, >= K elements
+    (256 * K for one workgroup per CU)."""
     _chk(stats, torch.float32, "softmax_stats.stats")
-    check(_lib.load().lt_softmax_stats_colsum(_p(logits), _p(center), _p(stats), _p(colsum), rows, K, inv_temp, _stream()), "lt_softmax_stats_colsum")
+    _chk(scratch, torch.float32, "softmax_stats.scratch")
+    check(_lib.load().lt_softmax_stats_colsum(_p(logits) if rows else None, _p(center), _p(stats) if rows else None, _p(colsum), rows, K, inv_temp,
+                                              _p(scratch), scratch.numel(), _stream()), "lt_softmax_stats_colsum")
 
 
 def ce_fwd_bwd_logits(s: Tensor, t_logits: Tensor, t_stats: Tensor, center_a: Optional[Tensor], center_b: Optional[Tensor], split_row: int,

@@ -1,0 +1,111 @@
+"""Test infrastructure (not a product path): the fixture of the configuration `bench.py` times.
+
+One step of the pinned fp32 restatement (oracle/dinov2_oracle.py, itself checked against the reference's own class on the smaller
+fixtures: tests/test_oracle_pin.py) at the BENCHMARK's shapes -- ViT-B/16 (D = 768, 12 blocks, LayerScale 1e-5), K = 65 536 prototypes,
+2 x 224^2 + 8 x 98^2 crops, softmax centering, drop-path 0 -- at the largest batch the build container's 62 GB hold for an autograd step
+(default 32: 6336 global / 12 800 local token rows, so every token GEMM is on the 256-row four-phase kernel and every weight gradient on
+the slab split-K kernel, with the 65 536-wide register-resident softmax / cross-entropy kernels).  LT/_methods/dinov2/dinov2.py:259-397.
+
+Stored (tests/golden/bench_vitb_b<batch>.pt, ~2 MB, not the state): the seeds that rebuild weights and views bit for bit, the iBOT masks,
+and from the step with KoLeo OFF (per-tensor gradients are well conditioned there, see tests/test_gpu_step.py): loss terms, total gradient
+norm, per-tensor gradient norms of EVERY parameter, 14 named gradient tensors (small ones whole, matrices as a strided sample), the two
+loss centers after the step's update; from a forward with the reference's default KoLeo weight: the four loss terms.
+
+    python oracle/make_bench_fixture.py [--batch 32] [--threads 8]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lightly_train_amd  # noqa: E402,F401
+from lightly_train_amd.dinov2 import DINOv2Args, init_head_state  # noqa: E402
+from lightly_train_amd.masking import MaskingGenerator, create_collated_masks  # noqa: E402
+from lightly_train_amd.vit import ViTConfig, init_vit_state  # noqa: E402
+from oracle import dinov2_oracle as O  # noqa: E402
+
+SAMPLED = ["cls_token", "pos_embed", "mask_token", "patch_embed.proj.weight", "blocks.0.norm1.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias",
+           "blocks.5.mlp.fc1.weight", "blocks.5.mlp.fc1.bias", "blocks.5.ls2.gamma", "blocks.11.attn.proj.weight", "blocks.11.mlp.fc2.weight", "norm.weight",
+           "head.mlp.0.weight", "head.mlp.4.bias", "head.last_layer.parametrizations.weight.original1"]
+
+
+def sample(t: torch.Tensor) -> torch.Tensor:
+    """Small tensors whole; matrices as every 16th row x every 8th column (the test applies the same stride)."""
+    if t.numel() <= 1 << 16:
+        return t.clone()
+    m = t.reshape(t.shape[0], -1) if t.dim() > 1 and t.shape[0] > 1 else t.reshape(-1, t.shape[-1])
+    return m[::16, ::8].clone()
+
+
+def build_inputs(batch: int, seed: int):
+    """Weights and views from one generator, in this order (tests/test_gpu_step.py rebuilds them the same way)."""
+    g = torch.Generator().manual_seed(seed)
+    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    views = [torch.randn(batch, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(batch, 3, 98, 98, generator=g) for _ in range(8)]
+    return vc, bsd, shs, ths, views
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=404)
+    ap.add_argument("--mask-seed", type=int, default=17)
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    b = a.batch
+    vc, bsd, shs, ths, views = build_inputs(b, a.seed)
+    cfg = dict(patch_size=16, num_heads=12, depth=12)
+    out = {"batch": b, "seed": a.seed, "mask_seed": a.mask_seed, "total_steps": 100, "config": "vit_base/16, K=65536, 2x224^2 + 8x98^2, softmax centering"}
+
+    # ---- step with KoLeo off: losses, gradients, centers
+    o = O.OracleDINOv2(bsd, shs, cfg, args=dict(koleo_loss_weight=0.0), global_batch_size=b, total_steps=100, teacher_head=ths)
+    # iBOT masks from the product's host sampler (bit-identical to the reference's MaskingGenerator: tests/test_host_logic.py), seeded
+    da = DINOv2Args()
+    random.seed(a.mask_seed)
+    gen = MaskingGenerator(input_size=(14, 14), max_num_patches=int(0.5 * 14 * 14))
+    masks = create_collated_masks(da.mask_ratio_min, da.mask_ratio_max, int(2 * b * da.mask_probability), 2 * b, gen)
+    t0 = time.time()
+    cap: dict = {}
+    loss, logs = o.forward_loss(views, masks, capture=cap)
+    loss.backward()
+    print(f"forward + backward: {time.time() - t0:.1f} s", flush=True)
+    out["masks"] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in masks.items()}
+    out["koleo0"] = {"loss": float(loss.detach()), "logs": {k: float(v) for k, v in logs.items()}}
+    norms, samples, sq = {}, {}, 0.0
+    for name, p in [("backbone." + n, p) for n, p in o.sb.items()] + [("head." + n, p) for n, p in o.sh.items()]:
+        gnorm2 = float((p.grad.double() ** 2).sum())
+        sq += gnorm2
+        norms[name] = gnorm2 ** 0.5
+        short = name[9:] if name.startswith("backbone.") else name
+        if short in SAMPLED:
+            samples[name] = sample(p.grad)
+    out["koleo0"].update(grad_norm=sq ** 0.5, tensor_norms=norms, grad_samples=samples)
+    # the teacher logits' statistics the step leaves behind: the centers after the update that the NEXT step applies (dinov2_loss.py:139-160)
+    o._apply_center_updates()
+    out["koleo0"]["dino_center"] = o.dino_center.detach().reshape(-1).clone()
+    out["koleo0"]["ibot_center"] = o.ibot_center.detach().reshape(-1).clone()
+    out["koleo0"]["logit_samples"] = {k: cap[k].detach()[:4, ::64].clone() for k in ("t_cls_logits", "s_cls_logits", "s_loc_logits", "s_patch_logits", "t_patch_logits")}
+    del o, loss, cap
+
+    # ---- forward with the reference's defaults (KoLeo 0.1), same weights / views / masks
+    o2 = O.OracleDINOv2(bsd, shs, cfg, args={}, global_batch_size=b, total_steps=100, teacher_head=ths)
+    with torch.no_grad():
+        loss2, logs2 = o2.forward_loss(views, masks)
+    out["default"] = {"loss": float(loss2), "logs": {k: float(v) for k, v in logs2.items()}}
+    path = os.path.join(ROOT, "tests", "golden", f"bench_vitb_b{b}.pt")
+    torch.save(out, path)
+    print(path, os.path.getsize(path) // 1024, "KiB", out["koleo0"]["logs"], out["default"]["logs"], "grad-norm", out["koleo0"]["grad_norm"])
+
+
+if __name__ == "__main__":
+    main()

@@ -517,9 +517,10 @@ def test_centering_without_the_probability_matrix(K, rows_a, rows_b):
     cb = (torch.randn(K, generator=g) * 0.05).to(DEV)
     itt = 1 / 0.05
     stats = torch.zeros(Rt, 2, device=DEV)
+    sws = torch.empty(256 * K if K != 20484 else 3 * K, device=DEV)     # 3 * K: fewer workgroups, longer row walks
     cs_a, cs_b = torch.full((K,), 7.0, device=DEV), torch.full((K,), 7.0, device=DEV)
-    o.softmax_stats_colsum(tl[:rows_a], ca, stats[:rows_a], cs_a, rows_a, K, itt)
-    o.softmax_stats_colsum(tl[rows_a:], cb, stats[rows_a:], cs_b, rows_b, K, itt)
+    o.softmax_stats_colsum(tl[:rows_a], ca, stats[:rows_a], cs_a, rows_a, K, itt, sws)
+    o.softmax_stats_colsum(tl[rows_a:], cb, stats[rows_a:], cs_b, rows_b, K, itt, sws)
     z = torch.cat([(tl[:rows_a] - ca) * itt, (tl[rows_a:] - cb) * itt]).double()
     assert torch.allclose(stats[:, 0].double(), z.max(-1).values, atol=1e-5)
     assert rel_err(1.0 / stats[:, 1], torch.exp(z - z.max(-1, keepdim=True).values).sum(-1)) < 1e-5
@@ -529,7 +530,7 @@ def test_centering_without_the_probability_matrix(K, rows_a, rows_b):
     o.colsum_f32(tl[rows_a:], ref_b, rows_b, K)
     assert rel_err(cs_a, ref_a) < 1e-5 and (rows_b == 0 or rel_err(cs_b, ref_b) < 1e-5)
     cs2 = torch.empty(K, device=DEV)
-    o.softmax_stats_colsum(tl[:rows_a], ca, torch.zeros(rows_a, 2, device=DEV), cs2, rows_a, K, itt)
+    o.softmax_stats_colsum(tl[:rows_a], ca, torch.zeros(rows_a, 2, device=DEV), cs2, rows_a, K, itt, sws)
     assert torch.equal(cs2, cs_a), "column sums must be bit-reproducible"
     # student rows: one target (cls / patch rows) and two targets (local crops against both global teachers)
     R = 40

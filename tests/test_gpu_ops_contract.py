@@ -102,13 +102,13 @@ def test_fused_centering_contract():
     R, K, Ta, Tb = 40, 256, 10, 14
     Tn = Ta + Tb
     T = dict(s=torch.randn(R, K, generator=g), tl=torch.randn(Tn, K, generator=g) * 0.3, ca=torch.randn(K, generator=g) * 0.1, cb=torch.randn(K, generator=g) * 0.1,
-             st=torch.zeros(Tn, 2), csa=torch.zeros(K), csb=torch.zeros(K), ta=torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32),
+             sws=torch.zeros(256 * K), st=torch.zeros(Tn, 2), csa=torch.zeros(K), csb=torch.zeros(K), ta=torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32),
              tb=torch.where(torch.rand(R, generator=g) < 0.5, torch.randint(0, Tn, (R,), generator=g, dtype=torch.int32), torch.full((R,), -1, dtype=torch.int32)),
              w=torch.rand(R, generator=g), slot=torch.randint(0, 3, (R,), generator=g, dtype=torch.int32), loss=torch.zeros(5), d=torch.zeros(R, K).bfloat16())
 
     def call(ops, t):
-        ops.softmax_stats_colsum(t["tl"][:Ta], t["ca"], t["st"][:Ta], t["csa"], Ta, K, 1.0 / 0.05)
-        ops.softmax_stats_colsum(t["tl"][Ta:], t["cb"], t["st"][Ta:], t["csb"], Tb, K, 1.0 / 0.05)
+        ops.softmax_stats_colsum(t["tl"][:Ta], t["ca"], t["st"][:Ta], t["csa"], Ta, K, 1.0 / 0.05, t["sws"])
+        ops.softmax_stats_colsum(t["tl"][Ta:], t["cb"], t["st"][Ta:], t["csb"], Tb, K, 1.0 / 0.05, t["sws"])
         ops.ce_fwd_bwd_logits(t["s"], t["tl"], t["st"], t["ca"], t["cb"], Ta, t["ta"], t["tb"], t["w"], 0.7, 10.0, 1.0 / 0.05, t["loss"], t["d"], R, K, slot=t["slot"])
 
     r = _both(call, T, ["st", "csa", "csb", "loss", "d"])

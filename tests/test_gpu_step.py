@@ -442,6 +442,141 @@ def test_vitb_batch24_step_dispatches_gemm256q_and_matches_oracle():
     assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=2e-2)
 
 
+def _bench_method(b, seed, **args):
+    """The method object, weights and views of the benchmark configuration exactly as oracle/make_bench_fixture.py builds them (one
+    generator: backbone, student head, teacher head, then the ten views)."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args, init_head_state
+    from lightly_train_amd.vit import ViTConfig, init_vit_state
+
+    g = torch.Generator().manual_seed(seed)
+    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    bsd = init_vit_state(vc, g)
+    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    views = [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(8)]
+    m = DINOv2(vc, DINOv2Args(**args), global_batch_size=b, total_steps=100, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
+    return m, views
+
+
+def _strided(t):
+    if t.numel() <= 1 << 16:
+        return t
+    m = t.reshape(t.shape[0], -1) if t.dim() > 1 and t.shape[0] > 1 else t.reshape(-1, t.shape[-1])
+    return m[::16, ::8]
+
+
+def test_bench_configuration_step_matches_the_committed_fixture():
+    """The configuration `bench.py` times -- ViT-B/16, K = 65 536, 2 x 224^2 + 8 x 98^2, softmax centering -- at batch 32 against
+    tests/golden/bench_vitb_b32.pt (oracle/make_bench_fixture.py: the pinned fp32 restatement run in the build container): loss terms with
+    KoLeo off and with the reference's default KoLeo weight, total gradient norm, the gradient norm of EVERY parameter tensor, 16 named
+    gradient tensors element by element (matrices as the fixture's strided sample), sampled logits of the five head calls, and the two
+    loss centers after the update.  The reduction ledger must not overflow (no silent fall-back to atomics) and the token GEMMs must be
+    the 256-row kernels."""
+    import json
+
+    from lightly_train_amd import ops
+
+    fx = torch.load(os.path.join(GOLD, "bench_vitb_b32.pt"), weights_only=False)
+    b, k0 = fx["batch"], fx["koleo0"]
+    m, views = _bench_method(b, fx["seed"], koleo_loss_weight=0.0)
+    ovf = ops.reduce_overflows()
+    calls, undo = _install_gemm_spy()
+    try:
+        res = m.training_step_impl({"views": views}, 0, masks=fx["masks"])
+    finally:
+        undo()
+    torch.cuda.synchronize()
+    assert ops.reduce_overflows() == ovf, "reduction ledger scratch exhausted at the benchmark's shapes"
+    tok = [c for c in calls if c[0] in ("fwd", "dgrad") and c[2] in (2 * b * 197, 8 * b * 50)]
+    assert tok and all(c[1] == "gemm256" for c in tok)
+    logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs[k] == pytest.approx(k0["logs"][k], rel=2e-3), k
+    assert float(res.loss) == pytest.approx(k0["loss"], rel=2e-3)
+    L = m._last
+    for key, ours in (("t_cls_logits", L["t_cls_logits"]), ("s_cls_logits", L["s_cls_logits"]), ("s_loc_logits", L["s_local_logits"]),
+                      ("s_patch_logits", L["s_patch_logits"]), ("t_patch_logits", L["t_patch_logits"])):
+        ref = k0["logit_samples"][key]
+        assert (ours[:4, ::64].float().cpu() - ref).abs().max().item() < 2e-2 * ref.abs().max().item(), key
+    report, bad, sq = {}, [], 0.0
+    for n in m.student.names:
+        ours = m.student.g[n].cpu()
+        sq += float((ours.double() ** 2).sum())
+        nrm, ref_n = float(ours.double().norm()), k0["tensor_norms"][n]
+        report[n] = {"norm": nrm, "norm_ref": ref_n}
+        if not nrm == pytest.approx(ref_n, rel=3e-2, abs=1e-9):
+            bad.append((n, nrm, ref_n))
+        if n in k0["grad_samples"]:
+            ref = k0["grad_samples"][n]
+            e = rel(_strided(ours).reshape(ref.shape), ref)
+            report[n]["sample_err"] = e
+            if not e < 6e-2:
+                bad.append((n, "sample", e))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "bench_vitb_b32_grad_report.json"), "w") as f:
+            json.dump({"loss": logs, "loss_fixture": k0["logs"], "grad_norm": sq ** 0.5, "grad_norm_fixture": k0["grad_norm"], "per_tensor": report}, f, indent=1)
+    assert not bad, f"{len(bad)} checks off: {bad[:8]}"
+    assert sq ** 0.5 == pytest.approx(k0["grad_norm"], rel=2e-2)
+    # the centers the NEXT step applies (dinov2_loss.py:139-160): column sums of this step's teacher logits through the EMA
+    m._apply_center_updates()
+    torch.cuda.synchronize()
+    assert rel(m.dino_center.view(-1), k0["dino_center"]) < 2e-2 and rel(m.ibot_center.view(-1), k0["ibot_center"]) < 2e-2
+    # the reference's default KoLeo weight (0.1), forward terms
+    m2, _ = _bench_method(b, fx["seed"])
+    res2 = m2.training_step_impl({"views": views}, 0, masks=fx["masks"])
+    logs2 = {k.split("/")[-1]: float(v) for k, v in res2.log_dict.items()}
+    for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+        assert logs2[k] == pytest.approx(fx["default"]["logs"][k], rel=2e-3), k
+    assert logs2["koleo_loss"] == pytest.approx(fx["default"]["logs"]["koleo_loss"], rel=3e-2)
+
+
+def test_batch128_step_is_the_mean_of_its_four_batch32_parts():
+    """Size-independent property at the benchmark's FULL per-GPU batch (128: other split-K plans, 5.7e8-element logit tensors, the ledger's
+    largest scratch demand): with KoLeo off and the softmax centers at their common initial value every loss term is a mean over images,
+    so the batch-128 gradient is the mean of the gradients of its four 32-image parts (each with the masks of its own images).  Checked per
+    tensor at the bf16 level, in the norm at 2e-3, and the ledger must not overflow."""
+    from lightly_train_amd import ops
+    from lightly_train_amd.masking import MaskingGenerator, create_collated_masks
+
+    b, parts = 128, 4
+    pb = b // parts
+    m, views = _bench_method(b, 505, koleo_loss_weight=0.0)
+    a = m.method_args
+    gen = MaskingGenerator(input_size=(14, 14), max_num_patches=int(0.5 * 14 * 14))
+    part_masks = []
+    for i in range(parts):   # a part's 2 * pb global crops: its images of view 0, then of view 1
+        random.seed(900 + i)
+        part_masks.append(create_collated_masks(a.mask_ratio_min, a.mask_ratio_max, int(2 * pb * a.mask_probability), 2 * pb, gen))
+    # the whole batch's masks: crop order [view 0 of all images | view 1 of all images]
+    cm = torch.cat([torch.cat([pm["collated_masks"][:pb] for pm in part_masks]), torch.cat([pm["collated_masks"][pb:] for pm in part_masks])])
+    whole = {"collated_masks": cm, "mask_indices_list": cm.flatten().nonzero().flatten(),
+             "masks_weight": (1.0 / cm.sum(-1).clamp(min=1.0)).unsqueeze(-1).expand_as(cm)[cm]}   # per-crop weights: the same in a part and in the whole
+    ovf = ops.reduce_overflows()
+    res = m.training_step_impl({"views": views}, 0, masks=whole)
+    torch.cuda.synchronize()
+    assert ops.reduce_overflows() == ovf, "reduction ledger scratch exhausted at batch 128"
+    m._pending.clear()   # no center update between the evaluations: all five see the initial (zero) centers
+    g_whole = {n: m.student.g[n].double().cpu() for n in m.student.names}
+    loss_whole = float(res.loss)
+    acc = {n: torch.zeros_like(t) for n, t in g_whole.items()}
+    loss_parts = 0.0
+    for i, pm in enumerate(part_masks):
+        sl = slice(i * pb, (i + 1) * pb)
+        r = m.training_step_impl({"views": [v[sl] for v in views]}, 0, masks=pm)   # global_step is not advanced: same schedules, zero centers
+        m._pending.clear()                                                            # the centers stay at their initial value for every part
+        torch.cuda.synchronize()
+        loss_parts += float(r.loss) / parts
+        for n in acc:
+            acc[n] += m.student.g[n].double().cpu() / parts
+    assert loss_whole == pytest.approx(loss_parts, rel=2e-4)
+    nw = sum(float((t ** 2).sum()) for t in g_whole.values()) ** 0.5
+    npt = sum(float((t ** 2).sum()) for t in acc.values()) ** 0.5
+    assert nw == pytest.approx(npt, rel=2e-3)
+    bad = [(n, rel(g_whole[n], acc[n])) for n in g_whole if not rel(g_whole[n], acc[n]) < 3e-2]
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("name", ["step_d64_softmax", "step_d64_reg4_swiglu14", "step_vittest_sephead"])
 def test_sparse_last_block_mlp_equals_the_dense_one(name):
     """The losses read the final-norm tokens only at the cls and masked-patch rows, so the last block's MLP branch runs on those rows

@@ -236,7 +236,7 @@ def emulate(ops):
         if dlogits is not None:
             dlogits.reshape(-1, K)[:rows] = ((coef * inv_temp)[:, None] * (lsm.exp() * t.sum(-1, keepdim=True) - t)).to(dlogits.dtype)
 
-    def softmax_stats_colsum(logits, center, stats, colsum, rows, K, inv_temp):
+    def softmax_stats_colsum(logits, center, stats, colsum, rows, K, inv_temp, scratch=None):
         x = logits.reshape(-1, K)[:rows]
         z = (x - center.view(1, K) if center is not None else x) * inv_temp
         m = z.max(-1).values if rows else z.new_zeros(0)
