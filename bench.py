@@ -84,9 +84,10 @@ def host_cpu_info() -> dict:
     return {"model": model, "physical_cores": n, "logical_cpus": logical or (os.cpu_count() or 1)}
 
 
-def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 5, warmups: int = 2) -> dict:
+def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 2, warmups: int = 1, batch: int = 8) -> dict:
     """CPU baseline (BASELINE.md section 3 / SURVEY 8(d)): a full training step (training_step_impl + backward + clip + AdamW + EMA)
-    in fp32 on the host cores, bounded sample: batch 2, `warmups` untimed + `timed_steps` timed steps, MEDIAN step time and spread,
+    in fp32 on the host cores, bounded sample: batch 8 (SURVEY 8(d) planned 8-16: the 2-image step of rounds 2-3 could not fill 128 cores
+    and understated the CPU: 0.29 img/s), `warmups` untimed + `timed_steps` timed steps (about a minute in all), MEDIAN step time and spread,
     one torch thread per PHYSICAL core (hyper-thread siblings only add contention to a GEMM-bound fp32 step; round 2 ran on
     torch's default = every logical CPU and its first timed steps were still warming up: 28.9 -> 18.1 -> 15.6 s).
     kind "reference": the reference's own DINOv2 class driven through oracle/ref_harness.py -- only where /root/reference exists
@@ -97,7 +98,7 @@ def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, tim
     info = host_cpu_info()
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(max(1, info["physical_cores"]))
-    b = 2
+    b = batch
     g = torch.Generator().manual_seed(0)
     name = {768: "vit_base", 384: "vit_small", 1024: "vit_large", 192: "vit_tiny"}[arch["embed_dim"]]
     views = [torch.randn(b, 3, g_size, g_size, generator=g) for _ in range(2)] + [

@@ -16,7 +16,13 @@ std::mutex mu;
 void* lib = nullptr;
 ncclComm_t comm = nullptr;
 hipStream_t cstream = nullptr;
-hipEvent_t ev_in = nullptr, ev_out = nullptr;
+// one fence event per collective in flight: an event re-recorded while an earlier wait on it has not been consumed by the device yet
+// would move that wait to the later record (HIP events are not counting semaphores), so a step that starts its 14 gradient all-reduces
+// back to back takes 14 different events; 32 cover two steps' worth, and re-use only happens after the oldest collective's record.
+constexpr int N_EV = 32;
+hipEvent_t ev_in[N_EV] = {nullptr};
+hipEvent_t ev_out = nullptr;
+unsigned ev_next = 0;
 int world = 0;
 
 ncclResult_t (*p_get_id)(ncclUniqueId*) = nullptr;
@@ -24,6 +30,15 @@ ncclResult_t (*p_init)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
 ncclResult_t (*p_allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
 const char* (*p_errstr)(ncclResult_t) = nullptr;
+
+void release_locked() {   // everything lt_comm_init created, in any partial state
+  if (cstream) (void)hipStreamSynchronize(cstream);
+  if (comm && p_destroy) p_destroy(comm);
+  if (cstream) (void)hipStreamDestroy(cstream);
+  for (int i = 0; i < N_EV; ++i) { if (ev_in[i]) (void)hipEventDestroy(ev_in[i]); ev_in[i] = nullptr; }
+  if (ev_out) (void)hipEventDestroy(ev_out);
+  comm = nullptr; cstream = nullptr; ev_out = nullptr; world = 0; ev_next = 0;
+}
 
 bool resolve() {
   if (lib) return true;
@@ -66,8 +81,10 @@ extern "C" int lt_comm_init(int rank, int world_size, const void* id_in, int byt
   memcpy(&id, id_in, sizeof(id));
   const ncclResult_t r = p_init(&comm, world_size, id, rank);
   if (r != ncclSuccess) { comm = nullptr; return fail("lt_comm_init", r); }
-  if (hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) {
+  bool ok = hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < N_EV; ++i) ok = hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {   // leave no half-built handle behind: a retry must not find "already holds a communicator" nor null streams / events
+    release_locked();
     lt_set_error("lt_comm_init: stream / event creation failed");
     return LT_ERR_HIP;
   }
@@ -81,7 +98,8 @@ extern "C" int lt_comm_allreduce_f32(float* buf, int64_t n, void* after_stream) 
   std::lock_guard<std::mutex> l(mu);
   if (!comm) { lt_set_error("lt_comm_allreduce_f32: no communicator (lt_comm_init)"); return LT_ERR_INVALID; }
   if (n == 0) return LT_OK;
-  if (hipEventRecord(ev_in, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(cstream, ev_in, 0) != hipSuccess) {
+  hipEvent_t ev = ev_in[ev_next++ % N_EV];
+  if (hipEventRecord(ev, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(cstream, ev, 0) != hipSuccess) {
     lt_set_error("lt_comm_allreduce_f32: event fence failed");
     return LT_ERR_HIP;
   }
@@ -109,11 +127,6 @@ extern "C" int lt_comm_size(void) {
 extern "C" int lt_comm_destroy(void) {
   std::lock_guard<std::mutex> l(mu);
   if (!comm) return LT_OK;
-  hipStreamSynchronize(cstream);
-  p_destroy(comm);
-  hipStreamDestroy(cstream);
-  hipEventDestroy(ev_in);
-  hipEventDestroy(ev_out);
-  comm = nullptr; cstream = nullptr; ev_in = ev_out = nullptr; world = 0;
+  release_locked();
   return LT_OK;
 }

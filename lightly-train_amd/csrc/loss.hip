@@ -171,16 +171,21 @@ __global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ 
 // column sums stay in registers over the block's rows (partial[blockIdx.x][K] at the end, added in block order by colsum_slabs_kernel),
 // the row statistics take one wave reduction + one barrier per row (combined by wave 0 from a double-buffered LDS slot).
 constexpr int SC_CHUNK = 4;   // float4 loads in flight per thread and chunk
+constexpr int SC_GROUP = 8;   // rows between two barriers
 __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float* __restrict__ logits, const float* __restrict__ center,
                                                                     float* __restrict__ stats, float* __restrict__ partial, int rows, int K,
                                                                     float inv_temp) {
-  __shared__ float red[2][32];
+  // wave partials (max, sum-exp) of SC_GROUP rows, double-buffered: ONE barrier per SC_GROUP rows (a barrier per row drained the
+  // memory pipeline at every row boundary: 4.2 TB/s); wave 0 combines group g while every wave already streams group g + 1
+  __shared__ float red[2][SC_GROUP][32];
   float4 cs[ROW_NV];
 #pragma unroll
   for (int i = 0; i < ROW_NV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  int par = 0;
-  for (long row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+  const long nmine = rows > (long)blockIdx.x ? (rows - 1 - blockIdx.x) / gridDim.x + 1 : 0;   // rows this workgroup walks
+  for (long it = 0; it < nmine; ++it) {
+    const long row = blockIdx.x + it * gridDim.x;
+    const int slot = (int)(it % SC_GROUP), par = (int)((it / SC_GROUP) & 1);
     const float* x = logits + row * K;
     MaxSum a; a.m = -INFINITY; a.s = 0.f;
 #pragma unroll
@@ -226,18 +231,28 @@ __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float*
       other.s = __shfl_xor(a.s, o, 64);
       a = ms_combine(a, other);
     }
-    if (l == 0) { red[par][2 * w] = a.m; red[par][2 * w + 1] = a.s; }
-    __syncthreads();   // also orders this slot's reuse two rows on: every wave passes the NEXT row's barrier only after wave 0 has read it
-    if (w == 0) {
-      MaxSum r; r.m = (l < 16) ? red[par][2 * l] : -INFINITY; r.s = (l < 16) ? red[par][2 * l + 1] : 0.f;
+    if (l == 0) { red[par][slot][2 * w] = a.m; red[par][slot][2 * w + 1] = a.s; }
+    if (slot == SC_GROUP - 1 || it == nmine - 1) {
+      __syncthreads();   // the group's partials are visible; also fences buffer `par` against its re-use two groups on
+      if (w == 0) {      // lanes: 4 rows x 16 wave partials per pass
+        const long first = it - slot;
+        for (int r0 = 0; r0 <= slot; r0 += 4) {
+          const int r = r0 + (l >> 4), ww = l & 15;
+          MaxSum rr; rr.m = -INFINITY; rr.s = 0.f;
+          if (r <= slot) { rr.m = red[par][r][2 * ww]; rr.s = red[par][r][2 * ww + 1]; }
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        MaxSum other;
-        other.m = __shfl_xor(r.m, o, 64);
-        other.s = __shfl_xor(r.s, o, 64);
-        r = ms_combine(r, other);
+          for (int o = 8; o > 0; o >>= 1) {
+            MaxSum other;
+            other.m = __shfl_xor(rr.m, o, 64);
+            other.s = __shfl_xor(rr.s, o, 64);
+            rr = ms_combine(rr, other);
+          }
+          if (ww == 0 && r <= slot) {
+            const long orow = blockIdx.x + (first + r) * gridDim.x;
+            stats[2 * orow] = rr.m; stats[2 * orow + 1] = 1.f / rr.s;
+          }
+        }
       }
-      if (l == 0) { stats[2 * row] = r.m; stats[2 * row + 1] = 1.f / r.s; }
     }
   }
   float* p = partial + (size_t)blockIdx.x * K;
@@ -247,16 +262,37 @@ __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float*
     if (k < K) *reinterpret_cast<float4*>(p + k) = cs[i];
   }
 }
-// out[c] = partial[0][c] + partial[1][c] + ...  (fixed order: the sums feed the loss centers, which must not depend on scheduling)
+// out[c] = sum over slabs of partial[s][c] in a fixed order (the sums feed the loss centers, which must not depend on scheduling): 64 column
+// lanes x 4 slab lanes per workgroup, slab lane q adds slabs q, q + 4, ... (four loads in flight), the lanes combine as ((0 + 1) + 2) + 3
 __global__ __launch_bounds__(256) void colsum_slabs_f32_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= N) return;
-  float4 a = *reinterpret_cast<const float4*>(partial + c);
-  for (int s = 1; s < slabs; ++s) {
-    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * N + c);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  __shared__ float4 red[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cl) * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (c < N) {
+    int s = q;
+    for (; s + 12 < slabs; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)s * N + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(partial + (size_t)(s + 4) * N + c);
+      const float4 v2 = *reinterpret_cast<const float4*>(partial + (size_t)(s + 8) * N + c);
+      const float4 v3 = *reinterpret_cast<const float4*>(partial + (size_t)(s + 12) * N + c);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < slabs; s += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)s * N + c);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
   }
-  *reinterpret_cast<float4*>(out + c) = a;
+  red[q][cl] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (q == 0 && c < N) {
+    const float4 s0 = red[0][cl], s1 = red[1][cl], s2 = red[2][cl], s3 = red[3][cl];
+    *reinterpret_cast<float4*>(out + c) = make_float4(((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y,
+                                                      ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w);
+  }
 }
 // generic widths: one 256-thread block per row (statistics only; the column sums come from lt_colsum_f32)
 __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ logits, const float* __restrict__ center,
@@ -678,7 +714,7 @@ extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center,
     if ((int64_t)grid * K > scratch_floats) grid = (int)(scratch_floats / K);   // fewer, longer row walks when the caller's scratch is small
     float* partial = scratch;
     hipLaunchKernelGGL(softmax_stats_colsum_kernel, dim3(grid), dim3(1024), 0, ST, logits, center, stats, partial, rows, K, inv_temp);
-    hipLaunchKernelGGL(colsum_slabs_f32_kernel, dim3(lt_cdiv(K, 1024)), dim3(256), 0, ST, partial, colsum, grid, K);
+    hipLaunchKernelGGL(colsum_slabs_f32_kernel, dim3(lt_cdiv(K, 256)), dim3(256), 0, ST, partial, colsum, grid, K);
     LT_CHECK_LAUNCH("lt_softmax_stats_colsum");
   }
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(rows), dim3(256), 0, ST, logits, center, stats, K, inv_temp);

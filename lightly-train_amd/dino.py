@@ -131,6 +131,8 @@ def head_state_from_ref(sd: Mapping[str, Tensor]) -> Dict[str, Tensor]:
 class DINO(DINOv2):
     """The method object; attribute / state_dict layout follows the reference's DINO."""
 
+    supports_accumulation = False   # this step zeroes its gradients and applies the update once per batch
+
     def __init__(self, vit_cfg: ViTConfig, method_args: Optional[DINOArgs] = None, global_batch_size: int = 256, total_steps: int = 125_000,
                  device: str | torch.device = "cuda", backbone_state: Optional[Dict[str, Tensor]] = None,
                  student_head_state: Optional[Dict[str, Tensor]] = None, teacher_head_state: Optional[Dict[str, Tensor]] = None,

@@ -349,6 +349,8 @@ class MockTrainerState:
 class DINOv2:
     """The method object.  Attribute / state_dict layout follows the reference."""
 
+    supports_accumulation = True   # `accum_first` / `accum_last` / `grad_scale` are honoured by training_step_impl (subclasses: see dino.py)
+
     def __init__(self, vit_cfg: ViTConfig, method_args: Optional[DINOv2Args] = None, global_batch_size: int = 128,
                  total_steps: int = 125_000, device: str | torch.device = "cuda",
                  backbone_state: Optional[Dict[str, Tensor]] = None, student_head_state: Optional[Dict[str, Tensor]] = None,
@@ -445,6 +447,13 @@ class DINOv2:
         # softmax centering without the [rows, K] probability matrix (training_step_impl); LT_FUSED_CENTERING=0: softmax, column sums and
         # cross-entropy as three passes
         self.fused_centering = os.environ.get("LT_FUSED_CENTERING", "1") != "0"
+        # gradient accumulation (the reference hands `gradient_accumulation_steps` to Lightning as accumulate_grad_batches,
+        # LT/_commands/train_helpers.py:224-236): a caller that accumulates k micro-batches per optimizer step sets, before each
+        # `training_step_impl`, accum_first (first micro-batch of the window: the flat gradient buffer is zeroed), grad_scale = 1 / k
+        # (Lightning divides the loss by k before backward) and accum_last (False: no gradient collective is started under this
+        # backward and the LayerScale gradients, which are formed from the ACCUMULATED weight gradients, wait for `optimizer_step`)
+        self.accum_first, self.accum_last, self.grad_scale = True, True, 1.0
+        self._ls_finished = True
         # reference _activation_checkpointing.py / DINOv2ViTModelWrapper: keep only block inputs of the student, recompute each
         # block in backward (+1 student forward, ~9x less activation memory); off by default -- 288 GB rarely needs it
         self.activation_checkpointing = False
@@ -610,7 +619,7 @@ class DINOv2:
         ws = self.ws
         main = torch.cuda.current_stream()
         side = self.side_stream if self.overlap_streams else None
-        sync = self._gradient_sync() if self.overlap_grad_reduce and self.reduce_stream is not None else None
+        sync = self._gradient_sync() if self.overlap_grad_reduce and self.reduce_stream is not None and self.accum_last else None
         done_blocks: List[int] = []
 
         def reduce_block(i: int, after: Tuple[Any, ...]) -> None:
@@ -673,7 +682,11 @@ class DINOv2:
                 import warnings
                 warnings.warn(f"reduction ledger scratch exhausted ({n_ovf} fallbacks to atomic sums so far): the step is not bitwise reproducible")
                 self._ledger_overflows = n_ovf
-        self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
+        # LayerScale gradients come from the accumulated weight gradients (dgamma = (W . dW + b db) / gamma, added once): inside an
+        # accumulation window they wait for the last micro-batch -- or for `optimizer_step` when the caller did not know it was the last
+        self._ls_finished = bool(self.accum_last)
+        if self.accum_last:
+            self.s_vit.finish_layerscale_grads(blocks=[i for i in range(self.cfg.depth) if i not in done_blocks])
 
     # ------------------------------------------------------------------ the step
     def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:
@@ -721,9 +734,11 @@ class DINOv2:
         n_p_l = (-(-lv.shape[2] // p)) * (-(-lv.shape[3] // p)) if lv is not None else 0
         Nl = n_p_l + 1 + n_reg
         ix = self._indices(B, n_p + n_reg, n_local, n_p_l + n_reg)
-        if self._grad_sync is not None:
-            self._grad_sync.reset()   # a step whose optimizer_step was skipped must not leak its ranges into this one
-        self.student.grad.zero_()
+        gs = float(self.grad_scale)
+        if self.accum_first:
+            if self._grad_sync is not None:
+                self._grad_sync.reset()   # a step whose optimizer_step was skipped must not leak its ranges into this one
+            self.student.grad.zero_()
         self._loss_slots.zero_()
 
         # the losses read the final tokens at the cls rows and the masked patch rows only: the last block's MLP branch runs there alone
@@ -839,6 +854,8 @@ class DINOv2:
                         torch.full((M,), -1, dtype=torch.int32)])
         coef = torch.cat([torch.full((2 * B,), a.dino_loss_weight * 2.0 / terms / (2 * B)), torch.full((Rl,), a.dino_loss_weight / terms / B),
                           a.ibot_loss_weight * mw / n_crops])
+        if gs != 1.0:
+            coef = coef * gs   # loss / k of a k-batch accumulation window: the slots hold scaled terms, the logs below undo it
         slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32)])
         ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
         main.wait_event(teacher_done)
@@ -866,7 +883,7 @@ class DINOv2:
         if B > 1:   # weight 0: the kernel only evaluates the term (logged by the reference regardless of its weight)
             kslot = self._loss_slots[3:] if a.koleo_loss_weight != 0.0 else self._loss_slots[4:]
             for c in range(2):  # per global-crop chunk, dinov2.py:377-380
-                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight, kws, knn)
+                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight * gs, kws, knn)
 
         # ---------------- backward
         self._reduce_begin()
@@ -887,12 +904,12 @@ class DINOv2:
         self._backward_backbone(sg, dxn_g, sl, dxn_l)
 
         ls = self._loss_slots
-        # slots hold weighted terms; report the unweighted terms like the reference's log_dict
+        # slots hold weighted (and, in an accumulation window, 1/k-scaled) terms; report the unweighted terms like the reference's log_dict
         logs = {
-            "train_loss/dino_global_loss": ls[0] / a.dino_loss_weight if a.dino_loss_weight else ls[0],
-            "train_loss/dino_local_loss": ls[1] / a.dino_loss_weight if a.dino_loss_weight else ls[1],
-            "train_loss/ibot_loss": ls[2] / a.ibot_loss_weight if a.ibot_loss_weight else ls[2],
-            "train_loss/koleo_loss": ls[3] / a.koleo_loss_weight if a.koleo_loss_weight else ls[4],
+            "train_loss/dino_global_loss": ls[0] / (a.dino_loss_weight * gs) if a.dino_loss_weight else ls[0],
+            "train_loss/dino_local_loss": ls[1] / (a.dino_loss_weight * gs) if a.dino_loss_weight else ls[1],
+            "train_loss/ibot_loss": ls[2] / (a.ibot_loss_weight * gs) if a.ibot_loss_weight else ls[2],
+            "train_loss/koleo_loss": ls[3] / (a.koleo_loss_weight * gs) if a.koleo_loss_weight else ls[4],
         }
         self._last_masks = masks
         s_patch_logits = sh["logits"][Rd:Rs] if not sep else shi["logits"][:M]
@@ -900,7 +917,7 @@ class DINOv2:
                           t_stats=t_stats, teacher_temp=teacher_temp, Rt=Rt,
                           s_cls_logits=sh["logits"][:2 * B], s_local_logits=sh["logits"][2 * B:Rd], s_patch_logits=s_patch_logits,
                           B=B, M=M, Rl=Rl)
-        return TrainingStepResult(loss=ls[:4].sum(), log_dict=logs)
+        return TrainingStepResult(loss=ls[:4].sum() / gs if gs != 1.0 else ls[:4].sum(), log_dict=logs)
 
     def teacher_probs(self) -> Tensor:
         """Teacher probabilities f32 [2B + M, K] of the last step ([cls rows, halves swapped | masked patch rows]): the matrix the fused
@@ -971,6 +988,9 @@ class DINOv2:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self.comm_events.append((ev0, ev1))
+        if not self._ls_finished:   # an accumulation window that ended on a micro-batch not announced as its last (end of an epoch)
+            self.s_vit.finish_layerscale_grads()   # linear in the (now rank-averaged) weight and bias gradients
+            self._ls_finished = True
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1

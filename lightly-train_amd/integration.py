@@ -9,7 +9,13 @@ envelope (LT/_checkpoint.py:85-123, read by LT/_commands/export.py:94,165-169) a
 `lightly_train_amd.dinov2.DINOv2` (flat fp32 storage + HIP kernels, explicit backward, fused AdamW / EMA):
 
   * `training_step_impl` hands the batch to the HIP step, which also does backward, clipping, the optimizer step and the EMA
-    (`automatic_optimization = False`: Lightning neither calls backward nor steps an optimizer; `configure_optimizers` returns None);
+    (`automatic_optimization = False`: Lightning neither calls backward nor steps an optimizer, and -- what makes manual optimization the
+    right mode here -- its DDP strategy then leaves the wrapper's reducer switched off, so the step's own RCCL exchange is the only one);
+  * gradient accumulation (`gradient_accumulation_steps`, handed to Lightning as accumulate_grad_batches by LT/_commands/train_helpers.py:224-236,
+    which Lightning refuses under manual optimization): `install_as()` wraps `train_helpers.get_trainer` so that the Trainer is built with
+    accumulate_grad_batches = 1 and carries the window length as `trainer.lt_amd_accumulate_grad_batches`; the binding accumulates k
+    micro-batches in the flat gradient buffer (loss / k, as Lightning scales it), steps on the k-th (or the epoch's last) and runs the EMA
+    after every micro-batch, as the reference's `on_train_batch_end` does; `precision` values other than "bf16-mixed" raise;
   * `on_save_checkpoint` copies the flat storage back into the reference containers (`sync_to_containers`) and puts the reference-format
     `state_dict` / `optimizer_states` / `lr_schedulers` into the checkpoint dict; the reference's ModelCheckpoint callback then pickles
     the (now current) containers into the envelope -- a file written here is read by the reference's `Checkpoint.from_dict` and exported
@@ -36,6 +42,43 @@ from .checkpoint import vit_key_to_flat
 from .vit import ViTConfig
 
 _CLS: Optional[type] = None
+
+SUPPORTED_PRECISIONS = ("bf16-mixed", "bf16")
+
+
+def accumulate_k(self: Any) -> int:
+    """Micro-batches per optimizer step: `trainer.lt_amd_accumulate_grad_batches` (set by the `get_trainer` wrapper of `install_as`) or the
+    method's `gradient_accumulation_steps` attribute (a caller driving the module itself)."""
+    k = getattr(self.trainer, "lt_amd_accumulate_grad_batches", None) or getattr(self, "gradient_accumulation_steps", 1)
+    return max(int(k or 1), 1)
+
+
+def total_optimizer_steps(self: Any) -> int:
+    """`trainer.estimated_stepping_batches` counts batches when the Trainer runs with accumulate_grad_batches = 1: k micro-batches make one step."""
+    return max(-(-int(self.trainer.estimated_stepping_batches) // accumulate_k(self)), 1)
+
+
+def begin_micro_batch(self: Any, batch_idx: int) -> Any:
+    """The engine, told where this micro-batch sits in its accumulation window; returns (engine, is_boundary).  A window ends when
+    (batch_idx + 1) % k == 0 or with the epoch (`trainer.is_last_batch`), as in Lightning's own accumulation."""
+    m = self.impl()
+    k = accumulate_k(self)
+    if int(self.trainer.global_step) > m.trainer.global_step:   # (a resumed Trainer is ahead of a freshly built step object)
+        m.trainer.global_step = int(self.trainer.global_step)
+    boundary = (batch_idx + 1) % k == 0 or bool(getattr(self.trainer, "is_last_batch", False))
+    if getattr(m, "supports_accumulation", False):
+        m.accum_first, m.grad_scale, m.accum_last = self._micro == 0, 1.0 / k, boundary
+    elif k > 1:
+        raise NotImplementedError(f"{type(m).__name__}: gradient accumulation is implemented for the DINOv2 step only")
+    self._micro = 0 if boundary else self._micro + 1
+    return m, boundary
+
+
+def check_precision(self: Any) -> None:
+    p = getattr(self.trainer, "precision", None)
+    if isinstance(p, str) and p not in SUPPORTED_PRECISIONS:
+        raise ValueError(f"precision={p!r}: the MI355X step computes with bf16 MFMA operands, fp32 accumulation and fp32 master weights, i.e. "
+                         f"the reference's 'bf16-mixed'; other precisions are not implemented (supported: {SUPPORTED_PRECISIONS})")
 
 
 def vit_config_from_reference(model: Any, drop_path_rate: float = 0.0) -> ViTConfig:
@@ -94,10 +137,12 @@ def dinov2_amd_method_cls() -> type:
         (logging with sync_dist); everything that computes is replaced."""
 
         def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
-                     device: Optional[torch.device] = None) -> None:
+                     device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
             super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
                              global_batch_size=global_batch_size, num_input_channels=num_input_channels)
             self.automatic_optimization = False     # the HIP step owns backward, clipping, AdamW and the EMA
+            self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+            self._micro = 0                         # position inside the accumulation window
             self._impl: Optional[_HipDINOv2] = None
             self._impl_device = device
             self._pending_resume: Optional[Dict[str, Any]] = None
@@ -105,6 +150,7 @@ def dinov2_amd_method_cls() -> type:
         # ---- the HIP step, built on first use (Lightning moves the module to its device only after __init__)
         def impl(self) -> _HipDINOv2:
             if self._impl is None:
+                check_precision(self)
                 dev = self._impl_device or next(self.parameters()).device
                 sd = Method.state_dict(self)
                 t_model = self.teacher_embedding_model.wrapped_model.get_model()
@@ -113,7 +159,7 @@ def dinov2_amd_method_cls() -> type:
                 bb = "embedding_model.wrapped_model._model."
                 self._impl = _HipDINOv2(
                     cfg, hip_args_from_reference(a), global_batch_size=self.global_batch_size,
-                    total_steps=int(self.trainer.estimated_stepping_batches), device=dev,
+                    total_steps=total_optimizer_steps(self), device=dev,
                     backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
                     student_head_state=_strip(sd, "student_head.dino_head."), teacher_head_state=_strip(sd, "teacher_head.dino_head."),
                     student_ibot_head_state=_strip(sd, "student_head.ibot_head.") if a.ibot_separate_head else None,
@@ -125,28 +171,25 @@ def dinov2_amd_method_cls() -> type:
             return self._impl
 
         def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
-            m = self.impl()
-            if int(self.trainer.global_step) > m.trainer.global_step:   # (a resumed Trainer is ahead of a freshly built step object)
-                m.trainer.global_step = int(self.trainer.global_step)
-            res = m.training_step_impl(batch, batch_idx)     # forward + explicit backward in HIP: gradients in m.student.grad
-            m.optimizer_step()                               # WD / lr schedules + freezes, clip 3.0, AdamW; global_step += 1 (dinov2.py:550-639)
-            m.on_train_batch_end()                           # EMA teacher at the incremented step             (dinov2.py:641-660)
-            self._tick_lightning()
+            m, boundary = begin_micro_batch(self, batch_idx)
+            res = m.training_step_impl(batch, batch_idx)     # forward + explicit backward in HIP: gradients accumulate in m.student.grad
+            if boundary:
+                m.optimizer_step()                           # WD / lr schedules + freezes, clip 3.0, AdamW; global_step += 1 (dinov2.py:550-639)
+                self._tick_lightning()
+            m.on_train_batch_end()                           # EMA teacher at the engine's step, every micro-batch (dinov2.py:641-660)
             return TrainingStepResult(loss=res.loss, log_dict=res.log_dict)
 
         def _tick_lightning(self) -> None:
             """Manual optimization: Lightning advances `trainer.global_step` when a LightningOptimizer steps.  `configure_optimizers`
-            returns a no-op SGD over a tensor that is not part of the module, stepped here once per batch, so that max_steps, the
-            checkpoint callback's step counter and `checkpoint["global_step"]` keep their meaning."""
-            opts = getattr(self, "optimizers", None)
-            if callable(opts):
-                try:
-                    o = opts()
-                except Exception:
-                    return
-                for one in (o if isinstance(o, (list, tuple)) else [o]):
-                    if one is not None and hasattr(one, "step"):
-                        one.step()
+            returns a no-op SGD over a tensor that is not part of the module, stepped here once per optimizer step, so that max_steps, the
+            checkpoint callback's step counter and `checkpoint["global_step"]` keep their meaning.  Only a module that is not attached to
+            a Lightning Trainer (this repo's CPU tests drive the hooks by hand) has no optimizers to step; any other failure propagates."""
+            strategy = getattr(self.trainer, "strategy", None)
+            if strategy is None:      # no Lightning Trainer behind `self.trainer`: the caller advances its own counter
+                return
+            o = self.optimizers()
+            for one in (o if isinstance(o, (list, tuple)) else [o]):
+                one.step()
 
         def configure_optimizers(self) -> Any:   # manual optimization: a counter for Lightning's progress tracking only (_tick_lightning)
             return torch.optim.SGD([torch.zeros((), requires_grad=True)], lr=0.0)
@@ -179,12 +222,20 @@ def dinov2_amd_method_cls() -> type:
                 checkpoint["optimizer_states"] = ck["optimizer_states"]
                 checkpoint["lr_schedulers"] = ck["lr_schedulers"]
 
-        def on_load_checkpoint(self, checkpoint: Mapping[str, Any]) -> None:
+        def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
             ck = {k: checkpoint[k] for k in ("state_dict", "optimizer_states", "global_step") if k in checkpoint}
             if self._impl is not None:
                 self._impl.load_checkpoint_dict(ck)
             else:
                 self._pending_resume = ck
+            # Lightning restores optimizers AFTER this hook from the same dict (`restore_optimizers`: optimizer.load_state_dict(
+            # checkpoint["optimizer_states"][i])): what it finds must fit the progress-counter SGD of `configure_optimizers`, not the
+            # reference-format AdamW / SGD state (many parameter groups) the engine has just taken -- for checkpoints written here and by
+            # the reference alike.  No scheduler is registered with Lightning (the engine owns the schedule): nothing to restore there.
+            if "optimizer_states" in checkpoint:
+                checkpoint["optimizer_states"] = [self.configure_optimizers().state_dict()]
+            if "lr_schedulers" in checkpoint:
+                checkpoint["lr_schedulers"] = []
 
     DINOv2AMD.__qualname__ = "DINOv2AMD"
     _CLS = DINOv2AMD
@@ -212,10 +263,12 @@ def dino_amd_method_cls() -> type:
 
     class DINOAMD(RefDINO):   # type: ignore[misc, valid-type]
         def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
-                     device: Optional[torch.device] = None) -> None:
+                     device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
             super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
                              global_batch_size=global_batch_size, num_input_channels=num_input_channels)
             self.automatic_optimization = False
+            self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+            self._micro = 0
             self._impl: Optional[HipDINO] = None
             self._impl_device = device
             self._pending_resume: Optional[Dict[str, Any]] = None
@@ -224,11 +277,23 @@ def dino_amd_method_cls() -> type:
             if self._impl is None:
                 import dataclasses
 
+                check_precision(self)
                 dev = self._impl_device or next(self.parameters()).device
                 sd = Method.state_dict(self)
                 a, oa = self.method_args, self.optimizer_args
                 kw = {f.name: getattr(a, f.name) for f in dataclasses.fields(HipDINOArgs)
                       if hasattr(a, f.name) and getattr(a, f.name) is not None and getattr(a, f.name) != "auto"}
+                # the deprecated epoch spellings (resolve_auto leaves *_steps at None when they are set): converted as dino.py:301-312 / :450-468
+                total = int(self.trainer.estimated_stepping_batches)
+                spe = -(-total // int(self.trainer.max_epochs or 1))
+                if getattr(a, "warmup_teacher_temp_steps", None) is None:
+                    if getattr(a, "warmup_teacher_temp_epochs", None) is None:
+                        raise ValueError("Either warmup_teacher_temp_epochs or warmup_teacher_temp_steps must be set.")
+                    kw["warmup_teacher_temp_steps"] = min(int(a.warmup_teacher_temp_epochs * spe), int(total * a.warmup_teacher_temp_max_steps_fraction))
+                if getattr(a, "student_freeze_last_layer_steps", None) is None:
+                    if getattr(a, "student_freeze_last_layer_epochs", None) is None:
+                        raise ValueError("Either student_freeze_last_layer_epochs or student_freeze_last_layer_steps must be set.")
+                    kw["student_freeze_last_layer_steps"] = int(a.student_freeze_last_layer_epochs * spe)
                 is_sgd = oa.type() == OptimizerType.SGD
                 kw.update(optimizer="sgd" if is_sgd else "adamw", lr=float(oa.lr), weight_decay=float(oa.weight_decay))
                 if is_sgd:
@@ -255,9 +320,7 @@ def dino_amd_method_cls() -> type:
             return self._impl
 
         def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
-            m = self.impl()
-            if int(self.trainer.global_step) > m.trainer.global_step:
-                m.trainer.global_step = int(self.trainer.global_step)
+            m, _ = begin_micro_batch(self, batch_idx)         # (k > 1 raises: accumulation is bound for the DINOv2 step)
             res = m.training_step_impl(batch, batch_idx)     # EMA first, then forward + explicit backward (dino.py:273-316)
             m.optimizer_step()                               # WD schedule, last-layer freeze, clip 3.0, SGD / AdamW (dino.py:330-477)
             self._tick_lightning()
@@ -314,10 +377,12 @@ def distillationv3_amd_method_cls() -> type:
 
     class DistillationV3AMD(RefDV3):   # type: ignore[misc, valid-type]
         def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
-                     device: Optional[torch.device] = None) -> None:
+                     device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
             super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
                              global_batch_size=global_batch_size, num_input_channels=num_input_channels)
             self.automatic_optimization = False
+            self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+            self._micro = 0
             self._impl: Optional[HipDV3] = None
             self._impl_device = device
             self._pending_resume: Optional[Dict[str, Any]] = None
@@ -326,6 +391,7 @@ def distillationv3_amd_method_cls() -> type:
             if self._impl is None:
                 dev = self._impl_device or next(self.parameters()).device
                 a, oa = self.method_args, self.optimizer_args
+                check_precision(self)
                 kw: Dict[str, Any] = dict(queue_size=int(a.queue_size), temperature_global=float(a.temperature_global), temperature_local=float(a.temperature_local),
                                           lr_scale_method=a.lr_scale_method, reference_batch_size=int(a.reference_batch_size),
                                           loss_local_weight=float(a.loss_local_weight))
@@ -370,9 +436,7 @@ def distillationv3_amd_method_cls() -> type:
             return self._impl
 
         def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
-            m = self.impl()
-            if int(self.trainer.global_step) > m.trainer.global_step:
-                m.trainer.global_step = int(self.trainer.global_step)
+            m, _ = begin_micro_batch(self, batch_idx)
             res = m.training_step_impl(batch, batch_idx)     # frozen teacher, mixup, student forward + explicit backward (:245-374)
             m.optimizer_step()                               # clip 1.0, AdamW / LARS, generic warmup-cosine schedule
             self._tick_lightning()
@@ -397,6 +461,10 @@ def distillationv3_amd_method_cls() -> type:
         def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
             ck = {"state_dict": dict(checkpoint["state_dict"]), "amd_optimizer_state": checkpoint.get("amd_optimizer_state")}
             RefDV3.on_load_checkpoint(self, checkpoint)                            # re-adds the teacher's keys for Lightning's strict load
+            if "optimizer_states" in checkpoint:                                   # see DINOv2AMD.on_load_checkpoint
+                checkpoint["optimizer_states"] = [self.configure_optimizers().state_dict()]
+            if "lr_schedulers" in checkpoint:
+                checkpoint["lr_schedulers"] = []
             if self._impl is not None:
                 self._impl.load_state_dict(ck["state_dict"], strict=False)
                 if ck["amd_optimizer_state"] is not None:
@@ -440,10 +508,12 @@ def distillation12_amd_method_cls(kind: str) -> type:
 
     class DistillationAMD(Ref):   # type: ignore[misc, valid-type]
         def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
-                     device: Optional[torch.device] = None) -> None:
+                     device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
             super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
                              global_batch_size=global_batch_size, num_input_channels=num_input_channels)
             self.automatic_optimization = False
+            self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+            self._micro = 0
             self._impl: Optional[Any] = None
             self._impl_device = device
             self._pending_resume: Optional[Dict[str, Any]] = None
@@ -452,6 +522,7 @@ def distillation12_amd_method_cls(kind: str) -> type:
             if self._impl is None:
                 dev = self._impl_device or next(self.parameters()).device
                 a, oa = self.method_args, self.optimizer_args
+                check_precision(self)
                 kw: Dict[str, Any] = dict(lr_scale_method=a.lr_scale_method, reference_batch_size=int(a.reference_batch_size))
                 if kind == "v1":
                     kw.update(queue_size=int(a.queue_size), temperature=float(a.temperature))
@@ -496,9 +567,7 @@ def distillation12_amd_method_cls(kind: str) -> type:
             return self._impl
 
         def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
-            m = self.impl()
-            if int(self.trainer.global_step) > m.trainer.global_step:
-                m.trainer.global_step = int(self.trainer.global_step)
+            m, _ = begin_micro_batch(self, batch_idx)
             res = m.training_step_impl(batch, batch_idx)
             m.optimizer_step()
             self._tick_lightning()
@@ -523,6 +592,10 @@ def distillation12_amd_method_cls(kind: str) -> type:
         def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
             ck = {"state_dict": dict(checkpoint["state_dict"]), "amd_optimizer_state": checkpoint.get("amd_optimizer_state")}
             Ref.on_load_checkpoint(self, checkpoint)
+            if "optimizer_states" in checkpoint:
+                checkpoint["optimizer_states"] = [self.configure_optimizers().state_dict()]
+            if "lr_schedulers" in checkpoint:
+                checkpoint["lr_schedulers"] = []
             if self._impl is not None:
                 self._impl.load_state_dict(ck["state_dict"], strict=False)
                 if ck["amd_optimizer_state"] is not None:
@@ -567,4 +640,29 @@ def install_as(name: str = "dinov2") -> type:
         return m
 
     method_helpers._method_name_to_cls = patched
+    _wrap_get_trainer()
     return cls
+
+
+def _wrap_get_trainer() -> None:
+    """`lightly_train.train(gradient_accumulation_steps=k)` reaches Lightning as Trainer(accumulate_grad_batches=k)
+    (LT/_commands/train_helpers.py:208-247), which Lightning rejects for a manual-optimization module.  Build the Trainer with 1 and let it
+    carry k as `lt_amd_accumulate_grad_batches`: the binding accumulates in its flat gradient buffer (`begin_micro_batch`)."""
+    from lightly_train._commands import train_helpers
+
+    if getattr(train_helpers.get_trainer, "_lt_amd_wrapped", False):
+        return
+    orig = train_helpers.get_trainer
+
+    def get_trainer(*args: Any, **kwargs: Any) -> Any:
+        import inspect
+
+        bound = inspect.signature(orig).bind(*args, **kwargs)
+        k = int(bound.arguments.get("gradient_accumulation_steps", 1) or 1)
+        bound.arguments["gradient_accumulation_steps"] = 1
+        trainer = orig(*bound.args, **bound.kwargs)
+        trainer.lt_amd_accumulate_grad_batches = k
+        return trainer
+
+    get_trainer._lt_amd_wrapped = True   # type: ignore[attr-defined]
+    train_helpers.get_trainer = get_trainer

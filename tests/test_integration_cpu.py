@@ -104,7 +104,7 @@ def test_dinov2_amd_is_a_registered_reference_method():
     assert issubclass(cls, Method) and isinstance(amd, Method)
     assert method_helpers.get_method_cls(amd) is cls
     assert cls.method_args_cls() is DINOv2Args and cls.transform_cls().__name__ == "DINOv2ViTTransform"
-    assert amd.automatic_optimization is False
+    assert amd.automatic_optimization is False      # manual optimization: Lightning's DDP strategy leaves the wrapper's reducer off
     orig = method_helpers._method_name_to_cls
     try:
         integration.install_as("dinov2")
@@ -219,6 +219,12 @@ def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
         # --- resume: a fresh object loads the file, its third step equals the original's third step
         _, amd2, _ = build_pair(0.0, total_steps=4)
         amd2.on_load_checkpoint(loaded)
+        # what Lightning does next with the SAME dict (checkpoint_connector.restore_optimizers -> strategy.load_optimizer_state_dict):
+        # the optimizer `configure_optimizers` returned takes checkpoint["optimizer_states"][0] -- the hook above has swapped the
+        # reference-format AdamW state (many parameter groups, consumed by the engine) for that optimizer's own
+        amd2.configure_optimizers().load_state_dict(loaded["optimizer_states"][0])
+        assert loaded["lr_schedulers"] == []
+        assert amd2._pending_resume is not None and len(amd2._pending_resume["optimizer_states"][0]["param_groups"]) > 1
         exactify(amd2.impl())
         amd2.impl()._refresh_derived()
         v = views_for(2)
@@ -234,6 +240,92 @@ def test_checkpoint_envelope_is_read_and_exported_by_the_reference(tmp_path):
         s1, s2 = amd.state_dict(), amd2.state_dict()
         for k in s1:
             assert torch.allclose(s1[k].float(), s2[k].float(), atol=1e-7), k
+
+
+def test_gradient_accumulation_equals_the_reference_under_accumulate_grad_batches():
+    """`gradient_accumulation_steps = 2` (LT/_commands/train_helpers.py:224-236 -> Trainer(accumulate_grad_batches=2)): the reference class
+    driven the way Lightning's automatic optimization drives it -- per micro-batch training_step, (loss / 2).backward(), the optimizer hooks
+    and step on every second batch, `on_train_batch_end` (the EMA) after EVERY micro-batch -- against the binding accumulating two
+    micro-batches of 8 in its flat gradient buffer: loss terms of all four micro-batches, and every student / EMA-teacher tensor after
+    the two optimizer steps."""
+    from lightly_train_amd import integration
+
+    H.install()
+    k, opt_steps = 2, 2
+    kw = dict(arch="_vit_test", patch_size=14, img_size=224, global_batch_size=16, seed=0, method_kwargs=dict(koleo_loss_weight=0.0))
+    ref = H.build_reference_method(total_steps=opt_steps, **kw)
+    cls = integration.dinov2_amd_method_cls()
+    amd = H.build_reference_method(method_cls=cls, method_cls_kwargs=dict(device=torch.device("cpu"), gradient_accumulation_steps=k),
+                                   total_steps=opt_steps * k, **kw)   # a Trainer built with accumulate_grad_batches = 1 counts batches
+    runner = H.ReferenceRunner(ref)
+    with ops_emu.emulate(ops):
+        assert integration.total_optimizer_steps(amd) == opt_steps
+        exactify(amd.impl())
+        assert amd.impl().trainer.estimated_stepping_batches == opt_steps
+        for mb in range(opt_steps * k):
+            v = views_for(mb, b=8)
+            batch = {"views": [x.clone() for x in v], "filename": []}
+            random.seed(170 + mb); torch.manual_seed(170 + mb)
+            res = ref.training_step_impl(batch, mb)
+            (res.loss / k).backward()
+            if (mb + 1) % k == 0:
+                ref.on_before_optimizer_step(runner.optim)
+                torch.nn.utils.clip_grad_norm_([p for g in runner.optim.param_groups for p in g["params"]], ref.method_args.gradient_clip_val)
+                runner.optim.step()
+                runner.optim.zero_grad(set_to_none=True)
+                runner.sched.step()
+                ref.trainer.global_step += 1
+            try:
+                ref.on_train_batch_end(None, batch, mb)
+            except Exception:
+                pass
+            want = {kk.split("/")[-1]: float(vv) for kk, vv in res.log_dict.items()}
+            random.seed(170 + mb); torch.manual_seed(170 + mb)
+            got_res = amd.training_step_impl({"views": v, "filename": []}, mb)
+            if (mb + 1) % k == 0:
+                amd.trainer.global_step += 1          # (Lightning: the progress-counter optimizer stepped)
+            got = {kk.split("/")[-1]: float(vv) for kk, vv in got_res.log_dict.items()}
+            for name in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+                assert got[name] == pytest.approx(want[name], rel=3e-5, abs=3e-5), (mb, name)
+            assert float(got_res.loss) == pytest.approx(float(res.loss), rel=3e-5), mb
+        assert amd.impl().opt_step == opt_steps and amd.impl().trainer.global_step == opt_steps
+        sd, rsd = amd.state_dict(), ref.state_dict()
+        for name in rsd:
+            assert torch.allclose(sd[name].float(), rsd[name].float(), atol=3e-5), (name, (sd[name].float() - rsd[name].float()).abs().max().item())
+
+
+def test_unsupported_precision_and_accumulation_raise():
+    from lightly_train_amd import integration
+
+    H.install()
+    kw = dict(arch="_vit_test", patch_size=14, img_size=224, global_batch_size=16, total_steps=2, seed=0)
+    amd = H.build_reference_method(method_cls=integration.dinov2_amd_method_cls(), method_cls_kwargs=dict(device=torch.device("cpu")), **kw)
+    amd.trainer.precision = "32-true"
+    with pytest.raises(ValueError, match="bf16-mixed"):
+        amd.impl()
+    amd.trainer.precision = "bf16-mixed"
+    with ops_emu.emulate(ops):
+        assert amd.impl() is not None
+    d = _build_dino(integration.dino_amd_method_cls())
+    d.gradient_accumulation_steps = 2
+    with ops_emu.emulate(ops), pytest.raises(NotImplementedError, match="accumulation"):
+        d.training_step_impl({"views": [torch.zeros(8, 3, 96, 96)] * 2, "filename": []}, 0)
+
+
+def test_dino_binding_converts_the_deprecated_epoch_arguments():
+    """`warmup_teacher_temp_epochs` / `student_freeze_last_layer_epochs` (resolve_auto leaves the *_steps fields at None): converted with the
+    trainer's steps per epoch as dino.py:301-312 / :450-468 do, not replaced by the step defaults."""
+    from lightly_train_amd import integration
+
+    d = _build_dino(integration.dino_amd_method_cls())
+    a = d.method_args
+    a.warmup_teacher_temp_steps, a.warmup_teacher_temp_epochs = None, 3
+    a.student_freeze_last_layer_steps, a.student_freeze_last_layer_epochs = None, 1
+    d.trainer.max_epochs, d.trainer.estimated_stepping_batches = 4, 20         # 5 steps per epoch
+    with ops_emu.emulate(ops):
+        ia = d.impl().method_args
+    assert ia.student_freeze_last_layer_steps == 5
+    assert ia.warmup_teacher_temp_steps == min(15, int(20 * a.warmup_teacher_temp_max_steps_fraction))
 
 
 def _build_dino(cls, seed=0, backbone="vit"):
