@@ -261,7 +261,48 @@ __device__ __forceinline__ void fwd_tile(const char* ldsK, const char* ldsV, int
   }
 }
 
-__global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// The same tile step with the softmax in base 2 on the RAW scores: the scale rides the exponent's FMA (exp2(s * c - m * c), c = scale *
+// log2 e: one v_fma + one v_exp per element where fwd_tile spends a scale multiply, a subtraction and __expf's own multiply), and only a
+// tile that reaches past the last key pays the compare + select per element.  `m` is the running maximum of the raw scores; the
+// kernels turn it into the natural-log lse at the end (m * scale + ln(lsum)).  The forward kernels are VALU-bound (7 key tiles x 16
+// elements per lane against 8 MFMAs per tile): this is ~30 % fewer VALU slots per tile.
+__device__ __forceinline__ void fwd_tile2(const char* ldsK, const char* ldsV, int tt, int key0, int N, float c, const bf16x8 (&qf)[4],
+                                          float& m, float& lsum, f32x16 (&o)[2], int hi) {
+  f32x16 s;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, tt, ks), qf[ks], s, 0, 0, 0);
+  if (key0 + 32 > N) {   // wave-uniform: only the tile that reaches past the last key masks its elements
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = (key0 + crow(e, hi) < N) ? s[e] : -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mnew = fmaxf(m, mx);                       // finite: every tile holds at least one valid key
+  const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);   // m = -inf on the first tile: exp2(-inf) = 0
+  const float mc = mnew * c;
+  float rs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c, -mc)); rs += s[e]; }
+  rs += __shfl_xor(rs, 32, 64);
+  lsum = lsum * alpha + rs;
+  m = mnew;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+  const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, tt * 32), p0, o[db], 0, 0, 0);
+    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsV, db, tt * 32 + 16), p1, o[db], 0, 0, 0);
+  }
+}
+constexpr float LOG2E_F = 1.4426950408889634f;
+
+template <bool B2>
+__global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsK = smem;
@@ -292,7 +333,11 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16_t* __restrict
     if (more) chunk_load8(kr, vr, kb, vb, ts, c0 + CH, N);   // in flight while this chunk is computed
     if (active) {
       const int ntile = min(4, (N - c0 + 31) / 32);
-      for (int t = 0; t < ntile; ++t) fwd_tile(ldsK, ldsV, t, c0 + t * 32, N, scale, qf, m, lsum, o, hi);
+      for (int t = 0; t < ntile; ++t) {
+        const int key0 = c0 + t * 32;
+        if (!B2) fwd_tile(ldsK, ldsV, t, key0, N, scale, qf, m, lsum, o, hi);
+        else fwd_tile2(ldsK, ldsV, t, key0, N, scale * LOG2E_F, qf, m, lsum, o, hi);
+      }
     }
     if (more) {
       __syncthreads();
@@ -302,12 +347,13 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16_t* __restrict
   }
   if (!active) return;
   const int q = q0 + (l & 31);
-  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
+  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = (B2 ? m * scale : m) + __logf(lsum);
   store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
 }
 
 // ---- forward, short sequences (N <= 64: local crops): two heads per 4-wave block, wave -> (head, query tile); the K / V
 // images hold [head][64 tokens], staged once, no chunk loop.
+template <bool B2>
 __global__ __launch_bounds__(256) void attn_fwd2h_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,9 +395,12 @@ __global__ __launch_bounds__(256) void attn_fwd2h_kernel(const bf16_t* __restric
   __syncthreads();
   if (!active) return;
   const int ntile = (N + 31) / 32;   // 1 or 2
-  for (int t = 0; t < ntile; ++t) fwd_tile(ldsK, ldsV, hh * 2 + t, t * 32, N, scale, qf, m, lsum, o, hi);
+  for (int t = 0; t < ntile; ++t) {
+    if (!B2) fwd_tile(ldsK, ldsV, hh * 2 + t, t * 32, N, scale, qf, m, lsum, o, hi);
+    else fwd_tile2(ldsK, ldsV, hh * 2 + t, t * 32, N, scale * LOG2E_F, qf, m, lsum, o, hi);
+  }
   const int q = q0 + (l & 31);
-  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = m + __logf(lsum);
+  if (hi == 0 && q < N && lse) lse[((long)b * H + h) * N + q] = (B2 ? m * scale : m) + __logf(lsum);
   store_qd_tile(scratch, o, 1.f / lsum, out + (long)b * N * H * DH + h * DH, (long)H * DH, q0, N);
 }
 
@@ -1109,19 +1158,28 @@ extern "C" int lt_attention_fwd(const void* qkv, void* out_bf16, float* lse, int
   if (dh == DH) {
     LT_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out_bf16 & 15) == 0, "lt_attention_fwd: 16-byte alignment required");
     static const int variant = [] { const char* e = getenv("LT_ATTN_FWD"); return e ? atoi(e) : 1; }();
+    // LT_ATTN_FWD_B2 (read per call: tools/ab_step.py, tools/attn_bench.py): 1 = the base-2 tile step without per-element masking on full
+    // key tiles (fwd_tile2), 0 = the natural-exponent tile step
+    const char* env_b2 = getenv("LT_ATTN_FWD_B2");
+    const bool b2 = env_b2 ? atoi(env_b2) != 0 : true;
     if (variant && N <= 64 && H % 2 == 0) {          // two heads per block
-      hipLaunchKernelGGL(attn_fwd2h_kernel, dim3(B * (H / 2)), dim3(256), 2 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
-                         (bf16_t*)out_bf16, lse, N, H, scale);
+      if (b2) hipLaunchKernelGGL(attn_fwd2h_kernel<true>, dim3(B * (H / 2)), dim3(256), 2 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
+                                 (bf16_t*)out_bf16, lse, N, H, scale);
+      else hipLaunchKernelGGL(attn_fwd2h_kernel<false>, dim3(B * (H / 2)), dim3(256), 2 * IMG + 4 * 32 * 144, ST, (const bf16_t*)qkv,
+                              (bf16_t*)out_bf16, lse, N, H, scale);
     } else if (variant && N > 128) {                 // eight query tiles per block, K/V chunks prefetched through registers
       static bool configured = false;
       const size_t smem8 = 2 * IMG + 8 * 32 * 144;
       if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
         if (e != hipSuccess) { lt_set_error("lt_attention_fwd: cannot enable %zu B of LDS: %s", smem8, hipGetErrorString(e)); return LT_ERR_HIP; }
         configured = true;
       }
-      hipLaunchKernelGGL(attn_fwd8_kernel, dim3(lt_cdiv(N, 256), B * H), dim3(512), smem8, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse,
-                         N, H, scale);
+      if (b2) hipLaunchKernelGGL(attn_fwd8_kernel<true>, dim3(lt_cdiv(N, 256), B * H), dim3(512), smem8, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse,
+                                 N, H, scale);
+      else hipLaunchKernelGGL(attn_fwd8_kernel<false>, dim3(lt_cdiv(N, 256), B * H), dim3(512), smem8, ST, (const bf16_t*)qkv, (bf16_t*)out_bf16, lse,
+                              N, H, scale);
     } else {
       dim3 grid(lt_cdiv(N, 128), B * H);
       const size_t smem = 2 * IMG + 4 * 32 * 144;

@@ -1309,10 +1309,14 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
       const int kt = d->K / BK;
       const size_t mn = (size_t)d->M * d->N;
       const int cap = d->workspace ? (int)std::min<size_t>(64, d->workspace_bytes / (mn * sizeof(float))) : 4;
+      // LT_GEMM_WGRAD_SLICES (read per call; tools/ab_step.py): cap on the slice count.  Fewer, longer slices leave CUs to the other
+      // streams' kernels and halve the fp32 slab traffic (S slabs written + read per weight gradient) at the cost of a longer launch
+      const char* env_ms = getenv("LT_GEMM_WGRAD_SLICES");
+      const int max_sl = env_ms ? std::max(1, atoi(env_ms)) : 64;
       double best = 0.0;
       for (int cand_bn : {256, 128}) {
         if (cand_bn == 256 && d->N < 256) continue;
-        for (int c = 1; c <= cap && kt / c >= 8; ++c) {
+        for (int c = 1; c <= cap && c <= max_sl && kt / c >= 8; ++c) {
           const double e2 = eff(cand_bn, c) * (cand_bn == 256 ? 1.0 : 0.9);
           if (e2 > best + 0.04) { best = e2; sp = c; bn = cand_bn; }
         }

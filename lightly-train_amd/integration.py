@@ -123,6 +123,117 @@ def _strip(sd: Mapping[str, Tensor], prefix: str, backbone: bool = False) -> Dic
     return {(vit_key_to_flat(k[len(prefix):]) if backbone else k[len(prefix):]): v.detach().clone() for k, v in sd.items() if k.startswith(prefix)}
 
 
+class DINOv2BindingMixin:
+    """Everything of `DINOv2AMD` that does not need the reference package: the HIP engine built from the containers' weights on first use,
+    the training-step hook (accumulation window, optimizer step, EMA), the flat-storage -> container sync and the checkpoint hooks.  The
+    host class provides the module containers under the reference's names (`teacher_embedding_model.wrapped_model._model`,
+    `student_head.dino_head`, `dino_loss.center`, ...: in production the reference's own `DINOv2(Method)`), `method_args`,
+    `global_batch_size`, `trainer`, and the attributes `__init__` of `DINOv2AMD` sets.  tests/test_gpu_step.py runs this mixin over the
+    real kernels on a container tree built from a reference-written fixture (the GPU box has no reference package)."""
+
+    _result_cls: Any = None     # the TrainingStepResult class the host's `training_step` expects (the reference's in production)
+
+    def _init_binding(self, device: Optional[torch.device], gradient_accumulation_steps: int) -> None:
+        self.automatic_optimization = False     # the HIP step owns backward, clipping, AdamW and the EMA
+        self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+        self._micro = 0                         # position inside the accumulation window
+        self._impl: Optional[_HipDINOv2] = None
+        self._impl_device = device
+        self._pending_resume: Optional[Dict[str, Any]] = None
+
+    # ---- the HIP step, built on first use (Lightning moves the module to its device only after __init__)
+    def impl(self) -> _HipDINOv2:
+        if self._impl is None:
+            check_precision(self)
+            dev = self._impl_device or next(self.parameters()).device
+            sd = torch.nn.Module.state_dict(self)
+            t_model = self.teacher_embedding_model.wrapped_model.get_model()
+            a = self.method_args
+            cfg = vit_config_from_reference(t_model)
+            bb = "embedding_model.wrapped_model._model."
+            self._impl = _HipDINOv2(
+                cfg, hip_args_from_reference(a), global_batch_size=self.global_batch_size,
+                total_steps=total_optimizer_steps(self), device=dev,
+                backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
+                student_head_state=_strip(sd, "student_head.dino_head."), teacher_head_state=_strip(sd, "teacher_head.dino_head."),
+                student_ibot_head_state=_strip(sd, "student_head.ibot_head.") if a.ibot_separate_head else None,
+                teacher_ibot_head_state=_strip(sd, "teacher_head.ibot_head.") if a.ibot_separate_head else None)
+            self._impl.load_state_dict(sd)   # centers, BatchNorm buffers, chunked-block key names
+            if self._pending_resume is not None:
+                self._impl.load_checkpoint_dict(self._pending_resume)
+                self._pending_resume = None
+        return self._impl
+
+    def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
+        m, boundary = begin_micro_batch(self, batch_idx)
+        res = m.training_step_impl(batch, batch_idx)     # forward + explicit backward in HIP: gradients accumulate in m.student.grad
+        if boundary:
+            m.optimizer_step()                           # WD / lr schedules + freezes, clip 3.0, AdamW; global_step += 1 (dinov2.py:550-639)
+            self._tick_lightning()
+        m.on_train_batch_end()                           # EMA teacher at the engine's step, every micro-batch (dinov2.py:641-660)
+        return self._result_cls(loss=res.loss, log_dict=res.log_dict)
+
+    def _tick_lightning(self) -> None:
+        """Manual optimization: Lightning advances `trainer.global_step` when a LightningOptimizer steps.  `configure_optimizers`
+        returns a no-op SGD over a tensor that is not part of the module, stepped here once per optimizer step, so that max_steps, the
+        checkpoint callback's step counter and `checkpoint["global_step"]` keep their meaning.  Only a module that is not attached to
+        a Lightning Trainer (this repo's CPU tests drive the hooks by hand) has no optimizers to step; any other failure propagates."""
+        strategy = getattr(self.trainer, "strategy", None)
+        if strategy is None:      # no Lightning Trainer behind `self.trainer`: the caller advances its own counter
+            return
+        o = self.optimizers()
+        for one in (o if isinstance(o, (list, tuple)) else [o]):
+            one.step()
+
+    def configure_optimizers(self) -> Any:   # manual optimization: a counter for Lightning's progress tracking only (_tick_lightning)
+        return torch.optim.SGD([torch.zeros((), requires_grad=True)], lr=0.0)
+
+    def configure_gradient_clipping(self, *a: Any, **k: Any) -> None:
+        return None
+
+    def on_before_optimizer_step(self, *a: Any, **k: Any) -> None:
+        return None
+
+    def on_train_batch_end(self, outputs: Any, batch: Any, batch_idx: int) -> None:
+        parent = getattr(super(), "on_train_batch_end", None)     # `Method.on_train_batch_end`: batch timing only -- the EMA has run
+        if parent is not None:
+            parent(outputs=outputs, batch=batch, batch_idx=batch_idx)
+
+    # ---- checkpoints
+    def sync_to_containers(self) -> None:
+        """Flat HIP storage -> the reference module containers (what `state_dict()`, the export commands and the pickled envelope read)."""
+        if self._impl is not None:
+            sd = {k: v.detach().to("cpu") for k, v in self._impl.state_dict().items()}
+            torch.nn.Module.load_state_dict(self, sd, strict=True)
+
+    def state_dict(self, *a: Any, **k: Any) -> Any:
+        self.sync_to_containers()
+        return torch.nn.Module.state_dict(self, *a, **k)
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        self.sync_to_containers()
+        checkpoint["state_dict"] = torch.nn.Module.state_dict(self)
+        if self._impl is not None:
+            ck = self._impl.checkpoint_dict()
+            checkpoint["optimizer_states"] = ck["optimizer_states"]
+            checkpoint["lr_schedulers"] = ck["lr_schedulers"]
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        ck = {k: checkpoint[k] for k in ("state_dict", "optimizer_states", "global_step") if k in checkpoint}
+        if self._impl is not None:
+            self._impl.load_checkpoint_dict(ck)
+        else:
+            self._pending_resume = ck
+        # Lightning restores optimizers AFTER this hook from the same dict (`restore_optimizers`: optimizer.load_state_dict(
+        # checkpoint["optimizer_states"][i])): what it finds must fit the progress-counter SGD of `configure_optimizers`, not the
+        # reference-format AdamW / SGD state (many parameter groups) the engine has just taken -- for checkpoints written here and by
+        # the reference alike.  No scheduler is registered with Lightning (the engine owns the schedule): nothing to restore there.
+        if "optimizer_states" in checkpoint:
+            checkpoint["optimizer_states"] = [self.configure_optimizers().state_dict()]
+        if "lr_schedulers" in checkpoint:
+            checkpoint["lr_schedulers"] = []
+
+
 def dinov2_amd_method_cls() -> type:
     """The `Method` subclass (needs the reference package importable)."""
     global _CLS
@@ -131,7 +242,7 @@ def dinov2_amd_method_cls() -> type:
     from lightly_train._methods.dinov2.dinov2 import DINOv2 as RefDINOv2
     from lightly_train._methods.method import Method, TrainingStepResult
 
-    class DINOv2AMD(RefDINOv2):   # type: ignore[misc, valid-type]
+    class DINOv2AMD(DINOv2BindingMixin, RefDINOv2):   # type: ignore[misc, valid-type]
         """`method="dinov2"` on MI355X.  Subclasses the reference method for its constructor (the module containers, built by the
         reference's own code), its static class hooks (`method_args_cls`, `optimizer_args_cls`, `transform_cls`) and `Method.training_step`
         (logging with sync_dist); everything that computes is replaced."""
@@ -140,103 +251,9 @@ def dinov2_amd_method_cls() -> type:
                      device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
             super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
                              global_batch_size=global_batch_size, num_input_channels=num_input_channels)
-            self.automatic_optimization = False     # the HIP step owns backward, clipping, AdamW and the EMA
-            self.gradient_accumulation_steps = int(gradient_accumulation_steps)
-            self._micro = 0                         # position inside the accumulation window
-            self._impl: Optional[_HipDINOv2] = None
-            self._impl_device = device
-            self._pending_resume: Optional[Dict[str, Any]] = None
+            self._init_binding(device, gradient_accumulation_steps)
 
-        # ---- the HIP step, built on first use (Lightning moves the module to its device only after __init__)
-        def impl(self) -> _HipDINOv2:
-            if self._impl is None:
-                check_precision(self)
-                dev = self._impl_device or next(self.parameters()).device
-                sd = Method.state_dict(self)
-                t_model = self.teacher_embedding_model.wrapped_model.get_model()
-                a = self.method_args
-                cfg = vit_config_from_reference(t_model)
-                bb = "embedding_model.wrapped_model._model."
-                self._impl = _HipDINOv2(
-                    cfg, hip_args_from_reference(a), global_batch_size=self.global_batch_size,
-                    total_steps=total_optimizer_steps(self), device=dev,
-                    backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
-                    student_head_state=_strip(sd, "student_head.dino_head."), teacher_head_state=_strip(sd, "teacher_head.dino_head."),
-                    student_ibot_head_state=_strip(sd, "student_head.ibot_head.") if a.ibot_separate_head else None,
-                    teacher_ibot_head_state=_strip(sd, "teacher_head.ibot_head.") if a.ibot_separate_head else None)
-                self._impl.load_state_dict(sd)   # centers, BatchNorm buffers, chunked-block key names
-                if self._pending_resume is not None:
-                    self._impl.load_checkpoint_dict(self._pending_resume)
-                    self._pending_resume = None
-            return self._impl
-
-        def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
-            m, boundary = begin_micro_batch(self, batch_idx)
-            res = m.training_step_impl(batch, batch_idx)     # forward + explicit backward in HIP: gradients accumulate in m.student.grad
-            if boundary:
-                m.optimizer_step()                           # WD / lr schedules + freezes, clip 3.0, AdamW; global_step += 1 (dinov2.py:550-639)
-                self._tick_lightning()
-            m.on_train_batch_end()                           # EMA teacher at the engine's step, every micro-batch (dinov2.py:641-660)
-            return TrainingStepResult(loss=res.loss, log_dict=res.log_dict)
-
-        def _tick_lightning(self) -> None:
-            """Manual optimization: Lightning advances `trainer.global_step` when a LightningOptimizer steps.  `configure_optimizers`
-            returns a no-op SGD over a tensor that is not part of the module, stepped here once per optimizer step, so that max_steps, the
-            checkpoint callback's step counter and `checkpoint["global_step"]` keep their meaning.  Only a module that is not attached to
-            a Lightning Trainer (this repo's CPU tests drive the hooks by hand) has no optimizers to step; any other failure propagates."""
-            strategy = getattr(self.trainer, "strategy", None)
-            if strategy is None:      # no Lightning Trainer behind `self.trainer`: the caller advances its own counter
-                return
-            o = self.optimizers()
-            for one in (o if isinstance(o, (list, tuple)) else [o]):
-                one.step()
-
-        def configure_optimizers(self) -> Any:   # manual optimization: a counter for Lightning's progress tracking only (_tick_lightning)
-            return torch.optim.SGD([torch.zeros((), requires_grad=True)], lr=0.0)
-
-        def configure_gradient_clipping(self, *a: Any, **k: Any) -> None:
-            return None
-
-        def on_before_optimizer_step(self, *a: Any, **k: Any) -> None:
-            return None
-
-        def on_train_batch_end(self, outputs: Any, batch: Any, batch_idx: int) -> None:
-            Method.on_train_batch_end(self, outputs=outputs, batch=batch, batch_idx=batch_idx)   # batch timing only: the EMA has run
-
-        # ---- checkpoints
-        def sync_to_containers(self) -> None:
-            """Flat HIP storage -> the reference module containers (what `state_dict()`, the export commands and the pickled envelope read)."""
-            if self._impl is not None:
-                sd = {k: v.detach().to("cpu") for k, v in self._impl.state_dict().items()}
-                Method.load_state_dict(self, sd, strict=True)
-
-        def state_dict(self, *a: Any, **k: Any) -> Any:
-            self.sync_to_containers()
-            return Method.state_dict(self, *a, **k)
-
-        def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
-            self.sync_to_containers()
-            checkpoint["state_dict"] = Method.state_dict(self)
-            if self._impl is not None:
-                ck = self._impl.checkpoint_dict()
-                checkpoint["optimizer_states"] = ck["optimizer_states"]
-                checkpoint["lr_schedulers"] = ck["lr_schedulers"]
-
-        def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
-            ck = {k: checkpoint[k] for k in ("state_dict", "optimizer_states", "global_step") if k in checkpoint}
-            if self._impl is not None:
-                self._impl.load_checkpoint_dict(ck)
-            else:
-                self._pending_resume = ck
-            # Lightning restores optimizers AFTER this hook from the same dict (`restore_optimizers`: optimizer.load_state_dict(
-            # checkpoint["optimizer_states"][i])): what it finds must fit the progress-counter SGD of `configure_optimizers`, not the
-            # reference-format AdamW / SGD state (many parameter groups) the engine has just taken -- for checkpoints written here and by
-            # the reference alike.  No scheduler is registered with Lightning (the engine owns the schedule): nothing to restore there.
-            if "optimizer_states" in checkpoint:
-                checkpoint["optimizer_states"] = [self.configure_optimizers().state_dict()]
-            if "lr_schedulers" in checkpoint:
-                checkpoint["lr_schedulers"] = []
-
+    DINOv2AMD._result_cls = TrainingStepResult
     DINOv2AMD.__qualname__ = "DINOv2AMD"
     _CLS = DINOv2AMD
     return _CLS

@@ -539,7 +539,7 @@ def test_batch128_step_is_the_mean_of_its_four_batch32_parts():
     from lightly_train_amd import ops
     from lightly_train_amd.masking import MaskingGenerator, create_collated_masks
 
-    b, parts = 128, 4
+    b, parts = int(os.environ.get("LT_ADDITIVITY_BATCH", "128")), 4   # (the environment override only serves CPU dry runs of this test's plumbing)
     pb = b // parts
     m, views = _bench_method(b, 505, koleo_loss_weight=0.0)
     a = m.method_args
@@ -575,6 +575,125 @@ def test_batch128_step_is_the_mean_of_its_four_batch32_parts():
     assert nw == pytest.approx(npt, rel=2e-3)
     bad = [(n, rel(g_whole[n], acc[n])) for n in g_whole if not rel(g_whole[n], acc[n]) < 3e-2]
     assert not bad, bad[:8]
+
+
+def _container_tree(sd):
+    """An nn.Module hierarchy whose state_dict() has exactly the keys (and order) of `sd`: the stand-in for the reference's module
+    containers on the GPU box, where the reference package does not exist.  Shared sub-modules (`ibot_head` is `dino_head`) are shared."""
+    root = torch.nn.Module()
+    for key, val in sd.items():
+        *path, leaf = key.split(".")
+        node = root
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, torch.nn.Module())
+            node = node._modules[part]
+        if leaf in ("center",) or "running_" in leaf or leaf == "num_batches_tracked":
+            node.register_buffer(leaf, val.clone())
+        else:
+            node.register_parameter(leaf, torch.nn.Parameter(val.clone()))
+    return root
+
+
+def _binding_host(fx, device, **hip_args):
+    """`DINOv2BindingMixin` on a container tree built from a reference-written fixture: what `DINOv2AMD` is in production, minus the
+    reference's constructor."""
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.dinov2 import DINOv2Args, MockTrainerState
+    from lightly_train_amd.integration import DINOv2BindingMixin
+
+    mk, cfgd, init = fx["method_kwargs"], fx["cfg"], fx["init"]
+    sb, sh, th = init["student_backbone"], init["student_head"], init["teacher_head"]
+    K = mk["output_dim"]
+    sd = {}
+    for role, bb, hd in (("teacher", sb, th), ("student", sb, sh)):   # Method.state_dict() order: teacher model, student model, heads, losses
+        for k, v in bb.items():
+            sd[f"{role}_embedding_model.wrapped_model._model.{k}"] = v
+    for role, hd in (("teacher", th), ("student", sh)):
+        for k, v in hd.items():
+            sd[f"{role}_head.dino_head.{k}"] = v
+    sd["dino_loss.center"] = torch.zeros(1, K)
+    sd["ibot_loss.center"] = torch.zeros(1, 1, K)
+
+    class Host(DINOv2BindingMixin, torch.nn.Module):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            tree = _container_tree(sd)
+            for name, child in tree._modules.items():
+                self.add_module(name, child)
+            for role in ("teacher", "student"):          # the shared head appears under both names (dinov2.py:221-234)
+                head = getattr(self, f"{role}_head")
+                head.add_module("ibot_head", head.dino_head)
+                model = getattr(self, f"{role}_embedding_model").wrapped_model._model
+                D = sb["cls_token"].shape[-1]
+                model.embed_dim, model.n_blocks, model.num_heads, model.patch_size = D, cfgd["depth"], cfgd["num_heads"], cfgd["patch_size"]
+                model.interpolate_offset, model.interpolate_antialias = cfgd.get("interpolate_offset", 0.1), cfgd.get("interpolate_antialias", False)
+                model.num_register_tokens, model.chunked_blocks = cfgd.get("num_register_tokens", 0), False
+                wm = getattr(self, f"{role}_embedding_model").wrapped_model
+                wm.get_model = (lambda mdl=model: mdl)
+            self.method_args = DINOv2Args(output_dim=K, hidden_dim=mk["hidden_dim"], dino_bottleneck_dim=mk["dino_bottleneck_dim"], **hip_args)
+            self.global_batch_size = fx["b"]
+            self.trainer = MockTrainerState(fx["total_steps"])
+            self._init_binding(device, 1)
+
+    from lightly_train_amd.dinov2 import TrainingStepResult
+    Host._result_cls = TrainingStepResult
+    return Host()
+
+
+def test_binding_mixin_runs_over_the_kernels_and_resumes_bitwise():
+    """`integration.DINOv2BindingMixin` -- `impl()`, the training-step hook, `sync_to_containers`, `on_save_checkpoint`,
+    `on_load_checkpoint` -- on real HIP buffers (the CPU tests run it over the kernels' fp32 contracts only): a container tree with the
+    reference's keys built from the reference-written fixture; two hook-driven steps reproduce the fixture's loss terms; the saved
+    checkpoint's state_dict is the flat storage bit for bit under the reference's keys, its optimizer state is the reference-format AdamW
+    state; a fresh host resumed through `on_load_checkpoint` (+ what Lightning then does with the dict) takes a third step that is
+    BITWISE the uninterrupted object's third step (order-fixed reductions: a step is reproducible to the last bit)."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    dev = torch.device("cuda")
+    host = _binding_host(fx, dev)
+    keys = list(torch.nn.Module.state_dict(host))
+    for si, rec in enumerate(fx["steps"]):
+        views = synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+        host.trainer.global_step = si
+        res = host.training_step_impl({"views": views, "filename": [], "masks": rec["masks"]}, si)
+        host.trainer.global_step = si + 1          # (Lightning: the progress-counter optimizer stepped)
+        logs = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+        for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
+            assert logs[k] == pytest.approx(rec["logs"][k], rel=5e-3), (si, k)
+    m = host.impl()
+    assert m.opt_step == 2 and m.trainer.global_step == 2
+    ckpt = {"epoch": 0, "global_step": 2, "state_dict": {}, "optimizer_states": [], "lr_schedulers": []}
+    host.on_save_checkpoint(ckpt)
+    assert list(ckpt["state_dict"]) == keys
+    flat = m.state_dict()
+    for k in keys:
+        assert torch.equal(ckpt["state_dict"][k].cpu(), flat[k].cpu()), k           # containers == flat storage after the sync
+    moved = sum(int(not torch.equal(ckpt["state_dict"]["student_embedding_model.wrapped_model._model." + k].cpu(), v))
+                for k, v in fx["init"]["student_backbone"].items())
+    assert moved > 10                                                                # ... and trained
+    osd = ckpt["optimizer_states"][0]
+    assert set(osd) == {"state", "param_groups"} and len(osd["param_groups"]) > 1 and all(int(s_["step"]) == 2 for s_ in osd["state"].values())
+    ckpt = {k: (v if k != "state_dict" else {kk: vv.clone() for kk, vv in v.items()}) for k, v in ckpt.items()}
+    # ---- resume into a fresh host built from the INITIAL weights
+    host2 = _binding_host(fx, dev)
+    host2.trainer.global_step = 2
+    host2.on_load_checkpoint(ckpt)
+    host2.configure_optimizers().load_state_dict(ckpt["optimizer_states"][0])        # Lightning's restore_optimizers on the same dict
+    assert ckpt["lr_schedulers"] == []
+    views = synth_views(777, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+    masks = fx["steps"][0]["masks"]
+    m._pending.clear()     # (the pending batch-center sums are no part of a checkpoint, in the reference either: dinov2_loss.py:139-160)
+    outs = []
+    for h in (host, host2):
+        h.trainer.global_step = 2
+        r = h.training_step_impl({"views": views, "filename": [], "masks": masks}, 2)
+        torch.cuda.synchronize()
+        outs.append((float(r.loss), {k: v.clone() for k, v in h.impl().state_dict().items()}, h.impl().exp_avg.clone()))
+    assert host2.impl().opt_step == 3
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    assert torch.equal(outs[0][2], outs[1][2])
 
 
 @pytest.mark.parametrize("name", ["step_d64_softmax", "step_d64_reg4_swiglu14", "step_vittest_sephead"])

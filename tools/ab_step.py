@@ -53,6 +53,7 @@ for i in range(a.steps * len(a.values)):
     m.train_step(views)
     torch.cuda.synchronize()
     t[v].append((time.perf_counter() - t0) * 1e3)
+print("per-step ms in launch order:", " ".join(f"{a.values[i % len(a.values)]}:{t[a.values[i % len(a.values)]][i // len(a.values)]:.1f}" for i in range(a.steps * len(a.values))))
 for v in a.values:
     x = sorted(t[v])
     print(f"{a.name}={v}: median {statistics.median(x):.2f} ms  mean {statistics.fmean(x):.2f}  min {x[0]:.2f}  max {x[-1]:.2f}  (n={len(x)})")
