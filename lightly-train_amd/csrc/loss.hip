@@ -342,9 +342,12 @@ __global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __rest
   const TRow r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
   const bool two = tb && tb[row] >= 0;
   const TRow r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
+  // The student row stays in registers, so its softmax takes ONE exponential per element: row maximum first (64 v_max per thread + one
+  // block reduction), then e = exp(u - max) overwrites u -- its sum gives the log-sum-exp, and e / sum is the probability the gradient
+  // needs.  (An online max / sum-exp pushes nearly every element through both of its branches, an exponential each, and the gradient
+  // pass then pays a third.)
   float4 v[ROW_NV];
-  MaxSum a; a.m = -INFINITY; a.s = 0.f;
-  float dot = 0.f, tsum = 0.f;
+  float mx = -INFINITY, dot = 0.f, tsum = 0.f;
 #pragma unroll
   for (int i = 0; i < ROW_NV; ++i) {
     const int k = (i * 1024 + threadIdx.x) * 4;
@@ -354,29 +357,41 @@ __global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __rest
       v[i] = u;
       float4 t = tprob4(r0, k, inv_temp_t);
       if (two) { const float4 t2 = tprob4(r1, k, inv_temp_t); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
-      ms_push(a, u.x); ms_push(a, u.y); ms_push(a, u.z); ms_push(a, u.w);
+      mx = fmaxf(mx, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
       dot += t.x * u.x + t.y * u.y + t.z * u.z + t.w * u.w;
       tsum += t.x + t.y + t.z + t.w;
     }
   }
-  a = block_ms(a, red);
+  mx = block_max(mx, red);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int k = (i * 1024 + threadIdx.x) * 4;
+    if (k < K) {
+      float4 e = v[i];
+      e.x = __expf(e.x - mx); e.y = __expf(e.y - mx); e.z = __expf(e.z - mx); e.w = __expf(e.w - mx);
+      v[i] = e;
+      se += (e.x + e.y) + (e.z + e.w);
+    }
+  }
+  se = block_sum(se, red);
   dot = block_sum(dot, red);
   tsum = block_sum(tsum, red);
-  const float lse = a.m + __logf(a.s);
+  const float lse = mx + __logf(se);
   const float coef = scale * (row_weight ? row_weight[row] : 1.f);
   if (threadIdx.x == 0) terms[row] = -coef * (dot - lse * tsum);
   if (dlogits) {
     const float c2 = coef * inv_temp;
+    const float pn = tsum / se;             // softmax(u) * sum(t) = e * (sum(t) / sum(e))
 #pragma unroll
     for (int i = 0; i < ROW_NV; ++i) {
       const int k = (i * 1024 + threadIdx.x) * 4;
       if (k < K) {
         float4 t = tprob4(r0, k, inv_temp_t);   // second read of the teacher row(s): L2 / Infinity Cache
         if (two) { const float4 t2 = tprob4(r1, k, inv_temp_t); t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w; }
-        const float4 u = v[i];
+        const float4 e = v[i];
         *reinterpret_cast<uint2*>(dlogits + row * K + k) =
-            make_uint2(pack_bf2(c2 * (__expf(u.x - lse) * tsum - t.x), c2 * (__expf(u.y - lse) * tsum - t.y)),
-                       pack_bf2(c2 * (__expf(u.z - lse) * tsum - t.z), c2 * (__expf(u.w - lse) * tsum - t.w)));
+            make_uint2(pack_bf2(c2 * (e.x * pn - t.x), c2 * (e.y * pn - t.y)), pack_bf2(c2 * (e.z * pn - t.z), c2 * (e.w * pn - t.w)));
       }
     }
   }
