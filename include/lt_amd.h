@@ -286,6 +286,27 @@ int lt_lars_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, 
 int lt_sgd_flat(float* p, const float* g, float* buf, void* p_bf16, int64_t n, const int32_t* seg_of_chunk, const float* seg_lr,
                 const uint8_t* seg_wd_on, float lr_factor, float wd, float momentum, float dampening, int nesterov, int first_step,
                 const float* sumsq, float max_norm, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * PaKA pieces of the DINOv31 method (LT/_methods/dinov31/dinov31.py:258-437; the loss itself and the RoI resampling are LightlySSL
+ * code the reference tree does not vendor: oracle/dinov31_oracle.py restates them, parity unpinned)
+ * ------------------------------------------------------------------------------------------ */
+/* RoI resampling of token maps with per-image 4-tap bilinear tables (dinov31.py:338-437 `_align_cross_view_pair` / `_roi_align_view`; the
+ * tables come from the crop geometry on the host, flips folded into the indices): out[(b * n_out + j), :] = sum_a w[b, j, a] *
+ * in[src_image[b] * img_stride + idx[b, j, a] * D + :].  `in` = first patch token of image 0, images img_stride floats apart;
+ * src_image NULL = identity; out_bf16 and / or out_f32 [B * n_out, D]. */
+int lt_roi_resample_tokens(const float* in, const int32_t* src_image, const int32_t* idx, const float* w, void* out_bf16, float* out_f32,
+                           int B, int64_t img_stride, int n_out, int D, void* stream);
+/* its backward in gather form (no atomics): din[b * img_stride + i * D + :] = sum_{(j, a): idx[b, j, a] == i} w[b, j, a] * dout[b, j, :]
+ * for every input cell i < n_in (overwrites those rows). */
+int lt_roi_resample_tokens_bwd(const float* dout, const int32_t* idx, const float* w, float* din, int B, int64_t img_stride, int n_in,
+                               int n_out, int D, void* stream);
+/* out[b, j, :] = z[b, j, :] - mean_j z[b, :, :] (centring the token kernel K = Z Z^T is centring Z over the image's n tokens) */
+int lt_center_tokens(const float* z, void* out_bf16, float* out_f32, int B, int n, int C, void* stream);
+/* per image b: cka = <Ks, Kt> / (||Ks|| ||Kt|| + eps) over the n x n centred Gram matrices (rows ld floats apart);
+ * loss[0] += sum_b coef[b] * (1 - cka_b) in image order;  G(bf16)[b] = d(coef[b] * (1 - cka_b)) / dKs[b], pad columns zero */
+int lt_cka_fwd_bwd(const float* Ks, const float* Kt, const float* coef, float* loss, void* G_bf16, int B, int n, int ld, float eps,
+                   void* stream);
+
 /* Order-fixed reductions (bitwise reproducible steps).  Between lt_reduce_begin and lt_reduce_end the kernels that end in a sum over
  * workgroups -- lt_layernorm_bwd(_fused) (dw, db, dbias_next), lt_layerscale_bwd (dgamma, dbias), lt_colsum_bf16, lt_assemble_tokens_bwd
  * (mask-token gradient) -- store per-workgroup partial rows into `scratch` instead of issuing fp32 atomics; their destinations are

@@ -110,6 +110,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_aug_crop_resize": [vp, vp, vp, i32, i32, vp],
     "lt_aug_color": [vp, vp, i32, i32, vp],
     "lt_aug_finish": [vp, vp, vp, i32, i32, vp, vp, vp],
+    "lt_roi_resample_tokens": [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp],
+    "lt_roi_resample_tokens_bwd": [vp, vp, vp, vp, i32, i64, i32, i32, i32, vp],
+    "lt_center_tokens": [vp, vp, vp, i32, i32, i32, vp],
+    "lt_cka_fwd_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "lt_sample_block_masks": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_double, C.c_double, vp],
 }
 

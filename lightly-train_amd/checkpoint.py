@@ -59,6 +59,9 @@ def method_key_to_flat(key: str, separate_ibot: bool) -> Optional[Tuple[str, str
         pre = f"{role}_head.ibot_head."
         if key.startswith(pre):
             return (role, "ihead." + key[len(pre):]) if separate_ibot else None
+        pre = f"{role}_paka_head."            # DINOv31 (LT/_methods/dinov31/dinov31.py:126-146)
+        if key.startswith(pre):
+            return role, "paka." + key[len(pre):]
     return None
 
 
@@ -93,6 +96,10 @@ def method_state_dict(student: FlatParams, teacher: FlatParams, centers: Mapping
                 emit(role, fp, n, src, "ibot_head")
     for k, v in centers.items():
         out[k] = v.detach().clone()
+    for role, fp in (("student", student), ("teacher", teacher)):       # DINOv31's PaKA heads: registered last, student first
+        for n in fp.names:
+            if n.startswith("paka."):
+                out[f"{role}_paka_head.{n[5:]}"] = fp.p[n].detach().clone()
     return out
 
 

@@ -382,6 +382,9 @@ class DINOv2:
             tis = teacher_ibot_head_state if teacher_ibot_head_state is not None else init_head_state(D, a.hidden_dim, a.dino_bottleneck_dim, a.output_dim, g, bn)
             s_named += [("ihead." + n, sis[n]) for n in order_h]
             t_named += [("ihead." + n, tis[n]) for n in order_h]
+        ex_s, ex_t = self._extra_params(D, g)      # further trained modules of a subclass (DINOv31: the PaKA heads), same layout on both sides
+        s_named += ex_s
+        t_named += ex_t
         self.student = FlatParams(s_named, self.device, True)
         self.teacher = FlatParams(t_named, self.device, False)
         if self.world > 1:
@@ -423,7 +426,12 @@ class DINOv2:
         self.param_groups: List[Dict[str, Any]] = []
         for n in self.student.names:
             is_bb = n.startswith("backbone.")
-            ref_name = n[len("backbone."):] if is_bb else ("ibot_head." + n[len("ihead."):] if n.startswith("ihead.") else "dino_head." + n[len("head."):])
+            if is_bb:
+                ref_name = n[len("backbone."):]
+            elif n.startswith(("head.", "ihead.")):
+                ref_name = "ibot_head." + n[len("ihead."):] if n.startswith("ihead.") else "dino_head." + n[len("head."):]
+            else:   # a subclass's extra module: named_parameters() of the bare module (get_optimizer_with_decay walks trainable modules)
+                ref_name = n.split(".", 1)[1]
             self.param_groups.append(param_group_hparams(ref_name, is_bb, vit_cfg.depth, self.base_lr, a))
         dev = self.device
         self.seg_lr = torch.tensor([g_["lr"] for g_ in self.param_groups], dtype=torch.float32, device=dev)
@@ -478,6 +486,10 @@ class DINOv2:
         self.teacher_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # teacher forward
         self.local_bwd_stream = torch.cuda.Stream(device=self.device) if use_streams else None  # local-crop dgrad chain
         self.reduce_stream = torch.cuda.Stream(device=self.device) if use_streams else None    # orders the early all-reduces
+
+    def _extra_params(self, D: int, g: torch.Generator) -> Tuple[List[Tuple[str, Tensor]], List[Tuple[str, Tensor]]]:
+        """(student, teacher) lists of further named parameters behind the heads (none for DINOv2)."""
+        return [], []
 
     # ------------------------------------------------------------------ reference-compatible views
     def close(self) -> None:
@@ -721,11 +733,11 @@ class DINOv2:
             gen = MaskingGenerator(input_size=(gh, gw), max_num_patches=int(0.5 * gh * gw))
             masks = create_collated_masks(a.mask_ratio_min, a.mask_ratio_max, int(n_crops * a.mask_probability), n_crops, gen)
         cm = masks["collated_masks"]
-        mask_u8 = cm.to(torch.uint8).to(dev, non_blocking=True)
+        mask_u8 = ops.h2d(cm.to(torch.uint8), dev)
         midx = masks["mask_indices_list"].to(torch.int64)
         M = int(midx.shape[0])
         mw = masks["masks_weight"].to(torch.float32)
-        patch_rows = ((midx // n_p) * Ng + 1 + n_reg + midx % n_p).to(dev, non_blocking=True)
+        patch_rows = ops.h2d((midx // n_p) * Ng + 1 + n_reg + midx % n_p, dev)
         # a masked crop holds at most int(n_p * ratio_max) patches (MaskingGenerator.__call__ caps the total, utils.py:120-152);
         # the 0.5 of `max_num_patches` only bounds one block.  Buffers are sized for the worst case of this configuration.
         cap_M = int(n_crops * a.mask_probability) * max(int(n_p * max(a.mask_ratio_max, 0.5)), 1)
@@ -859,7 +871,7 @@ class DINOv2:
         if gs != 1.0:
             coef = coef * gs   # loss / k of a k-batch accumulation window: the slots hold scaled terms, the logs below undo it
         slot = torch.cat([torch.zeros(2 * B, dtype=torch.int32), torch.ones(Rl, dtype=torch.int32), torch.full((M,), 2, dtype=torch.int32)])
-        ta, tb, coef, slot = (t.to(dev, non_blocking=True) for t in (ta, tb, coef, slot))
+        ta, tb, coef, slot = (ops.h2d(t, dev) for t in (ta, tb, coef, slot))
         main.wait_event(teacher_done)
         inv_ts = 1.0 / a.student_temp
         def ce(logits: Tensor, ta_: Tensor, tb_: Tensor, coef_: Tensor, out: Tensor, rows: int, slot_: Tensor) -> None:
@@ -996,9 +1008,7 @@ class DINOv2:
         self._sumsq.zero_()
         ops.sumsq(self.student.grad, self._sumsq)
         self.opt_step += 1
-        ops.adamw_flat(self.student.data, self.student.grad, self.exp_avg, self.exp_avg_sq, self.student.bf16, self.student.seg_of_chunk,
-                       self.seg_lr, self.seg_wd_on, self.seg_frozen, freeze, lr_factor, wd, a.betas[0], a.betas[1], a.eps,
-                       self.opt_step, self._sumsq, a.gradient_clip_val)
+        self._adamw(freeze, lr_factor, wd)
         self.s_head.refresh_weightnorm()
         if self.s_ihead is not self.s_head:
             self.s_ihead.refresh_weightnorm()
@@ -1006,6 +1016,17 @@ class DINOv2:
         self.last_grad_norm = self._sumsq  # squared norm, device scalar
         self.trainer.global_step += 1
         return {"weight_decay": wd, "lr_factor": lr_factor}
+
+    def _adamw(self, freeze: int, lr_factor: float, wd: float, lo: int = 0, hi: Optional[int] = None, step: Optional[int] = None) -> None:
+        """The fused clip + AdamW launch over elements [lo, hi) of the flat storage (whole tensors: multiples of the 1024-element chunk) at
+        Adam step `step` (default: everything at `opt_step`).  A subclass whose extra parameters received no gradient in some steps updates
+        them in a launch of their own, at their own step count, as torch.optim.AdamW does per parameter."""
+        a = self.method_args
+        hi = self.student.data.numel() if hi is None else hi
+        assert lo % 1024 == 0 and hi % 1024 == 0
+        ops.adamw_flat(self.student.data[lo:hi], self.student.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.student.bf16[lo:hi],
+                       self.student.seg_of_chunk[lo // 1024:hi // 1024], self.seg_lr, self.seg_wd_on, self.seg_frozen, freeze, lr_factor, wd, a.betas[0],
+                       a.betas[1], a.eps, self.opt_step if step is None else step, self._sumsq, a.gradient_clip_val)
 
     def on_train_batch_end(self) -> float:
         """EMA teacher update with momentum evaluated at the already-incremented global_step (dinov2.py:641-660)."""

@@ -1,0 +1,307 @@
+"""DINOv31 = DINOv2 + PaKA (LT/_methods/dinov31/dinov31.py:108-456): the DINOv2 step unchanged on the leading views, plus a cross-view patch
+kernel alignment term between clean-teacher global crops and high-overlap student local crops, on the HIP kernels.
+
+View layout (dinov31.py:22-31): [global0, global1, dino_local0..L-1, clean_global0, clean_global1, paka_local0..K-1] with one geometry
+tensor [B, 8] = (x0, y0, x1, y1, image_w, image_h, hflip, vflip) per view (`batch["geometries"]`).
+
+What runs where:
+  * DINO / iBOT / KoLeo on views[:2 + L]: `DINOv2.training_step_impl` as is, told not to finish the step (`accum_last = False`: the
+    LayerScale gradients come from the ACCUMULATED weight gradients, and PaKA adds to them);
+  * clean teacher pass (EMA backbone on the two clean globals, no head, :439-449) and student pass on the K PaKA locals (:451-456) through the
+    ViT engine; the student pass keeps its activations and gets its own backward;
+  * parent-only pairing (local k with global k % 2), shared region of the two crops, un-flip, boxes in grid units (:338-437): a few lines of
+    float32 tensor arithmetic on the host, the same formulas; the resulting bilinear sampling becomes per-image 4-tap tables
+    (`roi_tables`) for `lt_roi_resample_tokens` (+ its gather-form backward);
+  * the two 3-layer PaKA heads (embed -> 2048 -> 2048 -> 256, GELU; `_build_mlp`, :126-146) on the MFMA GEMMs with GELU / GELU' epilogues,
+    the student's trained with the rest (same parameter-group rules: `get_optimizer_with_decay` walks it as a bare module), the teacher's
+    EMA-averaged -- both heads live in the flat parameter storages behind the projection heads, so AdamW / EMA / clipping need no change;
+  * the loss: tokens centred over each image's grid (`lt_center_tokens`), per-image Gram matrices as batched GEMMs, `lt_cka_fwd_bwd`
+    (1 - CKA and its gradient with respect to the student Gram matrix), dZ = 2 G Zc as a batched GEMM.
+
+The loss and the RoI sampling are LightlySSL code the reference tree does not contain: restated by the test infrastructure (the checker's dinov31 module) from the call
+sites and the method's docstring -- **parity unpinned** for those two definitions; everything around them is pinned on a fixture written by
+the reference's own `DINOv31` class (tests/golden/dinov31_d64.pt).  Sequences longer than `paka_max_tokens` would need the loss's random
+token subsample: not implemented (the local grids of the recipes are 7 x 7 .. 16 x 16), raises.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .dinov2 import DINOv2, DINOv2Args, TrainingStepResult
+from .vit import ViTConfig, make_drop_plan, padded_rows, split_k_plan, _split_k
+
+PAKA_HIDDEN, PAKA_OUT = 2048, 256
+PAKA_LAYERS = ("0", "2", "4")       # nn.Sequential(Linear, GELU, Linear, GELU, Linear): the indices of the Linear layers
+
+
+@dataclass
+class DINOv31Args(DINOv2Args):
+    paka_weight: float = 1.0
+    paka_start_step: int = 0
+    paka_num_local: int = 8
+    paka_max_tokens: int = 512
+
+
+def init_paka_head_state(in_dim: int, generator: Optional[torch.Generator] = None, hidden: int = PAKA_HIDDEN, out_dim: int = PAKA_OUT) -> Dict[str, Tensor]:
+    """`_build_mlp(nlayers=3, ...)` outside a DINOv2ProjectionHead: plain nn.Linear default initialisation (kaiming-uniform, a = sqrt(5))."""
+    sd: Dict[str, Tensor] = {}
+    for name, (o, i) in zip(PAKA_LAYERS, ((hidden, in_dim), (hidden, hidden), (out_dim, hidden))):
+        bound = 1.0 / math.sqrt(i)
+        sd[name + ".weight"] = torch.empty(o, i).uniform_(-bound, bound, generator=generator)
+        sd[name + ".bias"] = torch.empty(o).uniform_(-bound, bound, generator=generator)
+    return sd
+
+
+def shared_region_boxes(s_geom: Tensor, t_geom: Tensor, s_hw: Tuple[int, int], t_hw: Tuple[int, int], out_hw: Tuple[int, int]):
+    """`_align_cross_view_pair` + the box part of `_roi_align_view` (dinov31.py:338-437), same float32 formulas: the shared region of a
+    student crop and a teacher crop in image pixels, expressed in each crop's own grid units.  Returns (student boxes [B, 4], teacher boxes
+    [B, 4], has_overlap [B])."""
+    oh, ow = out_hw
+    ix0 = torch.maximum(s_geom[:, 0], t_geom[:, 0]); iy0 = torch.maximum(s_geom[:, 1], t_geom[:, 1])
+    ix1 = torch.minimum(s_geom[:, 2], t_geom[:, 2]); iy1 = torch.minimum(s_geom[:, 3], t_geom[:, 3])
+    min_w = (s_geom[:, 2] - s_geom[:, 0]) / max(ow, 1)
+    min_h = (s_geom[:, 3] - s_geom[:, 1]) / max(oh, 1)
+    has = (ix1 - ix0 >= min_w) & (iy1 - iy0 >= min_h)
+    ix0 = torch.where(has, ix0, s_geom[:, 0]); iy0 = torch.where(has, iy0, s_geom[:, 1])
+    ix1 = torch.where(has, ix1, s_geom[:, 2]); iy1 = torch.where(has, iy1, s_geom[:, 3])
+
+    def boxes(geom: Tensor, hw: Tuple[int, int]) -> Tensor:
+        h, w = hw
+        cw = (geom[:, 2] - geom[:, 0]).clamp(min=1e-6)
+        ch = (geom[:, 3] - geom[:, 1]).clamp(min=1e-6)
+        gx0 = ((ix0 - geom[:, 0]) / cw * w).clamp(0.0, float(w)); gx1 = ((ix1 - geom[:, 0]) / cw * w).clamp(0.0, float(w))
+        gy0 = ((iy0 - geom[:, 1]) / ch * h).clamp(0.0, float(h)); gy1 = ((iy1 - geom[:, 1]) / ch * h).clamp(0.0, float(h))
+        return torch.stack([gx0, gy0, gx1, gy1], dim=1)
+
+    return boxes(s_geom, s_hw), boxes(t_geom, t_hw), has
+
+
+def roi_tables(boxes: Tensor, geom: Tensor, hw: Tuple[int, int], out_hw: Tuple[int, int]) -> Tuple[Tensor, Tensor]:
+    """4-tap bilinear tables of `roi_resample_to_grid` on the UN-FLIPPED map (dinov31.py:419-422 flips the map before sampling; here the
+    sampling indices are mirrored instead): idx int32 [B, oh * ow, 4] into the crop's own h x w token grid, weights f32 of the same shape.
+    Sampling rule (parity unpinned, restated by the test infrastructure): every output cell reads the map at the centre of its bin of the box,
+    bilinearly between cell centres, border-clamped."""
+    h, w = hw
+    oh, ow = out_hw
+    B = boxes.shape[0]
+    x0, y0, x1, y1 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    ox = (torch.arange(ow, dtype=boxes.dtype) + 0.5) / ow
+    oy = (torch.arange(oh, dtype=boxes.dtype) + 0.5) / oh
+    sx = (x0[:, None] + ox[None, :] * (x1 - x0)[:, None] - 0.5).clamp(0.0, w - 1.0)
+    sy = (y0[:, None] + oy[None, :] * (y1 - y0)[:, None] - 0.5).clamp(0.0, h - 1.0)
+    xl, yl = sx.floor(), sy.floor()
+    xh, yh = (xl + 1).clamp(max=w - 1.0), (yl + 1).clamp(max=h - 1.0)
+    wx, wy = (sx - xl)[:, None, :], (sy - yl)[:, :, None]
+    hf, vf = (geom[:, 6] > 0.5)[:, None], (geom[:, 7] > 0.5)[:, None]
+    xl, xh = xl.long(), xh.long()
+    yl, yh = yl.long(), yh.long()
+    xl, xh = torch.where(hf, w - 1 - xl, xl), torch.where(hf, w - 1 - xh, xh)       # the flipped map's column x is the stored column w-1-x
+    yl, yh = torch.where(vf, h - 1 - yl, yl), torch.where(vf, h - 1 - yh, yh)
+    xl, xh, yl, yh = xl[:, None, :], xh[:, None, :], yl[:, :, None], yh[:, :, None]
+    idx = torch.stack([yl * w + xl, yl * w + xh, yh * w + xl, yh * w + xh], dim=-1)
+    wts = torch.stack([(1 - wy) * (1 - wx), (1 - wy) * wx, wy * (1 - wx), wy * wx], dim=-1)
+    return idx.reshape(B, oh * ow, 4).to(torch.int32).contiguous(), wts.reshape(B, oh * ow, 4).to(torch.float32).contiguous()
+
+
+class DINOv31(DINOv2):
+    """The method object; state_dict adds `student_paka_head.*` / `teacher_paka_head.*` (dinov31.py:126-146)."""
+
+    supports_accumulation = False
+
+    def __init__(self, vit_cfg: ViTConfig, method_args: Optional[DINOv31Args] = None, *args: Any, paka_head_state: Optional[Mapping[str, Tensor]] = None,
+                 teacher_paka_head_state: Optional[Mapping[str, Tensor]] = None, **kw: Any) -> None:
+        self._paka_init = (paka_head_state, teacher_paka_head_state)
+        super().__init__(vit_cfg, method_args or DINOv31Args(), *args, **kw)
+        self._paka_slot = torch.zeros(1, device=self.device)
+        self._paka_span = self.student.span(("paka.",))     # the PaKA head's parameters: the tail of the flat storage
+        assert self._paka_span[1] == self.student.data.numel()
+        self._paka_had_grad = False      # did this step's backward reach the PaKA head (paka_start_step)?
+        self.paka_opt_steps = 0          # Adam steps the PaKA head has taken (torch.optim.AdamW counts per parameter, and skips parameters
+                                         # without a gradient: no weight decay, no moment update, no step -- dinov31.py:258-270 before paka_start_step)
+
+    def _extra_params(self, D: int, g: torch.Generator):
+        s_sd, t_sd = self._paka_init
+        if s_sd is None:
+            s_sd = init_paka_head_state(D, g)
+        if t_sd is None:
+            t_sd = s_sd                                   # the teacher head starts as a deep copy of the student's (:144-146)
+        order = [f"{l}.{p}" for l in PAKA_LAYERS for p in ("weight", "bias")]
+        return [("paka." + n, s_sd[n]) for n in order], [("paka." + n, t_sd[n]) for n in order]
+
+    def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
+        """A DINOv2 checkpoint (the post-training start, :180-205) legitimately lacks the PaKA heads: they keep their values."""
+        sd = dict(sd)
+        for role, fp in (("student", self.student), ("teacher", self.teacher)):
+            for n in fp.names:
+                if n.startswith("paka."):
+                    sd.setdefault(f"{role}_paka_head.{n[5:]}", fp.p[n].detach().clone())
+        super().load_state_dict(sd, strict=strict)
+
+    def _adamw(self, freeze: int, lr_factor: float, wd: float, lo: int = 0, hi: Optional[int] = None, step: Optional[int] = None) -> None:
+        p0, p1 = self._paka_span
+        super()._adamw(freeze, lr_factor, wd, 0, p0)
+        if self._paka_had_grad:
+            self.paka_opt_steps += 1
+            super()._adamw(freeze, lr_factor, wd, p0, p1, step=self.paka_opt_steps)
+
+    # ------------------------------------------------------------------ the PaKA heads
+    def _head_fwd(self, P: Any, tag: str, x: Tensor, R: int, cap: int, save: bool) -> Dict[str, Any]:
+        ws, D = self.ws, self.cfg.embed_dim
+        l0, l1, l2 = ("paka." + l for l in PAKA_LAYERS)
+        h1 = ws.get(tag + ".h1", (cap, PAKA_HIDDEN), torch.bfloat16, pad_rows=64)
+        h1p = ws.get(tag + ".h1p", (cap, PAKA_HIDDEN), torch.bfloat16) if save else None
+        ops.gemm(x, P.b[l0 + ".weight"], h1, M=R, N=PAKA_HIDDEN, K=D, epilogue=ops.EPI_BF16_GELU, bias=P.p[l0 + ".bias"], out2=h1p)
+        h2 = ws.get(tag + ".h2", (cap, PAKA_HIDDEN), torch.bfloat16, pad_rows=64)
+        h2p = ws.get(tag + ".h2p", (cap, PAKA_HIDDEN), torch.bfloat16) if save else None
+        ops.gemm(h1, P.b[l1 + ".weight"], h2, M=R, N=PAKA_HIDDEN, K=PAKA_HIDDEN, epilogue=ops.EPI_BF16_GELU, bias=P.p[l1 + ".bias"], out2=h2p)
+        z = ws.get(tag + ".z", (cap, PAKA_OUT), torch.float32)
+        ops.gemm(h2, P.b[l2 + ".weight"], z, M=R, N=PAKA_OUT, K=PAKA_HIDDEN, epilogue=ops.EPI_F32, bias=P.p[l2 + ".bias"])
+        return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, R=R, cap=cap, tag=tag)
+
+    def _head_bwd(self, c: Dict[str, Any], dz: Tensor) -> Tensor:
+        """dz bf16 [R, 256] -> d(head input) f32 [R, D]; parameter gradients accumulate (bias sums ride the weight-gradient GEMMs)."""
+        ws, D, P = self.ws, self.cfg.embed_dim, self.student
+        R, cap, tag = c["R"], c["cap"], c["tag"]
+        l0, l1, l2 = ("paka." + l for l in PAKA_LAYERS)
+        slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
+
+        def wgrad(dy: Tensor, xin: Tensor, lin: str, n_out: int, k_in: int) -> None:
+            kpad = (R + 63) // 64 * 64
+            dyp, xp = padded_rows(dy, R), padded_rows(xin, R)
+            if kpad != R and dyp is not None and xp is not None:
+                dyp[R:kpad].zero_(); xp[R:kpad].zero_()
+                dy, xin = dyp, xp
+            else:
+                kpad = R
+            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            ops.gemm(dy, xin, P.g[lin + ".weight"], M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, colsum=P.g[lin + ".bias"],
+                     lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
+
+        wgrad(dz, c["h2"], l2, PAKA_OUT, PAKA_HIDDEN)
+        dh2 = ws.get(tag + ".dh2", (cap, PAKA_HIDDEN), torch.bfloat16, pad_rows=64)
+        ops.gemm(dz, P.b[l2 + ".weight"], dh2, M=R, N=PAKA_HIDDEN, K=PAKA_OUT, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h2p"])
+        wgrad(dh2, c["h1"], l1, PAKA_HIDDEN, PAKA_HIDDEN)
+        dh1 = ws.get(tag + ".dh1", (cap, PAKA_HIDDEN), torch.bfloat16, pad_rows=64)
+        ops.gemm(dh2, P.b[l1 + ".weight"], dh1, M=R, N=PAKA_HIDDEN, K=PAKA_HIDDEN, trans_b=True, epilogue=ops.EPI_BF16_GELUGRAD, aux=c["h1p"])
+        wgrad(dh1, c["x"], l0, PAKA_HIDDEN, D)
+        dx = ws.get(tag + ".dx", (cap, D), torch.float32)
+        ops.gemm(dh1, P.b[l0 + ".weight"], dx, M=R, N=D, K=PAKA_HIDDEN, trans_b=True, epilogue=ops.EPI_F32)
+        return dx
+
+    # ------------------------------------------------------------------ the step
+    def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int, masks: Optional[Dict[str, Tensor]] = None) -> TrainingStepResult:
+        a = self.method_args
+        views: Sequence[Tensor] = batch["views"]
+        K, n_clean = int(a.paka_num_local), 2
+        n_dino = len(views) - n_clean - K
+        if n_dino < 2:
+            raise ValueError(f"DINOv31 expected at least 2 global views before the {n_clean} clean globals + {K} paka locals, but got {len(views)} views.")
+        active = self.trainer.global_step >= a.paka_start_step and K > 0
+        dino_batch = dict(batch, views=list(views[:n_dino]))
+        last = self.accum_last
+        self.accum_last = last and not active     # PaKA adds to the weight gradients the LayerScale gradients are formed from
+        try:
+            res = super().training_step_impl(dino_batch, batch_idx, masks=masks)
+        finally:
+            self.accum_last = last
+        self._paka_had_grad = bool(active)
+        if not active:
+            return res
+        self._paka_slot.zero_()
+        self._paka_fwd_bwd(views, batch["geometries"], n_dino, n_clean, K)
+        if last:
+            self.s_vit.finish_layerscale_grads()
+            self._ls_finished = True
+        logs = dict(res.log_dict)
+        logs["train_loss/paka_loss"] = self._paka_slot[0] / a.paka_weight if a.paka_weight else self._paka_slot[0]
+        return TrainingStepResult(loss=res.loss + self._paka_slot[0], log_dict=logs)
+
+    def _paka_fwd_bwd(self, views: Sequence[Tensor], geometries: Sequence[Tensor], n_dino: int, n_clean: int, K: int) -> None:
+        a, cfg, ws, dev = self.method_args, self.cfg, self.ws, self.device
+        D, p, n_reg = cfg.embed_dim, cfg.patch_size, cfg.num_register_tokens
+        cg = torch.cat([v.to(dev, torch.float32, non_blocking=True) for v in views[n_dino:n_dino + n_clean]])     # [2B, C, H, W]
+        pl = torch.cat([v.to(dev, torch.float32, non_blocking=True) for v in views[n_dino + n_clean:]])           # [K B, C, h, w]
+        B = cg.shape[0] // n_clean
+        gh, gw = cg.shape[2] // p, cg.shape[3] // p
+        lh, lw = pl.shape[2] // p, pl.shape[3] // p
+        n_out = lh * lw
+        if n_out > a.paka_max_tokens:
+            raise NotImplementedError(f"{n_out} tokens per PaKA local exceed paka_max_tokens={a.paka_max_tokens}: the loss's random token subsample is not implemented")
+        # ---- host: pairing, shared regions, sampling tables (float32, the reference's formulas)
+        gs = [geometries[g].to(torch.float32).cpu() for g in range(2)]
+        ls = [geometries[n_dino + n_clean + k].to(torch.float32).cpu() for k in range(K)]
+        ti, tw, si, sw, src, valid = [], [], [], [], [], []
+        for k in range(K):
+            gidx = k % 2                                    # parent-only pairing (:302)
+            sb, tb, has = shared_region_boxes(ls[k], gs[gidx], (lh, lw), (gh, gw), (lh, lw))
+            i_s, w_s = roi_tables(sb, ls[k], (lh, lw), (lh, lw))
+            i_t, w_t = roi_tables(tb, gs[gidx], (gh, gw), (lh, lw))
+            si.append(i_s); sw.append(w_s); ti.append(i_t); tw.append(w_t); valid.append(has)
+            src.append(torch.arange(B, dtype=torch.int32) + gidx * B)
+        valid_all = torch.cat(valid)
+        n_valid = int(valid_all.sum())
+        R = K * B * n_out
+        coef = valid_all.to(torch.float32) * (a.paka_weight / max(n_valid, 1))    # mean over the pairs that overlap (and have >= 2 tokens)
+        if n_out < 2:
+            coef.zero_()
+        si_d, sw_d, ti_d, tw_d, src_d, coef_d = (ops.h2d(torch.cat(t).contiguous(), dev) for t in (si, sw, ti, tw, src, [coef]))
+
+        # ---- clean teacher pass and PaKA-local student pass (backbone tokens, no projection head: :439-456)
+        main = torch.cuda.current_stream()
+        tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
+        tstream.wait_event(main.record_event())
+        torch.cuda.set_stream(tstream)
+        tc = self.t_vit.forward(ws, "tc", cg, None, save=False)
+        Ng = gh * gw + 1 + n_reg
+        t_al = ws.get("paka.t_al", (R, D), torch.bfloat16, pad_rows=64)
+        ops.roi_resample_tokens(tc["xn"].view(-1)[(1 + n_reg) * D:], src_d, ti_d, tw_d, K * B, Ng * D, n_out, D, out_bf16=t_al)
+        th = self._head_fwd(self.teacher, "paka.th", t_al, R, R, save=False)
+        # (+ 8 zero rows: the batched dZ = G Zc product below contracts over the PADDED token count, whose pad columns of G are zero -- the
+        # rows they meet must be finite: the next image's tokens, or these zeros behind the last image)
+        zt = ws.get("paka.zt", (R + 8, PAKA_OUT), torch.bfloat16, zero=True)
+        ops.center_tokens(th["z"], K * B, n_out, PAKA_OUT, out_bf16=zt)
+        npad = (n_out + 7) // 8 * 8
+        Kt = ws.get("paka.Kt", (R, npad), torch.float32)
+        ops.gemm(zt, zt, Kt, M=n_out, N=n_out, K=PAKA_OUT, epilogue=ops.EPI_F32, ldc=npad, batch=K * B, stride_a=n_out * PAKA_OUT,
+                 stride_b=n_out * PAKA_OUT, stride_c=n_out * npad)
+        teacher_done = tstream.record_event()
+        torch.cuda.set_stream(main)
+
+        plan = make_drop_plan(cfg, pl.shape[0], self._drop_gen)
+        sp = self.s_vit.forward(ws, "sp", pl, None, save=True, drop_plan=plan, checkpoint=self.activation_checkpointing)
+        Nl = n_out + 1 + n_reg
+        s_al = ws.get("paka.s_al", (R, D), torch.bfloat16, pad_rows=64)
+        ops.roi_resample_tokens(sp["xn"].view(-1)[(1 + n_reg) * D:], None, si_d, sw_d, K * B, Nl * D, n_out, D, out_bf16=s_al)
+        sh = self._head_fwd(self.student, "paka.sh", s_al, R, R, save=True)
+        zs = ws.get("paka.zs", (R + 8, PAKA_OUT), torch.bfloat16, zero=True)
+        ops.center_tokens(sh["z"], K * B, n_out, PAKA_OUT, out_bf16=zs)
+        Ks = ws.get("paka.Ks", (R, npad), torch.float32)
+        ops.gemm(zs, zs, Ks, M=n_out, N=n_out, K=PAKA_OUT, epilogue=ops.EPI_F32, ldc=npad, batch=K * B, stride_a=n_out * PAKA_OUT,
+                 stride_b=n_out * PAKA_OUT, stride_c=n_out * npad)
+        main.wait_event(teacher_done)
+
+        # ---- loss and backward: 1 - CKA per image -> G = dL/dKs -> dZc = 2 G Zc -> un-centre -> head -> RoI backward -> ViT backward
+        G = ws.get("paka.G", (R, npad), torch.bfloat16, zero=True)
+        ops.cka_fwd_bwd(Ks, Kt, coef_d, self._paka_slot, G, K * B, n_out, npad)
+        dzc = ws.get("paka.dzc", (R, PAKA_OUT), torch.float32)
+        ops.gemm(G, zs, dzc, M=n_out, N=PAKA_OUT, K=npad, trans_b=True, epilogue=ops.EPI_F32, alpha=2.0, lda=npad, batch=K * B, stride_a=n_out * npad,
+                 stride_b=n_out * PAKA_OUT, stride_c=n_out * PAKA_OUT)
+        dz = ws.get("paka.dz", (R, PAKA_OUT), torch.bfloat16, pad_rows=64)
+        ops.center_tokens(dzc, K * B, n_out, PAKA_OUT, out_bf16=dz)          # H is symmetric: the backward of the centring is the centring
+        self._reduce_begin()
+        dx_al = self._head_bwd(sh, dz)
+        dxn = ws.get("sp.dxn", (K * B * Nl, D), torch.float32)
+        dxn.zero_()
+        ops.roi_resample_tokens_bwd(dx_al, si_d, sw_d, dxn.view(-1)[(1 + n_reg) * D:], K * B, Nl * D, n_out, n_out, D)
+        side = self.side_stream if self.overlap_streams else None
+        self.s_vit.backward(ws, sp, dxn, side=side)
+        if side is not None:
+            main.wait_stream(side)
+        if self.deterministic and self.device.type == "cuda":
+            ops.reduce_end()

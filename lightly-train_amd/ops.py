@@ -41,6 +41,15 @@ def require_device(dev: torch.device, who: str) -> None:
         raise RuntimeError(f"{who} runs on an MI355X only (no CPU fallback for the HIP kernels)")
 
 
+def h2d(t: Tensor, dev: torch.device) -> Tensor:
+    """A small host tensor to the device WITHOUT stalling the launch thread: through torch's pinned-memory cache (a pageable source makes
+    hipMemcpyAsync wait on its staging path -- 7.5 ms per copy once the host runs a few steps ahead of the device, seven copies per step:
+    tools/host_ahead_probe.py -- while a pinned source is a queued DMA; the pinned block is recycled only after the copy's event)."""
+    if t.device.type == "cpu" and torch.device(dev).type == "cuda":
+        return t.pin_memory().to(dev, non_blocking=True)
+    return t.to(dev, non_blocking=True)
+
+
 def device_info() -> dict:
     lib = _lib.load()
     name = C.create_string_buffer(128)
@@ -265,6 +274,35 @@ def resample_tables(hs: int, ws_: int, ht: int, wt: int, mode: str = "bilinear")
 def resample_tokens(x: Tensor, idx: Tensor, w: Tensor, out: Tensor, B: int, n_in: int, n_out: int, D: int, taps: int) -> None:
     _chk(x, torch.float32, "resample.x"); _chk(idx, torch.int32, "resample.idx"); _chk(w, torch.float32, "resample.w")
     check(_lib.load().lt_resample_tokens(_p(x), _p(idx), _p(w), _p(out), B, n_in, n_out, D, taps, _stream()), "lt_resample_tokens")
+
+
+def roi_resample_tokens(x: Tensor, src_image: Optional[Tensor], idx: Tensor, w: Tensor, B: int, img_stride: int, n_out: int, D: int,
+                        out_bf16: Optional[Tensor] = None, out_f32: Optional[Tensor] = None) -> None:
+    """Bilinear RoI resampling of token maps with per-image 4-tap tables (lt_roi_resample_tokens).  `x`: f32 view starting at the first
+    patch token of image 0, images `img_stride` elements apart."""
+    _chk(idx, torch.int32, "roi.idx"); _chk(w, torch.float32, "roi.w")
+    assert x.dtype == torch.float32 and x.is_cuda
+    check(_lib.load().lt_roi_resample_tokens(x.data_ptr(), _p(src_image), _p(idx), _p(w), _p(out_bf16), _p(out_f32), B, img_stride, n_out, D, _stream()),
+          "lt_roi_resample_tokens")
+
+
+def roi_resample_tokens_bwd(dout: Tensor, idx: Tensor, w: Tensor, din: Tensor, B: int, img_stride: int, n_in: int, n_out: int, D: int) -> None:
+    """Gather-form backward of `roi_resample_tokens` into `din` (f32 view starting at the first patch token of image 0)."""
+    _chk(dout, torch.float32, "roi_bwd.dout"); _chk(idx, torch.int32, "roi_bwd.idx"); _chk(w, torch.float32, "roi_bwd.w")
+    assert din.dtype == torch.float32 and din.is_cuda
+    check(_lib.load().lt_roi_resample_tokens_bwd(_p(dout), _p(idx), _p(w), din.data_ptr(), B, img_stride, n_in, n_out, D, _stream()),
+          "lt_roi_resample_tokens_bwd")
+
+
+def center_tokens(z: Tensor, B: int, n: int, C: int, out_bf16: Optional[Tensor] = None, out_f32: Optional[Tensor] = None) -> None:
+    _chk(z, torch.float32, "center.z")
+    check(_lib.load().lt_center_tokens(_p(z), _p(out_bf16), _p(out_f32), B, n, C, _stream()), "lt_center_tokens")
+
+
+def cka_fwd_bwd(Ks: Tensor, Kt: Tensor, coef: Tensor, loss: Tensor, G: Optional[Tensor], B: int, n: int, ld: int, eps: float = 1e-8) -> None:
+    """loss[0] += sum_b coef[b] * (1 - CKA(Ks[b], Kt[b])), G[b] (bf16) = its gradient with respect to Ks[b] (lt_cka_fwd_bwd)."""
+    _chk(Ks, torch.float32, "cka.Ks"); _chk(Kt, torch.float32, "cka.Kt"); _chk(coef, torch.float32, "cka.coef")
+    check(_lib.load().lt_cka_fwd_bwd(_p(Ks), _p(Kt), _p(coef), _p(loss), _p(G), B, n, ld, eps, _stream()), "lt_cka_fwd_bwd")
 
 
 def rope_apply(qkv: Tensor, sin_t: Tensor, cos_t: Tensor, B: int, N: int, H: int, dh: int, prefix: int, inverse: bool = False) -> None:

@@ -408,11 +408,11 @@ class ViTEngine:
                 return br
             if kind == "persample":   # DropPath: per-image mask/keep expanded over the image's tokens
                 br["mode"] = "persample"
-                br["rowscale"] = val.to(torch.float32).repeat_interleave(N).to(self.dev, non_blocking=True)
+                br["rowscale"] = ops.h2d(val.to(torch.float32).repeat_interleave(N), self.dev)
                 return br
             sb = int(val.numel())      # batch-subset stochastic depth
             Ts = sb * N
-            idx = (val.to(torch.int64).view(-1, 1) * N + tok.view(1, -1)).reshape(-1).to(self.dev, non_blocking=True)
+            idx = ops.h2d((val.to(torch.int64).view(-1, 1) * N + tok.view(1, -1)).reshape(-1), self.dev)
             xs = ws.get(s + which + ".xs", (T, D), torch.float32)[:Ts]
             ops.gather_rows(xin, D, idx, Ts, D, out_f32=xs)
             br.update(mode="subset", rows=Ts, nb=sb, x=xs, idx=idx, scale=B / sb)

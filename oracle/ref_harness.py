@@ -195,6 +195,11 @@ def install() -> None:
 
     lul = importlib.import_module("lightly.utils.lars")
     lul.LARS = lars_oracle.LARS  # type: ignore[attr-defined]
+    # the two LightlySSL pieces of DINOv31 (LT/_methods/dinov31/dinov31.py:55), restated in oracle/dinov31_oracle.py (parity unpinned)
+    from oracle import dinov31_oracle as O31
+
+    ll.PatchKernelAlignmentLoss = O31.PatchKernelAlignmentLoss  # type: ignore[attr-defined]
+    ll.roi_resample_to_grid = O31.roi_resample_to_grid  # type: ignore[attr-defined]
     # torchvision is not installed: the convolutional student runs on the restated ResNet (oracle/resnet_oracle.py), registered
     # where the reference's ResNetModelWrapper imports it from (LT/_models/torchvision/resnet.py:9-10)
     from oracle import resnet_oracle as OR

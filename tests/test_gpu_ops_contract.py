@@ -115,6 +115,36 @@ def test_fused_centering_contract():
     _close(r["st"], atol=1e-5); _close(r["csa"], atol=1e-5); _close(r["csb"], atol=1e-5); _close(r["loss"], atol=1e-4); _close(r["d"])
 
 
+def test_paka_kernels_contract():
+    """lt_roi_resample_tokens (+ its gather-form backward), lt_center_tokens and lt_cka_fwd_bwd against their plain-torch statements: per-image
+    4-tap tables with a source-image map, an offset token view (cls row skipped), pad columns of the Gram matrices, an image with coef 0."""
+    g = torch.Generator().manual_seed(21)
+    B, Bs, n_in, n_out, D, C = 6, 4, 12, 9, 64, 32
+    N = n_in + 1
+    ld = 16
+    x = torch.randn(Bs * N * D, generator=g)
+    idx = torch.randint(0, n_in, (B, n_out, 4), generator=g, dtype=torch.int32)
+    w = torch.rand(B, n_out, 4, generator=g)
+    w[0, 0, 1] = 0.0
+    src = torch.randint(0, Bs, (B,), generator=g, dtype=torch.int32)
+    z = torch.randn(B * n_out, C, generator=g)
+    Ks = torch.randn(B * n_out, ld, generator=g); Kt = torch.randn(B * n_out, ld, generator=g)
+    coef = torch.rand(B, generator=g); coef[2] = 0.0
+    T = dict(x=x, idx=idx, w=w, src=src, ob=torch.zeros(B * n_out, D).bfloat16(), of=torch.zeros(B * n_out, D), dout=torch.randn(B * n_out, D, generator=g),
+             din=torch.zeros(B * N * D), z=z, zc=torch.zeros(B * n_out, C), zb=torch.zeros(B * n_out, C).bfloat16(), Ks=Ks, Kt=Kt, coef=coef, loss=torch.zeros(1),
+             G=torch.zeros(B * n_out, ld).bfloat16())
+
+    def call(ops, t):
+        ops.roi_resample_tokens(t["x"][D:], t["src"], t["idx"], t["w"], B, N * D, n_out, D, out_bf16=t["ob"], out_f32=t["of"])
+        ops.roi_resample_tokens_bwd(t["dout"], t["idx"], t["w"], t["din"][D:], B, N * D, n_in, n_out, D)
+        ops.center_tokens(t["z"], B, n_out, C, out_bf16=t["zb"], out_f32=t["zc"])
+        ops.cka_fwd_bwd(t["Ks"], t["Kt"], t["coef"], t["loss"], t["G"], B, n_out, ld)
+
+    r = _both(call, T, ["ob", "of", "din", "zc", "zb", "loss", "G"])
+    _close(r["of"], atol=1e-5); _close(r["ob"]); _close(r["din"], atol=1e-5); _close(r["zc"], atol=1e-5); _close(r["zb"]); _close(r["loss"], atol=1e-5); _close(r["G"])
+    assert float(r["din"][0].view(B, N, D)[:, 0].abs().max()) == 0.0       # the cls rows in front of every image stay untouched
+
+
 def test_softmax_center_sinkhorn_and_center_ema():
     g = torch.Generator().manual_seed(5)
     R, K = 48, 128

@@ -42,6 +42,8 @@ def emulate(ops):
             kw["colsum"].view(-1)[:M] += A.sum(1)
         Bm = (b.float().reshape(-1, ldb or (N if trans_b else K))[:K, :N] if trans_b else b.float().reshape(-1, ldb or K)[:N, :K].t())
         r = A @ Bm
+        if kw.get("alpha", 1.0) != 1.0:                # C = alpha * acc + bias (include/lt_amd.h)
+            r = r * kw["alpha"]
         if bias is not None:
             r = r + bias
         o2 = out.reshape(-1, ldc or N)
@@ -259,6 +261,45 @@ def emulate(ops):
         probs = torch.zeros(nt, K)       # only the rows that are referenced have statistics
         probs[used] = torch.exp((tl[used] - cen[used]) * inv_temp_t - st[used, 0:1]) * st[used, 1:2]
         ce_fwd_bwd(s_, probs, ta, tb, row_weight, scale, inv_temp, loss, dlogits, rows, K, slot=slot)
+
+    def roi_resample_tokens(x, src_image, idx, w, B, img_stride, n_out, D, out_bf16=None, out_f32=None):
+        flat = x.reshape(-1)
+        for b in range(B):
+            sb = int(src_image[b]) if src_image is not None else b
+            img = flat[sb * img_stride: sb * img_stride + (int(idx[b].max()) + 1) * D].view(-1, D)
+            r = (img[idx[b].long()] * w[b][:, :, None]).sum(1)                      # [n_out, D]
+            for o_ in (out_bf16, out_f32):
+                if o_ is not None:
+                    o_.reshape(-1, D)[b * n_out:(b + 1) * n_out] = r.to(o_.dtype)
+
+    def roi_resample_tokens_bwd(dout, idx, w, din, B, img_stride, n_in, n_out, D):
+        flat = din.reshape(-1)
+        for b in range(B):
+            acc = torch.zeros(n_in, D)
+            g_ = dout.reshape(-1, D)[b * n_out:(b + 1) * n_out].float()
+            for a_ in range(4):
+                acc.index_add_(0, idx[b][:, a_].long(), g_ * w[b][:, a_:a_ + 1])
+            flat[b * img_stride: b * img_stride + n_in * D] = acc.reshape(-1)
+
+    def center_tokens(z, B, n, C, out_bf16=None, out_f32=None):
+        zz = z.reshape(-1, C)[: B * n].view(B, n, C)
+        r = (zz - zz.mean(1, keepdim=True)).reshape(B * n, C)
+        for o_ in (out_bf16, out_f32):
+            if o_ is not None:
+                o_.reshape(-1, C)[: B * n] = r.to(o_.dtype)
+
+    def cka_fwd_bwd(Ks, Kt, coef, loss, G, B, n, ld, eps=1e-8):
+        ks = Ks.reshape(-1, ld)[: B * n].view(B, n, ld)[:, :, :n].float()
+        kt = Kt.reshape(-1, ld)[: B * n].view(B, n, ld)[:, :, :n].float()
+        hst, ns, nt = (ks * kt).sum((1, 2)), ks.pow(2).sum((1, 2)).sqrt(), kt.pow(2).sum((1, 2)).sqrt()
+        den = ns * nt + eps
+        loss[0] += (coef[:B] * (1.0 - hst / den)).sum()
+        if G is not None:
+            gs = torch.where(ns > 0, coef[:B] * hst * nt / (ns * den * den), torch.zeros_like(ns))
+            g = (-coef[:B] / den)[:, None, None] * kt + gs[:, None, None] * ks
+            Gv = G.reshape(-1, ld)[: B * n].view(B, n, ld)
+            Gv.zero_()
+            Gv[:, :, :n] = g.to(G.dtype)
 
     def sk_exp(logits, Q, inv_temp):
         Q.reshape(-1)[: logits.numel()] = torch.exp(logits.reshape(-1) * inv_temp)
@@ -545,7 +586,7 @@ def emulate(ops):
                      ("layernorm_bwd", layernorm_bwd), ("layerscale_bwd", layerscale_bwd), ("layerscale_dgamma", layerscale_dgamma), ("layerscale_dgamma_batched", layerscale_dgamma_batched),
                      ("gather_rows", gather_rows), ("scatter_add_rows", scatter_add_rows), ("attention_fwd", attention_fwd),
                      ("attention_bwd", attention_bwd), ("attention_bwd_ws_floats", lambda B, N, H, dh: 8), ("swiglu_fwd", swiglu_fwd),
-                     ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("softmax_stats_colsum", softmax_stats_colsum), ("ce_fwd_bwd_logits", ce_fwd_bwd_logits), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
+                     ("swiglu_bwd", swiglu_bwd), ("softmax_center", softmax_center), ("roi_resample_tokens", roi_resample_tokens), ("roi_resample_tokens_bwd", roi_resample_tokens_bwd), ("center_tokens", center_tokens), ("cka_fwd_bwd", cka_fwd_bwd), ("softmax_stats_colsum", softmax_stats_colsum), ("ce_fwd_bwd_logits", ce_fwd_bwd_logits), ("center_ema", center_ema), ("colsum_f32", colsum_f32),
                      ("scale_f32", scale_f32), ("fill_f32", fill_f32), ("ce_fwd_bwd", ce_fwd_bwd), ("sk_exp", sk_exp), ("sk_iter", sk_iter),
                      ("koleo_fwd_bwd", koleo_fwd_bwd), ("sumsq", sumsq), ("adamw_flat", adamw_flat), ("ema_flat", ema_flat),
                      ("resample_tokens", resample_tokens), ("kl_fwd_bwd", kl_fwd_bwd), ("cast_bf16", cast_bf16), ("symmetrize_bf16", symmetrize_bf16),
