@@ -119,25 +119,43 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
 #pragma unroll
   for (int v = 0; v < V; ++v) { sum[v] = 0.f; msum[v] = 0.f; }
   if (d < D) {
-    for (int b = bl; b < B; b += 4) {
-      float g[V];
-      if (V == 4) {
-        const float4 g4 = *reinterpret_cast<const float4*>(dx + ((long)b * N + t) * D + d);
-        g[0] = g4.x; g[1 % V] = g4.y; g[2 % V] = g4.z; g[3 % V] = g4.w;
-      } else {
-        g[0] = dx[((long)b * N + t) * D + d];
+    // four images per trip with their loads (token rows N * D floats apart) issued together: one load in flight per thread made the
+    // kernel latency-bound (64 dependent trips for batch 256: 153 us for 235 MB, 1.5 TB/s)
+    constexpr int U = 4;
+    for (int b0 = bl; b0 < B; b0 += 4 * U) {
+      float g[U][V];
+      bool mk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = b0 + 4 * u;
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[u][v] = 0.f;
+        mk[u] = false;
+        if (b < B) {
+          if (V == 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dx + ((long)b * N + t) * D + d);
+            g[u][0] = g4.x; g[u][1 % V] = g4.y; g[u][2 % V] = g4.z; g[u][3 % V] = g4.w;
+          } else {
+            g[u][0] = dx[((long)b * N + t) * D + d];
+          }
+          if (i >= 0) mk[u] = masks && masks[(long)b * n_p + i];
+        }
       }
 #pragma unroll
-      for (int v = 0; v < V; ++v) sum[v] += g[v];
-      if (i >= 0) {
-        const bool m = masks && masks[(long)b * n_p + i];
-        if (m) {
+      for (int u = 0; u < U; ++u) {   // (accumulation order: ascending image index within a batch lane, as before)
+        const int b = b0 + 4 * u;
+        if (b >= B) continue;
 #pragma unroll
-          for (int v = 0; v < V; ++v) msum[v] += g[v];
+        for (int v = 0; v < V; ++v) sum[v] += g[u][v];
+        if (i >= 0) {
+          if (mk[u]) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) msum[v] += g[u][v];
+          }
+          bf16_t* o = dpatch + ((long)b * n_p + i) * D + d;
+          if (V == 4) *reinterpret_cast<uint2*>(o) = mk[u] ? make_uint2(0, 0) : make_uint2(pack_bf2(g[u][0], g[u][1 % V]), pack_bf2(g[u][2 % V], g[u][3 % V]));
+          else o[0] = mk[u] ? (bf16_t)0 : f2bf(g[u][0]);
         }
-        bf16_t* o = dpatch + ((long)b * n_p + i) * D + d;
-        if (V == 4) *reinterpret_cast<uint2*>(o) = m ? make_uint2(0, 0) : make_uint2(pack_bf2(g[0], g[1 % V]), pack_bf2(g[2 % V], g[3 % V]));
-        else o[0] = m ? (bf16_t)0 : f2bf(g[0]);
       }
     }
   }

@@ -734,7 +734,7 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
   bf16x8 fa[2][4], fb0[4], fb1[4];
   const int bcol = (wn & 1) * 2;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};                 // CS: per 32-row block of the wave's 128 A rows, this lane's k half
-  const int cs_period = 4 * g.tiles_n, cs_mine = tn * 4 + wn;
+  const int cs_period = 4 * g.tiles_n, cs_mine = __builtin_amdgcn_readfirstlane(tn * 4 + wn);   // wave-uniform: a scalar compare + branch per phase
   int cs_cnt = 0;
 #define LT_CS_ADD(I0)                                                                                             \
   do {                                                                                                            \

@@ -95,7 +95,30 @@ def main() -> None:
     out["koleo0"]["dino_center"] = o.dino_center.detach().reshape(-1).clone()
     out["koleo0"]["ibot_center"] = o.ibot_center.detach().reshape(-1).clone()
     out["koleo0"]["logit_samples"] = {k: cap[k].detach()[:4, ::64].clone() for k in ("t_cls_logits", "s_cls_logits", "s_loc_logits", "s_patch_logits", "t_patch_logits")}
+    fp32_samples = samples
+    fp32_norms = norms
     del o, loss, cap
+
+    # ---- the yardstick column: the SAME restatement under torch.autocast("cpu", bfloat16) (what precision="bf16-mixed" does to the reference:
+    # bf16 matmul operands, fp32 master weights) against its own fp32 run -- per-tensor gradient errors of a bf16 pipeline that is not ours
+    ob = O.OracleDINOv2(bsd, shs, cfg, args=dict(koleo_loss_weight=0.0), global_batch_size=b, total_steps=100, teacher_head=ths)
+    t0 = time.time()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_b, logs_b = ob.forward_loss(views, masks)
+    loss_b.backward()
+    print(f"bf16-autocast forward + backward: {time.time() - t0:.1f} s", flush=True)
+    yard = {"loss": float(loss_b.detach()), "logs": {k: float(v) for k, v in logs_b.items()}, "norm_rel_err": {}, "sample_err": {}}
+    sqb = 0.0
+    for name, p in [("backbone." + n, p) for n, p in ob.sb.items()] + [("head." + n, p) for n, p in ob.sh.items()]:
+        nb = float(p.grad.double().norm())
+        sqb += nb * nb
+        yard["norm_rel_err"][name] = abs(nb - fp32_norms[name]) / max(fp32_norms[name], 1e-20)
+        if name in fp32_samples:
+            ref = fp32_samples[name]
+            yard["sample_err"][name] = float((sample(p.grad.float()).reshape(ref.shape) - ref).abs().max() / (ref.abs().max() + 1e-20))
+    yard["grad_norm"] = sqb ** 0.5
+    out["autocast_yardstick"] = yard
+    del ob, loss_b
 
     # ---- forward with the reference's defaults (KoLeo 0.1), same weights / views / masks
     o2 = O.OracleDINOv2(bsd, shs, cfg, args={}, global_batch_size=b, total_steps=100, teacher_head=ths)

@@ -515,7 +515,15 @@ def test_bench_configuration_step_matches_the_committed_fixture():
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "bench_vitb_b32_grad_report.json"), "w") as f:
-            json.dump({"loss": logs, "loss_fixture": k0["logs"], "grad_norm": sq ** 0.5, "grad_norm_fixture": k0["grad_norm"], "per_tensor": report}, f, indent=1)
+            yard = fx.get("autocast_yardstick", {})     # the reference restatement's own bf16-autocast errors against its fp32 run: the third column
+            for n_ in report:
+                if n_ in yard.get("norm_rel_err", {}):
+                    report[n_]["autocast_norm_rel_err"] = yard["norm_rel_err"][n_]
+                    report[n_]["norm_rel_err"] = abs(report[n_]["norm"] - report[n_]["norm_ref"]) / max(report[n_]["norm_ref"], 1e-20)
+                if n_ in yard.get("sample_err", {}):
+                    report[n_]["autocast_sample_err"] = yard["sample_err"][n_]
+            json.dump({"loss": logs, "loss_fixture": k0["logs"], "grad_norm": sq ** 0.5, "grad_norm_fixture": k0["grad_norm"],
+                       "autocast_grad_norm": yard.get("grad_norm"), "autocast_loss": yard.get("logs"), "per_tensor": report}, f, indent=1)
     assert not bad, f"{len(bad)} checks off: {bad[:8]}"
     assert sq ** 0.5 == pytest.approx(k0["grad_norm"], rel=2e-2)
     # the centers the NEXT step applies (dinov2_loss.py:139-160): column sums of this step's teacher logits through the EMA

@@ -4,13 +4,10 @@ O=$R/gpurun_out/${1:-r04a}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-run() { echo "== $*"; env "$@" timeout 200 python tools/host_ahead_probe.py --steps 30 2>&1 | grep -v amdgpu.ids | tail -4; }
-{
-run A=0
-run HSA_KERNARG_POOL_SIZE=33554432
-run HSA_KERNARG_POOL_SIZE=33554432 ROC_AQL_QUEUE_SIZE=65536
-run ROC_SIGNAL_POOL_SIZE=4096
-run HSA_KERNARG_POOL_SIZE=33554432 ROC_AQL_QUEUE_SIZE=65536 ROC_SIGNAL_POOL_SIZE=4096 GPU_MAX_HW_QUEUES=8
-run HIP_FORCE_DEV_KERNARG=1
-} > $O/host_ahead_env.log 2>&1
-cat $O/host_ahead_env.log
+timeout 600 python -m pytest tests/test_gpu_ops_contract.py tests/test_gpu_dinov31.py -x -q -m gpu > $O/tests_dinov31.log 2>&1
+tail -12 $O/tests_dinov31.log
+timeout 900 python -m pytest tests/test_gpu_step.py -x -q -m gpu -k "mid_size" > $O/tests_traj.log 2>&1
+tail -3 $O/tests_traj.log
+timeout 200 python tools/host_ahead_probe.py --steps 30 2>&1 | grep -v amdgpu.ids | tail -4 > $O/host_ahead_default.log; cat $O/host_ahead_default.log
+HSA_KERNARG_POOL_SIZE=33554432 timeout 200 python tools/host_ahead_probe.py --steps 30 2>&1 | grep -v amdgpu.ids | tail -4 > $O/host_ahead_pool32m.log; cat $O/host_ahead_pool32m.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-500
