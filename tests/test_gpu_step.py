@@ -585,6 +585,48 @@ def test_batch128_step_is_the_mean_of_its_four_batch32_parts():
     assert not bad, bad[:8]
 
 
+def test_gradient_accumulation_window_on_the_kernels():
+    """`accum_first` / `accum_last` / `grad_scale` (what the Method binding sets per micro-batch, LT/_commands/train_helpers.py:224-236): two
+    micro-batches accumulated in the flat gradient buffer at scale 1/2 equal the mean of their separately computed gradients -- every
+    tensor, to fp32 summation order (a power-of-two scale commutes with every bf16 rounding on the way) -- with the LayerScale gradients
+    formed ONCE from the accumulated weight gradients; a window whose last micro-batch was not announced is finished by `optimizer_step`."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    m = build(fx, koleo_loss_weight=0.0)
+    batches = [(synth_views(rec["view_seed"], fx["b"], fx["g_size"], fx["l_size"], fx["n_local"]), rec["masks"]) for rec in fx["steps"][:2]]
+    single = []
+    for views, masks in batches:
+        m.accum_first, m.accum_last, m.grad_scale = True, True, 1.0
+        m.training_step_impl({"views": views}, 0, masks=masks)
+        m._pending.clear()          # every evaluation sees the initial centers
+        torch.cuda.synchronize()
+        single.append({n: m.student.g[n].clone() for n in m.student.names})
+    want = {n: 0.5 * single[0][n] + 0.5 * single[1][n] for n in m.student.names}
+    for announce_last in (True, False):
+        m.accum_first, m.accum_last, m.grad_scale = True, False, 0.5
+        r0 = m.training_step_impl({"views": batches[0][0]}, 0, masks=batches[0][1])
+        m._pending.clear()
+        torch.cuda.synchronize()
+        gam = [n for n in m.student.names if n.endswith("gamma")]
+        assert gam and all(float(m.student.g[n].abs().max()) == 0.0 for n in gam)      # deferred: they come from the accumulated dW
+        m.accum_first, m.accum_last = False, announce_last
+        r1 = m.training_step_impl({"views": batches[1][0]}, 1, masks=batches[1][1])
+        m._pending.clear()
+        if not announce_last:       # (the end of an epoch inside a window): optimizer_step forms the LayerScale gradients first
+            assert m._ls_finished is False
+            p0 = m.student.data.clone()
+            m.optimizer_step()
+            torch.cuda.synchronize()
+            assert m._ls_finished and not torch.equal(p0, m.student.data)
+            assert all(float(m.student.g[n].abs().max()) > 0.0 for n in gam)
+            break
+        torch.cuda.synchronize()
+        bad = [(n, rel(m.student.g[n], want[n])) for n in m.student.names if not rel(m.student.g[n], want[n]) < 2e-4]
+        assert not bad, bad[:6]
+        # the logged terms are per micro-batch and unscaled
+        assert float(r0.loss) > 1.0 and float(r1.loss) > 1.0
+    m.accum_first, m.accum_last, m.grad_scale = True, True, 1.0
+
+
 def _container_tree(sd):
     """An nn.Module hierarchy whose state_dict() has exactly the keys (and order) of `sd`: the stand-in for the reference's module
     containers on the GPU box, where the reference package does not exist.  Shared sub-modules (`ibot_head` is `dino_head`) are shared."""

@@ -4,10 +4,14 @@ O=$R/gpurun_out/${1:-r04a}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_ops_contract.py tests/test_gpu_dinov31.py -x -q -m gpu > $O/tests_dinov31.log 2>&1
-tail -12 $O/tests_dinov31.log
-timeout 900 python -m pytest tests/test_gpu_step.py -x -q -m gpu -k "mid_size" > $O/tests_traj.log 2>&1
-tail -3 $O/tests_traj.log
-timeout 200 python tools/host_ahead_probe.py --steps 30 2>&1 | grep -v amdgpu.ids | tail -4 > $O/host_ahead_default.log; cat $O/host_ahead_default.log
-HSA_KERNARG_POOL_SIZE=33554432 timeout 200 python tools/host_ahead_probe.py --steps 30 2>&1 | grep -v amdgpu.ids | tail -4 > $O/host_ahead_pool32m.log; cat $O/host_ahead_pool32m.log
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-500
+timeout 1500 python -m pytest tests/ -x -q -m gpu > $O/gpu_tests.log 2>&1
+tail -6 $O/gpu_tests.log
+cd /tmp
+B="python $R/bench.py --no-cpu-baseline --no-roofline"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/ks_vits -o ks -- $B --steps 3 --warmup 1 --single-stream --model vit_small > $O/bench_vits_single.log 2>&1
+cd $R
+python tools/rocprof_summary.py $(find $O/ks_vits -name "*.db" | head -1) 36 > $O/kernel_stats_vits.md 2>&1
+rm -rf $O/ks_vits
+head -42 $O/kernel_stats_vits.md
+$B --steps 10 --warmup 3 --model vit_small > $O/bench_vits.log 2>&1; tail -1 $O/bench_vits.log | cut -c1-300
+timeout 200 python tools/host_overhead.py 2>&1 | grep -v amdgpu | head -30 > $O/host_overhead.log; cat $O/host_overhead.log
