@@ -105,17 +105,17 @@ def vit_config_from_reference(model: Any, drop_path_rate: float = 0.0) -> ViTCon
                      num_register_tokens=int(model.num_register_tokens), ffn_layer=ffn, block_chunks=chunks)
 
 
-def hip_args_from_reference(method_args: Any) -> _HipArgs:
+def hip_args_from_reference(method_args: Any, args_cls: type = _HipArgs) -> Any:
     """The reference's `DINOv2Args` (dinov2.py:70-153; "auto" values already resolved) -> the HIP step's dataclass of the same fields."""
     import dataclasses
 
     kw = {}
-    for f in dataclasses.fields(_HipArgs):
+    for f in dataclasses.fields(args_cls):
         if hasattr(method_args, f.name):
             v = getattr(method_args, f.name)
             if v is not None and not (isinstance(v, str) and v == "auto"):
                 kw[f.name] = tuple(v) if isinstance(v, list) else v
-    return _HipArgs(**kw)
+    return args_cls(**kw)
 
 
 def _strip(sd: Mapping[str, Tensor], prefix: str, backbone: bool = False) -> Dict[str, Tensor]:
@@ -151,18 +151,23 @@ class DINOv2BindingMixin:
             a = self.method_args
             cfg = vit_config_from_reference(t_model)
             bb = "embedding_model.wrapped_model._model."
-            self._impl = _HipDINOv2(
-                cfg, hip_args_from_reference(a), global_batch_size=self.global_batch_size,
+            engine_cls, args_cls, extra = self._engine(sd)
+            self._impl = engine_cls(
+                cfg, hip_args_from_reference(a, args_cls), global_batch_size=self.global_batch_size,
                 total_steps=total_optimizer_steps(self), device=dev,
                 backbone_state=_strip(sd, "student_" + bb, True), teacher_backbone_state=_strip(sd, "teacher_" + bb, True),
                 student_head_state=_strip(sd, "student_head.dino_head."), teacher_head_state=_strip(sd, "teacher_head.dino_head."),
                 student_ibot_head_state=_strip(sd, "student_head.ibot_head.") if a.ibot_separate_head else None,
-                teacher_ibot_head_state=_strip(sd, "teacher_head.ibot_head.") if a.ibot_separate_head else None)
+                teacher_ibot_head_state=_strip(sd, "teacher_head.ibot_head.") if a.ibot_separate_head else None, **extra)
             self._impl.load_state_dict(sd)   # centers, BatchNorm buffers, chunked-block key names
             if self._pending_resume is not None:
                 self._impl.load_checkpoint_dict(self._pending_resume)
                 self._pending_resume = None
         return self._impl
+
+    def _engine(self, sd: Mapping[str, Tensor]) -> Any:
+        """(engine class, its argument dataclass, extra constructor keywords) -- DINOv2 here; the DINOv31 binding overrides it."""
+        return _HipDINOv2, _HipArgs, {}
 
     def training_step_impl(self, batch: Mapping[str, Any], batch_idx: int) -> Any:
         m, boundary = begin_micro_batch(self, batch_idx)
@@ -257,6 +262,42 @@ def dinov2_amd_method_cls() -> type:
     DINOv2AMD.__qualname__ = "DINOv2AMD"
     _CLS = DINOv2AMD
     return _CLS
+
+
+_V31_CLS: Optional[type] = None
+
+
+def dinov31_amd_method_cls() -> type:
+    """`DINOv31AMD(Method)`: `method="dinov31"` (LT/_methods/dinov31/dinov31.py: DINOv2 + the PaKA term) on `lightly_train_amd.dinov31.DINOv31`
+    -- the DINOv2 binding with another engine: the reference's constructor also builds `student_paka_head` / `teacher_paka_head`, whose weights
+    start the engine's PaKA heads; the hooks (accumulation is refused by this engine, resume, checkpoints) are the mixin's."""
+    global _V31_CLS
+    if _V31_CLS is not None:
+        return _V31_CLS
+    from lightly_train._methods.dinov31.dinov31 import DINOv31 as RefDINOv31
+    from lightly_train._methods.method import TrainingStepResult
+
+    from .dinov31 import DINOv31 as HipDINOv31
+    from .dinov31 import DINOv31Args as HipDINOv31Args
+
+    class DINOv31AMD(DINOv2BindingMixin, RefDINOv31):   # type: ignore[misc, valid-type]
+        def __init__(self, method_args: Any, optimizer_args: Any, embedding_model: Any, global_batch_size: int, num_input_channels: int,
+                     device: Optional[torch.device] = None, gradient_accumulation_steps: int = 1) -> None:
+            super().__init__(method_args=method_args, optimizer_args=optimizer_args, embedding_model=embedding_model,
+                             global_batch_size=global_batch_size, num_input_channels=num_input_channels)
+            self._init_binding(device, gradient_accumulation_steps)
+
+        def _engine(self, sd: Mapping[str, Tensor]) -> Any:
+            return HipDINOv31, HipDINOv31Args, dict(paka_head_state=_strip(sd, "student_paka_head."), teacher_paka_head_state=_strip(sd, "teacher_paka_head."))
+
+        def on_train_batch_end(self, outputs: Any, batch: Any, batch_idx: int) -> None:
+            from lightly_train._methods.method import Method
+            Method.on_train_batch_end(self, outputs=outputs, batch=batch, batch_idx=batch_idx)    # batch timing only: both EMAs ran in the flat update
+
+    DINOv31AMD._result_cls = TrainingStepResult
+    DINOv31AMD.__qualname__ = "DINOv31AMD"
+    _V31_CLS = DINOv31AMD
+    return _V31_CLS
 
 
 _DINO_CLS: Optional[type] = None
@@ -646,7 +687,7 @@ def install_as(name: str = "dinov2") -> type:
     """Map a method name of `lightly_train.train(method=...)` to the MI355X class (method_helpers.py:54-69 builds its table per call)."""
     from lightly_train._methods import method_helpers
 
-    cls = {"dino": dino_amd_method_cls, "distillation": distillationv3_amd_method_cls, "distillationv3": distillationv3_amd_method_cls,
+    cls = {"dino": dino_amd_method_cls, "dinov31": dinov31_amd_method_cls, "distillation": distillationv3_amd_method_cls, "distillationv3": distillationv3_amd_method_cls,
            "distillationv1": lambda: distillation12_amd_method_cls("v1"), "distillationv2": lambda: distillation12_amd_method_cls("v2")}.get(
         name, dinov2_amd_method_cls)()
     orig = method_helpers._method_name_to_cls

@@ -328,6 +328,69 @@ def test_dino_binding_converts_the_deprecated_epoch_arguments():
     assert ia.warmup_teacher_temp_steps == min(15, int(20 * a.warmup_teacher_temp_max_steps_fraction))
 
 
+def test_dinov31_binding_three_steps_equal_the_reference_class():
+    """`DINOv31AMD(Method)` (integration.dinov31_amd_method_cls) behind the reference's own DINOv31 constructor: the three steps of the
+    fixture recipe (step 0 without PaKA, `paka_start_step = 1`) driven through the binding's hook equal the reference class driven in
+    Lightning's hook order -- loss terms incl. `paka_loss`, and every student / EMA-teacher tensor incl. both PaKA heads afterwards."""
+    from lightly_train_amd import integration
+    from oracle import make_dinov31_fixture as MK
+
+    H.install()
+    from lightly_train._methods.dinov2.dinov2 import DINOv2AdamWViTArgs
+    from lightly_train._methods.dinov31.dinov31 import DINOv31, DINOv31Args
+    from lightly_train._models.dinov2_vit.dinov2_vit import DINOv2ViTModelWrapper
+    from lightly_train._models.dinov2_vit.dinov2_vit_src.models import vision_transformer as vits
+    from lightly_train._models.embedding_model import EmbeddingModel
+
+    def make(cls, **kw):
+        torch.manual_seed(11); random.seed(11)
+        model = vits.DinoVisionTransformer(img_size=MK.G_SIZE, patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4.0, init_values=1.0,
+                                           drop_path_rate=0.0, ffn_layer="mlp", block_chunks=0, interpolate_offset=0.1)
+        wrapped = DINOv2ViTModelWrapper(model)
+        margs = DINOv31Args(output_dim=512, hidden_dim=128, dino_bottleneck_dim=64, koleo_loss_weight=0.0, paka_num_local=MK.K_PAKA, paka_start_step=1, paka_weight=0.7)
+        oargs = DINOv2AdamWViTArgs()
+        margs.resolve_auto(scaling_info=None, optimizer_args=oargs, wrapped_model=wrapped)
+        m = cls(method_args=margs, optimizer_args=oargs, embedding_model=EmbeddingModel(wrapped_model=wrapped), global_batch_size=MK.B, num_input_channels=3, **kw)
+        m.trainer = H.MockTrainer(20)
+        return m
+
+    ref = make(DINOv31)
+    cls = integration.dinov31_amd_method_cls()
+    amd = make(cls, device=torch.device("cpu"))
+    assert list(amd.state_dict()) == list(ref.state_dict())
+    runner = H.ReferenceRunner(ref)
+    with ops_emu.emulate(ops):
+        exactify(amd.impl())
+        for step in range(3):
+            views, geoms = MK.synth_batch(8100 + step)
+            batch = {"views": [v.clone() for v in views], "filename": [], "geometries": geoms}
+            random.seed(410 + step); torch.manual_seed(410 + step)
+            res = ref.training_step_impl(batch, step)
+            res.loss.backward()
+            ref.on_before_optimizer_step(runner.optim)
+            torch.nn.utils.clip_grad_norm_([p for g in runner.optim.param_groups for p in g["params"]], ref.method_args.gradient_clip_val)
+            runner.optim.step(); runner.optim.zero_grad(set_to_none=True); runner.sched.step()
+            ref.trainer.global_step += 1
+            try:
+                ref.on_train_batch_end(None, batch, step)
+            except Exception:
+                pass
+            want = {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}
+            random.seed(410 + step); torch.manual_seed(410 + step)
+            amd.trainer.global_step = step
+            got_res = amd.training_step_impl({"views": views, "filename": [], "geometries": geoms}, step)
+            amd.trainer.global_step = step + 1
+            got = {k.split("/")[-1]: float(v) for k, v in got_res.log_dict.items()}
+            assert set(got) == set(want)
+            for k in ("dino_global_loss", "dino_local_loss", "ibot_loss") + (("paka_loss",) if step >= 1 else ()):
+                assert got[k] == pytest.approx(want[k], rel=5e-5, abs=5e-5), (step, k)
+        sd, rsd = amd.state_dict(), ref.state_dict()
+        for k in rsd:
+            if k.endswith("paka_head.4.bias"):
+                continue      # no gradient (a bias in front of the centring): AdamW steps on summation round-off of opposite signs
+            assert torch.allclose(sd[k].float(), rsd[k].float(), atol=5e-5), (k, (sd[k].float() - rsd[k].float()).abs().max().item())
+
+
 def _build_dino(cls, seed=0, backbone="vit"):
     """The reference's DINO constructor calls (as in oracle/make_golden.py::make_dino_v1) around `cls`."""
     H.install()
