@@ -857,165 +857,6 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 #endif
 }
 
-// ---- one wave per SIMD ("1w" kernel, force_kernel 9: experiment) --------------------------------------------------------
-// 256 x 256 x 64 tile on FOUR waves (2 x 2, wave tile 128 x 128 = 4 x 4 MFMA tiles: 256 accumulator registers, possible because a
-// lone wave on its SIMD may use all 512): a third fewer fragment bytes out of LDS per MFMA than the 2 x 4 layout (8 instead of 12
-// 1-KiB reads per 16 MFMAs).  Two 64-KiB stages, ONE barrier per K-tile:
-//   ks 0: fragments(1) requested | second half of the DMA of tile t+1 | 16 MFMAs
-//   ks 1: fragments(2)           |                                     | 16 MFMAs
-//   ks 2: fragments(3)           |                                     | 16 MFMAs, then: fragments(3) landed, my DMAs of t+1 landed, barrier
-//         => every wave's reads of this stage are complete (the stage may be re-filled) and tile t+1 is visible
-//   ks 3: fragments(0) of t+1    | first half of the DMA of tile t+2   | 16 MFMAs
-// so a DMA has two to three 512-cycle steps to land before it is waited for, and the LDS latency of every fragment read runs
-// under the previous step's MFMAs.
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256) void gemm1w_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int OPB = 256 * 128, STG = 2 * OPB;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int id;
-  {
-    const int L = (int)blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = L & 7, j = L >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = g.K / BK;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // The LDS reads are asm (invisible to the waitcnt pass) and the hardware fills their registers later, so no compiler-made copy
-  // of a result may run before the wait that covers it: results stay in the registers the instructions name until LT_WAIT (the two
-  // halves of a transposing read are assembled into one 128-bit fragment AFTER it), and no read sits under a branch (see ks 3).
-  bf16x8 qa[2][4], qb[2][4];   // ds_read_b128 results (K-contiguous operands: A always, B of a forward GEMM)
-  s16x4 rb[2][4][2];           // ds_read_b64_tr_b16 halves (B of a dgrad GEMM)
-  bf16x8 fb[4];
-  typedef __attribute__((address_space(3))) void lptr1_t;
-#define LT_DMA_A(T) stage_dma<TA, 256, 4>(smem + ((T) & 1) * STG, g.A, g.lda, g.M, m0, (T) * BK)
-#define LT_DMA_B(T) stage_dma<TB, 256, 4>(smem + ((T) & 1) * STG + OPB, g.B, g.ldb, g.N, n0, (T) * BK)
-  auto read_rows = [&](const char* img, int rblk, int ks, bf16x8& v) {
-    const int row = rblk * 32 + (l & 31), c = ks * 2 + (l >> 5);
-    const unsigned a0 = (unsigned)(uintptr_t)(lptr1_t*)(img + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a0));
-  };
-  auto read_tr = [&](const char* img, int rblk, int ks, s16x4& lo, s16x4& hi) {
-    constexpr int NB = 16;
-    const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
-    const int b = rblk * 2 + cb;
-    const int inner = ((((i >> 2) + b) & 3) << 5) + ((i & 3) << 3);
-    const int q0 = ks * 4 + kh * 2;
-    const unsigned a0 = (unsigned)(uintptr_t)(lptr1_t*)(img + (q0 * NB + b) * 128 + inner);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(NB * 128));
-  };
-#define LT_READ(BUF, T, KS)                                                                                                 \
-  do {                                                                                                                      \
-    const char* st_ = smem + ((T) & 1) * STG;                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) read_rows(st_, wm * 4 + i_, KS, qa[BUF][i_]);                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                       \
-      if (TB) read_tr(st_ + OPB, wn * 4 + j_, KS, rb[BUF][j_][0], rb[BUF][j_][1]);                                          \
-      else read_rows(st_ + OPB, wn * 4 + j_, KS, qb[BUF][j_]);                                                               \
-    }                                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0); /* requests first, then the MFMAs that cover their latency */                        \
-  } while (0)
-// wait for the raw results of one buffer (tied to the registers: nothing that uses them can be scheduled in front), then assemble
-#define LT_WAIT(BUF)                                                                                                                     \
-  do {                                                                                                                                   \
-    if (TB) {                                                                                                                            \
-      asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                \
-                   : "+v"(qa[BUF][0]), "+v"(qa[BUF][1]), "+v"(qa[BUF][2]), "+v"(qa[BUF][3]), "+v"(rb[BUF][0][0]), "+v"(rb[BUF][0][1]),       \
-                     "+v"(rb[BUF][1][0]), "+v"(rb[BUF][1][1]), "+v"(rb[BUF][2][0]), "+v"(rb[BUF][2][1]), "+v"(rb[BUF][3][0]), "+v"(rb[BUF][3][1])); \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                                 \
-        union { struct { s16x4 a, b; } s; bf16x8 v; } ub_;                                                                               \
-        ub_.s.a = rb[BUF][j_][0]; ub_.s.b = rb[BUF][j_][1]; fb[j_] = ub_.v;                                                              \
-      }                                                                                                                                  \
-    } else {                                                                                                                             \
-      asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                \
-                   : "+v"(qa[BUF][0]), "+v"(qa[BUF][1]), "+v"(qa[BUF][2]), "+v"(qa[BUF][3]), "+v"(qb[BUF][0]), "+v"(qb[BUF][1]),             \
-                     "+v"(qb[BUF][2]), "+v"(qb[BUF][3]));                                                                                \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) fb[j_] = qb[BUF][j_];                                                             \
-    }                                                                                                                                    \
-  } while (0)
-#define LT_MFMAS(BUF)                                                                                             \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                              \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                            \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[BUF][i_], fb[j_], acc[i_][j_], 0, 0, 0);         \
-    __builtin_amdgcn_sched_barrier(0); /* the next step's wait must not be hoisted above these MFMAs (it has no data dependence on them) */ \
-  } while (0)
-
-#define LT_BARRIER()                  \
-  do {                                \
-    asm volatile("" ::: "memory");    \
-    __builtin_amdgcn_s_barrier();     \
-    asm volatile("" ::: "memory");    \
-  } while (0)
-  LT_DMA_A(0); LT_DMA_B(0);
-  if (nk > 1) { LT_DMA_A(1); __builtin_amdgcn_s_waitcnt(0xF78); }   // vmcnt(8): tile 0 landed (LDS-DMA returns in issue order)
-  else __builtin_amdgcn_s_waitcnt(0xF70);
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  LT_BARRIER();
-  LT_READ(0, 0, 0);
-  for (int t = 0; t < nk; ++t) {
-    // ---- ks 0
-    LT_WAIT(0);
-    LT_READ(1, t, 1);
-    if (t + 1 < nk) LT_DMA_B(t + 1);
-    LT_MFMAS(0);
-    // ---- ks 1
-    LT_WAIT(1);
-    LT_READ(0, t, 2);
-    LT_MFMAS(1);
-    // ---- ks 2
-    LT_WAIT(0);
-    LT_READ(1, t, 3);
-    LT_MFMAS(0);
-    LT_WAIT(1);                          // my last reads of this stage are complete
-    __builtin_amdgcn_s_waitcnt(0xF70);   // vmcnt(0): my pieces of tile t+1
-    LT_BARRIER();
-    // ---- ks 3
-    LT_READ(0, t + 1, 0);   // unconditional (after the last tile: unused bytes of the other stage).  Under a branch the asm
-    // results meet the loop-carried values in phi nodes, and a phi copy placed behind the reads moves registers the LDS has not
-    // written yet: the first fragments of every tile but the first came back with half their k-slots stale
-    if (t + 2 < nk) LT_DMA_A(t + 2);
-    LT_MFMAS(1);
-  }
-#undef LT_BARRIER
-#undef LT_DMA_A
-#undef LT_DMA_B
-#undef LT_READ
-#undef LT_WAIT
-#undef LT_MFMAS
-  __syncthreads();
-  // epilogue: the wave tile as four 64 x 64 quadrants through the wave's private 16 KiB of LDS
-  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-    for (int qj = 0; qj < 2; ++qj) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[qi * 2 + ii][qj * 2 + j][e];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      emit_subtile<EPI>(g, wl, m0 + wm * 128 + qi * 64, n0 + wn * 128 + qj * 64, l, false);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-}
-
 #ifdef LT_GEMM_TIMING
 extern "C" int lt_debug_gemm_timing(void* host_dst, int64_t n_u64, int clear) {
   hipDeviceSynchronize();
@@ -1028,29 +869,6 @@ extern "C" int lt_debug_gemm_timing(void* host_dst, int64_t n_u64, int clear) {
   return LT_OK;
 }
 #endif
-
-template <bool TA, bool TB, int EPI>
-int launch_1w_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1w_kernel<TA, TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm1w_kernel<TA, TB, EPI>), grid, dim3(256), LDS_BYTES, st, g);
-  return LT_OK;
-}
-template <bool TA, bool TB>
-int launch_1w(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
-  switch (epi) {
-    case EPI_BF16: return launch_1w_one<TA, TB, EPI_BF16>(g, grid, st);
-    case EPI_BF16_GELU: return launch_1w_one<TA, TB, EPI_BF16_GELU>(g, grid, st);
-    case EPI_RESID: return launch_1w_one<TA, TB, EPI_RESID>(g, grid, st);
-    case EPI_F32: return launch_1w_one<TA, TB, EPI_F32>(g, grid, st);
-    case EPI_BF16_GELUGRAD: return launch_1w_one<TA, TB, EPI_BF16_GELUGRAD>(g, grid, st);
-    default: lt_set_error("lt_gemm_bf16: the one-wave-per-SIMD kernel has no epilogue %d", epi); return LT_ERR_INVALID;
-  }
-}
 
 template <bool TA, bool TB, int EPI, bool SLAB, bool KT = false, bool CS = false>
 int launch_q_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
@@ -1253,23 +1071,9 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   const int wgrad_min_k = env_wk ? atoi(env_wk) : 4096;   // 8192 -> 4096: ResNet-50 distillation step 43.4 -> 42.5 ms
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= (ktail ? 256 : 128) &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= wgrad_min_k && d->M >= wgrad_min_m));
-  if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 9) {
+  if (d->force_kernel == 2 || d->force_kernel == 8) {
     LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
-  }
-  // ---- persistent 192 x 256 kernel with the epilogue under the next tile's K-loop (gemm_p.hip).  force_kernel 10, or LT_GEMM_1P (read
-  // per call: tools/ab_step.py flips it between steps), a bit mask over the eligible forward / dgrad GEMMs of >= 2048 rows: 1 = those
-  // with N >= 1024 (qkv, fc1, the GELU' dgrad), 2 = the narrower ones (proj, fc2 and their dgrads)
-  {
-    const char* env_1p = getenv("LT_GEMM_1P");
-    const int use_1p = env_1p ? atoi(env_1p) : 0;
-    const bool elig = batch == 1 && gemm1p_eligible(g, d->epilogue, d->trans_a != 0);
-    if (d->force_kernel == 10) LT_CHECK_ARG(elig, "lt_gemm_bf16: shape / layout / epilogue not served by the persistent kernel (force_kernel 10)");
-    if (elig && (d->force_kernel == 10 || ((use_1p & (d->N >= 1024 ? 1 : 2)) && d->force_kernel == 0 && d->M >= 2048))) {
-      rc = gemm1p_launch(g, d->epilogue, d->trans_b != 0, st);
-      if (rc != LT_OK) return rc;
-      LT_CHECK_LAUNCH("lt_gemm_bf16");
-    }
   }
   if (big && ktail) {
     LT_CHECK_ARG(d->N >= 256 || d->force_kernel == 8, "lt_gemm_bf16: partial K-tile needs the 256-wide kernel");
@@ -1277,20 +1081,6 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     g.k_per_split = lt_cdiv(d->K, BK) * BK;
     dim3 gridk(g.tiles_m * g.tiles_n, 1);
     rc = d->trans_b ? g256::launch_q_ktail<true>(g, d->epilogue, gridk, st) : g256::launch_q_ktail<false>(g, d->epilogue, gridk, st);
-    if (rc != LT_OK) return rc;
-    LT_CHECK_LAUNCH("lt_gemm_bf16");
-  }
-  // LT_GEMM_1W (read per call: tools/ab_step.py flips it between steps): 1 = the one-wave-per-SIMD kernel for every eligible
-  // forward / dgrad GEMM, 2 = for the K-contiguous (forward) layouts only
-  const char* env_1w = getenv("LT_GEMM_1W");
-  const int use_1w = env_1w ? atoi(env_1w) : 0;
-  const bool auto_1w = use_1w && big && d->force_kernel == 0 && !d->trans_a && d->epilogue != LT_EPI_F32_ACCUM && d->N >= 256 &&
-                       (use_1w == 1 || !d->trans_b);
-  if (d->force_kernel == 9 || auto_1w) {
-    LT_CHECK_ARG(!d->trans_a && d->epilogue != LT_EPI_F32_ACCUM, "lt_gemm_bf16: force_kernel 9 serves forward / dgrad layouts only");
-    g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 256);
-    dim3 grid9(g.tiles_m * g.tiles_n);
-    rc = d->trans_b ? g256::launch_1w<false, true>(g, d->epilogue, grid9, st) : g256::launch_1w<false, false>(g, d->epilogue, grid9, st);
     if (rc != LT_OK) return rc;
     LT_CHECK_LAUNCH("lt_gemm_bf16");
   }

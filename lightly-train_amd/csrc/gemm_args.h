@@ -1,4 +1,4 @@
-// Argument block shared by the MFMA GEMM kernels (gemm.hip: 128^2 / 256^2 tiles; gemm_p.hip: the persistent 192 x 256 kernel).
+// Argument block of the MFMA GEMM kernels (gemm.hip: 128^2 / 256^2 tiles).
 #pragma once
 #include "lt_common.h"
 
@@ -29,10 +29,5 @@ struct GemmArgs {
   float* cs;        // four-phase slab kernel with CS: per-(slice, column tile, wave column) partial sums over k of the transposed A operand,
                     // [gridDim.y * tiles_n * 4][M] floats (the bias gradient of the Linear whose weight gradient this GEMM forms)
 };
-
-// gemm_p.hip: persistent kernel with the epilogue drained under the next tile's K-loop (forward / dgrad layouts, bf16-rounded branch
-// outputs: EPI_BF16, EPI_BF16_GELU, EPI_RESID without C2, EPI_BF16_GELUGRAD).  Returns LT_OK or an error code.
-bool gemm1p_eligible(const GemmArgs& g, int epi, bool trans_a);
-int gemm1p_launch(const GemmArgs& g, int epi, bool trans_b, hipStream_t st);
 
 }  // namespace lt_gemm
