@@ -27,7 +27,7 @@ from .masking import MaskingGenerator, MaskProducer, create_collated_masks
 from .parallel import GradSync
 from .params import FlatParams
 from .schedules import cosine_schedule, linear_warmup_schedule, warmup_cosine_lr_factor
-from .vit import ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, make_drop_plan, padded_rows, split_k_plan, vit_param_shapes
+from .vit import JointWgrad, ViTConfig, ViTEngine, Workspace, _split_k, init_vit_state, make_drop_plan, padded_rows, split_k_plan, vit_param_shapes
 
 
 @dataclass
@@ -450,6 +450,10 @@ class DINOv2:
         # step is bitwise reproducible; LT_DETERMINISTIC=0 goes back to atomics
         self.deterministic = os.environ.get("LT_DETERMINISTIC", "1") != "0"
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
+        # one weight-gradient GEMM per layer for the global- and the local-crop pass (vit.JointWgrad): half the split-K slab traffic
+        self.joint_wgrad = int(os.environ.get("LT_JOINT_WGRAD", "1") != "0")
+        self._joint: Optional[JointWgrad] = None
+        self._joint_active: Optional[JointWgrad] = None
         # the last block's MLP branch, forward and backward, only at the token rows the losses read (cls + masked patches): vit.forward
         self.sparse_last_mlp = os.environ.get("LT_SPARSE_LAST_MLP", "1") != "0"
         # softmax centering without the [rows, K] probability matrix (training_step_impl); LT_FUSED_CENTERING=0: softmax, column sums and
@@ -660,7 +664,9 @@ class DINOv2:
             # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
             lstream2 = self.local_bwd_stream
             lstream2.wait_event(main.record_event())
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side)), (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side))]
+            jw = self._joint_active
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, joint=jw)),
+                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, joint=jw))]
             live = [True, True]
             blk = self.cfg.depth
             while any(live):
@@ -668,6 +674,8 @@ class DINOv2:
                     if live[ci]:
                         with torch.cuda.stream(st):
                             live[ci] = next(gen) != "tail"
+                if jw is not None:
+                    jw.flush()       # a layer only one of the passes ran on all rows
                 blk -= 1
                 if blk >= 0:
                     reduce_block(blk, (lstream2, main, side))
@@ -825,6 +833,15 @@ class DINOv2:
             plan_g = make_drop_plan(cfg, n_crops, self._drop_gen)
         if plan_l is None and lv is not None:
             plan_l = make_drop_plan(cfg, lv.shape[0], self._drop_gen)
+        # joint weight gradients of the two passes: their GEMM operands live side by side (seeded into the workspace before either pass asks)
+        self._joint_active = None
+        if (self.joint_wgrad and lv is not None and self.side_stream is not None and self.overlap_streams and self.local_bwd_stream is not None
+                and self.two_bwd_chains and not self.activation_checkpointing):
+            if self._joint is None:
+                self._joint = JointWgrad(ws, self.side_stream, ("sg", "sl"))
+            hid = cfg.hidden
+            if self._joint.seed(cfg.depth, (n_crops * Ng, lv.shape[0] * Nl), D, hid, 2 * hid if cfg.swiglu else hid):
+                self._joint_active = self._joint
         # local-crop forward on the side stream, concurrent with the global-crop forward (disjoint activation buffers)
         lstream = self.side_stream if (self.side_stream is not None and self.overlap_streams and lv is not None) else None
         sl = None

@@ -222,6 +222,89 @@ def _split_k(tiles: int, k: int, slots: int = 512) -> int:
     return best
 
 
+class JointWgrad:
+    """One weight-gradient GEMM for two backward passes that share the weights (the global- and the local-crop pass of the student).
+
+    Both passes contract their own rows of dY with their own rows of X into the same gradient; run as two GEMMs, each writes and re-reads
+    its own fp32 split-K slabs.  With the operands of the two passes ADJACENT in memory the pair is one contraction over T_a + T_b rows:
+    half the slab traffic and half the launches.  `seed` places the operand buffers of both passes in joint allocations under the
+    workspace names the passes ask for; `deposit` is called by each pass's `backward_iter` where it would have launched its own GEMM,
+    and the second deposit of a pair launches the joint one on `side`.  A deposited buffer may be overwritten only after that launch:
+    `backward_iter` rotates its upstream-gradient buffers so that this happens one block later (when both passes have deposited)."""
+
+    X_NAMES = (("ln1", 1), ("att", 1), ("ln2", 1), ("act", 0))   # saved operands per block: (name, width = D (1) | hidden (0))
+
+    def __init__(self, ws: Workspace, side: "torch.cuda.Stream", tags: Tuple[str, str]) -> None:
+        self.ws, self.side, self.tags = ws, side, tags
+        self.joint: Dict[int, Tensor] = {}      # data_ptr of the first pass's view -> (joint tensor, rows of the first, rows of the second)
+        self.pending: Dict[str, Dict[str, Any]] = {}
+        self.key: Optional[Tuple[Any, ...]] = None
+        self.launched = 0
+
+    def seed(self, depth: int, T: Tuple[int, int], D: int, hid: int, hid1: int) -> bool:
+        """Joint allocations for the operands of both passes (row counts `T`, both multiples of 64).  Idempotent per geometry."""
+        key = (depth, T, D, hid, hid1)
+        if self.key == key:
+            return True
+        if T[0] % 64 or T[1] % 64:
+            return False
+        self.joint.clear()
+        ta, tb = self.tags
+        dev = self.ws.device
+
+        def place(name_a: str, name_b: str, width: int) -> None:
+            j = torch.empty((T[0] + T[1], width), dtype=torch.bfloat16, device=dev)
+            self.ws.bufs[name_a], self.ws.bufs[name_b] = j[:T[0]], j[T[0]:]
+            self.joint[j.data_ptr()] = j
+
+        for i in range(depth):
+            for n, is_d in self.X_NAMES:
+                place(f"{ta}.b{i}.{n}", f"{tb}.b{i}.{n}", D if is_d else hid)
+        for n, width in (("dD0", D), ("dD1", D), ("dD2r", D), ("dD3r", D), ("dH", hid1), ("dQ", 3 * D)):
+            place(f"{ta}.{n}", f"{tb}.{n}", width)
+        self.key, self.T = key, T
+        return True
+
+    def deposit(self, tag: str, wname: str, dy: Tensor, xin: Tensor, rows: int, run, consumed: Dict[int, Any]) -> None:
+        """`run(dy, xin, K)` launches the accumulating GEMM (on the current stream); `consumed` is the depositing pass's map of
+        buffer -> event after which the side stream no longer reads it."""
+        main = torch.cuda.current_stream()
+        me = dict(tag=tag, dy=dy, xin=xin, rows=rows, run=run, consumed=consumed, ev=main.record_event())
+        other = self.pending.pop(wname, None)
+        if other is None:
+            self.pending[wname] = me
+            consumed[dy.data_ptr()] = wname    # placeholder: `before_write` forces the launch if the partner has not deposited by then
+            return
+        a, b = (me, other) if me["tag"] == self.tags[0] else (other, me)
+        jy, jx = self.joint.get(a["dy"].data_ptr()), self.joint.get(a["xin"].data_ptr())
+        adjacent = (jy is not None and jx is not None and a["rows"] == self.T[0] and b["rows"] == self.T[1]
+                    and b["dy"].data_ptr() == jy.data_ptr() + self.T[0] * jy.shape[1] * 2
+                    and b["xin"].data_ptr() == jx.data_ptr() + self.T[0] * jx.shape[1] * 2)
+        self.side.wait_event(a["ev"])
+        self.side.wait_event(b["ev"])
+        with torch.cuda.stream(self.side):
+            if adjacent:
+                me["run"](jy, jx, self.T[0] + self.T[1])
+                self.launched += 1
+            else:
+                a["run"](a["dy"], a["xin"], a["rows"])
+                b["run"](b["dy"], b["xin"], b["rows"])
+            ev = self.side.record_event()
+        a["consumed"][a["dy"].data_ptr()] = ev
+        b["consumed"][b["dy"].data_ptr()] = ev
+
+    def flush(self, only: Optional[str] = None) -> None:
+        """Deposits whose partner never came (a pass that ran this layer on a row subset): launched on their own."""
+        for wname, d in list(self.pending.items()):
+            if only is not None and wname != only:
+                continue
+            self.side.wait_event(d["ev"])
+            with torch.cuda.stream(self.side):
+                d["run"](d["dy"], d["xin"], d["rows"])
+                d["consumed"][d["dy"].data_ptr()] = self.side.record_event()
+            del self.pending[wname]
+
+
 class ViTEngine:
     """Runs one backbone (student or teacher) whose parameters live in a FlatParams under `prefix`."""
 
@@ -581,7 +664,8 @@ class ViTEngine:
                     ops.layerscale_dgamma(self.wb(lin + ".weight"), self.gw(lin + ".weight"), self.w(lin + ".bias"), self.gw(lin + ".bias"),
                                           self.w(gname), self.gw(gname), D, k_in)
 
-    def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Iterator[str]:
+    def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None,
+                      joint: Optional[JointWgrad] = None) -> Iterator[str]:
         """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
 
         Generator: yields "block" after enqueuing each transformer block and "tail" before the token-assembly /
@@ -592,15 +676,25 @@ class ViTEngine:
         `side`: optional second HIP stream for the weight-gradient GEMMs and bias column sums.  They depend only on
         tensors the main (dgrad) chain has already produced and feed nothing but the optimizer, so running them beside
         the dgrad chain fills the CUs the 591-tile dgrad GEMMs leave idle in their last wave.  The caller must make the
-        optimizer wait for `side`."""
+        optimizer wait for `side`.
+
+        `joint`: full-row weight gradients are deposited there instead of launched (`JointWgrad`); the upstream-gradient buffers then
+        rotate through four allocations instead of two and the qkv data gradient gets a buffer of its own, so that no deposited
+        operand is overwritten within the block iteration that deposited it."""
         cfg = self.cfg
         B, N, n_p, T, tag = ctx["B"], ctx["N"], ctx["n_p"], ctx["T"], ctx["tag"]
         D, Hh, dh, hid = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
         scale = dh ** -0.5
         dxa = ws.get(tag + ".dxa", (T, D), torch.float32)
         dxb = ws.get(tag + ".dxb", (T, D), torch.float32)
-        dDs = [ws.get(tag + ".dD", (T, D), torch.bfloat16, pad_rows=64), ws.get(tag + ".dDb", (T, D), torch.bfloat16, pad_rows=64)]  # upstream grads of
-        # consecutive branches alternate between two buffers: the LayerNorm backward of one branch writes the next one's
+        if joint is None:
+            dDs = [ws.get(tag + ".dD", (T, D), torch.bfloat16, pad_rows=64), ws.get(tag + ".dDb", (T, D), torch.bfloat16, pad_rows=64)]  # upstream grads of
+            # consecutive branches alternate between two buffers: the LayerNorm backward of one branch writes the next one's
+            dD3 = None
+        else:
+            dDs = [ws.get(tag + n, (T, D), torch.bfloat16, pad_rows=64) for n in (".dD0", ".dD1", ".dD2r", ".dD3r")]
+            dD3 = ws.get(tag + ".dD3", (T, D), torch.bfloat16, pad_rows=64)   # qkv data gradient (not a weight-gradient operand)
+        nring = len(dDs)
         dD2 = ws.get(tag + ".dD2", (T, D), torch.bfloat16, pad_rows=64)
         dH = ws.get(tag + ".dH", (T, 2 * hid if cfg.swiglu else hid), torch.bfloat16, pad_rows=64)
         dAct = ws.get(tag + ".dAct", (T, hid), torch.bfloat16, pad_rows=64) if cfg.swiglu else None
@@ -636,6 +730,9 @@ class ViTEngine:
 
         def before_write(buf: Tensor) -> None:
             ev = consumed.pop(buf.data_ptr(), None)
+            if isinstance(ev, str):     # a joint deposit still waiting for the other pass: launch it alone
+                joint.flush(only=ev)
+                ev = consumed.pop(buf.data_ptr(), None)
             if ev is not None:
                 main.wait_event(ev)
 
@@ -650,14 +747,17 @@ class ViTEngine:
             else:
                 kpad = rows
 
-            def run() -> None:
+            def run(dy_: Tensor = dy, xin_: Tensor = xin, k_: int = kpad) -> None:
                 # the bias gradient (column sums of dy) rides the weight-gradient GEMM, which holds dy's fragments anyway (pad rows are zero)
-                ops.gemm(dy, xin, self.gw(wname), M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
+                ops.gemm(dy_, xin_, self.gw(wname), M=n_out, N=k_in, K=k_, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM,
                          lda=n_out, ldb=k_in, ldc=k_in, workspace=slab, colsum=self.gw(bias) if bias is not None else None,
-                         **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
+                         **split_k_plan(n_out, k_in, k_, True, _split_k(tiles, k_)))
 
             if side is None:
                 run()
+                return
+            if joint is not None and rows == T and kpad == rows:
+                joint.deposit(tag, wname, dy, xin, rows, run, consumed)
                 return
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
@@ -706,13 +806,13 @@ class ViTEngine:
                 ops.scatter_add_rows(lng, m["idx"], dx, D, R2, D)   # dx += LN'(.) on the subset rows; identity path untouched
                 have = False
             else:
-                before_write(dDs[cur ^ 1])
-                nxt = fuse_args(a, pre + "ls1.gamma", pre + "attn.proj.bias", dDs[cur ^ 1])
+                before_write(dDs[(cur + 1) % nring])
+                nxt = fuse_args(a, pre + "ls1.gamma", pre + "attn.proj.bias", dDs[(cur + 1) % nring])
                 ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, dx, other,
                                   self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), T, D, **nxt)
                 dx, other = other, dx
                 have = bool(nxt)
-            cur ^= 1
+            cur = (cur + 1) % nring
             # ---- attention branch: xm = x + scale * g1 * proj(attn(qkv(ln1(rows))))
             R1, nb = a["rows"], a["nb"]
             dD = dDs[cur]
@@ -742,11 +842,12 @@ class ViTEngine:
             if ctx.get("rope") is not None:   # gradients w.r.t. the un-rotated q / k: transposed rotation
                 ops.rope_apply(dQ, ctx["rope"][i][0], ctx["rope"][i][1], nb, N, Hh, dh, 1 + cfg.num_register_tokens, inverse=True)
             wgrad(dQ, a["ln"], pre + "attn.qkv.weight", 3 * D, D, R1, bias=pre + "attn.qkv.bias")
-            before_write(dD)
-            ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dD, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
+            dX = dD if dD3 is None else dD3   # d(ln1 output): in place of the branch's upstream gradient, or its own buffer under `joint`
+            before_write(dX)
+            ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dX, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
             if a["mode"] == "subset":
                 lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R1]
-                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, None, lng,
+                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dX, None, lng,
                                   self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), R1, D)
                 ops.scatter_add_rows(lng, a["idx"], dx, D, R1, D)
                 have = False
@@ -754,13 +855,13 @@ class ViTEngine:
                 nxt = {}
                 if i > 0:
                     pp = f"blocks.{i - 1}."
-                    before_write(dDs[cur ^ 1])
-                    nxt = fuse_args(None if ckpt else blocks_ctx[i - 1]["mlp"], pp + "ls2.gamma", pp + fc2n + ".bias", dDs[cur ^ 1])
-                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dD, dx, other,
+                    before_write(dDs[(cur + 1) % nring])
+                    nxt = fuse_args(None if ckpt else blocks_ctx[i - 1]["mlp"], pp + "ls2.gamma", pp + fc2n + ".bias", dDs[(cur + 1) % nring])
+                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dX, dx, other,
                                   self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), T, D, **nxt)
                 dx, other = other, dx
                 have = bool(nxt)
-            cur ^= 1
+            cur = (cur + 1) % nring
             yield "block"
 
         yield "tail"
