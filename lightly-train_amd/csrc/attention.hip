@@ -261,11 +261,14 @@ __device__ __forceinline__ void fwd_tile(const char* ldsK, const char* ldsV, int
   }
 }
 
-// The same tile step with the softmax in base 2 on the RAW scores: the scale rides the exponent's FMA (exp2(s * c - m * c), c = scale *
-// log2 e: one v_fma + one v_exp per element where fwd_tile spends a scale multiply, a subtraction and __expf's own multiply), and only a
-// tile that reaches past the last key pays the compare + select per element.  `m` is the running maximum of the raw scores; the
-// kernels turn it into the natural-log lse at the end (m * scale + ln(lsum)).  The forward kernels are VALU-bound (7 key tiles x 16
-// elements per lane against 8 MFMAs per tile): this is ~30 % fewer VALU slots per tile.
+// The same tile step with the softmax in base 2 on the RAW scores (the forward kernels are VALU-bound: 7 key tiles x 16 elements per lane
+// against 8 MFMAs per tile).  (1) The scale rides the exponent's FMA: exp2(s * c - m * c), c = scale * log2 e; only a tile that reaches
+// past the last key pays the compare + select per element.  (2) A LAZY running maximum: the exponent's reference `m` (raw-score units)
+// moves only when a tile's row maximum exceeds it by more than 8 octaves (first tile: from -inf), so that on the later tiles the 32
+// accumulator multiplies, the alpha exponential and the lsum rescale are skipped by a wave-uniform branch (probabilities stay <= 2^8:
+// exact in fp32, the same relative precision in bf16; O / lsum and lse = m * scale + ln(lsum) do not depend on which reference was
+// used).  (3) The scale-subtract and the row sum run on fp32 pairs (v_pk_fma_f32 / v_pk_add_f32).  ~110 VALU issue slots per tile against
+// ~190 for fwd_tile: N = 197 forward 97 -> 79 us (profiles/r04_attn_fwd_b2.log).
 __device__ __forceinline__ void fwd_tile2(const char* ldsK, const char* ldsV, int tt, int key0, int N, float c, const bf16x8 (&qf)[4],
                                           float& m, float& lsum, f32x16 (&o)[2], int hi) {
   f32x16 s;
@@ -273,7 +276,7 @@ __device__ __forceinline__ void fwd_tile2(const char* ldsK, const char* ldsV, in
   for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsK, tt, ks), qf[ks], s, 0, 0, 0);
-  if (key0 + 32 > N) {   // wave-uniform: only the tile that reaches past the last key masks its elements
+  if (key0 + 32 > N) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = (key0 + crow(e, hi) < N) ? s[e] : -INFINITY;
   }
@@ -281,17 +284,29 @@ __device__ __forceinline__ void fwd_tile2(const char* ldsK, const char* ldsV, in
 #pragma unroll
   for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float mnew = fmaxf(m, mx);                       // finite: every tile holds at least one valid key
-  const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);   // m = -inf on the first tile: exp2(-inf) = 0
-  const float mc = mnew * c;
-  float rs = 0.f;
+  const bool grow = (mx - m) * c > 8.f;                  // per query (both half-wave partners agree); true on the first tile
+  if (__builtin_amdgcn_ballot_w64(grow) != 0) {          // wave-uniform: some query of this tile moves its reference
+    const float mnew = grow ? mx : m;
+    const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);   // 1 for the queries that keep theirs, 0 on the first tile
+    lsum *= alpha;
+    m = mnew;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c, -mc)); rs += s[e]; }
+    for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+  }
+  const f32x2 cc = {c, c}, nmc = {-m * c, -m * c};
+  f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) {
+    f32x2 v = {s[e], s[e + 1]};
+    v = v * cc + nmc;
+    v[0] = __builtin_amdgcn_exp2f(v[0]);
+    v[1] = __builtin_amdgcn_exp2f(v[1]);
+    rs2 += v;
+    s[e] = v[0]; s[e + 1] = v[1];
+  }
+  float rs = rs2[0] + rs2[1];
   rs += __shfl_xor(rs, 32, 64);
-  lsum = lsum * alpha + rs;
-  m = mnew;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+  lsum += rs;
   const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
 #pragma unroll
   for (int db = 0; db < 2; ++db) {
@@ -1158,8 +1173,8 @@ extern "C" int lt_attention_fwd(const void* qkv, void* out_bf16, float* lse, int
   if (dh == DH) {
     LT_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out_bf16 & 15) == 0, "lt_attention_fwd: 16-byte alignment required");
     static const int variant = [] { const char* e = getenv("LT_ATTN_FWD"); return e ? atoi(e) : 1; }();
-    // LT_ATTN_FWD_B2 (read per call: tools/ab_step.py, tools/attn_bench.py): 1 = the base-2 tile step without per-element masking on full
-    // key tiles (fwd_tile2), 0 = the natural-exponent tile step
+    // LT_ATTN_FWD_B2 (read per call: tools/ab_step.py, tools/attn_bench.py): 1 = the base-2 tile step with the lazy running maximum and
+    // paired fp32 math (fwd_tile2), 0 = the natural-exponent tile step
     const char* env_b2 = getenv("LT_ATTN_FWD_B2");
     const bool b2 = env_b2 ? atoi(env_b2) != 0 : true;
     if (variant && N <= 64 && H % 2 == 0) {          // two heads per block
