@@ -10,7 +10,8 @@ names = {"bench_default_full.log": f"{tag}_bench_default.json.log", "kernel_stat
          "kernel_stats_multi.md": f"{tag}_kernel_stats_multi.md", "pmc_step_report.md": f"{tag}_pmc_step_report.md", "gemm_traffic.txt": f"{tag}_gemm_traffic.txt",
          "gemm_timeline.txt": f"{tag}_gemm_timeline.txt", "bench_vits.log": f"{tag}_bench_vit_small.json.log", "cfg5.log": f"{tag}_cfg5_run.log",
          "bench_cfg4_resnet50.log": f"{tag}_bench_distillationv3_resnet50.json.log", "bench_gloo2.log": f"{tag}_bench_gloo2_one_gpu.json.log",
-         "gpu_tests_tail.log": f"{tag}_gpu_tests_tail.log"}
+         "gpu_tests_tail.log": f"{tag}_gpu_tests_tail.log", "step_timeline.txt": f"{tag}_step_timeline.txt", "kernel_stats_vits.md": f"{tag}_kernel_stats_vits.md",
+         "bench_default_b.log": f"{tag}_bench_default_b.json.log", "bench_default_c.log": f"{tag}_bench_default_c.json.log"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):
