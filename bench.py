@@ -26,6 +26,8 @@ import time
 # 32 MiB doubles the reach to ~14 steps, so a scheduler hiccup of the launch thread (100-300 ms on shared hosts) is absorbed by queued work
 # instead of idling the GPU.  Must be set before the runtime initialises; an explicit setting of the caller wins.
 os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(32 << 20))
+# one hardware queue per HIP stream of the step (the package sets the same default on import; see lightly-train_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 

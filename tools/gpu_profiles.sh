@@ -33,7 +33,7 @@ $B --steps 10 --warmup 3 --method distillationv3 --student resnet50 > $O/bench_c
 # the N > 1 code path on this 1-GPU box: two ranks folded onto cuda:0 over gloo (RCCL refuses two ranks per device); the line's `comm`
 # object carries the exposed all-reduce time per step -- a baseline to read the first real multi-GPU run against, not a scaling number
 LT_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --batch 32 > $O/bench_gloo2.log 2>&1
-timeout 1500 python -m pytest tests/ -q -m gpu > $O/gpu_tests_full.log 2>&1; tail -4 $O/gpu_tests_full.log > $O/gpu_tests_tail.log
+timeout 1500 python -m pytest tests/ -q -m gpu > $O/gpu_tests_full.log 2>&1; grep -E "passed|failed" $O/gpu_tests_full.log | tail -1 > $O/gpu_tests_tail.log
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_b.log 2>&1
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_c.log 2>&1
 rm -rf $O/ks_* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA
