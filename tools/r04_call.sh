@@ -1,8 +1,16 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r04z}
+O=$R/gpurun_out/${1:-r04aa}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-python tools/ab_lib.py lightly-train_amd/lib/liblt_amd_old.so --steps 15 > $O/ab_lib_old.log 2>&1; tail -3 $O/ab_lib_old.log
-python tools/ab_step.py joint_wgrad 0 1 --attr --steps 10 > $O/ab_joint.log 2>&1; tail -2 $O/ab_joint.log
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_distill.py -x -q -m gpu -k "batchnorm or bn or resnet" > $O/bn_tests.log 2>&1; tail -2 $O/bn_tests.log
+B="python $R/bench.py --no-cpu-baseline --no-roofline --method distillationv3 --student resnet50"
+$B --steps 10 --warmup 3 > $O/bench_cfg4_a.log 2>&1; tail -1 $O/bench_cfg4_a.log | cut -c100-230
+$B --steps 10 --warmup 3 > $O/bench_cfg4_b.log 2>&1; tail -1 $O/bench_cfg4_b.log | cut -c100-230
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/ks -o ks -- $B --steps 3 --warmup 1 --single-stream > $O/bench_cfg4_single.log 2>&1
+cd $R
+python tools/rocprof_summary.py $(find $O/ks -name "*.db" | head -1) 40 > $O/kernel_stats_cfg4.md 2>&1
+rm -rf $O/ks
+grep -E "bn_|total kernel" $O/kernel_stats_cfg4.md
