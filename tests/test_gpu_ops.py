@@ -54,14 +54,14 @@ def test_gemm_layouts(M, N, K, ta, tb):
     assert rel_err(out, ref) < 1e-5, f"mfma gemm mismatch ta={ta} tb={tb}"
 
 
-@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8, 9)] +
-                         # automatic dispatch on ViT-S widths: N = 256 m + r, r <= 128 => 256-wide kernel + 128-wide kernel on the last columns
+@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8)] +
+                         # automatic dispatch on ViT-S widths (N = 256 m + r: the last column tile is partly padding)
                          [(2309, 384, 384, 0), (4096, 1152, 384, 0), (2048, 328, 1536, 0), (2100, 640, 128, 0)] +
                          # K not a multiple of 64 (SwiGLU widths 2736 / 5472 and small cases): the partial last K-tile of the four-phase kernel
                          [(2100, 1024, 2736, 0), (2048, 512, 5472, 0), (2300, 256, 72, 0), (2048, 304, 200, 8), (2500, 768, 136, 8)])
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_256_kernel(M, N, K, tb, fk):
-    """the 256x256 LDS-DMA kernel (forced, or dispatched with its column split) against the fp32 reference, incl. M/N tails and every
+    """the 256x256 LDS-DMA kernel (forced, or dispatched) against the fp32 reference, incl. M/N tails and every
     epilogue it serves."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
