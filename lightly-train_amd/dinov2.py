@@ -271,12 +271,18 @@ class HeadEngine:
         ops.gemm(zn, self.wn, logits, M=R, N=K, K=bn, epilogue=ops.EPI_F32)
         return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, zn=zn, inv=inv, logits=logits, R=R, cap=cap, tag=tag, bn=bnc, segs=segs)
 
-    def backward(self, ws: Workspace, c: Dict[str, Any], dlogits: Tensor) -> Tensor:
-        """dlogits bf16 [R,K] -> returns d(x) f32 [R, in_dim]; accumulates parameter grads."""
+    def backward(self, ws: Workspace, c: Dict[str, Any], dlogits: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Tensor:
+        """dlogits bf16 [R,K] -> returns d(x) f32 [R, in_dim]; accumulates parameter grads.
+
+        `side`: the weight-gradient GEMMs (and `finish_weightnorm_grad`) go to this stream.  Between the cross-entropy and the start of the
+        backbone's backward the step is one dependent chain of small kernels on a mostly idle chip; the weight gradients feed only the
+        optimizer, so off the chain they run beside it (the 65 536 x 256 one alone is 0.3 ms).  The caller makes the optimizer -- and
+        the next use of `dlogits` / the saved activations -- wait for `side`."""
         R, cap, tag = c["R"], c["cap"], c["tag"]
         hid, bn, K, D = self.hid, self.bn, self.K, self.in_dim
 
         slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)
+        main = torch.cuda.current_stream() if side is not None else None
 
         def wgrad(dy: Tensor, xin: Tensor, out: Tensor, n_out: int, k_in: int, dbias: Optional[Tensor] = None) -> None:
             """dW[n_out, k_in] += dy[:R]^T xin[:R]; dbias[n_out] += column sums of dy[:R] (taken from the same GEMM's operand fragments).  The row count of a step (2B + local + masked rows) is data dependent and rarely a
@@ -285,21 +291,34 @@ class HeadEngine:
             reduction -- ragged, these four GEMMs fell to the 128-row kernel and fp32 atomics (1.3 ms per step at 0.3 PF/s)."""
             kpad = (R + 63) // 64 * 64
             dyp, xp = padded_rows(dy, R), padded_rows(xin, R)
-            if self.pad_wgrad_rows and kpad != R and dyp is not None and xp is not None:
-                dyp[R:kpad].zero_()
-                xp[R:kpad].zero_()
+            pad = self.pad_wgrad_rows and kpad != R and dyp is not None and xp is not None
+            if pad:
                 dy, xin = dyp, xp
             else:
                 kpad = R
             tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-            ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, colsum=dbias,
-                     lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
+
+            def run() -> None:
+                if pad:   # (rows no data-gradient GEMM of the chain reads: zeroed on the stream of the GEMM that does)
+                    dy[R:kpad].zero_()
+                    xin[R:kpad].zero_()
+                ops.gemm(dy, xin, out, M=n_out, N=k_in, K=kpad, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, colsum=dbias,
+                         lda=n_out, ldb=k_in, workspace=slab if kpad % 64 == 0 else None, **split_k_plan(n_out, k_in, kpad, True, _split_k(tiles, kpad)))
+
+            if side is None:
+                run()
+            else:
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    run()
 
         wgrad(dlogits, c["zn"], self.dwn, K, bn)
         dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
         # [R, bn] output = only ~35 tiles but a 65 536-long contraction: split-K into slabs, accumulate into zeros
         dzn.zero_()
-        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, workspace=slab, **split_k_plan(R, bn, K, False, 2))
+        # (its own slab scratch when the weight gradients run on another stream: theirs is in use there)
+        dslab = slab if side is None else ws.get("head.dgrad_slabs", (16 * 1024 * 1024,), torch.float32)
+        ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, workspace=dslab, **split_k_plan(R, bn, K, False, 2))
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         l0, l1, l2 = self.lin
@@ -332,9 +351,15 @@ class HeadEngine:
         ops.gemm(dh1, self.wb(l0 + ".weight"), dx, M=R, N=D, K=hid, trans_b=True, epilogue=ops.EPI_F32)
         return dx
 
-    def finish_weightnorm_grad(self) -> None:
-        ops.weightnorm_bwd(self.dwn, self.w(WN_V), self.w(WN_G), self.gw(WN_V), self.gw(WN_G), self.K, self.bn)
-        self.dwn.zero_()
+    def finish_weightnorm_grad(self, side: Optional["torch.cuda.Stream"] = None) -> None:
+        """(on `side` when the weight gradients ran there: it reads the prototype layer's, and feeds only the optimizer)"""
+        if side is None:
+            ops.weightnorm_bwd(self.dwn, self.w(WN_V), self.w(WN_G), self.gw(WN_V), self.gw(WN_G), self.K, self.bn)
+            self.dwn.zero_()
+            return
+        with torch.cuda.stream(side):
+            ops.weightnorm_bwd(self.dwn, self.w(WN_V), self.w(WN_G), self.gw(WN_V), self.gw(WN_G), self.K, self.bn)
+            self.dwn.zero_()
 
 
 class MockTrainerState:
@@ -452,6 +477,7 @@ class DINOv2:
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
         # one weight-gradient GEMM per layer for the global- and the local-crop pass (vit.JointWgrad): half the split-K slab traffic
         self.joint_wgrad = int(os.environ.get("LT_JOINT_WGRAD", "1") != "0")
+        self.head_side = int(os.environ.get("LT_HEAD_SIDE", "1") != "0")   # KoLeo and the heads' weight gradients beside the head chain
         self._joint: Optional[JointWgrad] = None
         self._joint_active: Optional[JointWgrad] = None
         # the last block's MLP branch, forward and backward, only at the token rows the losses read (cls + masked patches): vit.forward
@@ -655,10 +681,15 @@ class DINOv2:
             done_blocks.append(i)
 
         det = self.deterministic and self.device.type == "cuda"
-        if sync is not None:
-            if det:
-                ops.reduce_flush()         # the head's bias sums
-            sync.start(*self._head_span)   # the prototype heads are final: their all-reduce runs under the whole ViT backward
+        if sync is not None:               # the prototype heads are final: their all-reduce runs under the whole ViT backward,
+            rs0 = self.reduce_stream       # ordered after the streams that wrote their gradients (the side stream holds the weight gradients)
+            rs0.wait_event(main.record_event())
+            if side is not None:
+                rs0.wait_event(side.record_event())
+            with torch.cuda.stream(rs0):
+                if det:
+                    ops.reduce_flush()     # the head's bias sums
+                sync.start(*self._head_span)
         if sl is not None and side is not None and self.local_bwd_stream is not None and self.two_bwd_chains:
             # two independent dgrad chains (local / global crops) on two streams, launches interleaved block by block; the
             # weight-gradient GEMMs of both go to `side` in that order (ordered read-modify-writes of the shared gradient)
@@ -863,6 +894,34 @@ class DINOv2:
         Rs, cap_s = Rd + M, Rd + cap_M       # student row layout [2B cls | Rl local cls | M masked patches]
         s_in = ws.get("s.head_in", (cap_s, D), torch.bfloat16, pad_rows=64)
         sxn = sg["xn"].view(-1, D)
+        dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
+        kws = ws.get("koleo.ws", (2 * B * D + 2 * B,), torch.float32)
+        knn = ws.get("koleo.nn", (B,), torch.int32)
+        # the head phase (cross-entropy -> head backward -> first backbone kernel) is one dependent chain of small kernels: what does not
+        # lie on it runs beside it on the side stream -- the KoLeo term (a dozen tiny kernels over the student's cls tokens, which the final
+        # norm produced long before the cross-entropy) and the heads' weight gradients.  LT_HEAD_SIDE=0: everything on the main stream
+        hside = self.side_stream if (self.head_side and self.side_stream is not None and self.overlap_streams) else None
+
+        dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32) if sl is not None else None
+
+        def koleo_and_zero() -> None:
+            dxn_g.zero_()
+            if dxn_l is not None:
+                dxn_l.zero_()
+            if B > 1:   # weight 0: the kernel only evaluates the term (logged by the reference regardless of its weight)
+                kslot = self._loss_slots[3:] if a.koleo_loss_weight != 0.0 else self._loss_slots[4:]
+                for c in range(2):  # per global-crop chunk, dinov2.py:377-380
+                    ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight * gs, kws, knn)
+
+        koleo_done = None
+        if hside is None:
+            koleo_and_zero()
+        else:
+            hside.wait_event(main.record_event())
+            with torch.cuda.stream(hside):
+                koleo_and_zero()
+                koleo_done = hside.record_event()
+
         ops.gather_rows(sxn, D, ix["s_cls"], 2 * B, D, out_bf16=s_in[:2 * B])
         if sl is not None:
             ops.gather_rows(sl["xn"].view(-1, D), D, ix["l_cls"], Rl, D, out_bf16=s_in[2 * B:Rd])
@@ -907,30 +966,20 @@ class DINOv2:
             ce(sh["logits"], ta, tb, coef, dlogits, Rd, slot)
             ce(shi["logits"], ta[Rd:], tb[Rd:], coef[Rd:], dlogits_i, M, slot[Rd:])
 
-        dxn_g = ws.get("sg.dxn", (2 * B * Ng, D), torch.float32)
-        dxn_g.zero_()
-        kws = ws.get("koleo.ws", (2 * B * D + 2 * B,), torch.float32)
-        knn = ws.get("koleo.nn", (B,), torch.int32)
-        if B > 1:   # weight 0: the kernel only evaluates the term (logged by the reference regardless of its weight)
-            kslot = self._loss_slots[3:] if a.koleo_loss_weight != 0.0 else self._loss_slots[4:]
-            for c in range(2):  # per global-crop chunk, dinov2.py:377-380
-                ops.koleo_fwd_bwd(sxn[c * B * Ng:], Ng * D, kslot, dxn_g[c * B * Ng:], Ng * D, B, D, a.koleo_loss_weight * gs, kws, knn)
-
         # ---------------- backward
         self._reduce_begin()
-        dx_head = self.s_head.backward(ws, sh, dlogits)
-        self.s_head.finish_weightnorm_grad()
+        dx_head = self.s_head.backward(ws, sh, dlogits, side=hside)
+        self.s_head.finish_weightnorm_grad(hside)
+        if koleo_done is not None:
+            main.wait_event(koleo_done)
         ops.scatter_add_rows(dx_head[:2 * B], ix["s_cls"], dxn_g, D, 2 * B, D)
         if not sep:
             ops.scatter_add_rows(dx_head[Rd:Rs], patch_rows, dxn_g, D, M, D)
         else:
-            dx_ihead = self.s_ihead.backward(ws, shi, dlogits_i)
-            self.s_ihead.finish_weightnorm_grad()
+            dx_ihead = self.s_ihead.backward(ws, shi, dlogits_i, side=hside)
+            self.s_ihead.finish_weightnorm_grad(hside)
             ops.scatter_add_rows(dx_ihead[:M], patch_rows, dxn_g, D, M, D)
-        dxn_l = None
         if sl is not None:
-            dxn_l = ws.get("sl.dxn", (Rl * Nl, D), torch.float32)
-            dxn_l.zero_()
             ops.scatter_add_rows(dx_head[2 * B:Rd], ix["l_cls"], dxn_l, D, Rl, D)
         self._backward_backbone(sg, dxn_g, sl, dxn_l)
 

@@ -77,6 +77,16 @@ def main(db: str, top: int = 24) -> None:
     print("\nlargest idle gaps (us, at ms into the step, after -> before):")
     for dt, a, b, at in sorted(gaps, reverse=True)[:12]:
         print(f"  {dt/1e3:8.1f} us at {at*ms:6.2f} ms: {a} -> {b}")
+    if len(sys.argv) > 3:   # python tools/step_timeline.py <db> <top> <kernel-substring> [ms before] [ms after]: the launches around the first match
+        pat = sys.argv[3]
+        before = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
+        after = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0
+        hit = next((r for r in step if pat in r[0]), None)
+        if hit is not None:
+            print(f"\nlaunches from {before} ms before to {after} ms after the start of `{pat}` (start offset ms | duration us | {qcol} | kernel):")
+            for r in step:
+                if hit[1] - before * 1e6 <= r[1] <= hit[1] + after * 1e6:
+                    print(f"  {(r[1] - hit[1]) * ms:8.3f} | {(r[2] - r[1]) / 1e3:8.1f} | {r[3] if qcol else '-'} | {short(r[0])}")
     if qcol:
         q = defaultdict(lambda: [0, 0.0])
         for r in step:
