@@ -646,6 +646,9 @@ class DINOv2:
 
     def _reduce_begin(self) -> None:
         """Open the reduction ledger for this step's backward (before the projection-head backward); `_backward_backbone` closes it."""
+        if getattr(self, "_grad_zeroed", None) is not None:    # the gradient buffer was zeroed on the side stream: order this stream's writers after it
+            torch.cuda.current_stream().wait_event(self._grad_zeroed)
+            self._grad_zeroed = None
         if not self.deterministic or self.device.type != "cuda":
             return
         cfg, a = self.cfg, self.method_args
@@ -791,7 +794,17 @@ class DINOv2:
         if self.accum_first:
             if self._grad_sync is not None:
                 self._grad_sync.reset()   # a step whose optimizer_step was skipped must not leak its ranges into this one
-            self.student.grad.zero_()
+            # (on the side stream, which also carries every weight-gradient accumulation: the 344 MB fill runs beside the view concatenation
+            # instead of ahead of the whole step; the first gradient writer of the other streams waits for it in `_reduce_begin`)
+            zs = self.side_stream if (self.side_stream is not None and self.overlap_streams and os.environ.get("LT_GRAD_ZERO_SIDE", "1") != "0") else None
+            self._grad_zeroed = None
+            if zs is None:
+                self.student.grad.zero_()
+            else:
+                zs.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(zs):
+                    self.student.grad.zero_()
+                    self._grad_zeroed = zs.record_event()
         self._loss_slots.zero_()
 
         # the losses read the final tokens at the cls rows and the masked patch rows only: the last block's MLP branch runs there alone
@@ -800,12 +813,15 @@ class DINOv2:
         rows_l = (ix["l_cls"], n_local * B) if (self.sparse_last_mlp and n_local > 0) else None
         # ---------------- teacher (no grad) : dinov2.py:399-472 -- on its own stream, concurrent with the student forward
         main = torch.cuda.current_stream()
+        # the teacher and the student's global pass unfold the same images: one patch matrix for both (the iBOT masks act on the tokens)
+        shared_cols = ops.im2col(gv.contiguous(), p, self.s_vit.kpad) if (gv.shape[2] % p == 0 and gv.shape[3] % p == 0 and dev.type == "cuda"
+                                                                           and os.environ.get("LT_SHARED_COLS", "1") != "0") else None
         tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
         tstream.wait_event(main.record_event())
         torch.cuda.set_stream(tstream)
         if a.center_method == "softmax":
             self._apply_center_updates()
-        tctx = self.t_vit.forward(ws, "t", gv, None, save=False, last_mlp_rows=rows_g)
+        tctx = self.t_vit.forward(ws, "t", gv, None, save=False, last_mlp_rows=rows_g, cols=shared_cols)
         Rt, cap_t = 2 * B + M, 2 * B + cap_M
         t_in = ws.get("t.head_in", (cap_t, D), torch.bfloat16)
         txn = tctx["xn"].view(-1, D)
@@ -883,7 +899,7 @@ class DINOv2:
                                         last_mlp_rows=rows_l)
                 local_done = lstream.record_event()
         sg = self.s_vit.forward(ws, "sg", gv, mask_u8, save=True, drop_plan=plan_g, checkpoint=self.activation_checkpointing,
-                                last_mlp_rows=rows_g)
+                                last_mlp_rows=rows_g, cols=shared_cols)
         if lstream is not None:
             main.wait_event(local_done)
         elif lv is not None:

@@ -429,8 +429,11 @@ class ViTEngine:
     def forward(self, ws: Workspace, tag: str, img: Tensor, masks: Optional[Tensor], save: bool,
                 drop_plan: Optional[List[Any]] = None, rope_tables: Optional[List[Tuple[Tensor, Tensor]]] = None,
                 checkpoint: bool = False, capture_layers: Optional[Iterable[int]] = None, capture_norm: bool = True,
-                last_mlp_rows: Optional[Tuple[Tensor, int]] = None) -> Dict[str, Any]:
+                last_mlp_rows: Optional[Tuple[Tensor, int]] = None, cols: Optional[Tensor] = None) -> Dict[str, Any]:
         """img f32 [B,C,H,W] (H,W multiples of patch_size) -> ctx with "xn" f32 [B, N, D] (final-norm tokens).
+
+        cols: the patch matrix of `img` (`ops.im2col(img, patch_size, kpad)`) when the caller already has it -- the teacher and the
+        student's global-crop pass unfold the same images.
 
         drop_plan (training student only): 2*depth entries (attn, ffn branch per block) of None |
         ("subset", brange int64[s]) | ("persample", scale f32[B]) -- see make_drop_plan / layers/block.py:90-141.
@@ -466,7 +469,8 @@ class ViTEngine:
         scale = dh ** -0.5
         ctx: Dict[str, Any] = dict(B=B, N=N, n_p=n_p, gh=gh, gw=gw, T=T, masks=masks, tag=tag, rope=rope)
 
-        cols = ops.im2col(img.contiguous(), p, self.kpad)
+        if cols is None or tuple(cols.shape) != (B * n_p, self.kpad):
+            cols = ops.im2col(img.contiguous(), p, self.kpad)
         patch = ws.get(tag + ".patch", (B * n_p, D), torch.float32)
         ops.gemm(cols, self._patch_weight_bf16(), patch, M=B * n_p, N=D, K=self.kpad,
                  epilogue=ops.EPI_F32, bias=self.w("patch_embed.proj.bias"))
