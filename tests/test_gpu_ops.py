@@ -270,6 +270,45 @@ def test_layernorm_bwd_fused_next_branch_and_layerscale_dgamma():
     assert rel_err(dgam, (dxu * y).sum(0)) < 1e-2   # bf16 rounding of dD only
 
 
+@pytest.mark.parametrize("depth,N,K,with_bias", [(12, 768, 768, True), (2, 384, 1536, True), (5, 256, 64, False)])
+def test_layerscale_dgamma_batched_equals_the_per_layer_launches(depth, N, K, with_bias):
+    """lt_layerscale_dgamma_batched (every block's LayerScale gradient in one launch at the tail of the step): the arguments are layer 0's
+    tensors, layer i's lie i * stride elements further on in the bf16 shadow, the parameter and the gradient storages alike.  Against the
+    per-layer launches on the same strided layout: bit for bit (the same arithmetic per row), and accumulating (dgamma += ...)."""
+    o = ops()
+    g = torch.Generator().manual_seed(depth * 1000 + N + K)
+    per = N * K + 2 * N + 37 * 8          # weight | bias | gamma | unrelated tensors of the block: a stride that is not a multiple of the sizes
+    per = (per + 7) // 8 * 8
+    data = (torch.randn(depth * per, generator=g) * 0.05).to(DEV)
+    grad = torch.randn(depth * per, generator=g).to(DEV)
+    shadow = data.to(torch.bfloat16)
+    data[N * K + N:N * K + 2 * N].add_(1.0)   # gamma away from zero (every layer below gets its own values anyway)
+    for i in range(depth):
+        data[i * per + N * K + N:i * per + N * K + 2 * N] = (torch.rand(N, generator=g) + 0.5).to(DEV)
+
+    def views(buf, i):
+        o0 = i * per
+        return buf[o0:o0 + N * K].view(N, K), buf[o0 + N * K:o0 + N * K + N], buf[o0 + N * K + N:o0 + N * K + 2 * N]
+
+    g_ref, g_bat = grad.clone(), grad.clone()
+    for i in range(depth):
+        wb, _, _ = views(shadow, i)
+        _, b, gam = views(data, i)
+        dw, db, dgam = views(g_ref, i)
+        o.layerscale_dgamma(wb, dw, b if with_bias else None, db if with_bias else None, gam, dgam, N, K)
+    wb0, _, _ = views(shadow, 0)
+    _, b0, gam0 = views(data, 0)
+    dw0, db0, dgam0 = views(g_bat, 0)
+    o.layerscale_dgamma_batched(wb0, dw0, b0 if with_bias else None, db0 if with_bias else None, gam0, dgam0, N, K, depth, per)
+    torch.cuda.synchronize()
+    assert torch.equal(g_ref, g_bat)
+    assert not torch.equal(g_bat, grad)          # something was accumulated
+    i = depth - 1                                # and it is the LayerScale identity: dgamma += (rowdot(W, dW) + b * db) / gamma
+    wb, _, _ = views(shadow, i); _, b, gam = views(data, i); dw, db, _ = views(grad, i)
+    want = views(grad, i)[2] + ((wb.float() * dw).sum(1) + (b * db if with_bias else 0.0)) / gam
+    assert rel_err(views(g_bat, i)[2], want) < 1e-5
+
+
 def test_im2col_and_tokens():
     o = ops()
     B, C, H, W, p, D = 3, 3, 32, 48, 16, 24

@@ -1,9 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r04ah}
+O=$R/gpurun_out/${1:-r04ai}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-python tools/ab_step.py LT_SHARED_COLS 0 1 --steps 15 > $O/ab_cols.log 2>&1; tail -2 $O/ab_cols.log
-python tools/ab_step.py LT_GRAD_ZERO_SIDE 0 1 --steps 15 > $O/ab_zero.log 2>&1; tail -2 $O/ab_zero.log
-python tools/ab_step.py LT_SHARED_COLS 0 1 --steps 15 > $O/ab_cols2.log 2>&1; tail -2 $O/ab_cols2.log
+timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "layerscale" > $O/ls_tests.log 2>&1; tail -5 $O/ls_tests.log
