@@ -389,3 +389,69 @@ def test_lars_oracle_rule_by_hand():
     assert torch.allclose(b.detach(), torch.tensor([0.0 - 0.5 * (0.9 * 2.0 + 1.0)]))
 
 
+
+
+def test_joint_wgrad_pairs_deposits_checks_adjacency_and_flushes(monkeypatch):
+    """vit.JointWgrad (host logic, no GPU): the operand buffers of the two student passes are seeded side by side under the workspace names
+    the passes ask for; the second deposit of a layer launches ONE contraction over both passes' rows on the side stream, ordered after
+    both depositors; operands that are not the seeded neighbours (or row subsets) fall back to one launch each; a deposit without a
+    partner is launched alone by `flush` (or by the depositor's `before_write` placeholder) and every depositor gets its consumed event."""
+    import contextlib
+
+    from lightly_train_amd.vit import JointWgrad, Workspace
+
+    log = []
+
+    class Ev:
+        def __init__(self, who):
+            self.who = who
+
+    class Stream:
+        def __init__(self, name):
+            self.name = name
+
+        def record_event(self):
+            return Ev(self.name)
+
+        def wait_event(self, ev):
+            log.append((self.name, "waits", ev.who))
+
+    cur = {"s": Stream("chain_g")}
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: cur["s"])
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    ws, side = Workspace(torch.device("cpu")), Stream("side")
+    jw = JointWgrad(ws, side, ("sg", "sl"))
+    assert not jw.seed(2, (100, 128), 8, 16, 16)             # row counts must be whole 64-row K-tiles
+    assert jw.seed(2, (128, 192), 8, 16, 16) and jw.seed(2, (128, 192), 8, 16, 16)
+    a, b = ws.get("sg.b1.ln1", (128, 8), torch.bfloat16, pad_rows=64), ws.get("sl.b1.ln1", (192, 8), torch.bfloat16, pad_rows=64)
+    assert b.data_ptr() == a.data_ptr() + 128 * 8 * 2        # the passes get adjacent views of one allocation, under their own names
+    dy_g, dy_l = ws.get("sg.dQ", (128, 24), torch.bfloat16, pad_rows=64), ws.get("sl.dQ", (192, 24), torch.bfloat16, pad_rows=64)
+    runs = []
+
+    def runner(tag):
+        return lambda dy, x, k: runs.append((tag, tuple(dy.shape), tuple(x.shape), k))
+
+    cons_g, cons_l = {}, {}
+    cur["s"] = Stream("chain_l")
+    jw.deposit("sl", "blocks.1.attn.qkv.weight", dy_l, b, 192, runner("l"), cons_l)
+    assert runs == [] and isinstance(cons_l[dy_l.data_ptr()], str)      # placeholder until the partner arrives
+    cur["s"] = Stream("chain_g")
+    jw.deposit("sg", "blocks.1.attn.qkv.weight", dy_g, a, 128, runner("g"), cons_g)
+    assert runs == [("g", (320, 24), (320, 8), 320)] and jw.launched == 1   # one GEMM over 128 + 192 rows
+    assert ("side", "waits", "chain_l") in log and ("side", "waits", "chain_g") in log
+    assert cons_g[dy_g.data_ptr()] is cons_l[dy_l.data_ptr()] and cons_g[dy_g.data_ptr()].who == "side"
+
+    # operands that are not the seeded neighbours: two launches, still on the side stream, still both consumed events
+    runs.clear()
+    other = torch.empty(192, 8, dtype=torch.bfloat16)
+    jw.deposit("sl", "w2", dy_l, other, 192, runner("l"), cons_l)
+    jw.deposit("sg", "w2", dy_g, a, 128, runner("g"), cons_g)
+    assert sorted(r[0] for r in runs) == ["g", "l"] and all(r[3] in (128, 192) for r in runs) and jw.launched == 1
+
+    # a layer only one pass ran on all rows: launched alone by flush()
+    runs.clear()
+    cons_g.clear()
+    jw.deposit("sg", "w3", dy_g, a, 128, runner("g"), cons_g)
+    assert runs == [] and cons_g[dy_g.data_ptr()] == "w3"
+    jw.flush()
+    assert runs == [("g", (128, 24), (128, 8), 128)] and cons_g[dy_g.data_ptr()].who == "side" and not jw.pending

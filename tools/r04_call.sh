@@ -1,10 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r04aj}
+O=$R/gpurun_out/${1:-r04ak}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-bash tools/clock_probe.sh "default bench step (ViT-B/16, batch 128), 150 steps" python bench.py --no-cpu-baseline --no-roofline --steps 150 --warmup 5 > $O/clock_probe.log 2>&1
-bash tools/clock_probe.sh "single-stream schedule" python bench.py --no-cpu-baseline --no-roofline --steps 150 --warmup 5 --single-stream >> $O/clock_probe.log 2>&1
-/opt/rocm/bin/rocm-smi --showmaxpower 2>/dev/null | grep -i "power" >> $O/clock_probe.log
-cat $O/clock_probe.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-260
