@@ -1,8 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r04ak}
+O=$R/gpurun_out/${1:-r04al}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-260
+for i in 1 2 3 4 5; do python bench.py --no-cpu-baseline --no-roofline > $O/bench_$i.log 2>&1; tail -1 $O/bench_$i.log | cut -c150-175; done
