@@ -122,6 +122,57 @@ def test_gradient_allreduce_overlapped_with_backward(tmp_path):
     assert all(e == 0 for e in r0["after"][1])
 
 
+def _joint_ddp_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import random
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import test_gpu_step as T
+
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", "step_d64_softmax.pt"), weights_only=False)
+        B = 32       # 2 x 32 x 37 and 2 x 32 x 10 token rows: whole 64-row K-tiles, the condition for the joint weight-gradient launches
+        out = {}
+        for key, overlap, joint, head_side in (("joint_overlap", True, 1, 1), ("separate_after", False, 0, 0)):
+            m = T.build(fx, koleo_loss_weight=0.0)
+            m.overlap_grad_reduce, m.joint_wgrad, m.head_side = overlap, joint, head_side
+            early = []
+            for s in range(3):
+                views = T.synth_views(4000 + 10 * s + 1000 * rank, B, fx["g_size"], fx["l_size"], fx["n_local"])   # per-rank data
+                random.seed(50 + s)          # the same masks on both schedules (drawn by the step from the global generator)
+                m.training_step_impl({"views": views}, 0)
+                early.append(sum(b - a for a, b in m._grad_sync.covered) if m._grad_sync is not None else 0)
+                m.optimizer_step()
+                m.on_train_batch_end()
+            torch.cuda.synchronize()
+            out[key] = (m.student.data.cpu().clone(), early, m.student.numel, m._joint.launched if m._joint is not None else 0)
+        torch.save(out, os.path.join(out_dir, f"j{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_joint_weight_gradients_and_head_side_stream_under_data_parallel(tmp_path):
+    """The round-4 schedule changes in the data-parallel step: joint weight gradients of the two student passes (their GEMMs are launched
+    when the SECOND pass deposits, and a block's all-reduce starts only after them) and the heads' weight gradients on the side stream
+    (the head span's all-reduce is ordered after that stream).  Two ranks, different images: bit-identical parameters across ranks, equal
+    to the separate / one-all-reduce-at-the-end schedule to fp32 summation order, and the all-reduces still start during backward."""
+    mp.spawn(_joint_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "j0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "j1.pt", weights_only=False)
+    for key in ("joint_overlap", "separate_after"):
+        assert torch.equal(r0[key][0], r1[key][0]), key
+    a, b = r0["joint_overlap"], r0["separate_after"]
+    assert a[3] >= 3 * (4 * 2 - 3) and b[3] == 0                   # joint launches happened (all but the last block's row-subset layers), and only there
+    assert (a[0] - b[0]).abs().max().item() <= 2e-5 * max(1.0, b[0].abs().max().item())
+    assert all(e > 0.5 * a[2] for e in a[1]) and all(e == 0 for e in b[1])
+
+
 def _run_distill(n_steps: int = 3):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r04al}
+O=$R/gpurun_out/${1:-r04an}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-for i in 1 2 3 4 5; do python bench.py --no-cpu-baseline --no-roofline > $O/bench_$i.log 2>&1; tail -1 $O/bench_$i.log | cut -c150-175; done
+timeout 900 python -m pytest tests/test_gpu_ddp.py -x -q -m gpu -k "joint or overlapped_with_backward" > $O/ddp_tests.log 2>&1; tail -12 $O/ddp_tests.log
