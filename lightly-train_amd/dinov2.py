@@ -312,13 +312,15 @@ class HeadEngine:
                 with torch.cuda.stream(side):
                     run()
 
-        wgrad(dlogits, c["zn"], self.dwn, K, bn)
         dzn = ws.get(tag + ".dzn", (cap, bn), torch.float32)
         # [R, bn] output = only ~35 tiles but a 65 536-long contraction: split-K into slabs, accumulate into zeros
         dzn.zero_()
         # (its own slab scratch when the weight gradients run on another stream: theirs is in use there)
         dslab = slab if side is None else ws.get("head.dgrad_slabs", (16 * 1024 * 1024,), torch.float32)
         ops.gemm(dlogits, self.wn, dzn, M=R, N=bn, K=K, trans_b=True, epilogue=ops.EPI_F32_ACCUM, workspace=dslab, **split_k_plan(R, bn, K, False, 2))
+        # the prototype layer's weight gradient AFTER the data gradient it shares dlogits with: on the side stream it then starts behind
+        # that GEMM instead of beside it (two chip-filling launches at once made the chain's 13 us slab reduction wait 290 us for a CU)
+        wgrad(dlogits, c["zn"], self.dwn, K, bn)
         dz = ws.get(tag + ".dz", (cap, bn), torch.bfloat16)
         ops.l2norm_bwd(dzn, c["z"], c["inv"], dz, R, bn)
         l0, l1, l2 = self.lin
