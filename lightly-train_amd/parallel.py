@@ -10,6 +10,7 @@ module); after that nothing but gradients is exchanged -- identical students giv
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -96,12 +97,18 @@ class GradSync:
 
     `start(lo, hi)` may be called during backward for a range whose gradients are final (enqueued on the CURRENT stream:
     the collective is ordered after it); `finish()` reduces whatever no `start` has covered, waits for everything on the
-    current stream and applies the 1/world scale.  Every rank must issue the same ranges in the same order."""
+    current stream and applies the 1/world scale.  Every rank must issue the same ranges in the same order.
+
+    LT_GRAD_COMM_MODE=rsag ("for the large message prefer a direct reduce-scatter / all-gather"): every call of at least
+    `RSAG_MIN_ELEMS` elements runs as reduce_scatter_tensor + all_gather_into_tensor on the part divisible by the world size (the
+    remainder, and short calls, stay all-reduces).  Each element is summed once, by the rank that owns its shard, and gathered: the
+    replicas stay bit-identical.  Unmeasured on hardware like every N > 1 path here; the default is the plain all-reduce."""
+
+    RSAG_MIN_ELEMS = 1 << 16
 
     def __init__(self, flat_grad: Tensor, bucket_bytes: int = 64 << 20, comm: Optional[AbiComm] = None) -> None:
         self.g = flat_grad
         # LT_GRAD_COMM=abi: the all-reduces go through the library's own RCCL communicator (lt_comm_*) instead of torch.distributed
-        import os
         if comm is None and os.environ.get("LT_GRAD_COMM") == "abi" and flat_grad.is_cuda and world_size() > 1:
             comm = AbiComm.from_torch_group(flat_grad.device)
         self.comm = comm
@@ -109,6 +116,8 @@ class GradSync:
         self.ranges = bucket_ranges(flat_grad.numel(), self.bucket_elems)
         self.handles: List = []
         self.covered: List[Tuple[int, int]] = []
+        self.rsag = os.environ.get("LT_GRAD_COMM_MODE", "") == "rsag" and self.comm is None
+        self._shards: List[Tensor] = []     # reduce-scatter outputs, alive until their all-gather has run
 
     def uncovered(self, lo: int, hi: int) -> List[Tuple[int, int]]:
         """Sub-ranges of [lo, hi) no earlier `start` of this step has reduced."""
@@ -132,9 +141,29 @@ class GradSync:
             for c, d in bucket_ranges(b - a, self.bucket_elems):
                 if self.comm is not None:
                     self.comm.all_reduce(self.g[a + c:a + d])
+                elif self.rsag and d - c >= self.RSAG_MIN_ELEMS:
+                    self._reduce_scatter_all_gather(self.g[a + c:a + d])
                 else:
                     self.handles.append(dist.all_reduce(self.g[a + c:a + d], op=dist.ReduceOp.SUM, async_op=True))
             self.covered.append((a, b))
+
+    def _reduce_scatter_all_gather(self, t: Tensor) -> None:
+        """In-place sum of `t` over the ranks as reduce-scatter + all-gather (the tail that does not divide by the world size: all-reduce).
+        Both collectives go to the process group in this order; on the device they are stream-ordered by the backend, on gloo the
+        gather is issued once the scatter has completed."""
+        w = world_size()
+        n = t.numel() // w * w
+        if n:
+            shard = torch.empty(n // w, dtype=t.dtype, device=t.device)
+            h = dist.reduce_scatter_tensor(shard, t[:n], op=dist.ReduceOp.SUM, async_op=True)
+            if not t.is_cuda:
+                h.wait()
+            else:
+                self.handles.append(h)
+            self.handles.append(dist.all_gather_into_tensor(t[:n], shard, async_op=True))
+            self._shards.append(shard)
+        if n < t.numel():
+            self.handles.append(dist.all_reduce(t[n:], op=dist.ReduceOp.SUM, async_op=True))
 
     def reset(self) -> None:
         """Drop the bookkeeping of an unfinished step (waits for its collectives first)."""
@@ -144,6 +173,7 @@ class GradSync:
             self.comm.wait()
         self.handles.clear()
         self.covered.clear()
+        self._shards.clear()
 
     def finish(self) -> None:
         w = world_size()
@@ -156,6 +186,7 @@ class GradSync:
             self.comm.wait()
         self.handles.clear()
         self.covered.clear()
+        self._shards.clear()
         if self.g.is_cuda:
             from . import ops
 

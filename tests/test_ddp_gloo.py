@@ -71,3 +71,47 @@ def test_batch_must_divide():
     with pytest.raises(ValueError):
         per_rank_batch(100, 8)
     assert bucket_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]
+
+
+def _rsag_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import lightly_train_amd  # noqa: F401
+    from lightly_train_amd.parallel import GradSync
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3 * GradSync.RSAG_MIN_ELEMS + 1001            # odd length: tails that do not divide by the world size
+        base = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank))
+        out = {}
+        for mode in ("", "rsag"):
+            os.environ["LT_GRAD_COMM_MODE"] = mode
+            grad = base.clone()
+            sync = GradSync(grad, bucket_bytes=(GradSync.RSAG_MIN_ELEMS + 333) * 4)
+            assert sync.rsag == (mode == "rsag")
+            sync.start(GradSync.RSAG_MIN_ELEMS, 2 * GradSync.RSAG_MIN_ELEMS + 50)   # a range that became final early (split at the bucket size)
+            sync.start(10, 300)                                                      # a short one: stays an all-reduce
+            sync.finish()
+            assert not sync.handles and not sync._shards and not sync.covered
+            out[mode] = grad
+        torch.save(out, os.path.join(out_dir, f"rsag{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_reduce_scatter_all_gather_mode_equals_all_reduce(tmp_path):
+    """LT_GRAD_COMM_MODE=rsag: the large calls of the gradient exchange as reduce-scatter + all-gather.  Two ranks over gloo:
+    the mean is the all-reduce path's bit for bit (two addends commute), the ranks end identical, tails that do not divide by the world
+    size and short calls are covered."""
+    mp.spawn(_rsag_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rsag0.pt")
+    r1 = torch.load(tmp_path / "rsag1.pt")
+    for mode in ("", "rsag"):
+        assert torch.equal(r0[mode], r1[mode]), mode
+    assert torch.equal(r0[""], r0["rsag"])
+    n = r0[""].numel()
+    want = sum(torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) for r in range(2)) / 2
+    assert torch.allclose(r0["rsag"], want, atol=1e-6)
