@@ -92,20 +92,17 @@ def host_cpu_info() -> dict:
     return {"model": model, "physical_cores": n, "logical_cpus": logical or (os.cpu_count() or 1)}
 
 
-def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, timed_steps: int = 2, warmups: int = 1, batch: int = 8) -> dict:
+def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, batch: int = 8, patch: int = 16, ffn: str = "mlp") -> dict:
     """CPU baseline (BASELINE.md section 3 / SURVEY 8(d)): a full training step (training_step_impl + backward + clip + AdamW + EMA)
-    in fp32 on the host cores, bounded sample: batch 8 (SURVEY 8(d) planned 8-16: the 2-image step of rounds 2-3 could not fill 128 cores
-    and understated the CPU: 0.29 img/s), `warmups` untimed + `timed_steps` timed steps (about a minute in all), MEDIAN step time and spread,
-    one torch thread per PHYSICAL core (hyper-thread siblings only add contention to a GEMM-bound fp32 step; round 2 ran on
-    torch's default = every logical CPU and its first timed steps were still warming up: 28.9 -> 18.1 -> 15.6 s).
+    in fp32 on the host cores, bounded sample: batch 8 (SURVEY 8(d) planned 8-16), about a minute and a half in all.
+    The thread count is SWEPT (8 / 16 / 32 / 64 / one per physical core; round-4 verdict: 128 threads on a 4-TFLOP fp32 step is
+    oversubscription -- it measured 0.55 img/s where the survey's 8-thread probe had 1.1-1.3): one untimed warm-up step, one timed step per
+    thread count, one more at the best count; `value` = the best count's faster step, `cores` = that count, the whole sweep in `sweep`.
     kind "reference": the reference's own DINOv2 class driven through oracle/ref_harness.py -- only where /root/reference exists
     (the build container; it cannot travel to the GPU box) and can run the configuration; kind "port": oracle/dinov2_oracle.py, the pinned
     restatement of that step (bit-level equal losses, tests/test_oracle_pin.py).  Reported baseline only, never the measured path."""
-    import statistics
-
     info = host_cpu_info()
     prev_threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, info["physical_cores"]))
     b = batch
     g = torch.Generator().manual_seed(0)
     name = {768: "vit_base", 384: "vit_small", 1024: "vit_large", 192: "vit_tiny"}[arch["embed_dim"]]
@@ -115,9 +112,9 @@ def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, tim
     try:
         from oracle import ref_harness as H
 
-        if H.reference_available() and l_size % 16 == 0:   # the reference's wrapper cannot run 98^2 crops at patch 16
-            m = H.build_reference_method(arch=name, patch_size=16, img_size=g_size, method_kwargs=dict(output_dim=K), global_batch_size=b,
-                                         total_steps=1000)
+        if H.reference_available() and l_size % patch == 0:   # the reference's wrapper cannot run 98^2 crops at patch 16
+            m = H.build_reference_method(arch=name, patch_size=patch, img_size=g_size, method_kwargs=dict(output_dim=K), global_batch_size=b,
+                                         total_steps=1000, model_kwargs=dict(ffn_layer=ffn))
             runner = H.ReferenceRunner(m)
             kind, step = "reference", (lambda: runner.train_step(views))
     except Exception:
@@ -125,27 +122,35 @@ def cpu_baseline(arch: dict, K: int, g_size: int, l_size: int, n_local: int, tim
     if step is None:
         from oracle import dinov2_oracle as O
 
-        sb, cfg = O.init_vit_params(name, patch_size=16, img_size=g_size, generator=g)
+        sb, cfg = O.init_vit_params(name, patch_size=patch, img_size=g_size, generator=g)
         sh = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
         th = O.init_head_params(arch["embed_dim"], 2048, 256, K, generator=g)
         o = O.OracleDINOv2(sb, sh, cfg, args=dict(output_dim=K), global_batch_size=b, total_steps=1000, teacher_head=th)
         step = lambda: o.train_step(views)   # noqa: E731
     random.seed(0)
-    for _ in range(warmups):
-        step()
-    times = []
-    for _ in range(timed_steps):
+    phys = max(1, info["physical_cores"])
+    counts = sorted({c for c in (8, 16, 32, 64) if c < phys} | {phys})
+
+    def timed(n: int) -> float:
+        torch.set_num_threads(n)
         t0 = time.perf_counter()
         step()
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    timed(min(32, phys))        # untimed warm-up: allocator, the optimizer's lazily created state, the first-touch of the activations
+    sweep = {n: timed(n) for n in counts}
+    best = min(sweep, key=sweep.get)
+    again = timed(best)
     torch.set_num_threads(prev_threads)
-    dt = statistics.median(times)
+    dt = min(sweep[best], again)
     what = "the reference's own DINOv2.training_step_impl via oracle/ref_harness.py" if kind == "reference" else "oracle/dinov2_oracle.py"
-    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": info["physical_cores"], "kind": kind,
-            "cpu_model": info["model"], "logical_cpus": info["logical_cpus"],
-            "spread": round((max(times) - min(times)) / dt, 3),
-            "sample": f"{what}, fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}, {warmups} warm-ups + {timed_steps} timed steps on "
-                      f"{info['physical_cores']} torch threads (one per physical core), median (step times {', '.join(f'{t:.2f}' for t in times)} s)"}
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": best, "kind": kind,
+            "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
+            "sweep": {str(n): round(b / t, 4) for n, t in sweep.items()},
+            "spread": round(abs(sweep[best] - again) / dt, 3),
+            "sample": f"{what}, fp32 full step (fwd+bwd+clip+AdamW+EMA), batch {b}; 1 untimed warm-up step, then one timed step at each of "
+                      f"{counts} torch threads and a second one at the best count ({best}); value = batch / the faster of that count's two steps "
+                      f"({sweep[best]:.2f} s, {again:.2f} s); images/sec per thread count in `sweep`"}
 
 
 def raise_host_priority() -> str:
@@ -182,6 +187,10 @@ def main() -> None:
                     help="dinov2 = the BASELINE metric; distillationv3 = SURVEY 8(a) a22: frozen DINOv3 ViT-L/16 teacher -> ViT student, one 224^2 view")
     ap.add_argument("--student", default="dinov2", choices=["dinov2", "dinov3", "resnet50"],
                     help="distillationv3 only: student family -- dinov2 / dinov3 ViT of --model size, or torchvision's resnet50 (BASELINE configs[3])")
+    ap.add_argument("--patch-size", type=int, default=16, help="16 = the BASELINE metric; 14 = the reference's model-zoo default (dinov2/vit*14: 257 / 50 tokens)")
+    ap.add_argument("--ffn", default="mlp", choices=["mlp", "swiglufused"], help="FFN of the ViT blocks (vision_transformer.py:179-185)")
+    ap.add_argument("--drop-path", type=float, default=0.0, help="stochastic-depth rate of the student; > 0.1 = the batch-subset regime of "
+                    "layers/block.py:118-141 (the reference's ViT-B default is 0.2); 0 = the BASELINE metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true", help="views stay in pinned host memory; each step pays the H2D copy (PCIe-inclusive rate, never the headline value)")
@@ -216,7 +225,8 @@ def main() -> None:
     from lightly_train_amd.vit import ViTConfig
 
     arch = MODELS[args.model]
-    cfg = ViTConfig(patch_size=16, img_size=args.global_size, init_values=1e-5, **arch)
+    P = args.patch_size
+    cfg = ViTConfig(patch_size=P, img_size=args.global_size, init_values=1e-5, drop_path_rate=args.drop_path, ffn_layer=args.ffn, **arch)
     B = args.batch
     aug = aug_src = None
     g = torch.Generator().manual_seed(1234 + rank)
@@ -309,8 +319,8 @@ def main() -> None:
     ms_per_step = dt / args.steps * 1e3
     img_per_s = B * world * args.steps / dt
 
-    n_g = (-(-args.global_size // 16)) ** 2 + 1
-    n_l = (-(-args.local_size // 16)) ** 2 + 1  # 98 -> 112 (bicubic pad-resize of patch_embed.py:90-99) -> 7x7 patches
+    n_g = (-(-args.global_size // P)) ** 2 + 1
+    n_l = (-(-args.local_size // P)) ** 2 + 1  # patch 16: 98 -> 112 (bicubic pad-resize of patch_embed.py:90-99) -> 7x7 patches
     if args.method == "distillationv3":
         def vit_fwd(D: int, depth: int, T: int) -> float:
             return depth * (2 * T * 12 * D * D + 4 * T * T * D) + 2 * (n_g - 1) * D * 3 * 256
@@ -323,8 +333,10 @@ def main() -> None:
         gf_img = (vit_fwd(1024, 24, n_g + 4) + 3 * s_fwd) / 1e9
     else:
         m_tokens = method._last["M"] / B
-        gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], 4 * arch["embed_dim"], n_g, n_l, args.n_local, args.out_dim,
-                                      2048, 256, m_tokens) / 1e9
+        # (SwiGLU-fused: w12 [2h, D] + w3 [D, h] = 3 D h MACs per token against the MLP's 2 D hidden; `hidden` here is the MLP-equivalent width)
+        hid_eq = cfg.hidden * 3 / 2 if cfg.swiglu else cfg.hidden
+        gf_img = step_flops_per_image(arch["embed_dim"], arch["depth"], hid_eq, n_g, n_l, args.n_local, args.out_dim,
+                                      2048, 256, m_tokens, p=P) / 1e9
 
     roofline = None
     if not args.no_roofline:   # every rank runs the instrumented step (it contains the step's collectives); rank 0 reports
@@ -370,7 +382,7 @@ def main() -> None:
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         default_cfg = (args.method == "dinov2" and args.model == "vit_base" and B == 128 and args.global_size == 224 and args.local_size == 98 and args.n_local == 8
-                       and args.out_dim == 65536)
+                       and args.out_dim == 65536 and P == 16 and args.drop_path == 0.0 and args.ffn == "mlp")
         if default_cfg and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
@@ -400,7 +412,7 @@ def main() -> None:
         pass
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.method == "dinov2":
-        cpu = cpu_baseline(arch, args.out_dim, args.global_size, args.local_size, args.n_local)
+        cpu = cpu_baseline(arch, args.out_dim, args.global_size, args.local_size, args.n_local, patch=P, ffn=args.ffn)
 
     if rank == 0:
         if args.method == "distillationv3":
@@ -409,9 +421,12 @@ def main() -> None:
             workload = (f"DistillationV3 training step, frozen DINOv3 ViT-L/16 teacher -> {sname} student, per-GPU batch {B}, "
                         f"one {args.global_size}^2 view, queue 8192" + (" (= BASELINE configs[3])" if args.student == "resnet50" else ""))
         else:
-            metric = "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if args.model == "vit_base" else f"images/sec DINOv2 {args.model}/16 2g+8l crops"
-            workload = (f"DINOv2 {args.model}/16 training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops, "
-                        f"K={args.out_dim} prototypes, softmax centering, drop-path 0")
+            headline = args.model == "vit_base" and P == 16 and args.ffn == "mlp" and args.drop_path == 0.0
+            metric = "images/sec (whole node) DINOv2 ViT-B/16 2g+8l crops" if headline else f"images/sec DINOv2 {args.model}/{P} 2g+8l crops"
+            regime = ("" if args.drop_path == 0 else " (batch-subset stochastic depth, layers/block.py:118-141)" if args.drop_path > 0.1
+                      else " (per-sample DropPath)")
+            workload = (f"DINOv2 {args.model}/{P} training step, per-GPU batch {B}, 2x{args.global_size}^2 + {args.n_local}x{args.local_size}^2 crops "
+                        f"({n_g} / {n_l} tokens), K={args.out_dim} prototypes, softmax centering, FFN {args.ffn}, drop-path {args.drop_path:g}{regime}")
         out = {
             "metric": metric,
             "value": round(img_per_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

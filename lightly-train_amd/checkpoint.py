@@ -165,18 +165,28 @@ def _view(flat: Tensor, fp: FlatParams, name: str) -> Tensor:
 
 
 def optimizer_state_dict(student: FlatParams, exp_avg: Tensor, exp_avg_sq: Tensor, opt_step: int,
-                         param_groups: List[Dict[str, Any]], hyper: Dict[str, Any]) -> Dict[str, Any]:
+                         param_groups: List[Dict[str, Any]], hyper: Dict[str, Any],
+                         prefix_steps: Optional[Mapping[str, int]] = None) -> Dict[str, Any]:
     """`torch.optim.AdamW.state_dict()` of the reference's optimizer: {"state": {idx: {step, exp_avg, exp_avg_sq}},
     "param_groups": [{..., "params": [idx, ...]}]}.  `param_groups`: one entry per flat tensor (see `fused_groups`), `hyper`:
-    the group fields shared by all groups (betas, eps, ...); per-group "lr" / "weight_decay" are the values currently in effect."""
+    the group fields shared by all groups (betas, eps, ...); per-group "lr" / "weight_decay" are the values currently in effect.
+    `prefix_steps`: flat-name prefix -> the Adam step count of THOSE parameters where it differs from `opt_step` (torch counts per parameter
+    and skips parameters that had no gradient: DINOv31's PaKA head before `paka_start_step`); a count of 0 writes no state, as torch does."""
     state: Dict[int, Dict[str, Tensor]] = {}
+
+    def step_of(n: str) -> int:
+        for pre, st in (prefix_steps or {}).items():
+            if n.startswith(pre):
+                return int(st)
+        return int(opt_step)
+
     groups: List[Dict[str, Any]] = []
     idx = 0
     for g in fused_groups(param_groups):
         ids = []
         for n in g["members"]:
-            if opt_step > 0:   # torch creates the per-parameter state lazily at the first step
-                state[idx] = {"step": torch.tensor(float(opt_step)), "exp_avg": _view(exp_avg, student, n).detach().clone(),
+            if step_of(n) > 0:   # torch creates the per-parameter state lazily at the first step
+                state[idx] = {"step": torch.tensor(float(step_of(n))), "exp_avg": _view(exp_avg, student, n).detach().clone(),
                               "exp_avg_sq": _view(exp_avg_sq, student, n).detach().clone()}
             ids.append(idx)
             idx += 1
@@ -187,9 +197,12 @@ def optimizer_state_dict(student: FlatParams, exp_avg: Tensor, exp_avg_sq: Tenso
 
 
 def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_avg: Tensor, exp_avg_sq: Tensor,
-                              param_groups: List[Dict[str, Any]]) -> int:
+                              param_groups: List[Dict[str, Any]], prefix_steps: Optional[Dict[str, int]] = None) -> int:
     """Inverse of `optimizer_state_dict`: fills the flat moment buffers and returns the optimizer step count.  The group
-    structure of the checkpoint must be the fused structure of this model (same sizes, same order)."""
+    structure of the checkpoint must be the fused structure of this model (same sizes, same order).
+    `prefix_steps` (in/out): flat-name prefixes whose parameters may carry a step count of their own (or no state at all); on return it
+    holds the count found for each prefix (0 when the checkpoint has no state for them).  All other parameters must agree."""
+    own: Dict[str, set] = {pre: set() for pre in (prefix_steps or {})}
     fg = fused_groups(param_groups)
     if len(osd["param_groups"]) != len(fg):
         raise ValueError(f"optimizer state has {len(osd['param_groups'])} parameter groups, this model has {len(fg)}")
@@ -207,7 +220,12 @@ def load_optimizer_state_dict(osd: Mapping[str, Any], student: FlatParams, exp_a
                 if tuple(st[key].shape) != tuple(v.shape):
                     raise ValueError(f"optimizer state of {n}: shape {tuple(st[key].shape)} vs {tuple(v.shape)}")
                 plan.append((v, st[key]))
-            steps.add(int(float(st["step"])))
+            pre = next((q for q in own if n.startswith(q)), None)
+            (steps if pre is None else own[pre]).add(int(float(st["step"])))
+    for pre, found in own.items():
+        if len(found) > 1:
+            raise ValueError(f"parameters under {pre!r} disagree on their optimizer step count: {sorted(found)}")
+        prefix_steps[pre] = found.pop() if found else 0     # type: ignore[index]
     if len(steps) > 1:
         raise ValueError(f"parameters disagree on the optimizer step count: {sorted(steps)}")
     # validated: now replace the state.  Parameters without an entry (a step-0 or partial checkpoint) get zero moments, as

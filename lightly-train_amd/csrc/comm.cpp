@@ -18,9 +18,13 @@ ncclComm_t comm = nullptr;
 hipStream_t cstream = nullptr;
 // one fence event per collective in flight: an event re-recorded while an earlier wait on it has not been consumed by the device yet
 // would move that wait to the later record (HIP events are not counting semaphores), so a step that starts its 14 gradient all-reduces
-// back to back takes 14 different events; 32 cover two steps' worth, and re-use only happens after the oldest collective's record.
+// back to back takes 14 different events; 32 cover two steps' worth.  Re-use is guarded: every slot also carries a completion event recorded
+// on the communicator's stream behind its collective, and a slot is only taken again after that event has fired (the host blocks in
+// hipEventSynchronize when more than 32 collectives are in flight: ViT-g's 40 blocks x several buckets -- slower, never wrong).
 constexpr int N_EV = 32;
 hipEvent_t ev_in[N_EV] = {nullptr};
+hipEvent_t ev_done[N_EV] = {nullptr};
+bool ev_used[N_EV] = {false};
 hipEvent_t ev_out = nullptr;
 unsigned ev_next = 0;
 int world = 0;
@@ -35,7 +39,12 @@ void release_locked() {   // everything lt_comm_init created, in any partial sta
   if (cstream) (void)hipStreamSynchronize(cstream);
   if (comm && p_destroy) p_destroy(comm);
   if (cstream) (void)hipStreamDestroy(cstream);
-  for (int i = 0; i < N_EV; ++i) { if (ev_in[i]) (void)hipEventDestroy(ev_in[i]); ev_in[i] = nullptr; }
+  for (int i = 0; i < N_EV; ++i) {
+    if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
+    if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+    ev_in[i] = ev_done[i] = nullptr;
+    ev_used[i] = false;
+  }
   if (ev_out) (void)hipEventDestroy(ev_out);
   comm = nullptr; cstream = nullptr; ev_out = nullptr; world = 0; ev_next = 0;
 }
@@ -82,7 +91,8 @@ extern "C" int lt_comm_init(int rank, int world_size, const void* id_in, int byt
   const ncclResult_t r = p_init(&comm, world_size, id, rank);
   if (r != ncclSuccess) { comm = nullptr; return fail("lt_comm_init", r); }
   bool ok = hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < N_EV; ++i) ok = hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < N_EV; ++i)
+    ok = hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {   // leave no half-built handle behind: a retry must not find "already holds a communicator" nor null streams / events
     release_locked();
     lt_set_error("lt_comm_init: stream / event creation failed");
@@ -98,13 +108,23 @@ extern "C" int lt_comm_allreduce_f32(float* buf, int64_t n, void* after_stream) 
   std::lock_guard<std::mutex> l(mu);
   if (!comm) { lt_set_error("lt_comm_allreduce_f32: no communicator (lt_comm_init)"); return LT_ERR_INVALID; }
   if (n == 0) return LT_OK;
-  hipEvent_t ev = ev_in[ev_next++ % N_EV];
+  const unsigned slot = ev_next++ % N_EV;
+  if (ev_used[slot] && hipEventSynchronize(ev_done[slot]) != hipSuccess) {   // the slot's previous collective (and with it its fence wait) is over
+    lt_set_error("lt_comm_allreduce_f32: waiting for fence slot %u failed", slot);
+    return LT_ERR_HIP;
+  }
+  hipEvent_t ev = ev_in[slot];
   if (hipEventRecord(ev, (hipStream_t)after_stream) != hipSuccess || hipStreamWaitEvent(cstream, ev, 0) != hipSuccess) {
     lt_set_error("lt_comm_allreduce_f32: event fence failed");
     return LT_ERR_HIP;
   }
   const ncclResult_t r = p_allreduce(buf, buf, (size_t)n, ncclFloat, ncclSum, comm, cstream);
   if (r != ncclSuccess) return fail("lt_comm_allreduce_f32", r);
+  if (hipEventRecord(ev_done[slot], cstream) != hipSuccess) {
+    lt_set_error("lt_comm_allreduce_f32: completion event failed");
+    return LT_ERR_HIP;
+  }
+  ev_used[slot] = true;
   return LT_OK;
 }
 

@@ -487,6 +487,7 @@ class DINOv2:
         # softmax centering without the [rows, K] probability matrix (training_step_impl); LT_FUSED_CENTERING=0: softmax, column sums and
         # cross-entropy as three passes
         self.fused_centering = os.environ.get("LT_FUSED_CENTERING", "1") != "0"
+        self.sinkhorn_joint = os.environ.get("LT_SINKHORN_JOINT", "1") != "0"   # both heads' Sinkhorn iterations share one all-reduce each
         # gradient accumulation (the reference hands `gradient_accumulation_steps` to Lightning as accumulate_grad_batches,
         # LT/_commands/train_helpers.py:224-236): a caller that accumulates k micro-batches per optimizer step sets, before each
         # `training_step_impl`, accum_first (first micro-batch of the window: the flat gradient buffer is zeroed), grad_scale = 1 / k
@@ -658,6 +659,11 @@ class DINOv2:
         H1 = int(D * cfg.mlp_ratio) * (2 if cfg.swiglu else 1)
         per_pass = 2 * 256 * 3 * D + 128 * (3 * D + D + H1 + D) + 4 * 64 * D     # LayerNorm x 2, four bias sums, LayerScale x 2 of one block
         floats = 2 * (cfg.depth * per_pass + 256 * 3 * D + 2 * 1024 * D) + 4 * 128 * (2 * a.hidden_dim + 2 * D + 4096)
+        # the bias column sums that ride the weight-gradient GEMMs reserve (k-slices x column tiles x 4) partial rows of n_out floats each;
+        # the split-K plan keeps row tiles x k-slices within 512 workgroup slots, so a GEMM needs at most 2048 / (n_out / 256) rows, i.e.
+        # 2048 * 256 floats whatever its shape: four such GEMMs per block and pass (two passes, or their joint form), plus the heads'
+        # (projection MLP x 3, PaKA head x 3 in DINOv31, both iBOT / DINO heads).  HBM is not the scarce resource here (288 GB).
+        floats += (2 * 4 * cfg.depth + 12) * 2048 * 256
         ops.reduce_begin(self.ws.get("reduce.scratch", (int(floats * 1.25) // 4 * 4,), torch.float32))
 
     def _backward_backbone(self, sg: Dict[str, Any], dxn_g: Tensor, sl: Optional[Dict[str, Any]], dxn_l: Optional[Tensor]) -> None:
@@ -866,10 +872,16 @@ class DINOv2:
             self._pending["dino"] = (cs_d, 1.0 / (2 * B), hd)
             self._pending["ibot"] = (cs_i, 1.0, hi)
         else:
-            self._sinkhorn(t_logits[:2 * B], t_probs[:2 * B], 2 * B, K, teacher_temp, float(2 * B * self.world), "skd")
-            # n_masked_patches over all ranks (dinov2.py:441-449) only scales Q between iterations (see _sinkhorn): this rank's count
-            # times the world size stands in for it -- no collective and no host read-back of a device scalar in the step
-            self._sinkhorn(t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, K, teacher_temp, float(max(M, 1) * self.world), "ski")
+            # n_masked_patches over all ranks (dinov2.py:441-449) only scales Q between iterations (see _sinkhorn_joint): this rank's count
+            # times the world size stands in for it -- no collective and no host read-back of a device scalar in the step.  Both heads
+            # iterate in lockstep: one all-reduce per iteration carries the prototype sums of both
+            jobs = [(t_logits[:2 * B], t_probs[:2 * B], 2 * B, float(2 * B * self.world)),
+                    (t_logits[2 * B:Rt], t_probs[2 * B:Rt], M, float(max(M, 1) * self.world))]
+            if self.sinkhorn_joint:
+                self._sinkhorn_joint(jobs, K, teacher_temp, "sk")
+            else:
+                self._sinkhorn(*jobs[0][:3], K, teacher_temp, jobs[0][3], "skd")
+                self._sinkhorn(*jobs[1][:3], K, teacher_temp, jobs[1][3], "ski")
 
         teacher_done = tstream.record_event()
         torch.cuda.set_stream(main)
@@ -1039,19 +1051,31 @@ class DINOv2:
         return dict(zip(keys, vals))
 
     def _sinkhorn(self, logits: Tensor, out: Tensor, rows: int, K: int, temp: float, n_total: Any, tag: str) -> None:
-        """dinov2_loss.py:84-115 / :188-224.  The initial Q /= sum(Q) is a global scalar that cancels in the first
-        row normalisation, so it is skipped (same value up to fp32 rounding).  So does the sample count `n_total` (B in the
-        reference): every iteration ends with Q /= B, a factor common to all of Q, which the next iteration's Q /= sum_of_rows
-        removes again, and the closing Q *= B undoes the last one -- the result does not depend on it beyond rounding, which is why the
-        iBOT call may pass an estimate instead of all-reducing the masked-patch count (tests/test_dinov2_method_cpu.py checks it)."""
-        nt = float(n_total.item()) if isinstance(n_total, Tensor) else float(n_total)
-        ops.sk_exp(logits, out, 1.0 / temp)
-        cs = self.ws.get(tag + ".colsum", (K,), torch.float32)
+        """One head's Sinkhorn-Knopp (see `_sinkhorn_joint`)."""
+        self._sinkhorn_joint([(logits, out, rows, n_total)], K, temp, tag)
+
+    def _sinkhorn_joint(self, jobs: List[Tuple[Tensor, Tensor, int, Any]], K: int, temp: float, tag: str) -> None:
+        """dinov2_loss.py:84-115 / :188-224 for several (logits, out, rows, n_total) problems that share K and the temperature -- the DINO and
+        the iBOT head of one step -- iterated in lockstep: every iteration's prototype sums of ALL problems sit in one [len(jobs) * K] buffer
+        and cross the ranks in ONE all-reduce (3 collectives per step instead of 3 per head; the reference issues 1 scalar + 3 vector
+        all-reduces per head, dinov2_loss.py:97-106,200-215).  Each problem's arithmetic is untouched: results are bit-identical to
+        one-at-a-time calls (tests/test_ddp_gloo.py).
+        The initial Q /= sum(Q) is a global scalar that cancels in the first row normalisation, so it is skipped (same value up to fp32
+        rounding).  So does the sample count `n_total` (B in the reference): every iteration ends with Q /= B, a factor common to all of Q,
+        which the next iteration's Q /= sum_of_rows removes again, and the closing Q *= B undoes the last one -- the result does not depend
+        on it beyond rounding, which is why the iBOT call may pass an estimate instead of all-reducing the masked-patch count
+        (tests/test_dinov2_method_cpu.py checks it)."""
+        nts = [float(n.item()) if isinstance(n, Tensor) else float(n) for _, _, _, n in jobs]
+        for logits, out, _, _ in jobs:
+            ops.sk_exp(logits, out, 1.0 / temp)
+        cs = self.ws.get(tag + ".colsum", (len(jobs) * K,), torch.float32)
         for it in range(3):
-            ops.colsum_f32(out, cs, rows, K)
+            for j, (_, out, rows, _) in enumerate(jobs):
+                ops.colsum_f32(out, cs[j * K:(j + 1) * K], rows, K)
             if self.world > 1:
                 dist.all_reduce(cs)
-            ops.sk_iter(out, cs, rows, K, nt, nt if it == 2 else 1.0)
+            for j, (_, out, rows, _) in enumerate(jobs):
+                ops.sk_iter(out, cs[j * K:(j + 1) * K], rows, K, nts[j], nts[j] if it == 2 else 1.0)
 
     # ------------------------------------------------------------------ optimizer / EMA hooks
     def _gradient_sync(self) -> Optional[GradSync]:

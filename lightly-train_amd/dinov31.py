@@ -32,7 +32,7 @@ from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from . import ops
+from . import checkpoint, ops
 from .dinov2 import DINOv2, DINOv2Args, TrainingStepResult
 from .vit import ViTConfig, make_drop_plan, padded_rows, split_k_plan, _split_k
 
@@ -142,6 +142,20 @@ class DINOv31(DINOv2):
                 if n.startswith("paka."):
                     sd.setdefault(f"{role}_paka_head.{n[5:]}", fp.p[n].detach().clone())
         super().load_state_dict(sd, strict=strict)
+
+    # ---- optimizer state: the PaKA head counts its own Adam steps (torch.optim.AdamW keeps `step` per parameter and skips parameters
+    # without a gradient, dinov31.py:258-270 before `paka_start_step`); both directions of a checkpoint carry that count
+    def optimizer_state_dict(self) -> Dict[str, Any]:
+        a = self.method_args
+        hyper = dict(betas=tuple(a.betas), eps=a.eps, amsgrad=False, maximize=False, foreach=True, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=True)
+        return checkpoint.optimizer_state_dict(self.student, self.exp_avg, self.exp_avg_sq, self.opt_step, self._group_entries(), hyper,
+                                               prefix_steps={"paka.": self.paka_opt_steps})
+
+    def load_optimizer_state_dict(self, osd: Mapping[str, Any]) -> None:
+        own = {"paka.": 0}
+        self.opt_step = checkpoint.load_optimizer_state_dict(osd, self.student, self.exp_avg, self.exp_avg_sq, self._group_entries(), prefix_steps=own)
+        self.paka_opt_steps = int(own["paka."])
 
     def _adamw(self, freeze: int, lr_factor: float, wd: float, lo: int = 0, hi: Optional[int] = None, step: Optional[int] = None) -> None:
         p0, p1 = self._paka_span

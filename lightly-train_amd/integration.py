@@ -54,8 +54,27 @@ def accumulate_k(self: Any) -> int:
 
 
 def total_optimizer_steps(self: Any) -> int:
-    """`trainer.estimated_stepping_batches` counts batches when the Trainer runs with accumulate_grad_batches = 1: k micro-batches make one step."""
-    return max(-(-int(self.trainer.estimated_stepping_batches) // accumulate_k(self)), 1)
+    """Optimizer steps of the whole run, counted the way the windows really close (`begin_micro_batch`: every k-th batch AND the last batch
+    of every epoch, like Lightning's own accumulation): epochs * ceil(batches_per_epoch / k), capped by `max_steps` -- which, with the
+    Trainer running at accumulate_grad_batches = 1 and ticking once per optimizer step (`_tick_lightning`), already counts optimizer steps.
+    `ceil(all_batches / k)` undercounts whenever an epoch is not a multiple of k (10 batches, k = 4, 100 epochs: 300 steps, not 250), and
+    the schedules raise once the step passes their total.  Without a per-epoch batch count (iterable datasets, a hand-driven module) the
+    Trainer's estimate is all there is: `trainer.estimated_stepping_batches` counts batches there."""
+    k = accumulate_k(self)
+    tr = self.trainer
+    est = int(tr.estimated_stepping_batches)
+    if k == 1:
+        return max(est, 1)
+    nb, ep, ms = getattr(tr, "num_training_batches", None), getattr(tr, "max_epochs", None), getattr(tr, "max_steps", None)
+    finite = isinstance(nb, (int, float)) and nb == nb and nb not in (float("inf"),) and nb > 0
+    total: Optional[int] = None
+    if finite and isinstance(ep, int) and ep > 0:
+        total = ep * -(-int(nb) // k)
+    if isinstance(ms, int) and ms > 0:
+        total = ms if total is None else min(total, ms)
+    if total is None:
+        total = -(-est // k)
+    return max(total, 1)
 
 
 def begin_micro_batch(self: Any, batch_idx: int) -> Any:
@@ -698,15 +717,24 @@ def install_as(name: str = "dinov2") -> type:
         return m
 
     method_helpers._method_name_to_cls = patched
+    _AMD_CLASSES.add(cls)
     _wrap_get_trainer()
     return cls
+
+
+_AMD_CLASSES: set = set()             # the classes `install_as` has put into the method table of this process
+_LAST_TRAINER: Dict[str, Any] = {}    # the Trainer the wrapped `get_trainer` built last, and the k it was asked for
 
 
 def _wrap_get_trainer() -> None:
     """`lightly_train.train(gradient_accumulation_steps=k)` reaches Lightning as Trainer(accumulate_grad_batches=k)
     (LT/_commands/train_helpers.py:208-247), which Lightning rejects for a manual-optimization module.  Build the Trainer with 1 and let it
-    carry k as `lt_amd_accumulate_grad_batches`: the binding accumulates in its flat gradient buffer (`begin_micro_batch`)."""
+    carry k as `lt_amd_accumulate_grad_batches`: the binding accumulates in its flat gradient buffer (`begin_micro_batch`).
+    `train()` builds the Trainer BEFORE it resolves the method class (LT/_commands/train.py:433 / :476), so the rewrite cannot look at the
+    method; it is undone in the wrapped `get_method_cls` when the class that comes out is not one of the installed MI355X classes -- a
+    `simclr` run in the same process keeps Lightning's own accumulation."""
     from lightly_train._commands import train_helpers
+    from lightly_train._methods import method_helpers
 
     if getattr(train_helpers.get_trainer, "_lt_amd_wrapped", False):
         return
@@ -720,7 +748,22 @@ def _wrap_get_trainer() -> None:
         bound.arguments["gradient_accumulation_steps"] = 1
         trainer = orig(*bound.args, **bound.kwargs)
         trainer.lt_amd_accumulate_grad_batches = k
+        _LAST_TRAINER.update(trainer=trainer, k=k)
         return trainer
+
+    orig_get_cls = method_helpers.get_method_cls
+
+    def get_method_cls(method: Any) -> Any:
+        cls = orig_get_cls(method)
+        tr, k = _LAST_TRAINER.get("trainer"), _LAST_TRAINER.get("k", 1)
+        if tr is not None and cls not in _AMD_CLASSES:
+            # not ours: hand the window back to Lightning (Trainer.accumulate_grad_batches is a plain attribute the epoch loop reads)
+            tr.accumulate_grad_batches = k
+            if hasattr(tr, "lt_amd_accumulate_grad_batches"):
+                del tr.lt_amd_accumulate_grad_batches
+        _LAST_TRAINER.clear()
+        return cls
 
     get_trainer._lt_amd_wrapped = True   # type: ignore[attr-defined]
     train_helpers.get_trainer = get_trainer
+    method_helpers.get_method_cls = get_method_cls

@@ -12,6 +12,12 @@ norm, per-tensor gradient norms of EVERY parameter, 14 named gradient tensors (s
 loss centers after the step's update; from a forward with the reference's default KoLeo weight: the four loss terms.
 
     python oracle/make_bench_fixture.py [--batch 32] [--threads 8]
+
+`--reference --local-size 96 [--batch 16]` (round 5): the SAME quantities written by the REFERENCE's own DINOv2 class
+(oracle/ref_harness.py imports it from /root/reference; its wrapper refuses 98^2 crops at patch 16, SURVEY 8(d), so the local crops are the
+upstream default 96^2 = 37 tokens) -> tests/golden/bench_vitb_ref_b<batch>.pt.  The seeded weights are loaded into the reference module
+(asserted equal), the masks are the ones its own `create_collated_masks` call sampled, the gradients are autograd's on its parameters.
+This pins ViT-B/16 with K = 65 536 on the reference itself rather than on the restatement.
 """
 from __future__ import annotations
 
@@ -44,14 +50,126 @@ def sample(t: torch.Tensor) -> torch.Tensor:
     return m[::16, ::8].clone()
 
 
-def build_inputs(batch: int, seed: int):
+def build_inputs(batch: int, seed: int, local: int = 98):
     """Weights and views from one generator, in this order (tests/test_gpu_step.py rebuilds them the same way)."""
     g = torch.Generator().manual_seed(seed)
     vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
     bsd = init_vit_state(vc, g)
     shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
-    views = [torch.randn(batch, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(batch, 3, 98, 98, generator=g) for _ in range(8)]
+    views = [torch.randn(batch, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(batch, 3, local, local, generator=g) for _ in range(8)]
     return vc, bsd, shs, ths, views
+
+
+def reference_step(b: int, seed: int, mask_seed: int, local: int, koleo, backward: bool, autocast: bool = False):
+    """One `training_step_impl` (+ backward) of the reference's own class from the seeded state.  Returns a dict in the layout of the
+    restatement's record ("loss", "logs", and with `backward`: grad_norm / tensor_norms / grad_samples / centers / logit_samples / masks)."""
+    from oracle import ref_harness as H
+
+    H.install()
+    import lightly_train._methods.dinov2.dinov2 as ref_dinov2
+
+    vc, bsd, shs, ths, views = build_inputs(b, seed, local)
+    mk = dict(output_dim=65536)
+    if koleo is not None:
+        mk["koleo_loss_weight"] = koleo
+    m = H.build_reference_method(arch="vit_base", patch_size=16, img_size=224, method_kwargs=mk, global_batch_size=b, total_steps=100, seed=1)
+    sd, new = m.state_dict(), {}
+    for k, v in sd.items():
+        for role, head in (("student", shs), ("teacher", ths)):
+            pre = f"{role}_embedding_model.wrapped_model._model."
+            if k.startswith(pre):
+                new[k] = bsd[k[len(pre):]].reshape(v.shape)
+            for hn in ("dino_head", "ibot_head"):
+                pre = f"{role}_head.{hn}."
+                if k.startswith(pre):
+                    new[k] = head[k[len(pre):]].reshape(v.shape)
+        new.setdefault(k, v)
+    m.load_state_dict(new, strict=True)
+    assert torch.equal(m.state_dict()["student_embedding_model.wrapped_model._model.blocks.3.mlp.fc1.weight"], bsd["blocks.3.mlp.fc1.weight"])
+    cap: dict = {}
+    t_calls, s_calls = [], []
+
+    def spy(mod, sink):
+        orig = mod.forward
+
+        def fwd(x):
+            out = orig(x)
+            sink.append(out.detach()[:4, ::64].float().clone())
+            return out
+        mod.forward = fwd
+
+    spy(m.teacher_head.dino_head, t_calls)
+    spy(m.student_head.dino_head, s_calls)
+    orig_ccm = ref_dinov2.create_collated_masks
+
+    def spy_ccm(**kw):
+        out = orig_ccm(**kw)
+        cap["masks"] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        return out
+
+    ref_dinov2.create_collated_masks = spy_ccm
+    random.seed(mask_seed)
+    t0 = time.time()
+    try:
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                res = m.training_step_impl({"views": views, "filename": []}, 0)
+        elif backward:
+            res = m.training_step_impl({"views": views, "filename": []}, 0)
+        else:
+            with torch.no_grad():
+                res = m.training_step_impl({"views": views, "filename": []}, 0)
+    finally:
+        ref_dinov2.create_collated_masks = orig_ccm
+    rec = {"loss": float(res.loss.detach()), "logs": {k.split("/")[-1]: float(v) for k, v in res.log_dict.items()}, "masks": cap["masks"]}
+    if not backward:
+        return rec
+    res.loss.backward()
+    print(f"reference forward + backward ({'bf16 autocast' if autocast else 'fp32'}): {time.time() - t0:.1f} s", flush=True)
+    norms, samples, sq = {}, {}, 0.0
+    for role_pre, ours in (("student_embedding_model.wrapped_model._model.", "backbone."), ("student_head.dino_head.", "head.")):
+        for n, p in m.named_parameters():
+            if not n.startswith(role_pre) or p.grad is None:
+                continue
+            short = n[len(role_pre):]
+            g2 = float((p.grad.double() ** 2).sum())
+            sq += g2
+            norms[ours + short] = g2 ** 0.5
+            if (short if ours == "backbone." else ours + short) in SAMPLED:
+                samples[ours + short] = sample(p.grad.float())
+    rec.update(grad_norm=sq ** 0.5, tensor_norms=norms, grad_samples=samples)
+    m.dino_loss.apply_center_update()
+    m.ibot_loss.apply_center_update()
+    rec["dino_center"] = m.dino_loss.center.detach().reshape(-1).clone()
+    rec["ibot_center"] = m.ibot_loss.center.detach().reshape(-1).clone()
+    # head calls in the reference's order: teacher (cls, masked patches), student (cls, masked patches, local cls)
+    rec["logit_samples"] = {"t_cls_logits": t_calls[0], "t_patch_logits": t_calls[1], "s_cls_logits": s_calls[0], "s_patch_logits": s_calls[1],
+                            "s_loc_logits": s_calls[2]}
+    return rec
+
+
+def main_reference(a) -> None:
+    b = a.batch
+    out = {"batch": b, "seed": a.seed, "mask_seed": a.mask_seed, "total_steps": 100, "local_size": a.local_size, "writer": "reference class",
+           "config": f"vit_base/16, K=65536, 2x224^2 + 8x{a.local_size}^2, softmax centering -- LT/_methods/dinov2/dinov2.py:259-397 run from /root/reference"}
+    k0 = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True)
+    out["masks"] = k0.pop("masks")
+    out["koleo0"] = k0
+    yb = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True, autocast=True)
+    yard = {"loss": yb["loss"], "logs": yb["logs"], "grad_norm": yb["grad_norm"], "norm_rel_err": {}, "sample_err": {}}
+    for n, v in yb["tensor_norms"].items():
+        yard["norm_rel_err"][n] = abs(v - k0["tensor_norms"][n]) / max(k0["tensor_norms"][n], 1e-20)
+    for n, v in yb["grad_samples"].items():
+        ref = k0["grad_samples"][n]
+        yard["sample_err"][n] = float((v.reshape(ref.shape) - ref).abs().max() / (ref.abs().max() + 1e-20))
+    out["autocast_yardstick"] = yard
+    d = reference_step(b, a.seed, a.mask_seed, a.local_size, None, backward=False)
+    assert all(torch.equal(d["masks"][k], out["masks"][k]) for k in out["masks"] if torch.is_tensor(out["masks"][k]))
+    out["default"] = {"loss": d["loss"], "logs": d["logs"]}
+    path = os.path.join(ROOT, "tests", "golden", f"bench_vitb_ref_b{b}.pt")
+    torch.save(out, path)
+    print(path, os.path.getsize(path) // 1024, "KiB", out["koleo0"]["logs"], out["default"]["logs"], "grad-norm", out["koleo0"]["grad_norm"],
+          "autocast grad-norm", yard["grad_norm"])
 
 
 def main() -> None:
@@ -60,8 +178,14 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=404)
     ap.add_argument("--mask-seed", type=int, default=17)
     ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--reference", action="store_true", help="write the fixture with the reference's own class (needs /root/reference; --local-size 96)")
+    ap.add_argument("--local-size", type=int, default=98)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
+    if a.reference:
+        if a.local_size % 16:
+            raise SystemExit("the reference's wrapper cannot run local crops that are not a multiple of the patch size (SURVEY 8(d)): use --local-size 96")
+        return main_reference(a)
     b = a.batch
     vc, bsd, shs, ths, views = build_inputs(b, a.seed)
     cfg = dict(patch_size=16, num_heads=12, depth=12)

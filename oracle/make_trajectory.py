@@ -44,6 +44,15 @@ MID = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=192, depth=
            cfg=dict(patch_size=16, num_heads=3, depth=4), b=8, g_size=112, l_size=48, n_local=4, init_seed=2024, init_values=1.0)
 
 
+# `--config vits` (round 5): ViT-S width -- D = 384, 6 heads of 64, 6 blocks, K = 16 384 prototypes, head 2048 / 256 (the reference's default
+# head widths), 2 x 112^2 + 4 x 48^2 crops, batch 8: 800 global / 320 local token rows, i.e. the 256-row four-phase GEMM, the slab split-K
+# weight gradients and the register-resident wide-row softmax / cross-entropy kernels all take part.  Seeded state like `mid`.
+VITS = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=384, depth=6, num_heads=6, mlp_ratio=4.0, init_values=1.0),
+            method_kwargs=dict(output_dim=16384, hidden_dim=2048, dino_bottleneck_dim=256),
+            cfg=dict(patch_size=16, num_heads=6, depth=6), b=8, g_size=112, l_size=48, n_local=4, init_seed=2025, init_values=1.0)
+CONFIGS = {"d64": CFG, "mid": MID, "vits": VITS}
+
+
 def seeded_init(cfg):
     """The initial state of the `mid` configuration: (student backbone, student head, teacher head) from one seeded generator."""
     import lightly_train_amd  # noqa: F401
@@ -113,8 +122,9 @@ def run(koleo: float, steps: int, mode: str, init_state=None, CFG=CFG):
 
 def main() -> None:
     steps = 100
-    mid = "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "mid"
-    cfg = MID if mid else CFG
+    name = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "d64"
+    cfg = CONFIGS[name]
+    mid = "init_seed" in cfg     # seeded initial state (mid, vits)
     out = {"cfg": cfg, "steps": steps, "view_seed0": 5000, "mask_seed0": 900, "runs": {}}
     for koleo in (0.1, 0.0):
         for mode in ("fp32", "bf16", "fp32_perturbed"):
@@ -139,7 +149,7 @@ def main() -> None:
             summary[(koleo, mode)] = {k: max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for a, b in zip(alt, ref)) for k in KEYS}
             print("max rel dev vs fp32", koleo, mode, {k: f"{v:.2e}" for k, v in summary[(koleo, mode)].items()})
     out["summary"] = summary
-    path = os.path.join(OUT, "trajectory_mid.pt" if mid else "trajectory_d64.pt")
+    path = os.path.join(OUT, f"trajectory_{name}.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

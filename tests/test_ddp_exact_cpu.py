@@ -82,17 +82,29 @@ def _run(name: str, ranks, world: int, n_steps: int = 2):
                     offsets=dict(m.student.offsets))
 
 
-def _worker(rank: int, world: int, port: int, out_dir: str, name: str) -> None:
+def _worker(rank: int, world: int, port: int, out_dir: str, name: str, env: dict = None, tag: str = "") -> None:
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env or {})
     torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"all_reduce": 0}
+    real = dist.all_reduce
+
+    def counted(*a, **k):
+        calls["all_reduce"] += 1
+        return real(*a, **k)
+
+    dist.all_reduce = counted
     try:
-        torch.save(_run(name, [rank], world), os.path.join(out_dir, f"r{rank}.pt"))
+        out = _run(name, [rank], world)
+        out["all_reduce_calls"] = calls["all_reduce"]
+        torch.save(out, os.path.join(out_dir, f"{tag}r{rank}.pt"))
     finally:
+        dist.all_reduce = real
         dist.destroy_process_group()
 
 
@@ -119,6 +131,24 @@ def test_two_ranks_with_their_own_data_equal_one_process_on_all_of_it(tmp_path, 
         for k, v in one[which].items():
             assert torch.equal(r[0][which][k], r[1][which][k]), k
             assert torch.allclose(r[0][which][k].float(), v.float(), atol=5e-5 if k.endswith("running_mean") else 2e-6), (which, k)
+
+
+def test_joint_sinkhorn_allreduce_is_bit_identical_to_one_head_at_a_time(tmp_path):
+    """Sinkhorn-Knopp centering under data parallelism (dinov2_loss.py:97-106,200-215): the DINO and the iBOT head iterate in lockstep and
+    each iteration's prototype sums of BOTH heads cross the ranks in one all-reduce (`DINOv2._sinkhorn_joint`) -- 3 collectives per step
+    where one head at a time (`LT_SINKHORN_JOINT=0`) takes 6.  Two gloo ranks with their own data, two optimizer steps: every parameter,
+    the EMA teacher and the losses are bit-identical between the two schedules, and the collective count drops by 3 per step."""
+    outs = {}
+    for tag, env in (("joint_", {"LT_SINKHORN_JOINT": "1"}), ("sep_", {"LT_SINKHORN_JOINT": "0"})):
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "step_vittest_sinkhorn", env, tag), nprocs=2, join=True)
+        outs[tag] = [torch.load(tmp_path / f"{tag}r{i}.pt", weights_only=False) for i in range(2)]
+    j, s_ = outs["joint_"], outs["sep_"]
+    for r in range(2):
+        assert j[r]["loss"] == s_[r]["loss"]
+        assert torch.equal(j[r]["student"], s_[r]["student"]) and torch.equal(j[r]["teacher"], s_[r]["teacher"])
+    assert torch.equal(j[0]["student"], j[1]["student"])
+    n_steps = len(j[0]["loss"])
+    assert s_[0]["all_reduce_calls"] - j[0]["all_reduce_calls"] == 3 * n_steps, (s_[0]["all_reduce_calls"], j[0]["all_reduce_calls"])
 
 
 def _run_dino_v1(ranks, world: int, n_steps: int = 3):

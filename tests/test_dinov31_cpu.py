@@ -132,3 +132,49 @@ def test_dinov2_checkpoint_loads_without_the_paka_heads():
         assert torch.equal(m.student.p["paka.2.weight"], before)
         with pytest.raises(KeyError):
             m.load_state_dict({k: v for k, v in sd.items() if "cls_token" not in k}, strict=True)
+
+
+def test_resume_keeps_the_paka_heads_own_adam_step_count():
+    """torch.optim.AdamW counts steps per parameter and skips parameters without a gradient: with `paka_start_step = 1` the PaKA head has
+    taken one Adam step less than everything else.  A checkpoint written after two steps carries both counts (state "step" 2 / 1), a fresh
+    object resumed from it takes a third step BITWISE equal to the uninterrupted run's (same exact-arithmetic kernels), and a checkpoint
+    written before the PaKA head's first step holds no state for it -- as torch writes none -- and loads."""
+    fx = torch.load(os.path.join(GOLD, "dinov31_d64.pt"), weights_only=False)
+    with ops_emu.emulate(ops):
+        m = build(fx)
+        exactify(m)
+
+        def step(obj, si):
+            rec = fx["steps"][si]
+            obj.training_step_impl({"views": synth_views(fx, rec["seed"]), "geometries": rec["geometries"]}, si, masks=rec["masks"])
+            obj.optimizer_step()
+            obj.on_train_batch_end()
+
+        step(m, 0)
+        early = m.checkpoint_dict()
+        names = [n for g in m.optimizer_state_dict()["param_groups"] for n in [g["name"]]]
+        assert m.opt_step == 1 and m.paka_opt_steps == 0 and names
+        osd = early["optimizer_states"][0]
+        n_state = len(osd["state"])
+        n_params = sum(len(g["params"]) for g in osd["param_groups"])
+        assert n_params - n_state == 6, "the six PaKA tensors have no optimizer state before their first step"
+        step(m, 1)
+        ck = m.checkpoint_dict()
+        steps = sorted({int(float(st["step"])) for st in ck["optimizer_states"][0]["state"].values()})
+        assert steps == [1, 2] and m.paka_opt_steps == 1
+        m._pending.clear()     # (the pending batch-center sums are no part of a checkpoint, in the reference either: dinov2_loss.py:139-160)
+        step(m, 2)
+
+        r = build(fx)
+        exactify(r)
+        r.load_checkpoint_dict(ck)
+        assert r.opt_step == 2 and r.paka_opt_steps == 1
+        step(r, 2)
+        assert torch.equal(r.student.data, m.student.data) and torch.equal(r.exp_avg, m.exp_avg) and torch.equal(r.exp_avg_sq, m.exp_avg_sq)
+
+        e = build(fx)
+        exactify(e)
+        e.load_checkpoint_dict(early)
+        assert e.opt_step == 1 and e.paka_opt_steps == 0
+        p0, p1 = e._paka_span
+        assert float(e.exp_avg[p0:p1].abs().max()) == 0.0

@@ -182,11 +182,13 @@ def test_cfg5_vit_large14_swiglu_518_step_matches_oracle(n_reg):
     views = [torch.randn(b, 3, 518, 518, generator=g) for _ in range(2)] + [torch.randn(b, 3, 98, 98, generator=g) for _ in range(8)]
     random.seed(9)
     gemms, attn, undo = _install_spies()
+    ovf = ops.reduce_overflows()
     try:
         res = m.training_step_impl({"views": views}, 0)
     finally:
         undo()
     torch.cuda.synchronize()
+    assert ops.reduce_overflows() == ovf, "reduction ledger scratch exhausted at ViT-L widths (the step would fall back to atomics)"
     ntok = 1370 + n_reg
     assert ("fwd", ntok, 16) in attn and ("bwd", ntok, 16) in attn and ("fwd", 50 + n_reg, 16) in attn
     kt = [c for c in gemms if c[1] == "gemm256q_ktail"]

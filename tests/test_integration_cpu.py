@@ -110,6 +110,33 @@ def test_dinov2_amd_is_a_registered_reference_method():
         integration.install_as("dinov2")
         assert method_helpers.get_method_cls("dinov2") is cls
         assert method_helpers.get_method_cls("dino").__name__ == "DINO"
+        # gradient accumulation: the Trainer is built with 1 and carries k for OUR classes only; when the method that is resolved
+        # afterwards (LT/_commands/train.py:433 then :476) is not one of them, Lightning's own window is restored
+        from types import SimpleNamespace
+
+        from lightly_train._commands import train_helpers
+
+        wrapped = train_helpers.get_trainer
+        inner = wrapped.__closure__[[c for c in wrapped.__code__.co_freevars].index("orig")]
+        real = inner.cell_contents
+
+        def fake_get_trainer(out, epochs, gradient_accumulation_steps, accelerator, strategy, devices, num_nodes, log_every_n_steps, precision, loggers,
+                             callbacks, trainer_args):
+            return SimpleNamespace(accumulate_grad_batches=gradient_accumulation_steps)
+
+        inner.cell_contents = fake_get_trainer
+        try:
+            kw = dict(out=None, epochs=1, accelerator="cpu", strategy="auto", devices=1, num_nodes=1, log_every_n_steps=1, precision=None, loggers=[],
+                      callbacks=[], trainer_args=None)
+            tr = train_helpers.get_trainer(gradient_accumulation_steps=4, **kw)
+            assert tr.accumulate_grad_batches == 1 and tr.lt_amd_accumulate_grad_batches == 4
+            assert method_helpers.get_method_cls("dinov2") is cls
+            assert tr.accumulate_grad_batches == 1 and tr.lt_amd_accumulate_grad_batches == 4       # ours: the binding accumulates
+            tr = train_helpers.get_trainer(gradient_accumulation_steps=4, **kw)
+            assert method_helpers.get_method_cls("dino").__name__ == "DINO"
+            assert tr.accumulate_grad_batches == 4 and not hasattr(tr, "lt_amd_accumulate_grad_batches")   # not ours: Lightning accumulates
+        finally:
+            inner.cell_contents = real
     finally:
         method_helpers._method_name_to_cls = orig
     # identical containers: the state_dict keys of the drop-in are the reference's, in order
@@ -292,6 +319,41 @@ def test_gradient_accumulation_equals_the_reference_under_accumulate_grad_batche
         sd, rsd = amd.state_dict(), ref.state_dict()
         for name in rsd:
             assert torch.allclose(sd[name].float(), rsd[name].float(), atol=3e-5), (name, (sd[name].float() - rsd[name].float()).abs().max().item())
+
+
+def test_optimizer_step_total_counts_the_window_that_closes_with_every_epoch():
+    """A window also closes with the epoch's last batch (`begin_micro_batch`, like Lightning): 10 batches per epoch at k = 4 are 3 optimizer
+    steps per epoch -- 300 over 100 epochs, not ceil(1000 / 4) = 250 (the schedules raise past their total).  `max_steps` caps it; without a
+    per-epoch batch count the Trainer's estimate is used."""
+    from types import SimpleNamespace
+
+    from lightly_train_amd import integration
+
+    def host(**tr):
+        return SimpleNamespace(trainer=SimpleNamespace(**tr), gradient_accumulation_steps=1)
+
+    h = host(estimated_stepping_batches=1000, num_training_batches=10, max_epochs=100, max_steps=-1, lt_amd_accumulate_grad_batches=4)
+    assert integration.total_optimizer_steps(h) == 300
+    # drive the window logic over one run and count the boundaries it reports
+    class Eng:
+        supports_accumulation = True
+        trainer = SimpleNamespace(global_step=0)
+    eng = Eng()
+    h.impl, h._micro, h.trainer.global_step = (lambda: eng), 0, 0
+    steps = 0
+    for _ in range(100):
+        for bi in range(10):
+            h.trainer.is_last_batch = bi == 9
+            _, boundary = integration.begin_micro_batch(h, bi)
+            steps += int(boundary)
+    assert steps == 300
+    h.trainer.max_steps = 120
+    assert integration.total_optimizer_steps(h) == 120
+    assert integration.total_optimizer_steps(host(estimated_stepping_batches=1000, num_training_batches=12, max_epochs=100, max_steps=-1,
+                                                  lt_amd_accumulate_grad_batches=4)) == 300
+    assert integration.total_optimizer_steps(host(estimated_stepping_batches=1000, num_training_batches=float("inf"), max_epochs=-1, max_steps=-1,
+                                                  lt_amd_accumulate_grad_batches=4)) == 250
+    assert integration.total_optimizer_steps(host(estimated_stepping_batches=1000, lt_amd_accumulate_grad_batches=1)) == 1000
 
 
 def test_unsupported_precision_and_accumulation_raise():
