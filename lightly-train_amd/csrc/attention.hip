@@ -1085,6 +1085,169 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
   }
 }
 
+// ================================================================================================ backward, fused, short sequences
+// N <= 64 (the local crops: 50 / 37 tokens), two heads per 4-wave block like attn_bwd_dkdv_v2_kernel<4, true>: wave -> (head, key tile).
+// One pass replaces the dQ + dK/dV pair for these lengths: q / k / v / dO / O are read ONCE, delta = rowsum(dO * O) is formed while
+// staging (no delta buffer), S / P / dP / dS are formed once per (query tile, key tile) -- 40 MFMAs per wave instead of 56 -- and dQ comes
+// from the same dS:
+//   phase A  as the dK/dV kernel (a single chunk: the whole sequence of both heads is staged at once); the two dS tiles of a wave stay
+//            in registers as packed bf16 (16 VGPRs);
+//   phase B  after a barrier the images are dead: every wave writes its dS tiles as rows dS[q][key] over the Q images (row stride 136 B =
+//            34 dwords: the 32 rows a lane group reads land on 32 distinct bank pairs) and its K fragments as a transposable image over
+//            the dO row image; wave (head, tile t) then forms dQ^T[d][q] of QUERY tile t = K^T dS^T over the head's keys, dS rows read
+//            as B fragments (two ds_read_b64 per lane).
+// dS stays unscaled until the stores (exact for the power-of-two scale of head_dim 64).  LDS = the dK/dV kernel's 4 images + statistics
+// (65 KiB: two blocks per CU); dK / dV / dQ leave through the wave-private transpose scratch once everything else in LDS is dead.
+constexpr int F2_DS = 136;
+__global__ __launch_bounds__(256) void attn_bwd_fused2h_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using St = Stager<256, true>;
+  char* ldsQ = smem;            // row image of Q          [2 heads][64 tok]
+  char* ldsQt = smem + IMG;     // T image of Q
+  char* ldsD = smem + 2 * IMG;  // row image of dO
+  char* ldsDt = smem + 3 * IMG; // T image of dO
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * IMG);  // -lse / scale [128], -delta [128]  (image-row indexed)
+  char* ldsS = smem;            // phase B: dS rows [2 heads * 64 q][F2_DS] over the Q images (17 KiB of their 32)
+  char* ldsKt = smem + 2 * IMG; // phase B: T image of K over the dO row image
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int hp = H >> 1;
+  const int b = blockIdx.x / hp, h0 = (blockIdx.x % hp) * 2, hl = wave >> 1, h = h0 + hl, k0 = (wave & 1) * 32, tb = hl * 2;
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qst = qkv + (long)b * N * ts + h0 * DH;
+  const bf16_t* dst = dout + (long)b * N * tso + h0 * DH;
+  const bf16_t* ost = out + (long)b * N * tso + h0 * DH;
+  const bf16_t* kb = qkv + (long)b * N * ts + (long)H * DH + h * DH;
+  const bf16_t* vb = qkv + (long)b * N * ts + 2L * H * DH + h * DH;
+  const bool active = k0 < N;
+  const bool key_ok = k0 + (l & 31) < N;
+  const float inv_scale = 1.f / scale, c_exp = scale * 1.4426950408889634f;
+
+  uint4 qr[St::PER], dr[St::PER], orr[St::PER];
+  St::load(qr, qst, ts, 0, N);
+  St::load(dr, dst, tso, 0, N);
+  St::load(orr, ost, tso, 0, N);
+  float l_reg = -INFINITY;
+  if (threadIdx.x < CH) {
+    const int r = threadIdx.x, tok = r & 63;
+    if (tok < N) l_reg = -lse[((long)b * H + h0 + (r >> 6)) * N + tok] * inv_scale;   // S accumulates onto -lse / scale (-inf: P = 0)
+  }
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_global<true>(kb, ts, k0, N, ks); vf[ks] = frag_global<true>(vb, ts, k0, N, ks); }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+  St::store_rows(ldsQ, qr); St::store_tr(ldsQt, qr); St::store_rows(ldsD, dr); St::store_tr(ldsDt, dr);
+  // delta[q] = sum_d dO[q,d] * O[q,d]: item i of a thread is (image row (tid >> 3) + 32 i, 16-byte piece tid & 7); the 8 threads of a row
+  // are consecutive lanes.  Rows past the sequence end were staged as zeros.
+#pragma unroll
+  for (int i = 0; i < St::PER; ++i) {
+    const unsigned dw[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w}, ow[4] = {orr[i].x, orr[i].y, orr[i].z, orr[i].w};
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = fmaf(bf2f((bf16_t)(dw[j] & 0xffff)), bf2f((bf16_t)(ow[j] & 0xffff)), acc);
+      acc = fmaf(bf2f((bf16_t)(dw[j] >> 16)), bf2f((bf16_t)(ow[j] >> 16)), acc);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if ((threadIdx.x & 7) == 0) ldsL[CH + (threadIdx.x >> 3) + 32 * i] = -acc;   // dP accumulates onto -delta
+  }
+  if (threadIdx.x < CH) ldsL[threadIdx.x] = l_reg;
+  __syncthreads();
+  // ---- phase A: key tile (h, k0) against the head's query tiles
+  union { bf16x8 v; unsigned u[4]; } ds0[2], ds1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { ds0[t].v = pack8(dk[0], 0); ds1[t].v = ds0[t].v; }   // zeros (a tile past the end contributes nothing)
+  if (active) {
+    const int ntile = (N + 31) / 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t < ntile) {
+        const int it = tb + t;
+        f32x16 s, dp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+          const float4 dl = *reinterpret_cast<const float4*>(&ldsL[CH + it * 32 + 8 * g + 4 * hi]);
+          s[4 * g] = key_ok ? ls.x : -INFINITY; s[4 * g + 1] = key_ok ? ls.y : -INFINITY;
+          s[4 * g + 2] = key_ok ? ls.z : -INFINITY; s[4 * g + 3] = key_ok ? ls.w : -INFINITY;
+          dp[4 * g] = dl.x; dp[4 * g + 1] = dl.y; dp[4 * g + 2] = dl.z; dp[4 * g + 3] = dl.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[e] * c_exp);
+          s[e] = pe;
+          dp[e] *= pe;   // dS / scale
+        }
+        const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
+        ds0[t].v = pack8(dp, 0); ds1[t].v = pack8(dp, 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ds0[t].v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ds1[t].v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- phase B
+  __syncthreads();   // every wave is done with the images
+  {
+    // dS tiles -> rows dS[q][key]: register pair (2j, 2j+1) = two consecutive query rows crow(2j, hi), crow(2j, hi) + 1; column = key lane
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      char* scol = ldsS + (size_t)(hl * 64 + t * 32 + 4 * hi) * F2_DS + (k0 + (l & 31)) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned w = j < 4 ? ds0[t].u[j] : ds1[t].u[j - 4];
+        const int row = (2 * j & 3) + 8 * (2 * j >> 2);
+        *reinterpret_cast<unsigned short*>(scol + row * F2_DS) = (unsigned short)(w & 0xffff);
+        *reinterpret_cast<unsigned short*>(scol + (row + 1) * F2_DS) = (unsigned short)(w >> 16);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {   // kf[ks] = 16 B of image row r (token k0 + lane of head hl) at piece c = 2 ks + hi: Stager::store_tr's placement
+      const int r = hl * 64 + k0 + (l & 31), c = ks * 2 + hi, sb = c >> 1, half = c & 1;
+      *reinterpret_cast<bf16x8*>(ldsKt + ((r >> 2) * 4 + sb) * 128 + ((((r & 3) + sb) & 3) << 5) + (half << 4)) = kf[ks];
+    }
+  }
+  __syncthreads();
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+  if (active) {   // query tile k0 of head hl (the tile this wave owned as keys)
+    const int nkb = 2 * ((N + 31) / 32);
+    const char* srow = ldsS + (size_t)(hl * 64 + k0 + (l & 31)) * F2_DS + hi * 8;
+    for (int kbk = 0; kbk < nkb; ++kbk) {
+      // B fragment: lane -> query, k-slots -> keys kbk*16 + {4hi..4hi+3, 8+4hi..8+4hi+3} (the C-layout slot order of frag_tr)
+      union { struct { uint2 a, b; } s; bf16x8 v; } f;
+      f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
+      f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, hl * 64 + kbk * 16), f.v, dq[db], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // dS and K^T are dead: LDS becomes the store scratch
+  if (!active) return;
+  char* scratch = smem + wave * (32 * 144);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] *= scale; dk[1][e] *= scale; }   // dS was kept unscaled
+  bf16_t* dqkv_b = dqkv + (long)b * N * ts;
+  store_td_tile(scratch, dk, dqkv_b + (long)H * DH + h * DH, ts, k0, N);
+  store_td_tile(scratch, dv, dqkv_b + 2L * H * DH + h * DH, ts, k0, N);
+  store_qd_tile(scratch, dq, scale, dqkv_b + h * DH, ts, k0, N);
+}
+
 // ================================================================================================ generic head dims
 // one block (64 threads) per (b, h, q); scores in LDS (N <= 4096)
 __global__ void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N,
@@ -1245,6 +1408,19 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
       else
         hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(B * lt_cdiv(H, hpb)), dim3(512), FB_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
                            (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
+      LT_CHECK_LAUNCH("lt_attention_bwd");
+    }
+    const char* f2_env = getenv("LT_ATTN_BWD_F2");   // per call, like LT_ATTN_BWD: 0 = the dQ + dK/dV pair for the local crops
+    if (variant >= 2 && N <= 64 && H % 2 == 0 && (f2_env ? atoi(f2_env) != 0 : true)) {   // local crops: the fused two-heads-per-block pass
+      static bool f2_configured = false;
+      const int lds_f2 = 4 * IMG + 2 * CH * (int)sizeof(float);
+      if (!f2_configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused2h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f2);
+        if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", lds_f2, hipGetErrorString(e)); return LT_ERR_HIP; }
+        f2_configured = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_fused2h_kernel, dim3(B * (H / 2)), dim3(256), lds_f2, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, scale);
       LT_CHECK_LAUNCH("lt_attention_bwd");
     }
     if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels

@@ -477,6 +477,10 @@ class DINOv2:
         # step is bitwise reproducible; LT_DETERMINISTIC=0 goes back to atomics
         self.deterministic = os.environ.get("LT_DETERMINISTIC", "1") != "0"
         self.two_bwd_chains = os.environ.get("LT_BWD_TWO_CHAINS", "1") != "0"
+        # forward concurrency: the local-crop pass on the side stream beside the global-crop pass, the teacher on a stream of its own
+        # (0: that pass runs on the main stream -- tools/ab_schedule.py measures the fewer-streams corners)
+        self.fwd_local_stream = int(os.environ.get("LT_FWD_LOCAL_STREAM", "1") != "0")
+        self.fwd_teacher_stream = int(os.environ.get("LT_FWD_TEACHER_STREAM", "1") != "0")
         # one weight-gradient GEMM per layer for the global- and the local-crop pass (vit.JointWgrad): half the split-K slab traffic
         self.joint_wgrad = int(os.environ.get("LT_JOINT_WGRAD", "1") != "0")
         self.head_side = int(os.environ.get("LT_HEAD_SIDE", "1") != "0")   # KoLeo and the heads' weight gradients beside the head chain
@@ -824,7 +828,7 @@ class DINOv2:
         # the teacher and the student's global pass unfold the same images: one patch matrix for both (the iBOT masks act on the tokens)
         shared_cols = ops.im2col(gv.contiguous(), p, self.s_vit.kpad) if (gv.shape[2] % p == 0 and gv.shape[3] % p == 0 and dev.type == "cuda"
                                                                            and os.environ.get("LT_SHARED_COLS", "1") != "0") else None
-        tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams) else main
+        tstream = self.teacher_stream if (self.teacher_stream is not None and self.overlap_streams and self.fwd_teacher_stream) else main
         tstream.wait_event(main.record_event())
         torch.cuda.set_stream(tstream)
         if a.center_method == "softmax":
@@ -904,7 +908,7 @@ class DINOv2:
             if self._joint.seed(cfg.depth, (n_crops * Ng, lv.shape[0] * Nl), D, hid, 2 * hid if cfg.swiglu else hid):
                 self._joint_active = self._joint
         # local-crop forward on the side stream, concurrent with the global-crop forward (disjoint activation buffers)
-        lstream = self.side_stream if (self.side_stream is not None and self.overlap_streams and lv is not None) else None
+        lstream = self.side_stream if (self.side_stream is not None and self.overlap_streams and lv is not None and self.fwd_local_stream) else None
         sl = None
         if lstream is not None:
             lstream.wait_event(main.record_event())

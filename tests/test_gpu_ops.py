@@ -479,7 +479,9 @@ def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
                                        (2, 201, 3, 64), (1, 224, 2, 64), (2, 225, 1, 64), (2, 193, 2, 64), (3, 96, 2, 64), (2, 100, 4, 64),
                                        (130, 197, 2, 64),
                                        # packed block-diagonal backward (32..64 tokens: several images per 224-token sequence, ragged last sequence)
-                                       (9, 37, 2, 64), (5, 50, 2, 64), (7, 33, 2, 64), (5, 32, 2, 64), (4, 48, 3, 64), (33, 50, 4, 64), (7, 64, 2, 64)])
+                                       (9, 37, 2, 64), (5, 50, 2, 64), (7, 33, 2, 64), (5, 32, 2, 64), (4, 48, 3, 64), (33, 50, 4, 64), (7, 64, 2, 64),
+                                       # fused two-heads-per-block backward (N <= 64, even head count): one key tile only, a ragged first tile, 12 heads
+                                       (2, 20, 2, 64), (3, 31, 4, 64), (2, 2, 2, 64), (2, 50, 12, 64)])
 def test_attention(B, N, H, dh):
     o = ops()
     g = torch.Generator().manual_seed(N + dh)
