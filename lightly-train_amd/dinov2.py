@@ -787,7 +787,8 @@ class DINOv2:
             gen = MaskingGenerator(input_size=(gh, gw), max_num_patches=int(0.5 * gh * gw))
             masks = create_collated_masks(a.mask_ratio_min, a.mask_ratio_max, int(n_crops * a.mask_probability), n_crops, gen)
         cm = masks["collated_masks"]
-        mask_u8 = ops.h2d(cm.to(torch.uint8), dev)
+        # (bool -> uint8 as a reinterpretation: a converting copy of > 32 768 elements opens an OpenMP region on the launch thread)
+        mask_u8 = ops.h2d(cm.view(torch.uint8) if cm.dtype == torch.bool else cm.to(torch.uint8), dev)
         midx = masks["mask_indices_list"].to(torch.int64)
         M = int(midx.shape[0])
         mw = masks["masks_weight"].to(torch.float32)

@@ -41,12 +41,50 @@ def require_device(dev: torch.device, who: str) -> None:
         raise RuntimeError(f"{who} runs on an MI355X only (no CPU fallback for the HIP kernels)")
 
 
+class _PinnedRing:
+    """Persistent pinned staging slots for `h2d`, handed out round-robin; a slot is taken again only after the event recorded behind its
+    last copy has fired.  `Tensor.pin_memory()` costs the launch thread 0.6-2 ms per call once the host runs a few steps ahead of the
+    device (every cached pinned block is still in flight, so each call is a fresh hipHostMalloc: tools/host_profile.py,
+    profiles/r05_host_profile_dp02.log); a slot here is one memcpy into memory pinned once."""
+
+    def __init__(self, slots: int, min_bytes: int) -> None:
+        self.bufs: list = [None] * slots
+        self.evs: list = [None] * slots
+        self.i = 0
+        self.min_bytes = min_bytes
+
+    def stage(self, t: Tensor):
+        n = t.numel() * t.element_size()
+        i = self.i
+        self.i = (i + 1) % len(self.bufs)
+        if self.evs[i] is not None:
+            self.evs[i].synchronize()      # (never waits in practice: the ring is deeper than the host's lead over the device)
+        b = self.bufs[i]
+        if b is None or b.numel() < n:
+            b = torch.empty(max(n, self.min_bytes), dtype=torch.uint8, pin_memory=True)
+            self.bufs[i] = b
+        v = b[:n].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        return v, i
+
+
+_rings = {"small": _PinnedRing(1024, 4096), "large": _PinnedRing(96, 1 << 20)}
+
+
 def h2d(t: Tensor, dev: torch.device) -> Tensor:
-    """A small host tensor to the device WITHOUT stalling the launch thread: through torch's pinned-memory cache (a pageable source makes
-    hipMemcpyAsync wait on its staging path -- 7.5 ms per copy once the host runs a few steps ahead of the device, seven copies per step:
-    tools/host_ahead_probe.py -- while a pinned source is a queued DMA; the pinned block is recycled only after the copy's event)."""
+    """A small host tensor to the device WITHOUT stalling the launch thread: through a pinned staging slot (a pageable source makes
+    hipMemcpyAsync wait on its staging path -- 7.5 ms per copy once the host runs a few steps ahead of the device:
+    tools/host_ahead_probe.py -- while a pinned source is a queued DMA; the slot is recycled only after the copy's event)."""
     if t.device.type == "cpu" and torch.device(dev).type == "cuda":
-        return t.pin_memory().to(dev, non_blocking=True)
+        if t.numel() == 0:
+            return torch.empty(t.shape, dtype=t.dtype, device=dev)
+        ring = _rings["small" if t.numel() * t.element_size() <= 65536 else "large"]
+        v, i = ring.stage(t.contiguous())
+        out = v.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring.evs[i] = ev
+        return out
     return t.to(dev, non_blocking=True)
 
 

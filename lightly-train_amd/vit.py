@@ -13,6 +13,7 @@ import os
 from dataclasses import dataclass
 from typing import Any, Dict, Iterable, Iterator, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -317,6 +318,8 @@ class ViTEngine:
         self._rope_ang: Dict[Tuple[int, int], Tensor] = {}
         self._rope: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
         self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
+        self._fwd_graphs: Dict[Any, Dict[str, Any]] = {}
+        self.graph_forward = os.environ.get("LT_GRAPH_FWD", "0") != "0"   # HIP-graph replay of the static forward blocks (`_graphed_blocks`)
         D = cfg.embed_dim
         kreal = cfg.in_chans * cfg.patch_size ** 2
         self.kreal = kreal
@@ -329,6 +332,32 @@ class ViTEngine:
         if cfg.init_values is not None and float(cfg.init_values) == 0.0:
             # the LayerScale gradient is recovered from the weight gradient by dividing by gamma (lt_layerscale_dgamma): gamma == 0 has none
             raise ValueError("LayerScale init_values == 0 is not supported (use None for no LayerScale): its gradient is formed as (W . dW) / gamma")
+
+    def _graphed_blocks(self, tag: str, x: Tensor, save: bool, n: int, run_block: Any) -> Tuple[Tensor, List[Dict[str, Any]]]:
+        """Blocks 0 .. n-1 of a forward pass from the token buffer `x`: eagerly on the first two calls of a (pass, shape), then captured
+        into a HIP graph (stream capture of the same launches) and replayed with one launch on the caller's stream."""
+        key = (tag, tuple(x.shape), bool(save), n, x.data_ptr())
+        ent = self._fwd_graphs.setdefault(key, {"calls": 0, "graph": None})
+
+        def eager() -> Tuple[Tensor, List[Dict[str, Any]]]:
+            xs, blks = x, []
+            for i in range(n):
+                xs, a_, m_ = run_block(i, xs, f"{tag}.b{i}." if save else f"{tag}.tmp.", save, save)
+                blks.append({"attn": a_, "mlp": m_})
+            return xs, blks
+
+        if ent["graph"] is None:
+            ent["calls"] += 1
+            if ent["calls"] < 3:
+                return eager()
+            g = torch.cuda.CUDAGraph()
+            cur = torch.cuda.current_stream()
+            with torch.cuda.graph(g):        # (synchronises the device, captures on a side stream; nothing executes yet)
+                xo, blks = eager()
+            torch.cuda.set_stream(cur)
+            ent.update(graph=g, out=xo, blocks=blks)
+        ent["graph"].replay()
+        return ent["out"], [{"attn": dict(b["attn"]), "mlp": dict(b["mlp"])} for b in ent["blocks"]]
 
     def refresh_padded_weights(self) -> None:
         """Re-derive the zero-padded bf16 patch-embedding matrix after the fp32 weights changed (optimizer / EMA)."""
@@ -479,9 +508,29 @@ class ViTEngine:
         ops.assemble_tokens(patch, self.w("cls_token").view(D), pos, self.w("mask_token").view(D), masks, B, n_p, D, out=x,
                             reg=self.w("register_tokens").view(-1, D) if n_reg else None, n_reg=n_reg)
         ctx["cols"] = cols
-        tok = torch.arange(N, dtype=torch.int64)
+        tok_np = np.arange(N, dtype=np.int64)
+        # every stochastic-depth draw of this pass goes to the device in ONE upload per kind: the subset branches' token-row indices
+        # (int64, (b * N + token) for the drawn images b) and the per-sample branches' row scales (f32, mask / keep per token row).  One
+        # pinned copy each instead of one per branch: 24 branches per pass made the step host-bound (0.6 ms per pin_memory + 0.7 ms per
+        # copy with the launch thread ahead of the device: profiles/r05_host_profile_dp02.log).  numpy on purpose: a torch CPU op over
+        # more than 32 768 elements opens an OpenMP region, and waking the thread pool costs the launch thread ~0.5 ms per op.
+        staged: Dict[int, Tensor] = {}
+        if drop_plan is not None and self.dev.type == "cuda":
+            sub = [(j, e[1]) for j, e in enumerate(drop_plan) if e is not None and e[0] == "subset"]
+            per = [(j, e[1]) for j, e in enumerate(drop_plan) if e is not None and e[0] == "persample"]
+            if sub:
+                parts = [(v.numpy().astype(np.int64)[:, None] * N + tok_np[None, :]).reshape(-1) for _, v in sub]
+                flat = ops.h2d(torch.from_numpy(np.concatenate(parts)), self.dev)
+                o = 0
+                for (j, _), prt in zip(sub, parts):
+                    staged[j] = flat[o:o + prt.size]
+                    o += prt.size
+            if per:
+                flat = ops.h2d(torch.from_numpy(np.concatenate([np.repeat(v.to(torch.float32).numpy(), N) for _, v in per])), self.dev)
+                for k, (j, _) in enumerate(per):
+                    staged[j] = flat[k * T:(k + 1) * T]
 
-        def branch_setup(entry: Any, s: str, which: str, xin: Tensor) -> Dict[str, Any]:
+        def branch_setup(entry: Any, s: str, which: str, xin: Tensor, j: int = -1) -> Dict[str, Any]:
             """Decide the rows a residual branch runs on: all T rows, or the gathered rows of a batch subset."""
             br: Dict[str, Any] = {"mode": "plain", "rows": T, "nb": B, "x": xin, "rowscale": None, "scale": 1.0}
             if entry is None:
@@ -495,11 +544,11 @@ class ViTEngine:
                 return br
             if kind == "persample":   # DropPath: per-image mask/keep expanded over the image's tokens
                 br["mode"] = "persample"
-                br["rowscale"] = ops.h2d(val.to(torch.float32).repeat_interleave(N), self.dev)
+                br["rowscale"] = staged[j] if j in staged else ops.h2d(torch.from_numpy(np.repeat(val.to(torch.float32).numpy(), N)), self.dev)
                 return br
             sb = int(val.numel())      # batch-subset stochastic depth
             Ts = sb * N
-            idx = ops.h2d((val.to(torch.int64).view(-1, 1) * N + tok.view(1, -1)).reshape(-1), self.dev)
+            idx = staged[j] if j in staged else ops.h2d(torch.from_numpy((val.numpy().astype(np.int64)[:, None] * N + tok_np[None, :]).reshape(-1)), self.dev)
             xs = ws.get(s + which + ".xs", (T, D), torch.float32)[:Ts]
             ops.gather_rows(xin, D, idx, Ts, D, out_f32=xs)
             br.update(mode="subset", rows=Ts, nb=sb, x=xs, idx=idx, scale=B / sb)
@@ -517,7 +566,7 @@ class ViTEngine:
             if i == cfg.depth - 1 and e2 is None and last_mlp_rows is not None and 0 < last_mlp_rows[1] < T:
                 e2 = ("rows", last_mlp_rows)
             # ---------------- attention branch
-            a = branch_setup(e1, s, "a", x)
+            a = branch_setup(e1, s, "a", x, 2 * i)
             R, nb = a["rows"], a["nb"]
             ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16, pad_rows=64)
             a["mean"], a["rstd"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
@@ -557,7 +606,7 @@ class ViTEngine:
                 ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
                          gamma=g1, resid=x, out2=y1, rowscale=a["rowscale"])
             # ---------------- MLP branch
-            m = branch_setup(e2, s, "m", xm)
+            m = branch_setup(e2, s, "m", xm, 2 * i + 1)
             R2 = m["rows"]
             ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16, pad_rows=64)
             m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
@@ -600,7 +649,18 @@ class ViTEngine:
                 out.view(T, D).copy_(xb)
             captured[i] = out
 
-        for i in range(cfg.depth):
+        # HIP-graph replay of the leading STATIC blocks (no stochastic-depth draws, no rotary tables that change per step, not the last
+        # block when it runs on the rows the losses read, no activation checkpointing, no intermediate captures): ~7 launches per block
+        # become one graph launch per pass.  Buffers are the workspace's named allocations and the weights are views of the flat storage,
+        # so every pointer a captured kernel holds stays valid; the first two calls of a shape run eagerly (they also allocate).
+        n_graph = 0
+        if (self.graph_forward and x.is_cuda and drop_plan is None and rope is None and not (save and checkpoint) and not cap_set):
+            n_graph = cfg.depth - 1 if (last_mlp_rows is not None and 0 < last_mlp_rows[1] < T) else cfg.depth
+        if n_graph > 0:
+            x, gblocks = self._graphed_blocks(tag, x, save, n_graph, run_block)
+            if save:
+                blocks.extend(gblocks)
+        for i in range(n_graph, cfg.depth):
             if save and checkpoint:
                 # activation checkpointing (reference _activation_checkpointing.py): keep only the block input, recompute the
                 # block in backward.  Subset stochastic depth updates x in place, so the input is copied aside first.

@@ -415,7 +415,7 @@ def test_vitb_batch24_step_dispatches_gemm256q_and_matches_oracle():
     big = [c for c in calls if c[1] == "gemm256"]
     assert {c[0] for c in big} == {"fwd", "dgrad", "wgrad"}
     assert {ops.EPI_BF16_GELU, ops.EPI_RESID, ops.EPI_BF16_GELUGRAD, ops.EPI_BF16, ops.EPI_F32_ACCUM} <= {c[5] for c in big}
-    tok = [c for c in calls if c[0] in ("fwd", "dgrad") and c[2] in (2 * b * 197, 8 * b * n_loc_tok)]
+    tok = [c for c in calls if c[0] in ("fwd", "dgrad") and c[2] in (2 * b * 197, 8 * b * 50)]
     assert tok and all(c[1] == "gemm256" for c in tok), [c for c in tok if c[1] != "gemm256"][:3]
 
     loss, ologs = o.forward_loss(views, m._last_masks)

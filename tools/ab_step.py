@@ -40,12 +40,13 @@ torch.cuda.synchronize()
 t = {v: [] for v in a.values}
 for i in range(a.steps * len(a.values)):
     v = a.values[i % len(a.values)]
-    if a.attr:   # dotted paths reach into sub-objects: s_head.pad_wgrad_rows
-        obj = m
-        *path, leaf = a.name.split(".")
-        for part in path:
-            obj = getattr(obj, part)
-        setattr(obj, leaf, type(getattr(obj, leaf))(int(v)))
+    if a.attr:   # dotted paths reach into sub-objects: s_head.pad_wgrad_rows; several attributes at once separated by commas
+        for name in a.name.split(","):
+            obj = m
+            *path, leaf = name.split(".")
+            for part in path:
+                obj = getattr(obj, part)
+            setattr(obj, leaf, type(getattr(obj, leaf))(int(v)))
     else:
         os.environ[a.name] = v
     torch.cuda.synchronize()

@@ -6,7 +6,8 @@ import lightly_train_amd
 from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
 from lightly_train_amd.vit import ViTConfig
 ARCH = {"vit_small": (384, 6), "vit_base": (768, 12)}[sys.argv[1] if len(sys.argv) > 1 else "vit_base"]
-cfg = ViTConfig(embed_dim=ARCH[0], depth=12, num_heads=ARCH[1], patch_size=16, img_size=224, init_values=1e-5)
+DROP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0     # python tools/host_overhead.py vit_base 0.2: the batch-subset stochastic-depth regime
+cfg = ViTConfig(embed_dim=ARCH[0], depth=12, num_heads=ARCH[1], patch_size=16, img_size=224, init_values=1e-5, drop_path_rate=DROP)
 m = DINOv2(cfg, DINOv2Args(), global_batch_size=128, total_steps=125000, device="cuda")
 g = torch.Generator().manual_seed(0)
 B = 128
@@ -34,4 +35,4 @@ for _ in range(5):
     create_collated_masks(0.1, 0.5, 128, 256, gen)
 print("mask sampling ms:", (time.perf_counter() - t0) / 5 * 1e3)
 pr = cProfile.Profile(); pr.enable(); m.train_step(views); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
