@@ -315,6 +315,10 @@ int lt_cka_fwd_bwd(const float* Ks, const float* Kt, const float* coef, float* l
  * every stream the producers ran on.  When `scratch` runs out the kernels fall back to atomics; lt_reduce_overflows counts that.
  * (The loss scalars of lt_ce_fwd_bwd / lt_kl_fwd_bwd / lt_koleo_fwd_bwd, the KoLeo gradient and lt_colsum_f32 are order-fixed always.) */
 int lt_reduce_begin(float* scratch, int64_t floats);
+/* Same, with the cached flush tables of this region numbered from `first_slot`: a step that opens several regions (an eagerly launched
+ * part, a part replayed from a HIP graph, an eager tail) gives each its own slot range, so that a captured flush kernel keeps reading
+ * the table it was captured with.  A flush may be captured into a graph once the same region has run eagerly (its table buffers exist). */
+int lt_reduce_begin_at(float* scratch, int64_t floats, int first_slot);
 int lt_reduce_flush(void* stream);
 int lt_reduce_end(void* stream);
 int64_t lt_reduce_overflows(void);

@@ -89,6 +89,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_comm_size": [],
     "lt_comm_destroy": [],
     "lt_reduce_begin": [vp, i64],
+    "lt_reduce_begin_at": [vp, i64, C.c_int],
     "lt_reduce_flush": [vp],
     "lt_reduce_end": [vp],
     "lt_sgd_flat": [vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, f32, vp],

@@ -23,7 +23,7 @@ bool on = false;
 std::vector<Ent> pending;
 long overflows = 0;
 int flush_idx = 0;
-struct Slot { std::vector<char> host; void* dev = nullptr; size_t dev_cap = 0; };
+struct Slot { std::vector<char> host; void* dev = nullptr; size_t dev_cap = 0; void* pinned = nullptr; size_t pinned_cap = 0; };
 std::vector<Slot> slots;   // one cached device table per flush of a step: identical steps upload nothing
 
 // One workgroup per (destination, 256-column group): 64 column lanes x 4 columns, 4 part lanes.  Part lane q adds the partial rows
@@ -109,13 +109,27 @@ int flush_locked(hipStream_t st) {
   if ((int)slots.size() <= flush_idx) slots.resize(flush_idx + 1);
   Slot& s = slots[flush_idx++];
   if (s.host != host) {
-    if (s.dev_cap < host.size()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    if (s.dev_cap < host.size() || s.pinned_cap < host.size()) {
+      // (allocation is not legal while a stream captures: a flush that is captured into a HIP graph must have run once, eagerly, with the
+      // same table size before -- the step that precedes the capture does exactly that)
+      if (capturing) { lt_set_error("lt_reduce_flush: slot %d has no table buffers yet and the stream is capturing", flush_idx - 1); return LT_ERR_INVALID; }
       if (s.dev) hipFree(s.dev);
-      s.dev_cap = host.size() * 2;
-      if (hipMalloc(&s.dev, s.dev_cap) != hipSuccess) { s.dev = nullptr; s.dev_cap = 0; lt_set_error("lt_reduce_flush: hipMalloc failed"); return LT_ERR_HIP; }
+      if (s.pinned) hipHostFree(s.pinned);
+      s.dev_cap = s.pinned_cap = host.size() * 2;
+      if (hipMalloc(&s.dev, s.dev_cap) != hipSuccess || hipHostMalloc(&s.pinned, s.pinned_cap, hipHostMallocDefault) != hipSuccess) {
+        s.dev = s.pinned = nullptr; s.dev_cap = s.pinned_cap = 0; lt_set_error("lt_reduce_flush: table allocation failed"); return LT_ERR_HIP;
+      }
     }
-    // pageable source: the runtime stages it before returning, so `host` may change afterwards
-    if (hipMemcpyAsync(s.dev, host.data(), host.size(), hipMemcpyHostToDevice, st) != hipSuccess) { lt_set_error("lt_reduce_flush: table upload failed"); return LT_ERR_HIP; }
+    // Eagerly the table is uploaded from pageable memory: the runtime stages it before returning, so `host` may change afterwards and the
+    // launch thread never waits for the device.  Under stream capture the copy becomes a graph node that re-reads its source at every
+    // replay: it goes through the slot's own pinned buffer, written here and left alone afterwards (a slot range that is captured
+    // belongs to the graph's region: lt_reduce_begin_at).
+    const void* src = host.data();
+    if (capturing) { memcpy(s.pinned, host.data(), host.size()); src = s.pinned; }
+    if (hipMemcpyAsync(s.dev, src, host.size(), hipMemcpyHostToDevice, st) != hipSuccess) { lt_set_error("lt_reduce_flush: table upload failed"); return LT_ERR_HIP; }
     s.host = host;
   }
   const DevGrp* dg = reinterpret_cast<const DevGrp*>(s.dev);
@@ -162,13 +176,15 @@ void record(float* dst, const float* src, int nparts, long stride, int C) {
 }
 }  // namespace lt_ledger
 
-extern "C" int lt_reduce_begin(float* scratch_f32, int64_t floats) {
-  LT_CHECK_ARG(scratch_f32 && floats > 0 && ((uintptr_t)scratch_f32 & 15) == 0, "lt_reduce_begin: scratch must be a 16-byte aligned region");
+extern "C" int lt_reduce_begin_at(float* scratch_f32, int64_t floats, int first_slot) {
+  LT_CHECK_ARG(scratch_f32 && floats > 0 && ((uintptr_t)scratch_f32 & 15) == 0 && first_slot >= 0 && first_slot < 4096,
+               "lt_reduce_begin: scratch must be a 16-byte aligned region (and 0 <= first_slot < 4096)");
   std::lock_guard<std::mutex> l(mu);
   pending.clear();   // entries of a step that was abandoned half-way (its gradients are discarded with it)
-  scratch = scratch_f32; cap = (size_t)floats; used = 0; on = true; flush_idx = 0;
+  scratch = scratch_f32; cap = (size_t)floats; used = 0; on = true; flush_idx = first_slot;
   return LT_OK;
 }
+extern "C" int lt_reduce_begin(float* scratch_f32, int64_t floats) { return lt_reduce_begin_at(scratch_f32, floats, 0); }
 extern "C" int lt_reduce_flush(void* stream) {
   std::lock_guard<std::mutex> l(mu);
   return flush_locked((hipStream_t)stream);

@@ -481,6 +481,10 @@ class DINOv2:
         # (0: that pass runs on the main stream -- tools/ab_schedule.py measures the fewer-streams corners)
         self.fwd_local_stream = int(os.environ.get("LT_FWD_LOCAL_STREAM", "1") != "0")
         self.fwd_teacher_stream = int(os.environ.get("LT_FWD_TEACHER_STREAM", "1") != "0")
+        # HIP-graph replay of the static blocks of the backward pass (`_backward_backbone`); the forward's switch lives on the ViT engines
+        self.graph_backward = int(os.environ.get("LT_GRAPH_BWD", "0") != "0")
+        self._bwd_graph: Dict[str, Any] = {}
+        self._graph_chain_stream: Optional["torch.cuda.Stream"] = None
         # one weight-gradient GEMM per layer for the global- and the local-crop pass (vit.JointWgrad): half the split-K slab traffic
         self.joint_wgrad = int(os.environ.get("LT_JOINT_WGRAD", "1") != "0")
         self.head_side = int(os.environ.get("LT_HEAD_SIDE", "1") != "0")   # KoLeo and the heads' weight gradients beside the head chain
@@ -668,7 +672,11 @@ class DINOv2:
         # 2048 * 256 floats whatever its shape: four such GEMMs per block and pass (two passes, or their joint form), plus the heads'
         # (projection MLP x 3, PaKA head x 3 in DINOv31, both iBOT / DINO heads).  HBM is not the scarce resource here (288 GB).
         floats += (2 * 4 * cfg.depth + 12) * 2048 * 256
-        ops.reduce_begin(self.ws.get("reduce.scratch", (int(floats * 1.25) // 4 * 4,), torch.float32))
+        self._reduce_floats = int(floats * 1.25) // 4 * 4
+        ops.reduce_begin(self._reduce_scratch("reduce.scratch"))
+
+    def _reduce_scratch(self, name: str) -> Tensor:
+        return self.ws.get(name, (self._reduce_floats,), torch.float32)
 
     def _backward_backbone(self, sg: Dict[str, Any], dxn_g: Tensor, sl: Optional[Dict[str, Any]], dxn_l: Optional[Tensor]) -> None:
         """Backward of the student ViT from the gradients at its final-norm output: global crops (`sg`) and local crops (`sl`), with the
@@ -711,20 +719,118 @@ class DINOv2:
             lstream2 = self.local_bwd_stream
             lstream2.wait_event(main.record_event())
             jw = self._joint_active
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, joint=jw)),
-                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, joint=jw))]
+            depth = self.cfg.depth
+            # HIP-graph replay of the static blocks depth-2 .. 0 (all but the first one processed, which runs on the rows the losses read):
+            # both dgrad chains, the weight-gradient stream and their event choreography become ONE graph launch.  Eligible when nothing
+            # in those blocks depends on the step (no stochastic-depth draws, no rotary draws, no early all-reduces, no recomputation).
+            plain = lambda c: all(b[k]["mode"] == "plain" and b[k]["rowscale"] is None for b in c["blocks"][:-1] for k in ("attn", "mlp"))   # noqa: E731
+            gkey = None
+            if (self.graph_backward and sync is None and depth > 1 and self.device.type == "cuda" and not self.activation_checkpointing
+                    and sl.get("rope") is None and sl.get("block_in") is None and sg.get("block_in") is None and plain(sl) and plain(sg)):
+                gkey = (sg["T"], sl["T"], jw is not None, det, dxn_g.data_ptr(), dxn_l.data_ptr())
+            G = self._bwd_graph
+            if gkey is None or G.get("key") != gkey:
+                G.clear()
+                G.update(key=gkey, calls=0, graph=None, state=None)
+            G["calls"] += 1
+            replaying = gkey is not None and G["graph"] is not None
+            stop = 1 if replaying else None
+            dbg = os.environ.get("LT_BWD_GRAPH_DEBUG", "")
+            gside = None if (gkey is not None and dbg == "noside") else side
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=gside, joint=jw, stop_after=stop)),
+                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=gside, joint=jw, stop_after=stop))]
+            if gkey is not None and dbg == "onechain":
+                chains[0] = (main, chains[0][1])
             live = [True, True]
-            blk = self.cfg.depth
-            while any(live):
+
+            def one_iteration() -> None:
                 for ci, (st, gen) in enumerate(chains):
                     if live[ci]:
                         with torch.cuda.stream(st):
                             live[ci] = next(gen) != "tail"
                 if jw is not None:
                     jw.flush()       # a layer only one of the passes ran on all rows
-                blk -= 1
-                if blk >= 0:
-                    reduce_block(blk, (lstream2, main, side))
+
+            def boundary() -> None:
+                """Between the eagerly launched first block and the (captured / replayed / eagerly launched) static blocks: the main stream
+                joins the other two, the ledger's first region is summed, and a region of its own opens for the static blocks -- their
+                partial rows live at addresses the graph holds, which no eagerly launched kernel of any later step may be handed."""
+                main.wait_stream(lstream2)
+                main.wait_stream(side)
+                for c in (sl, sg):
+                    c["_bwd_consumed"].clear()     # every event in there is behind the join
+                if det:
+                    ops.reduce_flush()
+                    ops.reduce_begin(self._reduce_scratch("reduce.scratch_graph"), 64)
+
+            def after_static(stream_now: "torch.cuda.Stream") -> None:
+                """End of the static blocks, on a stream that is behind all three: their region's ordered sums."""
+                if det:
+                    ops.reduce_flush()
+
+            blk = depth
+            if gkey is None:
+                while any(live):
+                    one_iteration()
+                    blk -= 1
+                    if blk >= 0:
+                        reduce_block(blk, (lstream2, main, side))
+            else:
+                one_iteration()                       # block depth-1: eager in every step
+                boundary()
+                if replaying:
+                    G["graph"].replay()
+                elif G["calls"] < 2:                  # first step of this geometry: the same structure, launched eagerly (allocates)
+                    for _ in range(depth - 1):
+                        one_iteration()
+                    main.wait_stream(lstream2)
+                    main.wait_stream(side)
+                    after_static(main)
+                else:                                 # second step: capture, then run it
+                    g = torch.cuda.CUDAGraph()
+                    # The capture's ORIGIN is the weight-gradient stream; both dgrad chains are streams forked off it (the global-crop
+                    # chain on a stream of its own: the caller's stream may be the legacy default stream, which cannot take part).
+                    # ROCm 7.0's capture dies in hipStreamEndCapture when a forked stream waits for an event of another forked stream
+                    # that depends on it (chain -> weight-gradient stream -> same chain); edges to and from the origin are fine
+                    # (tools/graph_min_probe.py v6 / v7 / v10, profiles/r05_graph_capture_probe.log).
+                    if self._graph_chain_stream is None:
+                        self._graph_chain_stream = torch.cuda.Stream(device=self.device)
+                    gstream = self._graph_chain_stream
+                    with torch.cuda.graph(g, stream=side):
+                        chains[1] = (gstream, chains[1][1])
+                        for st in (lstream2, gstream):
+                            st.wait_stream(side)      # fork
+                        n_cap = int(os.environ.get("LT_BWD_GRAPH_ITERS", depth - 1))     # (diagnostic: capture fewer iterations)
+                        for _ in range(n_cap):
+                            one_iteration()
+                        for c in (sl, sg):
+                            c["_bwd_consumed"].clear()
+                        for st in (lstream2, gstream):
+                            side.wait_stream(st)      # join
+                        if n_cap == depth - 1:
+                            after_static(side)
+                    chains[1] = (main, chains[1][1])
+                    torch.cuda.set_stream(main)
+                    g.replay()
+                    if n_cap == depth - 1:
+                        G["graph"] = g
+                    else:
+                        for _ in range(depth - 1 - n_cap):
+                            one_iteration()
+                        main.wait_stream(lstream2)
+                        main.wait_stream(side)
+                        after_static(main)
+                        G["calls"] = 1
+                if det:                               # third region: the tails (and whatever follows until reduce_end)
+                    ops.reduce_begin(self._reduce_scratch("reduce.scratch"), 128)
+                if replaying:
+                    chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, joint=jw, resume=G["state"][0])),
+                              (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, joint=jw, resume=G["state"][1]))]
+                    live = [True, True]
+                one_iteration()                       # both generators arrive at "tail" (nothing is launched)
+                assert not any(live)
+                if G["graph"] is not None and G["state"] is None:
+                    G["state"] = (sl["_bwd_state"], sg["_bwd_state"])
             main.wait_stream(lstream2)
             for _, gen in chains:   # tails: plain accumulations into cls/pos/patch-embedding gradients, one after the other
                 for _ in gen:

@@ -510,10 +510,11 @@ def lars_flat(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tens
                            dampening, int(nesterov), trust, eps, int(first_step), _p(sumsq_t), max_norm, _stream()), "lt_lars_flat")
 
 
-def reduce_begin(scratch: Tensor) -> None:
-    """Start deferring the cross-workgroup sums of the backward kernels into `scratch` (lt_reduce_begin: order-fixed reductions)."""
+def reduce_begin(scratch: Tensor, first_slot: int = 0) -> None:
+    """Start deferring the cross-workgroup sums of the backward kernels into `scratch` (lt_reduce_begin_at: order-fixed reductions;
+    `first_slot`: number range of this region's cached flush tables -- one range per region of a step, see include/lt_amd.h)."""
     _chk(scratch, torch.float32, "reduce_begin.scratch")
-    check(_lib.load().lt_reduce_begin(_p(scratch), scratch.numel()), "lt_reduce_begin")
+    check(_lib.load().lt_reduce_begin_at(_p(scratch), scratch.numel(), int(first_slot)), "lt_reduce_begin_at")
 
 
 def reduce_flush() -> None:

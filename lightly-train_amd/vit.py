@@ -729,7 +729,8 @@ class ViTEngine:
                                           self.w(gname), self.gw(gname), D, k_in)
 
     def backward_iter(self, ws: Workspace, ctx: Dict[str, Any], dxn: Tensor, side: Optional["torch.cuda.Stream"] = None,
-                      joint: Optional[JointWgrad] = None) -> Iterator[str]:
+                      joint: Optional[JointWgrad] = None, stop_after: Optional[int] = None,
+                      resume: Optional[Dict[str, Any]] = None) -> Iterator[str]:
         """dxn f32 [B,N,D] = dL/d(final-norm tokens).  Accumulates into the FlatParams grad views.
 
         Generator: yields "block" after enqueuing each transformer block and "tail" before the token-assembly /
@@ -744,7 +745,12 @@ class ViTEngine:
 
         `joint`: full-row weight gradients are deposited there instead of launched (`JointWgrad`); the upstream-gradient buffers then
         rotate through four allocations instead of two and the qkv data gradient gets a buffer of its own, so that no deposited
-        operand is overwritten within the block iteration that deposited it."""
+        operand is overwritten within the block iteration that deposited it.
+
+        HIP-graph replay of the static blocks (the caller captures the launches of blocks depth-2 .. 0 once and replays them):
+        `stop_after` = n ends the generator after n blocks; `resume` = the state a full run left in ctx["_bwd_state"] skips the final
+        norm and the block loop and goes straight to "tail".  ctx["_bwd_consumed"] is the buffer -> event map of `before_write`, which
+        the caller clears where it has joined the streams anyway (events recorded outside a capture must not be waited for inside it)."""
         cfg = self.cfg
         B, N, n_p, T, tag = ctx["B"], ctx["N"], ctx["n_p"], ctx["T"], ctx["tag"]
         D, Hh, dh, hid = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
@@ -781,16 +787,20 @@ class ViTEngine:
         fc2n = "mlp.w3" if cfg.swiglu else "mlp.fc2"
         cur = 0   # index into dDs of the branch about to be processed
         last = f"blocks.{cfg.depth - 1}."
-        nxt = fuse_args(None if ckpt else blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
-        ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
-                          self.gw("norm.weight"), self.gw("norm.bias"), T, D, **nxt)
-        have = bool(nxt)   # dDs[cur] already holds the upstream gradient of the branch about to be processed
-        dx = dxa
-        other = dxb
-
         slab = ws.get("wgrad.slabs", (32 * 1024 * 1024,), torch.float32)  # 128 MiB split-K scratch (deterministic reduction)
         main = torch.cuda.current_stream()
         consumed: Dict[int, Any] = {}  # buffer data_ptr -> event after which the side stream no longer reads it
+        ctx["_bwd_consumed"] = consumed
+        dx = dxa
+        other = dxb
+        have = False
+        if resume is None:
+            nxt = fuse_args(None if ckpt else blocks_ctx[-1]["mlp"], last + "ls2.gamma", last + fc2n + ".bias", dDs[cur])
+            ops.layernorm_bwd(ctx["x_last"], self.w("norm.weight"), ctx["meanf"], ctx["rstdf"], dxn, None, dxa,
+                              self.gw("norm.weight"), self.gw("norm.bias"), T, D, **nxt)
+            have = bool(nxt)   # dDs[cur] already holds the upstream gradient of the branch about to be processed
+        else:
+            dx = resume["dx"]
 
         def before_write(buf: Tensor) -> None:
             ev = consumed.pop(buf.data_ptr(), None)
@@ -836,7 +846,8 @@ class ViTEngine:
             ops.gather_rows(dx, D, br["idx"], br["rows"], D, out_f32=dxs)
             return dxs
 
-        for i in reversed(range(cfg.depth)):
+        for i in (reversed(range(cfg.depth)) if resume is None else ()):
+            main = torch.cuda.current_stream()   # (re-read per block: under a graph capture the chain runs on the capturing stream)
             if ckpt:
                 if side is not None:
                     main.wait_stream(side)   # the previous block's weight-gradient GEMMs still read the shared activation buffers
@@ -927,7 +938,11 @@ class ViTEngine:
                 have = bool(nxt)
             cur = (cur + 1) % nring
             yield "block"
+            if stop_after is not None and cfg.depth - i >= stop_after:
+                return
 
+        if resume is None:
+            ctx["_bwd_state"] = dict(dx=dx)
         yield "tail"
         main = torch.cuda.current_stream()   # the tail may be resumed on another stream than the block loop
         # ---- token assembly + patch embedding

@@ -1215,6 +1215,49 @@ def test_activation_checkpointing_gives_the_same_gradients(rate):
     assert d <= 2e-5 * outs[0][1].abs().max().item(), d
 
 
+def test_hip_graph_replay_of_the_static_blocks_is_bitwise_equal_to_eager_launches():
+    """`graph_forward` (vit.ViTEngine) / `graph_backward` (DINOv2): blocks 0 .. depth-2 of the three forward passes and blocks depth-2 .. 0 of
+    both backward chains with the weight-gradient stream are captured into HIP graphs on the second step and replayed afterwards (one launch
+    per forward pass, one for the backward).  The captured kernels are the eagerly launched ones with the same arguments, and every
+    cross-workgroup sum goes through the order-fixed ledger (a region of its own for the replayed part), so five steps with replay must
+    equal five eagerly launched steps BIT FOR BIT: loss terms of every step, parameters, EMA teacher, last gradients, centers.  Shapes on
+    the 64-row grid at ViT-S width (joint weight gradients active) and off it (197-token crops at batch 6: pad-row fills inside the graph)."""
+    import random
+
+    from lightly_train_amd import ops
+    from lightly_train_amd.dinov2 import DINOv2, DINOv2Args
+    from lightly_train_amd.vit import ViTConfig
+
+    for B, gsz, lsz in ((8, 112, 48), (6, 224, 96)):
+        cfg = ViTConfig(embed_dim=384, depth=4, num_heads=6, mlp_ratio=4.0, patch_size=16, img_size=gsz, init_values=1e-2)
+        args = DINOv2Args(output_dim=8192, hidden_dim=512, dino_bottleneck_dim=256)
+        g = torch.Generator().manual_seed(0)
+        views = [torch.randn(B, 3, gsz, gsz, generator=g) for _ in range(2)] + [torch.randn(B, 3, lsz, lsz, generator=g) for _ in range(4)]
+        before = ops.reduce_overflows()
+        finals = []
+        for graphs in (0, 1):
+            m = DINOv2(cfg, args, global_batch_size=B, total_steps=100, device="cuda", seed=3)
+            m.graph_backward = graphs
+            m.s_vit.graph_forward = m.t_vit.graph_forward = bool(graphs)
+            losses = []
+            for step in range(5):
+                random.seed(100 + step)
+                m.train_step(views)
+                losses.append(m._loss_slots.clone())
+            torch.cuda.synchronize()
+            if graphs:
+                assert m._bwd_graph.get("graph") is not None, "the backward graph was never captured"
+                assert any(e["graph"] is not None for e in m.s_vit._fwd_graphs.values()) and any(e["graph"] is not None for e in m.t_vit._fwd_graphs.values())
+            finals.append((torch.stack(losses), m.student.data.clone(), m.student.grad.clone(), m.teacher.data.clone(), m.dino_center.clone()))
+        for what, a, b in zip(("loss terms", "student parameters", "last gradients", "teacher parameters", "center"), *finals):
+            if what == "last gradients" and not torch.equal(a, b):
+                bad = [n for n in m.student.names if not torch.equal(a[m.student.offsets[n]:m.student.offsets[n] + m.student.p[n].numel()],
+                                                                     b[m.student.offsets[n]:m.student.offsets[n] + m.student.p[n].numel()])]
+                raise AssertionError(f"gradients differ between replay and eager launches (B={B}): {bad}")
+            assert torch.equal(a, b), (what, B)
+        assert ops.reduce_overflows() == before
+
+
 def test_step_is_bitwise_reproducible():
     """Two runs of the same step from the same state give bit-identical gradients, loss terms and, after the optimizer, parameters:
     the cross-workgroup sums of backward go through the order-fixed reduction ledger (csrc/reduce.hip) instead of fp32 atomics, the
