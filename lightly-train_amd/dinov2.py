@@ -780,7 +780,7 @@ class DINOv2:
                 boundary()
                 if replaying:
                     G["graph"].replay()
-                elif G["calls"] < 2:                  # first step of this geometry: the same structure, launched eagerly (allocates)
+                elif G["calls"] < 2 or dbg == "eager":   # first step of this geometry: the same structure, launched eagerly (allocates)
                     for _ in range(depth - 1):
                         one_iteration()
                     main.wait_stream(lstream2)
