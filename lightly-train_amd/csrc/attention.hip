@@ -1085,6 +1085,234 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
   }
 }
 
+// ================================================================================================ backward, fused, 225..288 tokens
+// The global crops of the patch-14 models (257 tokens; 261 with registers): nine key tiles do not fit the eight waves of
+// attn_bwd_fused_kernel, and dS for 257 x 257 does not fit LDS beside the images.  Same kernel in TWO key passes per head: the key tiles
+// are split into two groups (5 + 4 for nine tiles), a pass runs phase A for its group's key tiles over ALL queries (the Q / dO / O chunks
+// are staged once per pass) and phase B adds the group's share of dQ; the dQ accumulators of query tile `wave` stay in registers across
+// the two passes.  dS lives as [288 queries][<= 160 keys of the group] (row stride 328 B = 82 dwords: 32 rows -> 32 distinct bank pairs),
+// the K^T image holds the group's keys.  The ninth query tile (rows 256 .. N-1: one row at 257 tokens) is formed by wave 7 -- which owns
+// no key tile in either pass -- into short-lived accumulators and summed over the passes in a small fp32 LDS tile.
+// 8 waves are 5 / 4 busy in phase A (the eight-tile kernel: 7), so the rate per MFMA is lower than at 197 tokens, but S / P / dP / dS are
+// still formed once per tile pair and q / k / v / dO / O are read from HBM twice instead of by two kernels with three passes.
+constexpr int P2_MAXQ = 288, P2_DS = 328;
+constexpr int P2_LDS = 4 * FB_IMG + 2 * FB_CH * (int)sizeof(float) + P2_MAXQ * P2_DS + 32 * 64 * (int)sizeof(float);
+
+__global__ __launch_bounds__(512) void attn_bwd_fused2p_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int N, int H, int hpb, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsQ = smem;
+  char* ldsQt = smem + FB_IMG;
+  char* ldsD = smem + 2 * FB_IMG;
+  char* ldsDt = smem + 3 * FB_IMG;
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * FB_IMG);   // -lse / scale [64], -delta [64] of the staged chunk
+  char* ldsS = smem + 4 * FB_IMG + 2 * FB_CH * sizeof(float);
+  float* ldsX = reinterpret_cast<float*>(ldsS + P2_MAXQ * P2_DS);   // dQ of the ninth query tile, [32 q][64 d] fp32, summed over the passes
+  char* ldsKt = smem;                                          // phase B: transposable image of the group's K over the images
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, hi = l >> 5;
+  const int groups = (H + hpb - 1) / hpb;
+  const int b = blockIdx.x / groups, h_begin = (blockIdx.x % groups) * hpb, h_end = min(H, h_begin + hpb);
+  const int ntile = (N + 31) / 32, g0t = (ntile + 1) / 2;      // key tiles in all / in the first group
+  const int npass = 2 * (h_end - h_begin);
+  const long ts = 3L * H * DH, tso = (long)H * DH;
+  const bf16_t* qkv_b = qkv + (long)b * N * ts;
+  const bf16_t* dout_b = dout + (long)b * N * tso;
+  const bf16_t* out_b = out + (long)b * N * tso;
+  bf16_t* dqkv_b = dqkv + (long)b * N * ts;
+  const float inv_scale = 1.f / scale, c_exp = scale * 1.4426950408889634f;
+  const int sr = tid >> 3, sc = tid & 7;   // staging: thread -> (chunk row, 16-byte piece)
+  const int kloc0 = wave * 32;             // this wave's key tile inside its group
+  const bool fringe = ntile > 8 && wave == 7;
+
+  uint4 qr, dr, orr;
+  float l_reg;
+  bool l_ok;
+  auto load_chunk = [&](int h, int tok0) {   // branch-free prefetch: rows past the end read row N-1 and are neutralised where consumed
+    const int tok = min(tok0 + sr, N - 1);
+    qr = *reinterpret_cast<const uint4*>(qkv_b + (long)tok * ts + h * DH + sc * 8);
+    dr = *reinterpret_cast<const uint4*>(dout_b + (long)tok * tso + h * DH + sc * 8);
+    orr = *reinterpret_cast<const uint4*>(out_b + (long)tok * tso + h * DH + sc * 8);
+    l_ok = tok0 + (tid & 63) < N;
+    l_reg = lse[((long)b * H + h) * N + min(tok0 + (tid & 63), N - 1)];
+  };
+  auto store_chunk = [&]() {
+    const int sb = sc >> 1, half = sc & 1;
+    const int rows_off = sr * 128 + ((sc ^ ((sr >> 1) & 7)) << 4);
+    const int tr_off = ((sr >> 2) * 4 + sb) * 128 + ((((sr & 3) + sb) & 3) << 5) + (half << 4);
+    *reinterpret_cast<uint4*>(ldsQ + rows_off) = qr;
+    *reinterpret_cast<uint4*>(ldsQt + tr_off) = qr;
+    *reinterpret_cast<uint4*>(ldsD + rows_off) = dr;
+    *reinterpret_cast<uint4*>(ldsDt + tr_off) = dr;
+    const unsigned dw[4] = {dr.x, dr.y, dr.z, dr.w}, ow[4] = {orr.x, orr.y, orr.z, orr.w};
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = fmaf(bf2f((bf16_t)(dw[j] & 0xffff)), bf2f((bf16_t)(ow[j] & 0xffff)), acc);
+      acc = fmaf(bf2f((bf16_t)(dw[j] >> 16)), bf2f((bf16_t)(ow[j] >> 16)), acc);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sc == 0) ldsL[FB_CH + sr] = -acc;
+    if (tid < FB_CH) ldsL[tid] = l_ok ? -l_reg * inv_scale : -INFINITY;
+  };
+  bf16x8 kf[4], vf[4];
+  auto load_kv = [&](int h, int grp) {
+    const int k0 = ((grp ? g0t : 0) + wave) * 32;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16_t* row = qkv_b + (long)min(k0 + (l & 31), N - 1) * ts + h * DH + ks * 16 + hi * 8;
+      kf[ks] = *reinterpret_cast<const bf16x8*>(row + (long)H * DH);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(row + 2L * H * DH);
+    }
+  };
+
+  load_chunk(h_begin, 0);
+  load_kv(h_begin, 0);
+  store_chunk();
+  __syncthreads();
+  f32x16 dq[2];
+  for (int p = 0; p < npass; ++p) {
+    const int h = h_begin + (p >> 1), grp = p & 1;
+    const bool next_pass = p + 1 < npass;
+    const int hn = h_begin + ((p + 1) >> 1), grpn = (p + 1) & 1;
+    const int gt = grp ? ntile - g0t : g0t;          // key tiles of this group
+    const int k0 = ((grp ? g0t : 0) + wave) * 32;
+    const bool active = wave < gt;
+    const bool key_ok = k0 + (l & 31) < N;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f; }
+    if (grp == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+      for (int i = tid; i < 32 * 64; i += 512) ldsX[i] = 0.f;   // (read again only behind the barriers of this pass)
+    }
+    // ---- phase A: this group's key tiles against every query chunk
+    for (int c0 = 0; c0 < N; c0 += FB_CH) {
+      const bool more = c0 + FB_CH < N;
+      load_chunk(more || !next_pass ? h : hn, more ? c0 + FB_CH : 0);   // (the very last request of a block is a dummy)
+      if (active) {
+        const int nt = min(2, (N - c0 + 31) / 32);
+        for (int it = 0; it < nt; ++it) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 ls = *reinterpret_cast<const float4*>(&ldsL[it * 32 + 8 * g + 4 * hi]);
+            const float4 dl = *reinterpret_cast<const float4*>(&ldsL[FB_CH + it * 32 + 8 * g + 4 * hi]);
+            s[4 * g] = key_ok ? ls.x : -INFINITY; s[4 * g + 1] = key_ok ? ls.y : -INFINITY;
+            s[4 * g + 2] = key_ok ? ls.z : -INFINITY; s[4 * g + 3] = key_ok ? ls.w : -INFINITY;
+            dp[4 * g] = dl.x; dp[4 * g + 1] = dl.y; dp[4 * g + 2] = dl.z; dp[4 * g + 3] = dl.w;
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsQ, it, ks), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ldsD, it, ks), vf[ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(s[e] * c_exp);
+            s[e] = pe;
+            dp[e] *= pe;
+          }
+          union { bf16x8 v; unsigned u[4]; } p0, p1, d0, d1;
+          p0.v = pack8(s, 0); p1.v = pack8(s, 8); d0.v = pack8(dp, 0); d1.v = pack8(dp, 8);
+          char* scol = ldsS + (size_t)(c0 + it * 32 + 4 * hi) * P2_DS + (kloc0 + (l & 31)) * 2;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned w = j < 4 ? d0.u[j] : d1.u[j - 4];
+            const int row = (2 * j & 3) + 8 * (2 * j >> 2);
+            *reinterpret_cast<unsigned short*>(scol + row * P2_DS) = (unsigned short)(w & 0xffff);
+            *reinterpret_cast<unsigned short*>(scol + (row + 1) * P2_DS) = (unsigned short)(w >> 16);
+          }
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0.v, frag_tr(ldsDt, db, it * 32), dv[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1.v, frag_tr(ldsDt, db, it * 32 + 16), dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0.v, frag_tr(ldsQt, db, it * 32), dk[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1.v, frag_tr(ldsQt, db, it * 32 + 16), dk[db], 0, 0, 0);
+          }
+        }
+      }
+      if (more) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+      }
+    }
+    // ---- phase B: the group's share of dQ
+    __syncthreads();   // the images are dead, every dS tile of this group is in LDS
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int r = kloc0 + (l & 31), c = ks * 2 + hi, sb = c >> 1, half = c & 1;
+        *reinterpret_cast<bf16x8*>(ldsKt + ((r >> 2) * 4 + sb) * 128 + ((((r & 3) + sb) & 3) << 5) + (half << 4)) = kf[ks];
+      }
+    }
+    if (next_pass) load_kv(hn, grpn);   // K went to LDS, V died with phase A
+    __syncthreads();
+    const int nkb = 2 * gt;
+    {   // query tile `wave` (N > 224: all eight exist)
+      const char* srow = ldsS + (size_t)(wave * 32 + (l & 31)) * P2_DS + hi * 8;
+#pragma unroll 2
+      for (int kbk = 0; kbk < nkb; ++kbk) {
+        union { struct { uint2 a, b; } s; bf16x8 v; } f;
+        f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
+        f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, kbk * 16), f.v, dq[db], 0, 0, 0);
+      }
+    }
+    if (fringe) {   // ninth query tile: rows 256 .. N-1 (dS rows past N are zeros: lse staged as -inf)
+      f32x16 dx[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dx[0][e] = 0.f; dx[1][e] = 0.f; }
+      const char* srow = ldsS + (size_t)(256 + (l & 31)) * P2_DS + hi * 8;
+      for (int kbk = 0; kbk < nkb; ++kbk) {
+        union { struct { uint2 a, b; } s; bf16x8 v; } f;
+        f.s.a = *reinterpret_cast<const uint2*>(srow + kbk * 32);
+        f.s.b = *reinterpret_cast<const uint2*>(srow + kbk * 32 + 16);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dx[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, db, kbk * 16), f.v, dx[db], 0, 0, 0);
+      }
+      // C layout of dQ^T[d][q]: lane -> query column, register e -> d = 32 db + crow(e, hi); only this wave touches ldsX
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ldsX[(l & 31) * 64 + db * 32 + crow(e, hi)] += dx[db][e];
+    }
+    __syncthreads();   // dS and K^T are dead: the dS area becomes the store scratch, the image area takes the next pass
+    if (next_pass) store_chunk();
+    {
+      char* scratch = ldsS + wave * (32 * 144);
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[0][e] *= scale; dk[1][e] *= scale; }   // dS was kept unscaled
+        store_td_tile(scratch, dk, dqkv_b + (long)H * DH + h * DH, ts, k0, N);
+        store_td_tile(scratch, dv, dqkv_b + 2L * H * DH + h * DH, ts, k0, N);
+      }
+      if (grp == 1) {
+        store_qd_tile(scratch, dq, scale, dqkv_b + h * DH, ts, wave * 32, N);
+        if (fringe) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's own ldsX updates
+          for (int idx = l; idx < 32 * 8; idx += 64) {
+            const int r = idx >> 3, c = idx & 7;
+            if (256 + r < N) {
+              const float4 x0 = *reinterpret_cast<const float4*>(&ldsX[r * 64 + c * 8]);
+              const float4 x1 = *reinterpret_cast<const float4*>(&ldsX[r * 64 + c * 8 + 4]);
+              *reinterpret_cast<uint4*>(dqkv_b + (long)(256 + r) * ts + h * DH + c * 8) =
+                  make_uint4(pack_bf2(x0.x * scale, x0.y * scale), pack_bf2(x0.z * scale, x0.w * scale),
+                             pack_bf2(x1.x * scale, x1.y * scale), pack_bf2(x1.z * scale, x1.w * scale));
+            }
+          }
+        }
+      }
+    }
+    if (next_pass) __syncthreads();   // the next pass's images are staged; every scratch / ldsX reader is done
+  }
+}
+
 // ================================================================================================ backward, fused, short sequences
 // N <= 64 (the local crops: 50 / 37 tokens), two heads per 4-wave block like attn_bwd_dkdv_v2_kernel<4, true>: wave -> (head, key tile).
 // One pass replaces the dQ + dK/dV pair for these lengths: q / k / v / dO / O are read ONCE, delta = rowsum(dO * O) is formed while
@@ -1382,6 +1610,21 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
     // survives the box-to-box and minute-to-minute drift of whole-run timings
     const char* variant_env = getenv("LT_ATTN_BWD");
     const int variant = variant_env ? atoi(variant_env) : 2;
+    const char* p2_env = getenv("LT_ATTN_BWD_2P");   // per call: 0 = the 8-wave dQ + dK/dV pair for 225..288 tokens
+    if (variant >= 2 && N > FB_MAXN && N <= P2_MAXQ && (p2_env ? atoi(p2_env) != 0 : true)) {   // patch-14 global crops: fused, two key passes
+      static bool p2_configured = false;
+      if (!p2_configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        if (e != hipSuccess) { lt_set_error("lt_attention_bwd: cannot enable %d B of LDS: %s", P2_LDS, hipGetErrorString(e)); return LT_ERR_HIP; }
+        p2_configured = true;
+      }
+      int hpb = 1;
+      for (int c = 2; c <= H; ++c)
+        if (H % c == 0 && (long)B * (H / c) >= 256) hpb = c;
+      hipLaunchKernelGGL(attn_bwd_fused2p_kernel, dim3(B * lt_cdiv(H, hpb)), dim3(512), P2_LDS, ST, (const bf16_t*)qkv, (const bf16_t*)out_bf16,
+                         (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, hpb, scale);
+      LT_CHECK_LAUNCH("lt_attention_bwd");
+    }
     if (variant >= 2 && N > 64 && N <= FB_MAXN) {   // one fused pass: S / dP / dS once, 20 instead of 28 MFMAs per tile pair
       static bool fused_configured = false;
       if (!fused_configured) {
@@ -1423,7 +1666,9 @@ extern "C" int lt_attention_bwd(const void* qkv, const void* out_bf16, const voi
                          (const bf16_t*)dout_bf16, lse, (bf16_t*)dqkv, N, H, scale);
       LT_CHECK_LAUNCH("lt_attention_bwd");
     }
-    if (variant && !(N > 256 && N <= 320)) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels
+    const char* v2all = getenv("LT_ATTN_BWD_V2_ALL");   // (per call; 0: the 4-wave pair for 257..320 tokens, which round 2 preferred there --
+    // re-measured in round 5: 747 vs 839 us at 257 tokens, 774 vs 934 at 320, profiles/r05_attn_bwd_257.log)
+    if (variant && (!(N > 256 && N <= 320) || !(v2all && atoi(v2all) == 0))) {   // 257..320 tokens (patch 14 at 224^2): 9-10 tiles fill 8-wave blocks badly, keep the 4-wave kernels
       static bool configured = false;
       const int lds_dq = 3 * IMG, lds_kv = 4 * IMG + 2 * CH * (int)sizeof(float);
       if (!configured) {

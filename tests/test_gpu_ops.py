@@ -481,7 +481,9 @@ def _attn_ref(qkv, B, N, H, dh, scale, dout=None):
                                        # packed block-diagonal backward (32..64 tokens: several images per 224-token sequence, ragged last sequence)
                                        (9, 37, 2, 64), (5, 50, 2, 64), (7, 33, 2, 64), (5, 32, 2, 64), (4, 48, 3, 64), (33, 50, 4, 64), (7, 64, 2, 64),
                                        # fused two-heads-per-block backward (N <= 64, even head count): one key tile only, a ragged first tile, 12 heads
-                                       (2, 20, 2, 64), (3, 31, 4, 64), (2, 2, 2, 64), (2, 50, 12, 64)])
+                                       (2, 20, 2, 64), (3, 31, 4, 64), (2, 2, 2, 64), (2, 50, 12, 64),
+                                       # fused backward in two key passes (225..288 tokens: the patch-14 global crops): eight and nine tiles, ragged last tile, the cap, head walk
+                                       (2, 261, 3, 64), (1, 288, 2, 64), (3, 256, 2, 64), (2, 240, 1, 64), (44, 257, 12, 64), (2, 289, 2, 64)])
 def test_attention(B, N, H, dh):
     o = ops()
     g = torch.Generator().manual_seed(N + dh)
