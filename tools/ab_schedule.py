@@ -9,6 +9,7 @@ Presets (attributes of the DINOv2 method object):
   bwd2     forward as shipped; backward = ONE dgrad chain (local crops, then global crops) + the weight-gradient stream (separate wgrads)
   two      two streams throughout: forward teacher || (global, then local crops on the main stream); backward as `bwd2`
   fwdmain  forward entirely on the main stream (teacher, global, local one after the other); backward as shipped
+  tfirst   the teacher's forward on the main stream ahead of the student's (global || local); backward as shipped
   one      every launch on one stream
 """
 import argparse
@@ -30,6 +31,7 @@ PRESETS = {
     "bwd2": dict(overlap_streams=True, two_bwd_chains=False, fwd_local_stream=1, fwd_teacher_stream=1),
     "two": dict(overlap_streams=True, two_bwd_chains=False, fwd_local_stream=0, fwd_teacher_stream=1),
     "fwdmain": dict(overlap_streams=True, two_bwd_chains=True, fwd_local_stream=0, fwd_teacher_stream=0),
+    "tfirst": dict(overlap_streams=True, two_bwd_chains=True, fwd_local_stream=1, fwd_teacher_stream=0),   # teacher alone first, then global || local
     "one": dict(overlap_streams=False, two_bwd_chains=True, fwd_local_stream=1, fwd_teacher_stream=1),
 }
 ap = argparse.ArgumentParser()
