@@ -45,30 +45,42 @@ class _PinnedRing:
     """Persistent pinned staging slots for `h2d`, handed out round-robin; a slot is taken again only after the event recorded behind its
     last copy has fired.  `Tensor.pin_memory()` costs the launch thread 0.6-2 ms per call once the host runs a few steps ahead of the
     device (every cached pinned block is still in flight, so each call is a fresh hipHostMalloc: tools/host_profile.py,
-    profiles/r05_host_profile_dp02.log); a slot here is one memcpy into memory pinned once."""
+    profiles/r05_host_profile_dp02.log); a slot here is one memcpy into memory pinned once.  The ring is ONE pinned allocation made at
+    its first use (slot size = the first request rounded up to a power of two, at least `min_bytes`): pinning slot by slot as the ring
+    index advances spread hundreds of hipHostMalloc calls over the first steps of a run.  A request larger than the slot size gets a
+    slot of its own (grown on demand)."""
 
     def __init__(self, slots: int, min_bytes: int) -> None:
+        self.n = slots
         self.bufs: list = [None] * slots
         self.evs: list = [None] * slots
         self.i = 0
         self.min_bytes = min_bytes
+        self.slot_bytes = 0
 
     def stage(self, t: Tensor):
         n = t.numel() * t.element_size()
+        if self.slot_bytes == 0:
+            sb = self.min_bytes
+            while sb < n:
+                sb *= 2
+            arena = torch.empty(self.n * sb, dtype=torch.uint8, pin_memory=True)
+            self.bufs = [arena[k * sb:(k + 1) * sb] for k in range(self.n)]
+            self.slot_bytes = sb
         i = self.i
-        self.i = (i + 1) % len(self.bufs)
+        self.i = (i + 1) % self.n
         if self.evs[i] is not None:
             self.evs[i].synchronize()      # (never waits in practice: the ring is deeper than the host's lead over the device)
         b = self.bufs[i]
-        if b is None or b.numel() < n:
-            b = torch.empty(max(n, self.min_bytes), dtype=torch.uint8, pin_memory=True)
+        if b.numel() < n:
+            b = torch.empty(n, dtype=torch.uint8, pin_memory=True)
             self.bufs[i] = b
         v = b[:n].view(t.dtype).view(t.shape)
         v.copy_(t)
         return v, i
 
 
-_rings = {"small": _PinnedRing(1024, 4096), "large": _PinnedRing(96, 1 << 20)}
+_rings = {"small": _PinnedRing(512, 65536), "large": _PinnedRing(32, 1 << 20)}
 
 
 def h2d(t: Tensor, dev: torch.device) -> Tensor:

@@ -1,9 +1,10 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-T=${1:-r05n}
+T=${1:-r05o}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-python tools/ab_schedule.py --steps 12 five tfirst > $O/ab_tfirst.log 2>&1; tail -2 $O/ab_tfirst.log | cut -c1-150
-timeout 1500 python -m pytest tests/ -q -m gpu > $O/gpu_tests_full.log 2>&1; tail -2 $O/gpu_tests_full.log
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --drop-path 0.2 > $O/bench_dp02.log 2>&1; tail -1 $O/bench_dp02.log | cut -c1-200
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --drop-path 0.2 > $O/bench_dp02_b.log 2>&1; tail -1 $O/bench_dp02_b.log | cut -c1-200
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-200
