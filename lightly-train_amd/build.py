@@ -82,3 +82,17 @@ def build_timing() -> str:
 if __name__ == "__main__":
     import sys
     print(build_timing() if "--timing" in sys.argv else build(verbose=True))
+
+
+def build_variant(defines: list, name: str) -> str:
+    """gemm.hip rebuilt with extra -D flags, linked with the shipped objects as lib/liblt_amd_<name>.so (tools/ab_lib.py alternates it with the
+    shipped library step by step in one process)."""
+    build()
+    hipcc = _hipcc()
+    obj = os.path.join(OBJDIR, f"gemm_{name}.o")
+    out = os.path.join(os.path.dirname(LIB), f"liblt_amd_{name}.so")
+    src = [s_ for s_ in sources() if s_.endswith("gemm.hip")][0]
+    subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-x", "hip", "-c", src, "-o", obj], check=True)
+    others = [os.path.join(OBJDIR, os.path.basename(s_) + ".o") for s_ in sources() if not s_.endswith("gemm.hip")]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *others, obj, "-o", out], check=True)
+    return out
