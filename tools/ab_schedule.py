@@ -38,7 +38,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("presets", nargs="*", default=["five", "bwd2", "two", "one"])
 ap.add_argument("--steps", type=int, default=12, help="timed steps per preset")
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--env", default=None, help="NAME=v1,v2: a per-call environment switch crossed with the presets (e.g. LT_GEMM_1P=0,3 on a library that has the persistent GEMM)")
 a = ap.parse_args()
+env_name, env_vals = (a.env.split("=")[0], a.env.split("=")[1].split(",")) if a.env else (None, [None])
+cells = [(p_, v_) for p_ in a.presets for v_ in env_vals]
 
 dev = torch.device("cuda", 0)
 cfg = ViTConfig(patch_size=16, img_size=224, init_values=1e-5, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0)
@@ -53,20 +56,27 @@ def apply(name: str) -> None:
         setattr(m, k, v)
 
 
-for name in a.presets:      # every preset's buffers exist before the timing starts
-    apply(name)
+def enter(cell) -> None:
+    apply(cell[0])
+    if env_name is not None:
+        os.environ[env_name] = cell[1]
+
+
+for cell in cells:      # every cell's buffers exist before the timing starts
+    enter(cell)
     for _ in range(2):
         m.train_step(views)
 torch.cuda.synchronize()
-t = {v: [] for v in a.presets}
-for i in range(a.steps * len(a.presets)):
-    v = a.presets[i % len(a.presets)]
-    apply(v)
+t = {c: [] for c in cells}
+for i in range(a.steps * len(cells)):
+    c = cells[i % len(cells)]
+    enter(c)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     m.train_step(views)
     torch.cuda.synchronize()
-    t[v].append((time.perf_counter() - t0) * 1e3)
-for v in a.presets:
-    x = sorted(t[v])
-    print(f"{v:8s}: median {statistics.median(x):.2f} ms  mean {statistics.fmean(x):.2f}  min {x[0]:.2f}  max {x[-1]:.2f}  (n={len(x)})  {PRESETS[v]}")
+    t[c].append((time.perf_counter() - t0) * 1e3)
+for c in cells:
+    x = sorted(t[c])
+    tag = c[0] if env_name is None else f"{c[0]} {env_name}={c[1]}"
+    print(f"{tag:24s}: median {statistics.median(x):.2f} ms  mean {statistics.fmean(x):.2f}  min {x[0]:.2f}  max {x[-1]:.2f}  (n={len(x)})")
