@@ -88,6 +88,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_comm_wait": [vp],
     "lt_comm_size": [],
     "lt_comm_destroy": [],
+    "lt_gemm_resid_ln768": [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp],
     "lt_reduce_begin": [vp, i64],
     "lt_reduce_begin_at": [vp, i64, C.c_int],
     "lt_reduce_flush": [vp],
