@@ -144,6 +144,11 @@ int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, co
                            const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats, void* dnext_bf16,
                            const float* gamma_next, const float* rowscale_next, float scale_next, float* dbias_next, int rows,
                            int D, void* stream);
+/* the LayerNorm backward of a branch that ran on a row subset (batch-subset stochastic depth, block.py:118-141): row r of (x, mean, rstd, dy)
+ * belongs to row ridx[r] (int64, device, no repeats) of the gradient stream: dx[ridx[r]] = dres[ridx[r]] + LN'(dy[r]); dres may be dx (in
+ * place).  bf16 dy, D % 4 == 0, D <= 1024 */
+int lt_layernorm_bwd_rows(const float* x, const float* w, const float* mean, const float* rstd, const void* dy, int dy_is_f32,
+                          const float* dres, float* dx, const int64_t* ridx, float* dw, float* db, int rows, int D, void* stream);
 
 /* LayerScale (+ stochastic depth) backward (layer_scale.py:27-28, block.py:118-141, drop_path.py:16-28):
  *   m_r = scale * (rowscale ? rowscale[r] : 1);  dy(bf16) = dout*gamma*m_r;  dgamma += sum_r dout*y*m_r;
@@ -151,6 +156,11 @@ int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, co
  * gamma == NULL: dy = bf16(dout*m_r). */
 int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
                       float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
+/* same, with row r of the branch reading its upstream gradient at row ridx[r] of `dout` (int64 on the device; NULL = row r): the rows of a
+ * batch-subset stochastic-depth branch (block.py:118-141) or of the last block's loss rows inside the full gradient stream, without a gathered
+ * copy in between.  y / dy / rowscale stay indexed by r.  D % 4 == 0 */
+int lt_layerscale_bwd_rows(const float* dout, const int64_t* ridx, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
+                           float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
 /* LayerScale gradient from the weight gradient instead of the saved branch output (layer_scale.py:27-28 backward):
  * dgamma[c] += (sum_k W[c,k] dW[c,k] + bias[c] dbias[c]) / gamma[c], W bf16 [N,K] = the Linear feeding the LayerScale,
  * dW/dbias = its accumulated gradients (computed from dD = dx*gamma).  Call once per step after all weight gradients.

@@ -53,6 +53,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_layerscale_dgamma": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "lt_layerscale_dgamma_batched": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, vp],
     "lt_layerscale_bwd": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],
+    "lt_layernorm_bwd_rows": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp],
+    "lt_layerscale_bwd_rows": [vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp],
     "lt_colsum_bf16": [vp, vp, i32, i32, vp],
     "lt_colsum_f32": [vp, vp, i32, i32, i32, vp],
     "lt_gather_rows": [vp, i32, vp, vp, vp, i32, i32, vp],

@@ -494,18 +494,21 @@ struct LnbRow {
   float4 dvf[DYF32 ? NV : 1];
   uint2 dvh[DYF32 ? 1 : NV];
   float mu, rs, rsn;   // rsn: row scale of the fused next-branch output (loaded with the row, not at its use)
+  long rr;             // IDX: the row of dres / dx this row's gradient is added to (ridx[row]); otherwise the row itself
   bool ok;
 };
 
-template <bool DYF32, int NV>
+template <bool DYF32, int NV, bool IDX = false>
 __device__ __forceinline__ void lnb_load(LnbRow<DYF32, NV>& R, long row, int rows, int D, int lane, const float* __restrict__ x,
                                          const float* __restrict__ mean, const float* __restrict__ rstd, const void* __restrict__ dyv,
-                                         const float* __restrict__ dres, const float* __restrict__ rowscale_next) {
+                                         const float* __restrict__ dres, const float* __restrict__ rowscale_next,
+                                         const int64_t* __restrict__ ridx = nullptr) {
   // branch-free on purpose: rows / columns out of range load from a clamped (valid) address and are ignored by lnb_compute.
   // With one basic block per guarded load the waitcnt pass cannot count, and the wait for THIS row's operands became
   // vmcnt(0) -- i.e. it also waited for the next row's loads issued just before, which is the whole point of the pipeline.
   R.ok = row < rows;
   const long r = R.ok ? row : (long)rows - 1;
+  R.rr = IDX ? (long)ridx[r] : r;
   R.mu = mean[r];
   R.rs = rstd[r];
   R.rsn = rowscale_next ? rowscale_next[r] : 1.f;
@@ -514,7 +517,7 @@ __device__ __forceinline__ void lnb_load(LnbRow<DYF32, NV>& R, long row, int row
     const int c0 = (i * 64 + lane) * 4;
     const int c = c0 < D ? c0 : 0;
     R.xv[i] = *reinterpret_cast<const float4*>(x + r * D + c);
-    R.rv[i] = dres ? *reinterpret_cast<const float4*>(dres + r * D + c) : make_float4(0, 0, 0, 0);
+    R.rv[i] = dres ? *reinterpret_cast<const float4*>(dres + (IDX ? R.rr : r) * D + c) : make_float4(0, 0, 0, 0);
     if (DYF32) R.dvf[i] = *reinterpret_cast<const float4*>((const float*)dyv + r * D + c);
     else R.dvh[i] = *reinterpret_cast<const uint2*>((const bf16_t*)dyv + r * D + c);
   }
@@ -525,7 +528,7 @@ struct LnbNext {
   bf16_t* dnext; const float* rowscale; float scale;
 };
 
-template <bool DYF32, int NV>
+template <bool DYF32, int NV, bool IDX = false>
 __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int D, int lane, const float4 (&wv4)[NV], float4 (&aw)[NV],
                                             float4 (&ab)[NV], float* __restrict__ dx, const LnbNext& nx, const float4 (&gn4)[NV],
                                             float4 (&abn)[NV]) {
@@ -563,7 +566,7 @@ __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int 
                              R.rs * (gy.z - c1 - xh.z * c2), R.rs * (gy.w - c1 - xh.w * c2));
       const float4 rr = R.rv[i];
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-      *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      *reinterpret_cast<float4*>(dx + (IDX ? R.rr : row) * D + c) = o;
       if (nx.dnext) {
         const float m_r = nx.scale * R.rsn;
         const float4 dn = make_float4(o.x * m_r * gn4[i].x, o.y * m_r * gn4[i].y, o.z * m_r * gn4[i].z, o.w * m_r * gn4[i].w);
@@ -577,13 +580,17 @@ __device__ __forceinline__ void lnb_compute(LnbRow<DYF32, NV>& R, long row, int 
 // dx = dres + LN'(dy);  dw/db column sums.  Persistent waves (grid <= 512 blocks) stream rows with a two-deep software
 // pipeline: the loads of the NEXT row are issued before the current row is reduced and stored, so a wave always has a row
 // (7.5 KiB at D = 768) in flight -- without it every iteration paid one full HBM round trip (3.5 TB/s at 512 blocks).
-template <bool DYF32, int NV>
+// IDX: row r of (x, mean, rstd, dy) is row ridx[r] of the gradient stream: dx[ridx[r]] = dres[ridx[r]] + LN'(dy[r]) -- the LayerNorm backward
+// of a batch-subset stochastic-depth branch (block.py:118-141) added in place to the rows it belongs to, instead of a compact result
+// plus a scatter-add pass.  A separate instantiation: the default kernels' code is unchanged.
+template <bool DYF32, int NV, bool IDX = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const void* __restrict__ dyv, const float* __restrict__ dres,
                                                                 float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
                                                                 float* __restrict__ partial, int prows, int rows, int D, LnbNext nx,
-                                                                const float* __restrict__ gamma_next, float* __restrict__ dbias_next) {
+                                                                const float* __restrict__ gamma_next, float* __restrict__ dbias_next,
+                                                                const int64_t* __restrict__ ridx = nullptr) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float4 aw[NV], ab[NV], wv4[NV], gn4[NV], abn[NV];
@@ -598,14 +605,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   const long stride = (long)gridDim.x * 4;
   long row = (long)blockIdx.x * 4 + wv;
   LnbRow<DYF32, NV> A, B;
-  lnb_load<DYF32, NV>(A, row, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
+  lnb_load<DYF32, NV, IDX>(A, row, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale, ridx);
   while (row < rows) {
-    lnb_load<DYF32, NV>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
-    lnb_compute<DYF32, NV>(A, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
+    lnb_load<DYF32, NV, IDX>(B, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale, ridx);
+    lnb_compute<DYF32, NV, IDX>(A, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
     if (row >= rows) break;
-    lnb_load<DYF32, NV>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale);
-    lnb_compute<DYF32, NV>(B, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
+    lnb_load<DYF32, NV, IDX>(A, row + stride, rows, D, lane, x, mean, rstd, dyv, dres, nx.rowscale, ridx);
+    lnb_compute<DYF32, NV, IDX>(B, row, D, lane, wv4, aw, ab, dx, nx, gn4, abn);
     row += stride;
   }
 #pragma unroll
@@ -735,11 +742,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // ------------------------------------------------------------------------------------ LayerScale bwd
 // block = 32 column-chunks (4 columns each = 128 columns) x 8 row-lanes; grid.x over 128-column groups, grid.y row slabs.
 // dy(bf16) = dout*gamma; dgamma += sum_rows dout*y; dbias += sum_rows dout*gamma (bias of the Linear feeding LayerScale).
+// ridx (optional): row r of the branch reads its upstream gradient at row ridx[r] of `dout` (the rows of a batch-subset branch or of the last
+// block's loss rows inside the full gradient stream: no gathered copy in between); y / dy / rowscale stay indexed by r.
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ y,
                                                              const float* __restrict__ gamma, bf16_t* __restrict__ dy,
                                                              float* __restrict__ dgamma, float* __restrict__ dbias,
                                                              const float* __restrict__ rowscale, float scale, int rows, int D,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const int64_t* __restrict__ ridx) {
   __shared__ float4 red[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cl) * 4;
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
     const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     for (long r = (long)blockIdx.y * 8 + rl; r < rows; r += (long)gridDim.y * 8) {
       const float m_r = scale * (rowscale ? rowscale[r] : 1.f);
-      float4 g = *reinterpret_cast<const float4*>(dout + r * D + c);
+      float4 g = *reinterpret_cast<const float4*>(dout + (ridx ? (long)ridx[r] : r) * D + c);
       g.x *= m_r; g.y *= m_r; g.z *= m_r; g.w *= m_r;
       const float4 o = make_float4(g.x * gm.x, g.y * gm.y, g.z * gm.z, g.w * gm.w);
       *reinterpret_cast<uint2*>(dy + r * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
@@ -1098,10 +1107,27 @@ extern "C" int lt_layernorm_bwd(const float* x, const float* w, const float* mea
   return lt_layernorm_bwd_fused(x, w, mean, rstd, dy, dy_is_f32, dres, dx, dw, db, ws, ws_floats, nullptr, nullptr, nullptr, 1.f,
                                 nullptr, rows, D, stream);
 }
+static int layernorm_bwd_impl(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                              int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                              void* dnext_bf16, const float* gamma_next, const float* rowscale_next, float scale_next,
+                              float* dbias_next, int rows, int D, const int64_t* ridx, void* stream);
 extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
                                       int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
                                       void* dnext_bf16, const float* gamma_next, const float* rowscale_next, float scale_next,
                                       float* dbias_next, int rows, int D, void* stream) {
+  return layernorm_bwd_impl(x, w, mean, rstd, dy, dy_is_f32, dres, dx, dw, db, ws, ws_floats, dnext_bf16, gamma_next, rowscale_next, scale_next,
+                            dbias_next, rows, D, nullptr, stream);
+}
+// dx[ridx[r]] = dres[ridx[r]] + LN'(dy[r]) for r < rows (dres may be dx: each target row is read, then written, by one wave; ridx without repeats)
+extern "C" int lt_layernorm_bwd_rows(const float* x, const float* w, const float* mean, const float* rstd, const void* dy, int dy_is_f32,
+                                     const float* dres, float* dx, const int64_t* ridx, float* dw, float* db, int rows, int D, void* stream) {
+  LT_CHECK_ARG(ridx && D % 4 == 0, "lt_layernorm_bwd_rows: needs the row index and D %% 4 == 0");
+  return layernorm_bwd_impl(x, w, mean, rstd, dy, dy_is_f32, dres, dx, dw, db, nullptr, 0, nullptr, nullptr, nullptr, 1.f, nullptr, rows, D, ridx, stream);
+}
+static int layernorm_bwd_impl(const float* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                              int dy_is_f32, const float* dres, float* dx, float* dw, float* db, float* ws, int64_t ws_floats,
+                              void* dnext_bf16, const float* gamma_next, const float* rowscale_next, float scale_next,
+                              float* dbias_next, int rows, int D, const int64_t* ridx, void* stream) {
   LT_CHECK_ARG(x && w && mean && rstd && dy && dx && dw && db && D > 0 && D <= 2048, "lt_layernorm_bwd: bad arguments (D=%d)", D);
   LnbNext nx{(bf16_t*)dnext_bf16, rowscale_next, scale_next};
   if (rows == 0) return LT_OK;
@@ -1124,6 +1150,13 @@ extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const floa
     if (!ledger) prows = 2;
   }
 #define LT_LNB(F32, NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<F32, NV>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, prows, rows, D, nx, gamma_next, dbias_next)
+  if (ridx) {   // indexed rows: the bf16-dy, D <= 1024 instantiations the ViT step uses
+    LT_CHECK_ARG(vec && !dy_is_f32 && D <= 1024, "lt_layernorm_bwd_rows: vector path only (bf16 dy, D %% 4 == 0, D <= 1024, 16-byte aligned rows)");
+    const int nv = (D + 255) / 256;
+#define LT_LNBI(NV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<false, NV, true>), dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, partial, prows, rows, D, nx, gamma_next, dbias_next, ridx)
+    if (nv <= 2) LT_LNBI(2); else if (nv <= 3) LT_LNBI(3); else LT_LNBI(4);
+#undef LT_LNBI
+  } else
   if (vec) {
     const int nv = (D + 255) / 256;
     if (dy_is_f32) { if (nv <= 2) LT_LNB(true, 2); else if (nv <= 3) LT_LNB(true, 3); else if (nv <= 4) LT_LNB(true, 4); else LT_LNB(true, 8); }
@@ -1143,8 +1176,14 @@ extern "C" int lt_layernorm_bwd_fused(const float* x, const float* w, const floa
     hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST, x, w, mean, rstd, dy, dres, dx, dw, db, rows, D);
   LT_CHECK_LAUNCH("lt_layernorm_bwd");
 }
+extern "C" int lt_layerscale_bwd_rows(const float* dout, const int64_t* ridx, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
+                                      float* dbias, const float* rowscale, float scale, int rows, int D, void* stream);
 extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
                                  float* dbias, const float* rowscale, float scale, int rows, int D, void* stream) {
+  return lt_layerscale_bwd_rows(dout, nullptr, y_bf16, gamma, dy_bf16, dgamma, dbias, rowscale, scale, rows, D, stream);
+}
+extern "C" int lt_layerscale_bwd_rows(const float* dout, const int64_t* ridx, const void* y_bf16, const float* gamma, void* dy_bf16, float* dgamma,
+                                      float* dbias, const float* rowscale, float scale, int rows, int D, void* stream) {
   LT_CHECK_ARG(dout && dy_bf16 && (!y_bf16 || (gamma && dgamma)), "lt_layerscale_bwd: null pointer");
   if (rows == 0) return LT_OK;
   if (D % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dy_bf16 % 8 == 0 && (!y_bf16 || (uintptr_t)y_bf16 % 8 == 0) &&
@@ -1154,12 +1193,13 @@ extern "C" int lt_layerscale_bwd(const float* dout, const void* y_bf16, const fl
     dim3 grid(lt_cdiv(D, 128), min(lt_cdiv(rows, 8), defer ? 64 : 256));
     float* partial = defer ? lt_ledger::reserve((size_t)grid.y * 2 * D) : nullptr;
     hipLaunchKernelGGL(layerscale_bwd_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16, dgamma,
-                       dbias, rowscale, scale, rows, D, partial);
+                       dbias, rowscale, scale, rows, D, partial, ridx);
     if (partial) {
       if (gamma && y_bf16) lt_ledger::record(dgamma, partial, (int)grid.y, 2L * D, D);
       if (dbias) lt_ledger::record(dbias, partial + D, (int)grid.y, 2L * D, D);
     }
   } else {
+    LT_CHECK_ARG(!ridx, "lt_layerscale_bwd_rows: indexed rows need D %% 4 == 0 and 16-byte aligned rows");
     dim3 grid(lt_cdiv(D, 64), min(lt_cdiv(rows, 4), 256));
     hipLaunchKernelGGL(layerscale_bwd_scalar_kernel, grid, dim3(256), 0, ST, dout, (const bf16_t*)y_bf16, gamma, (bf16_t*)dy_bf16,
                        dgamma, dbias, rowscale, scale, rows, D);

@@ -227,9 +227,17 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, rows: int, D: int, y_bf16: Op
 def layernorm_bwd(x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dy: Tensor, dres: Optional[Tensor], dx: Tensor, dw: Tensor,
                   db: Tensor, rows: int, D: int, ws: Optional[Tensor] = None, dnext: Optional[Tensor] = None,
                   gamma_next: Optional[Tensor] = None, rowscale_next: Optional[Tensor] = None, scale_next: float = 1.0,
-                  dbias_next: Optional[Tensor] = None) -> None:
+                  dbias_next: Optional[Tensor] = None, ridx: Optional[Tensor] = None) -> None:
     """dx = dres + LN'(dy).  With `dnext` (bf16 [rows, D]) the kernel also emits the next branch's upstream gradient
-    dx * gamma_next * scale_next * rowscale_next and adds its column sums to `dbias_next`."""
+    dx * gamma_next * scale_next * rowscale_next and adds its column sums to `dbias_next`.
+    `ridx` (int64, device, no repeats): row r of (x, mean, rstd, dy) belongs to row ridx[r] of the gradient stream:
+    dx[ridx[r]] = dres[ridx[r]] + LN'(dy[r]) (lt_layernorm_bwd_rows; dres may be dx)."""
+    if ridx is not None:
+        assert dnext is None and ws is None
+        _chk(ridx, torch.int64, "layernorm_bwd.ridx")
+        check(_lib.load().lt_layernorm_bwd_rows(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx), _p(ridx),
+                                                _p(dw), _p(db), rows, D, _stream()), "lt_layernorm_bwd_rows")
+        return
     if dnext is not None:
         _chk(dnext, torch.bfloat16, "layernorm_bwd.dnext")
     check(_lib.load().lt_layernorm_bwd_fused(_p(x), _p(w), _p(mean), _p(rstd), _p(dy), int(dy.dtype == torch.float32), _p(dres), _p(dx),
@@ -254,9 +262,13 @@ def layerscale_dgamma_batched(w_bf16: Tensor, dw: Tensor, bias: Optional[Tensor]
 
 
 def layerscale_bwd(dout: Tensor, y: Optional[Tensor], gamma: Optional[Tensor], dy: Tensor, dgamma: Optional[Tensor], rows: int,
-                   D: int, dbias: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, scale: float = 1.0) -> None:
-    check(_lib.load().lt_layerscale_bwd(_p(dout), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), _p(rowscale), scale, rows, D,
-                                        _stream()), "lt_layerscale_bwd")
+                   D: int, dbias: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, scale: float = 1.0,
+                   ridx: Optional[Tensor] = None) -> None:
+    """`ridx` (int64, device): row r of the branch takes its upstream gradient from row ridx[r] of `dout` (lt_layerscale_bwd_rows)."""
+    if ridx is not None:
+        _chk(ridx, torch.int64, "layerscale_bwd.ridx")
+    check(_lib.load().lt_layerscale_bwd_rows(_p(dout), _p(ridx), _p(y), _p(gamma), _p(dy), _p(dgamma), _p(dbias), _p(rowscale), scale, rows, D,
+                                             _stream()), "lt_layerscale_bwd_rows")
 
 
 def colsum_bf16(x: Tensor, out: Tensor, rows: int, N: int) -> None:

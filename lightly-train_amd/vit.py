@@ -838,13 +838,16 @@ class ViTEngine:
                 run()
                 consumed[dy.data_ptr()] = side.record_event()
 
-        def branch_grad_in(br: Dict[str, Any], tagx: str) -> Tensor:
-            """Upstream gradient rows of a branch: all of dx, or the gathered subset rows."""
-            if br["mode"] != "subset":
-                return dx
-            dxs = ws.get(tag + tagx, (T, D), torch.float32)[:br["rows"]]
-            ops.gather_rows(dx, D, br["idx"], br["rows"], D, out_f32=dxs)
-            return dxs
+        def ln_rows(br: Dict[str, Any], norm: str, dy: Tensor, R: int) -> None:
+            """LayerNorm backward of a branch that ran on the rows br["idx"]: dx[idx] += LN'(dy), in place through the row index (the kernel's
+            indexed form serves D <= 1024; wider models take the compact result + scatter-add pass)."""
+            if D <= 1024 and D % 4 == 0:
+                ops.layernorm_bwd(br["x"], self.w(norm + ".weight"), br["mean"], br["rstd"], dy, dx, dx, self.gw(norm + ".weight"), self.gw(norm + ".bias"),
+                                  R, D, ridx=br["idx"])
+                return
+            lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R]
+            ops.layernorm_bwd(br["x"], self.w(norm + ".weight"), br["mean"], br["rstd"], dy, None, lng, self.gw(norm + ".weight"), self.gw(norm + ".bias"), R, D)
+            ops.scatter_add_rows(lng, br["idx"], dx, D, R, D)
 
         for i in (reversed(range(cfg.depth)) if resume is None else ()):
             main = torch.cuda.current_stream()   # (re-read per block: under a graph capture the chain runs on the capturing stream)
@@ -861,10 +864,10 @@ class ViTEngine:
             # ---- MLP branch: xo = xm + scale * g2 * (fc2(gelu(fc1(ln2(rows)))))
             R2 = m["rows"]
             dD = dDs[cur]
-            if not have:   # subset rows (gathered), or the producing LayerNorm backward ran on a subset
-                din = branch_grad_in(m, ".dxs")
+            if not have:   # subset rows (read through their row index: no gathered copy), or the producing LayerNorm backward ran on a subset
                 before_write(dD)
-                ops.layerscale_bwd(din, None, g2, dD, None, R2, D, dbias=self.gw(pre + fc2 + ".bias"), rowscale=m["rowscale"], scale=m["scale"])
+                ops.layerscale_bwd(dx, None, g2, dD, None, R2, D, dbias=self.gw(pre + fc2 + ".bias"), rowscale=m["rowscale"], scale=m["scale"],
+                                   ridx=m["idx"] if m["mode"] == "subset" else None)
             wgrad(dD, m["act"], pre + fc2 + ".weight", D, hid, R2)
             before_write(dH)
             if cfg.swiglu:
@@ -875,10 +878,8 @@ class ViTEngine:
             wgrad(dH, m["ln"], pre + fc1 + ".weight", hid1, D, R2, bias=pre + fc1 + ".bias")
             ops.gemm(dH, self.wb(pre + fc1 + ".weight"), dD2, M=R2, N=D, K=hid1, trans_b=True, epilogue=ops.EPI_BF16)
             if m["mode"] == "subset":
-                lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R2]
-                ops.layernorm_bwd(m["x"], self.w(pre + "norm2.weight"), m["mean"], m["rstd"], dD2, None, lng,
-                                  self.gw(pre + "norm2.weight"), self.gw(pre + "norm2.bias"), R2, D)
-                ops.scatter_add_rows(lng, m["idx"], dx, D, R2, D)   # dx += LN'(.) on the subset rows; identity path untouched
+                # dx[idx] += LN'(.) on the subset rows, in place through the row index (no compact result + scatter-add pass); identity path untouched
+                ln_rows(m, pre + "norm2", dD2, R2)
                 have = False
             else:
                 before_write(dDs[(cur + 1) % nring])
@@ -896,10 +897,8 @@ class ViTEngine:
                 # the projection ran on `R` rows (forward): its gradients come from those rows of dx; d(att) is zero elsewhere
                 assert not have
                 Rr, ridx = pr["R"], pr["idx"]
-                dxs = ws.get(tag + ".dxs", (T, D), torch.float32)[:Rr]
-                ops.gather_rows(dx, D, ridx, Rr, D, out_f32=dxs)
                 before_write(dD)
-                ops.layerscale_bwd(dxs, None, g1, dD, None, Rr, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=None, scale=1.0)
+                ops.layerscale_bwd(dx, None, g1, dD, None, Rr, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=None, scale=1.0, ridx=ridx)
                 wgrad(dD, pr["att_r"], pre + "attn.proj.weight", D, D, Rr)
                 dAr = ws.get(tag + ".dAr", (T, D), torch.bfloat16, pad_rows=64)
                 ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dAr, M=Rr, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
@@ -907,9 +906,9 @@ class ViTEngine:
                 dD2.index_copy_(0, ridx[:Rr], dAr[:Rr])
             else:
                 if not have:
-                    din = branch_grad_in(a, ".dxs")
                     before_write(dD)
-                    ops.layerscale_bwd(din, None, g1, dD, None, R1, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"])
+                    ops.layerscale_bwd(dx, None, g1, dD, None, R1, D, dbias=self.gw(pre + "attn.proj.bias"), rowscale=a["rowscale"], scale=a["scale"],
+                                       ridx=a["idx"] if a["mode"] == "subset" else None)
                 wgrad(dD, a["att"], pre + "attn.proj.weight", D, D, R1)
                 ops.gemm(dD, self.wb(pre + "attn.proj.weight"), dD2, M=R1, N=D, K=D, trans_b=True, epilogue=ops.EPI_BF16)
             before_write(dQ)
@@ -921,10 +920,7 @@ class ViTEngine:
             before_write(dX)
             ops.gemm(dQ, self.wb(pre + "attn.qkv.weight"), dX, M=R1, N=D, K=3 * D, trans_b=True, epilogue=ops.EPI_BF16)
             if a["mode"] == "subset":
-                lng = ws.get(tag + ".lng", (T, D), torch.float32)[:R1]
-                ops.layernorm_bwd(a["x"], self.w(pre + "norm1.weight"), a["mean"], a["rstd"], dX, None, lng,
-                                  self.gw(pre + "norm1.weight"), self.gw(pre + "norm1.bias"), R1, D)
-                ops.scatter_add_rows(lng, a["idx"], dx, D, R1, D)
+                ln_rows(a, pre + "norm1", dX, R1)
                 have = False
             else:
                 nxt = {}

@@ -547,6 +547,44 @@ def test_head_pieces():
     assert rel_err(dv, vr.grad) < 1e-5 and rel_err(dg, gr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("T,R,D", [(1000, 640, 768), (300, 37, 384), (513, 513, 1024), (70, 1, 64)])
+def test_indexed_row_forms_of_the_subset_branch_backward(T, R, D):
+    """Round 5 (batch-subset stochastic depth, block.py:118-141, and the last block's loss rows): lt_layerscale_bwd_rows reads the upstream
+    gradient of the R subset rows through their row index instead of a gathered copy, lt_layernorm_bwd_rows adds the LayerNorm backward
+    of those rows in place to the rows of the full gradient stream instead of a compact result + scatter-add pass.  Both against the
+    two-kernel forms they replace (bitwise for the LayerScale form; the LayerNorm form to fp32 round-off: one add order), rows outside
+    the subset untouched."""
+    o = ops()
+    g = torch.Generator().manual_seed(T + R)
+    idx = torch.randperm(T, generator=g)[:R].sort().values.to(torch.int64).to(DEV)
+    dx = torch.randn(T, D, generator=g).to(DEV)
+    gamma, rowscale = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.rand(R, generator=g) + 0.5).to(DEV)
+    # LayerScale backward: gathered copy vs index
+    dxs = torch.empty(R, D, device=DEV)
+    o.gather_rows(dx, D, idx, R, D, out_f32=dxs)
+    dy0, dy1 = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16), torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    db0, db1 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    o.layerscale_bwd(dxs, None, gamma, dy0, None, R, D, dbias=db0, rowscale=rowscale, scale=1.25)
+    o.layerscale_bwd(dx, None, gamma, dy1, None, R, D, dbias=db1, rowscale=rowscale, scale=1.25, ridx=idx)
+    assert torch.equal(dy0, dy1) and rel_err(db1, db0) < 1e-5
+    # LayerNorm backward: compact result + scatter-add vs in place through the index
+    x = torch.randn(R, D, generator=g).to(DEV)
+    w = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    mean, rstd = x.mean(-1), (x.var(-1, unbiased=False) + 1e-6).rsqrt()
+    dyl = bf(torch.randn(R, D, generator=g)).to(DEV)
+    lng = torch.empty(R, D, device=DEV)
+    dw0, dbn0, dw1, dbn1 = (torch.zeros(D, device=DEV) for _ in range(4))
+    ref = dx.clone()
+    o.layernorm_bwd(x, w, mean, rstd, dyl, None, lng, dw0, dbn0, R, D)
+    o.scatter_add_rows(lng, idx, ref, D, R, D)
+    got = dx.clone()
+    o.layernorm_bwd(x, w, mean, rstd, dyl, got, got, dw1, dbn1, R, D, ridx=idx)
+    assert rel_err(got, ref) < 1e-6 and rel_err(dw1, dw0) < 1e-5 and rel_err(dbn1, dbn0) < 1e-5
+    keep = torch.ones(T, dtype=torch.bool, device=DEV)
+    keep[idx] = False
+    assert torch.equal(got[keep], dx[keep])
+
+
 @pytest.mark.parametrize("M,K,plain", [(300, 64, False), (1000, 768, False), (129, 3072, False), (128, 768, True), (2048 + 17, 768, False), (513, 1024, True)])
 def test_row_owning_residual_gemm_with_the_fused_layernorm(M, K, plain):
     """lt_gemm_resid_ln768 (csrc/gemm_rows.hip, round 5: a workgroup owns 128 whole 768-wide rows; LayerScale + residual epilogue and the NEXT

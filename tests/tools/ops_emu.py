@@ -134,7 +134,14 @@ def emulate(ops):
             rstd.view(-1)[:rows] = r
 
     def layernorm_bwd(x, w, mean, rstd, dy, dres, dx, dw, db, rows, D, ws=None, dnext=None, gamma_next=None, rowscale_next=None,
-                      scale_next=1.0, dbias_next=None):
+                      scale_next=1.0, dbias_next=None, ridx=None):
+        if ridx is not None:      # dx[ridx[r]] = dres[ridx[r]] + LN'(dy[r])
+            ii = ridx[:rows].long()
+            tmp = torch.zeros(rows, D)
+            layernorm_bwd(x, w, mean, rstd, dy, None, tmp, dw, db, rows, D)
+            base = dres.reshape(-1, D)[ii] if dres is not None else 0.0
+            dx.reshape(-1, D)[ii] = base + tmp
+            return
         xr = x.reshape(-1, D)[:rows]
         d = dy.reshape(-1, D)[:rows].float()
         xh = (xr - mean.view(-1)[:rows, None]) * rstd.view(-1)[:rows, None]
@@ -153,8 +160,8 @@ def emulate(ops):
             if dbias_next is not None:
                 dbias_next += dn.sum(0)
 
-    def layerscale_bwd(dout, y, gamma, dy, dgamma, rows, D, dbias=None, rowscale=None, scale=1.0):
-        d = dout.reshape(-1, D)[:rows]
+    def layerscale_bwd(dout, y, gamma, dy, dgamma, rows, D, dbias=None, rowscale=None, scale=1.0, ridx=None):
+        d = dout.reshape(-1, D)[:rows] if ridx is None else dout.reshape(-1, D)[ridx[:rows].long()]
         m = scale * (rowscale[:rows, None] if rowscale is not None else 1.0)
         if gamma is not None and y is not None:
             dgamma += (d * y.reshape(-1, D)[:rows].float() * m).sum(0)
