@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c80-200
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --drop-path 0.2 2>/dev/null | tail -1 | cut -c80-200
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c80-200
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --drop-path 0.2 2>/dev/null | tail -1 | cut -c80-200
+python tools/host_overhead.py 2>&1 | grep "host-only"
+LT_GRAPH_FWD=1 python tools/host_overhead.py 2>&1 | grep "host-only"
+LT_GRAPH_FWD=1 LT_GRAPH_BWD=1 python tools/host_overhead.py 2>&1 | grep "host-only"
