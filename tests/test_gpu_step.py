@@ -959,7 +959,10 @@ def test_mid_size_loss_trajectory_matches_the_reference(koleo):
     `python -m oracle.make_trajectory --config mid`; the initial state is rebuilt from the fixture's seed).  At LayerScale 1.0 the cls tokens
     of a batch are well separated and the KoLeo term is NOT chaotic (the fixture: a 1e-7 perturbation of the reference's fp32 run moves its
     loss by 1.5e-7), so both KoLeo settings are held to the north-star's 1e-3 on the total loss; the reference's own bf16-autocast run is
-    the yardstick column (5.4e-4 without, 2.0e-3 with KoLeo)."""
+    the yardstick column (5.4e-4 without, 2.0e-3 with KoLeo).  How firm the KoLeo-on figure is (profiles/r05_trajectory_sensitivity.md): 9.05e-4
+    with the shipped kernels; exchanging ONE LayerNorm-backward kernel of the last block for a form that differs by one ulp in 4 % of its
+    elements gave 1.13e-3 and 1.52e-3 -- bf16 operand rounding is a far larger perturbation than the fixture's 1e-7, and with KoLeo the worst
+    step of 100 lands anywhere between 0.9e-3 and the reference's own 2.0e-3.  The KoLeo-off bound (4.0e-5) does not move."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
@@ -985,7 +988,9 @@ def test_vits_width_loss_trajectory_matches_the_reference(koleo):
     split-K weight gradients and the wide-row register-resident softmax / cross-entropy kernels all take part -- against the trajectory the
     REFERENCE's own class wrote in fp32 (tests/golden/trajectory_vits.pt, `python -m oracle.make_trajectory --config vits`; initial state
     rebuilt from the fixture's seed).  The fixture's own columns: the reference's bf16-autocast run deviates from its fp32 run by 1.3e-3
-    (both KoLeo settings), a 1e-7 perturbation by 2.6e-7 (well conditioned).  Total loss held to the north-star's 1e-3 at every step."""
+    (both KoLeo settings), a 1e-7 perturbation by 2.6e-7 (well conditioned).  Total loss held to the north-star's 1e-3 at every step
+    (1.0e-5 without KoLeo; with it 9.5e-4 for the shipped kernels and 1.08e-3 / 1.09e-3 when one LayerNorm-backward kernel differs by one ulp,
+    profiles/r05_trajectory_sensitivity.md: the KoLeo-on bound holds by the draw of the rounding, inside the reference's own bf16 band)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory
