@@ -1,8 +1,4 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05y
-mkdir -p $O
-cd $R
-timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log | cut -c1-200
-python bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-200
-python bench.py --steps 20 --warmup 5 --drop-path 0.2 > $O/bench_dp02.log 2>&1; tail -1 $O/bench_dp02.log | cut -c1-200
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05z
+python tools/ab_schedule.py five --env LT_HACK_EARLY_LOCAL=0,1 --steps 20 2>&1 | grep -v amdgpu | tee gpurun_out/r05z/hack_early_local.log | tail -6
