@@ -587,7 +587,7 @@ class ViTEngine:
                 xm = x
             elif e2 is not None and e2[0] == "rows" and a["rowscale"] is None and os.environ.get("LT_SPARSE_LAST_PROJ", "1") != "0":
                 # last block, output read at `ridx` only: the attention projection + LayerScale + residual are row-local too -- R rows of
-                # them, written into an otherwise ZERO block-middle tensor (finite everywhere: the final LayerNorm still runs densely)
+                # them, written into a block-middle tensor that is FINITE everywhere else (the final LayerNorm still runs densely)
                 ridx, Rr = e2[1]
                 att_r = ws.get(s + "att_r", (T, D), torch.bfloat16, pad_rows=64)
                 words = att.element_size() * D // 4    # a row as 32-bit words (bf16: D / 2): the row gather moves words, whatever they hold
@@ -597,8 +597,10 @@ class ViTEngine:
                 xm_r = ws.get(tag + ".xm_r", (T, D), torch.float32)
                 ops.gemm(att_r, self.wb(pre + "attn.proj.weight"), xm_r, M=Rr, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
                          gamma=g1, resid=x_r, out2=y1)
-                xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
-                xm.zero_()
+                # (finite, not zero, is what the other rows have to be: the buffer is zero-filled when it is allocated and only ever holds block
+                # outputs after that -- a per-step fill of it was 0.09 ms of HBM writes per pass, and under this schedule every kernel's time
+                # shows in the step one for one, profiles/r05_sensitivity.md; rows outside `ridx` give exact zeros in backward either way)
+                xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32, zero=True)
                 xm.index_copy_(0, ridx[:Rr], xm_r[:Rr])
                 a["proj_rows"] = dict(idx=ridx, R=Rr, att_r=att_r)
             else:
