@@ -1,13 +1,11 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05aa
+O=$R/gpurun_out/r05ab
 mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/ks_single -o ks -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 1 --single-stream > $O/bench_single.log 2>&1
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_step.py -q > $O/t_step.log 2>&1; tail -3 $O/t_step.log | cut -c1-200
-python - <<'PY'
-import json
-for n in ("mid_koleo0.1", "vits_koleo0.1", "mid_koleo0.0", "vits_koleo0.0"):
-    d = json.load(open(f"gpurun_out/trajectory_{n}.json")); print(n, d["hip_vs_reference_fp32"]["loss"])
-PY
-python tools/ab_schedule.py five --env LT_DXN_FULL_ZERO=1,0 --steps 20 2>&1 | grep -v amdgpu | tail -2
-python bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-200
+python tools/rocprof_summary.py $(find $O/ks_single -name "*.db" | head -1) 90 > $O/kernel_stats_single_90.md 2>&1
+rm -rf $O/ks_single
+tail -60 $O/kernel_stats_single_90.md | cut -c1-150
