@@ -1055,6 +1055,11 @@ class DINOv2:
             if prev is None or prev[0] != buf.data_ptr() or prev[1] != tuple(buf.shape) or os.environ.get("LT_DXN_FULL_ZERO", "0") == "1":
                 buf.zero_()
             else:
+                if prev[2].is_cuda:
+                    # the index tensor was allocated on the main stream and is released below, while this fill may still be queued on the
+                    # side stream: tell the caching allocator, or the main stream's next allocation overwrites the indices under the kernel
+                    # (seen as a GPU fault with two ranks on one device, tests/test_gpu_ddp.py)
+                    prev[2].record_stream(torch.cuda.current_stream())
                 buf.index_fill_(0, prev[2], 0.0)
             self._dxn_rows[key] = (buf.data_ptr(), tuple(buf.shape), rows_now)
 
