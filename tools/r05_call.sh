@@ -1,7 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05af
+O=$R/gpurun_out/r05ag
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; grep -a "passed\|failed" $O/gpu_tests.log | tail -2
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-200
+LT_AMD_LIB=$R/lightly-train_amd/lib/liblt_amd_epipre.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "gemm" > $O/t_gemm.log 2>&1; tail -1 $O/t_gemm.log | cut -c1-200
+for lib in liblt_amd_epinopre.so liblt_amd_epipre.so liblt_amd_epinopre.so liblt_amd_epipre.so; do LT_AMD_LIB=$R/lightly-train_amd/lib/$lib python tools/gemm_resid_probe.py 2>&1 | grep -v amdgpu; done | tee $O/resid_probe.log
+LT_AMD_LIB=$R/lightly-train_amd/lib/liblt_amd_epinopre.so python tools/ab_lib.py lightly-train_amd/lib/liblt_amd_epipre.so --steps 16 > $O/ab_epipre.log 2>&1; tail -3 $O/ab_epipre.log | cut -c1-200
