@@ -67,7 +67,8 @@ typedef struct lt_gemm_desc {
   float alpha;
   int split_k;                    /* >1 only honoured for LT_EPI_F32_ACCUM */
   int force_kernel;               /* 0 = auto, 1 = 128x128 register-staged kernel, 2 = 256x256 LDS-DMA kernel with the 2-stage K-loop,
-                                     8 = 256x256 LDS-DMA kernel with the four-phase ping-pong K-loop (the default for large shapes) */
+                                     8 = 256x256 LDS-DMA kernel with the four-phase ping-pong K-loop, 11 = the same tile and phases with the static-address
+                                     K-loop (round 6; the default for large shapes with K % 64 == 0; falls back to 8 where it is not eligible) */
   const float* rowscale;          /* [M] per-row multiplier of the LayerScale branch (LT_EPI_RESID; per-sample DropPath) or NULL */
   float branch_scale;             /* scalar multiplier of the branch (LT_EPI_RESID; batch-subset stochastic depth b/s); 0 = 1 */
   void* workspace; size_t workspace_bytes; /* optional f32 scratch for deterministic slab split-K (LT_EPI_F32_ACCUM) */

@@ -857,6 +857,328 @@ __global__ __launch_bounds__(NT2) void gemm256q_kernel(const GemmArgs g) {
 #endif
 }
 
+
+// ---- static-address K-loop ("e" kernel, round 6) ---------------------------------------------------------------------------
+// Same tile, wave layout, phases, hazards and epilogue as gemm256q_kernel; what changes is what a wave has to EXECUTE in its load
+// segments.  In the q kernel every fragment read carried a v_add for its address and every LDS-DMA piece five VALU instructions
+// (64-bit source address, readfirstlane of the destination) -- ~60 VALU per K-tile issued while the SIMD's other wave runs its MFMA
+// segment at raised priority, which is where VALU is dearest (MI355X_MICROARCH.md, "Two waves per SIMD" item 2: a prioritised partner
+// makes 16 VALU in a load segment cost 300-400 cycles).  Here the load segments contain NO vector ALU work:
+//   * the K-loop is unrolled over the two LDS stages, so every LDS address is a loop-invariant per-lane base (<= 8 VGPRs, computed
+//     once) plus an immediate `offset:` field; the half-tile buffers are laid out [half][stage] (16 KiB each) so that both stages of
+//     the half a wave reads lie inside the 16-bit immediate range of one base;
+//   * operands arrive by `buffer_load_dwordx4 ... offen lds` through a wave-uniform descriptor: the per-lane source offsets
+//     (swizzle, row clamps) are loop-invariant VGPRs, the K advance and the piece index live in the scalar offset, the LDS
+//     destination in M0 comes from scalar adds.
+// Restrictions (dispatcher falls back to the q kernel): K % 64 == 0 (no partial K-tile variant), operand panels addressable with
+// 31-bit byte offsets from the workgroup's base.
+template <bool TR, int OFF>
+__device__ __forceinline__ bf16x8 lds_frag(unsigned a) {
+  if constexpr (!TR) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+  } else {
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 1024));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+  }
+}
+// the four k16 steps of one 32-row block RB of the half-tile at byte offset BUF0 from the wave's base registers
+//   K-contiguous image: base[ks] differs per step (the XOR swizzle is not additive), immediate = BUF0 + RB * 4096
+//   transposed image  : base[RB & 1] (the k-row rotation depends on the block's parity), immediate = BUF0 + ks * 4096 + RB * 256
+template <bool TR, int BUF0, int RB>
+__device__ __forceinline__ void lds_frag4(bf16x8 (&f)[4], const unsigned (&base)[4]) {
+  if constexpr (!TR) {
+    f[0] = lds_frag<false, BUF0 + RB * 4096>(base[0]);
+    f[1] = lds_frag<false, BUF0 + RB * 4096>(base[1]);
+    f[2] = lds_frag<false, BUF0 + RB * 4096>(base[2]);
+    f[3] = lds_frag<false, BUF0 + RB * 4096>(base[3]);
+  } else {
+    f[0] = lds_frag<true, BUF0 + 0 * 4096 + RB * 256>(base[RB & 1]);
+    f[1] = lds_frag<true, BUF0 + 1 * 4096 + RB * 256>(base[RB & 1]);
+    f[2] = lds_frag<true, BUF0 + 2 * 4096 + RB * 256>(base[RB & 1]);
+    f[3] = lds_frag<true, BUF0 + 3 * 4096 + RB * 256>(base[RB & 1]);
+  }
+}
+
+// loop-invariant source side of one operand's LDS-DMA
+struct DmaSrcE {
+  __amdgpu_buffer_rsrc_t srd;   // base = the workgroup's first row (column) of the operand at the slice's first k
+  unsigned voff[4];             // per-lane byte offsets: K-contiguous [half * 2 + piece]; transposed [half] (pieces differ by `jstep`)
+  int wave_off;                 // transposed: byte offset of this wave's first k-row group (w * 8 rows)
+  int tile_step;                // bytes per K-tile
+  int jstep;                    // transposed: bytes between the two pieces of a wave (4 k-rows)
+};
+template <bool TR>
+__device__ __forceinline__ DmaSrcE make_dma_src(const bf16_t* P, int ld, int rows, int row0, int kbeg, int w, int l) {
+  DmaSrcE d;
+  if (!TR) {
+    const bf16_t* base = P + (size_t)row0 * ld + kbeg;
+    d.srd = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = hh * 128 + (w * 2 + j) * 8 + (l >> 3), slot = l & 7;
+        const int c = slot ^ ((row >> 1) & 7);
+        const int gr = min(row0 + row, rows - 1) - row0;
+        d.voff[hh * 2 + j] = (unsigned)gr * (unsigned)ld * 2u + (unsigned)c * 16u;
+      }
+    d.wave_off = 0; d.tile_step = BK * 2; d.jstep = 0;
+  } else {
+    const bf16_t* base = P + (size_t)kbeg * ld;
+    d.srd = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    const int b = l >> 3, slot = l & 7;
+    const int kr = ((slot >> 1) - b) & 3;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      int col = row0 + hh * 128 + b * 16 + (slot & 1) * 8;
+      if (col >= rows) col = 0;
+      d.voff[hh] = (unsigned)kr * (unsigned)ld * 2u + (unsigned)col * 2u;
+      d.voff[2 + hh] = 0;
+    }
+    d.wave_off = w * 8 * ld * 2; d.tile_step = BK * ld * 2; d.jstep = 4 * ld * 2;
+  }
+  return d;
+}
+
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
+__global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HB = 128 * 128;            // one half-tile buffer; buffer index = half * 2 + stage (halves: A0 A1 B0 B1)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id, slice;
+  {
+    const int W = ntiles * (int)gridDim.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const int q = W >> 3, r = W & 7, xcd = L & 7, j = L >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    slice = w / ntiles; id = w - slice * ntiles;
+  }
+  int tm, tn;
+  if (g.band > 0 && g.band < g.tiles_n) {
+    const int per_band = g.tiles_m * g.band, full_b = g.tiles_n / g.band;
+    if (id < full_b * per_band) { const int bnd = id / per_band, r = id - bnd * per_band; tm = r / g.band; tn = bnd * g.band + (r - tm * g.band); }
+    else { const int rem_b = g.tiles_n - full_b * g.band, r = id - full_b * per_band; tm = r / rem_b; tn = full_b * g.band + (r - tm * rem_b); }
+  } else { tm = id / g.tiles_n; tn = id % g.tiles_n; }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int kbeg = slice * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg) / BK;
+  const int l = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
+  const int wm = wave >> 2, wn = wave & 3;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- loop-invariant addresses
+  DmaSrcE sa = make_dma_src<TA>(g.A, g.lda, g.M, m0, kbeg, wave, l);
+  DmaSrcE sb = make_dma_src<TB>(g.B, g.ldb, g.N, n0, kbeg, wave, l);
+  unsigned ab[4], bb[4];
+  {
+    const unsigned a_half = (unsigned)(wm * 2) * HB, b_half = (unsigned)((2 + (wn >> 1)) * 2) * HB;
+    const int bcol = (wn & 1) * 2;
+    if (!TA) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ab[ks] = a_half + (l & 31) * 128 + ((((ks * 2 + (l >> 5)) ^ (((l & 31) >> 1) & 7))) << 4);
+    } else {
+      const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ab[p] = a_half + kh * 2048 + cb * 128 + ((((i >> 2) + cb + 2 * p) & 3) << 5) + ((i & 3) << 3);
+      ab[2] = ab[3] = 0;
+    }
+    if (!TB) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bb[ks] = b_half + bcol * 4096 + (l & 31) * 128 + ((((ks * 2 + (l >> 5)) ^ (((l & 31) >> 1) & 7))) << 4);
+    } else {
+      const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) bb[p] = b_half + bcol * 256 + kh * 2048 + cb * 128 + ((((i >> 2) + cb + 2 * p) & 3) << 5) + ((i & 3) << 3);
+      bb[2] = bb[3] = 0;
+    }
+    // opaque to the optimiser from here on: no re-derivation of these inside the loop
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(ab[k])); asm volatile("" : "+v"(bb[k])); asm volatile("" : "+v"(sa.voff[k])); asm volatile("" : "+v"(sb.voff[k])); }
+  }
+  const int lds_w = wave * 2048;   // this wave's two 1-KiB pieces inside every half-tile buffer
+
+  // one half-tile (H: 0 A rows 0-127, 1 A rows 128-255, 2 B cols 0-127, 3 B cols 128-255) of K-tile TILE into stage ST
+#define LT_E_DMA(TILE, ST, H)                                                                                             \
+  do {                                                                                                                    \
+    const DmaSrcE& s_ = (H) < 2 ? sa : sb;                                                                                \
+    constexpr bool TR_ = (H) < 2 ? TA : TB;                                                                               \
+    const int so_ = (TILE) * s_.tile_step + s_.wave_off;                                                                  \
+    char* d_ = smem + ((H) * 2 + (ST)) * HB + lds_w;                                                                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)d_, 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2], so_, 0, 0);                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)(d_ + 1024), 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2 + 1], so_ + s_.jstep, 0, 0); \
+  } while (0)
+#define LT_E_SYNC_IN()                          \
+  do {                                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);         \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_setprio(1);              \
+  } while (0)
+#define LT_E_SYNC_OUT()                         \
+  do {                                          \
+    __builtin_amdgcn_s_setprio(0);              \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+  if (nk > 0) { LT_E_DMA(0, 0, 0); LT_E_DMA(0, 0, 1); LT_E_DMA(0, 0, 2); LT_E_DMA(0, 0, 3); }
+  if (nk > 1) { LT_E_DMA(1, 1, 2); LT_E_DMA(1, 1, 3); LT_E_DMA(1, 1, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6): tile 0 landed
+  else __builtin_amdgcn_s_waitcnt(0xF70);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of each SIMD by one barrier
+
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cs_period = 4 * g.tiles_n, cs_mine = tn * 4 + wn;
+  int cs_cnt = 0;
+#define LT_E_CS_ADD(I0)                                                                                           \
+  do {                                                                                                            \
+    if (CS && cs_cnt == cs_mine) {                                                                                \
+      const bf16x2_t one_ = {(__bf16)1.0f, (__bf16)1.0f};                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                            \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                       \
+        const bf16x8 f_ = fa[i_][ks_];                                                                            \
+        float c_ = csum[(I0) + i_];                                                                               \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 0, 1), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 2, 3), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 4, 5), one_, c_, false);             \
+        c_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f_, f_, 6, 7), one_, c_, false);             \
+        csum[(I0) + i_] = c_;                                                                                     \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  // one K-tile in stage ST (a literal): the q kernel's four phases
+#define LT_E_TILE(T, ST)                                                                                                   \
+  do {                                                                                                                     \
+    /* P1 */                                                                                                               \
+    lds_frag4<TB, (ST) * HB, 0>(fb0, bb);                                                                                  \
+    lds_frag4<TA, (ST) * HB, 0>(fa[0], ab);                                                                                \
+    lds_frag4<TA, (ST) * HB, 1>(fa[1], ab);                                                                                \
+    if ((T) + 1 < nk) LT_E_DMA((T) + 1, (ST) ^ 1, 1);                                                                      \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[i][0], 0, 0, 0); \
+    LT_E_SYNC_OUT();                                                                                                       \
+    /* P2 */                                                                                                               \
+    lds_frag4<TB, (ST) * HB, 1>(fb1, bb);                                                                                  \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[i][1], 0, 0, 0); \
+    LT_E_CS_ADD(0);                                                                                                        \
+    LT_E_SYNC_OUT();                                                                                                       \
+    /* P3 */                                                                                                               \
+    lds_frag4<TA, (ST) * HB, 2>(fa[0], ab);                                                                                \
+    lds_frag4<TA, (ST) * HB, 3>(fa[1], ab);                                                                                \
+    if ((T) + 2 < nk) LT_E_DMA((T) + 2, (ST), 2);                                                                          \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[2 + i][1], 0, 0, 0); \
+    LT_E_SYNC_OUT();                                                                                                       \
+    /* P4 */                                                                                                               \
+    if ((T) + 2 < nk) { LT_E_DMA((T) + 2, (ST), 3); LT_E_DMA((T) + 2, (ST), 0); __builtin_amdgcn_s_waitcnt(0xF76); }       \
+    else __builtin_amdgcn_s_waitcnt(0xF70);                                                                                \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[2 + i][0], 0, 0, 0); \
+    LT_E_CS_ADD(2);                                                                                                        \
+    if (CS) cs_cnt = (cs_cnt + 1 == cs_period) ? 0 : cs_cnt + 1;                                                           \
+    LT_E_SYNC_OUT();                                                                                                       \
+  } while (0)
+
+  // two K-tiles per iteration (one per LDS stage) in ONE straight-line body with one back-edge; an odd last tile is a peeled copy.  (A
+  // `break` between the two copies made the register allocator carry the 128 accumulators through copies and scratch.)
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    LT_E_TILE(t, 0);
+    LT_E_TILE(t + 1, 1);
+  }
+  if (t < nk) LT_E_TILE(t, 0);
+#undef LT_E_TILE
+#undef LT_E_CS_ADD
+#undef LT_E_DMA
+#undef LT_E_SYNC_IN
+#undef LT_E_SYNC_OUT
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+  __syncthreads();
+  if (CS) {
+    float* dst = g.cs + (size_t)((slice * g.tiles_n + tn) * 4 + wn) * g.M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+      const int row = m0 + wm * 128 + i * 32 + (l & 31);
+      if (l < 32 && row < g.M) dst[row] = v;
+    }
+  }
+  GemmArgs ge = g;
+  if (SLAB) {
+    ge.C = (float*)g.C2 + (size_t)slice * g.M * g.N;
+    ge.ldc = g.N; ge.alpha = 1.f; ge.bias = nullptr;
+  }
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[h * 2 + ii][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (SLAB) emit_subtile<EPI_F32>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, false);
+    else emit_subtile<EPI>(ge, wl, m0 + wm * 128 + h * 64, n0 + wn * 64, l, gridDim.y > 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
+int launch_e_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256e_kernel<TA, TB, EPI, SLAB, CS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm256e_kernel<TA, TB, EPI, SLAB, CS>), grid, dim3(NT2), LDS_BYTES, st, g);
+  return LT_OK;
+}
+template <bool TA, bool TB>
+int launch_e(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_e_one<TA, TB, EPI_BF16, false>(g, grid, st);
+    case EPI_BF16_GELU: return launch_e_one<TA, TB, EPI_BF16_GELU, false>(g, grid, st);
+    case EPI_RESID: return launch_e_one<TA, TB, EPI_RESID, false>(g, grid, st);
+    case EPI_F32: return launch_e_one<TA, TB, EPI_F32, false>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_e_one<TA, TB, EPI_BF16_GELUGRAD, false>(g, grid, st);
+    case EPI_F32_ACCUM:
+      if (TA && slab && g.cs) return launch_e_one<TA, TB, EPI_F32_ACCUM, true, TA>(g, grid, st);
+      return slab ? launch_e_one<TA, TB, EPI_F32_ACCUM, true>(g, grid, st) : launch_e_one<TA, TB, EPI_F32_ACCUM, false>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: unknown epilogue %d", epi); return LT_ERR_INVALID;
+  }
+}
+
 #ifdef LT_GEMM_TIMING
 extern "C" int lt_debug_gemm_timing(void* host_dst, int64_t n_u64, int clear) {
   hipDeviceSynchronize();
@@ -1071,7 +1393,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   const int wgrad_min_k = env_wk ? atoi(env_wk) : 4096;   // 8192 -> 4096: ResNet-50 distillation step 43.4 -> 42.5 ms
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= (ktail ? 256 : 128) &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= wgrad_min_k && d->M >= wgrad_min_m));
-  if (d->force_kernel == 2 || d->force_kernel == 8) {
+  if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 11) {
     LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
@@ -1127,7 +1449,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
     static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
-    const bool q_kernel = bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || use_q);
+    const bool q_kernel = bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || d->force_kernel == 11 || use_q);
     if (cs_pending && q_kernel && slab && d->trans_a && d->trans_b) {
       // LT_GEMM_CS=0 (read per call: tools/ab_step.py): keep the separate column-sum pass
       const char* env_cs = getenv("LT_GEMM_CS");
@@ -1141,6 +1463,18 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     }
     rc = cs_standalone();
     if (rc != LT_OK) return rc;
+    // static-address K-loop (round 6): the same tiles and phases with no vector ALU work in the load segments.  LT_GEMM_E=0 (read per call:
+    // tools/ab_step.py) / force_kernel = 8 keep the q kernel; force_kernel = 11 insists.  Byte offsets from the workgroup's operand base must
+    // fit 31 bits: a 256-row panel of a K-contiguous operand, a k-slice of a transposed one.
+    const char* env_e = getenv("LT_GEMM_E");
+    const bool e_fits = (d->trans_a ? (size_t)g.k_per_split * d->lda : (size_t)256 * d->lda + d->K) * 2 < 0x7fffffffull &&
+                        (d->trans_b ? (size_t)g.k_per_split * d->ldb : (size_t)256 * d->ldb + d->K) * 2 < 0x7fffffffull;
+    const bool e_kernel = q_kernel && d->K % BK == 0 && e_fits && d->force_kernel != 8 && (d->force_kernel == 11 || !env_e || atoi(env_e) != 0);
+    if (e_kernel) {
+      if (!d->trans_a && !d->trans_b) rc = g256::launch_e<false, false>(g, d->epilogue, slab, grid2, st);
+      else if (!d->trans_a) rc = g256::launch_e<false, true>(g, d->epilogue, slab, grid2, st);
+      else rc = g256::launch_e<true, true>(g, d->epilogue, slab, grid2, st);
+    } else
     if (q_kernel) {
       if (!d->trans_a && !d->trans_b) rc = g256::launch_q<false, false>(g, d->epilogue, slab, grid2, st);
       else if (!d->trans_a) rc = g256::launch_q<false, true>(g, d->epilogue, slab, grid2, st);

@@ -50,7 +50,15 @@ MID = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=192, depth=
 VITS = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=384, depth=6, num_heads=6, mlp_ratio=4.0, init_values=1.0),
             method_kwargs=dict(output_dim=16384, hidden_dim=2048, dino_bottleneck_dim=256),
             cfg=dict(patch_size=16, num_heads=6, depth=6), b=8, g_size=112, l_size=48, n_local=4, init_seed=2025, init_values=1.0)
-CONFIGS = {"d64": CFG, "mid": MID, "vits": VITS}
+# `--config vitb` (round 6): the HEADLINE model -- ViT-B/16: D = 768, 12 heads of 64, 12 blocks, K = 65 536 prototypes, head 2048 / 256, 2 x 224^2 +
+# 8 x 96^2 crops (the benchmark's crop geometry with the local crops at the multiple of the patch size the reference class accepts), batch 8:
+# 3152 global / 2304 local token rows per pass.  Seeded state like `mid` / `vits`, LayerScale 1.0 for the same reason.  Six runs of 100 steps are
+# hours of CPU in the build container, so every (KoLeo weight, mode) run is its own restartable piece (`--piece koleo mode`, cached under
+# tests/golden/.trajectory_vitb_parts/) and `--config vitb` without `--piece` assembles the fixture from the pieces that exist.
+VITB = dict(arch="DinoVisionTransformer", model_kwargs=dict(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, init_values=1.0),
+            method_kwargs=dict(output_dim=65536, hidden_dim=2048, dino_bottleneck_dim=256),
+            cfg=dict(patch_size=16, num_heads=12, depth=12), b=8, g_size=224, l_size=96, n_local=8, init_seed=2026, init_values=1.0)
+CONFIGS = {"d64": CFG, "mid": MID, "vits": VITS, "vitb": VITB}
 
 
 def seeded_init(cfg):
@@ -126,6 +134,37 @@ def main() -> None:
     cfg = CONFIGS[name]
     mid = "init_seed" in cfg     # seeded initial state (mid, vits)
     out = {"cfg": cfg, "steps": steps, "view_seed0": 5000, "mask_seed0": 900, "runs": {}}
+    parts = os.path.join(OUT, f".trajectory_{name}_parts")
+    if "--piece" in sys.argv:      # one restartable run: python -m oracle.make_trajectory --config vitb --piece 0.1 bf16
+        i = sys.argv.index("--piece")
+        koleo, mode = float(sys.argv[i + 1]), sys.argv[i + 2]
+        os.makedirs(parts, exist_ok=True)
+        rows, init = run(koleo, steps, mode, CFG=cfg)
+        if mode == "fp32" and mid:
+            _, bsd, shs, ths = seeded_init(cfg)
+            for part, want in (("student_backbone", bsd), ("student_head", shs), ("teacher_head", ths)):
+                for k, v in init[part].items():
+                    assert torch.equal(v, want[k].reshape(v.shape)), (part, k)
+        torch.save(rows, os.path.join(parts, f"{koleo}_{mode}.pt"))
+        print("wrote piece", koleo, mode)
+        return
+    if os.path.isdir(parts):       # assemble the fixture from the pieces that exist (fp32 is required per KoLeo weight)
+        for koleo in (0.1, 0.0):
+            for mode in ("fp32", "bf16", "fp32_perturbed"):
+                f = os.path.join(parts, f"{koleo}_{mode}.pt")
+                if os.path.exists(f):
+                    out["runs"][(koleo, mode)] = torch.load(f, weights_only=False)
+        summary = {}
+        for (koleo, mode), alt in out["runs"].items():
+            if mode != "fp32":
+                ref = out["runs"][(koleo, "fp32")]
+                summary[(koleo, mode)] = {k: max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for a, b in zip(alt, ref)) for k in KEYS}
+                print("max rel dev vs fp32", koleo, mode, {k: f"{v:.2e}" for k, v in summary[(koleo, mode)].items()})
+        out["summary"] = summary
+        path = os.path.join(OUT, f"trajectory_{name}.pt")
+        torch.save(out, path)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB", sorted(out["runs"]))
+        return
     for koleo in (0.1, 0.0):
         for mode in ("fp32", "bf16", "fp32_perturbed"):
             rows, init = run(koleo, steps, mode, CFG=cfg)

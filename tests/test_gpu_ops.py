@@ -54,7 +54,7 @@ def test_gemm_layouts(M, N, K, ta, tb):
     assert rel_err(out, ref) < 1e-5, f"mfma gemm mismatch ta={ta} tb={tb}"
 
 
-@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8)] +
+@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(2048, 256, 64), (2500, 768, 768), (4099, 2304, 192), (2048, 264, 128)] for f in (2, 8, 11)] +
                          # automatic dispatch on ViT-S widths (N = 256 m + r: the last column tile is partly padding)
                          [(2309, 384, 384, 0), (4096, 1152, 384, 0), (2048, 328, 1536, 0), (2100, 640, 128, 0)] +
                          # K not a multiple of 64 (SwiGLU widths 2736 / 5472 and small cases): the partial last K-tile of the four-phase kernel
@@ -87,7 +87,7 @@ def test_gemm_256_kernel(M, N, K, tb, fk):
     assert rel_err(ob, ref * x.grad) < 6e-3
 
 
-@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256)] for f in (2, 8)] +
+@pytest.mark.parametrize("M,N,K,fk", [(m, n, k, f) for (m, n, k) in [(768, 768, 8192), (3072, 768, 12800), (256, 136, 8256), (512, 768, 8256)] for f in (2, 8, 11)] +
                          # automatic dispatch: few output rows (ResNet layer1 / layer2 convolutions) and a layer4-sized contraction
                          [(64, 576, 16384, 0), (128, 1152, 8192, 0), (512, 4608, 6272, 0), (2048, 512, 4096, 0)])
 def test_gemm_256_wgrad_slab_and_atomic(M, N, K, fk):
@@ -109,7 +109,7 @@ def test_gemm_256_wgrad_slab_and_atomic(M, N, K, fk):
     assert torch.equal(outs[0], outs[2]), "slab split-K must be bit-reproducible"
 
 
-@pytest.mark.parametrize("M,N,K,fk", [(2304, 768, 50432, 0), (3072, 768, 51200, 8), (768, 768, 50176, 0), (256, 2048, 8832, 8), (2048, 768, 8832, 0),
+@pytest.mark.parametrize("M,N,K,fk", [(2304, 768, 50432, 0), (3072, 768, 51200, 8), (3072, 768, 51200, 11), (768, 768, 50176, 0), (256, 2048, 8832, 8), (256, 2048, 8832, 11), (2048, 768, 8832, 0),
                                       (2000, 776, 8192, 8), (64, 576, 16384, 0), (768, 768, 1000, 0)])
 def test_gemm_wgrad_fused_bias_column_sums(M, N, K, fk):
     """`colsum=`: db[M] += column sums of dY[K,M] beside dW += dY^T X -- fused into the four-phase slab kernel while the reduction ledger
