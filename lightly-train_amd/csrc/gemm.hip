@@ -946,7 +946,7 @@ __device__ __forceinline__ DmaSrcE make_dma_src(const bf16_t* P, int ld, int row
   return d;
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false, int PH = 4>
 __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HB = 128 * 128;            // one half-tile buffer; buffer index = half * 2 + stage (halves: A0 A1 B0 B1)
@@ -1038,8 +1038,13 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   } while (0)
 
   if (nk > 0) { LT_E_DMA(0, 0, 0); LT_E_DMA(0, 0, 1); LT_E_DMA(0, 0, 2); LT_E_DMA(0, 0, 3); }
-  if (nk > 1) { LT_E_DMA(1, 1, 2); LT_E_DMA(1, 1, 3); LT_E_DMA(1, 1, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6): tile 0 landed
-  else __builtin_amdgcn_s_waitcnt(0xF70);
+  if (PH == 4) {
+    if (nk > 1) { LT_E_DMA(1, 1, 2); LT_E_DMA(1, 1, 3); LT_E_DMA(1, 1, 0); __builtin_amdgcn_s_waitcnt(0xF76); }  // vmcnt(6): tile 0 landed
+    else __builtin_amdgcn_s_waitcnt(0xF70);
+  } else {
+    if (nk > 1) { LT_E_DMA(1, 1, 2); LT_E_DMA(1, 1, 3); __builtin_amdgcn_s_waitcnt(0xF74); }                     // vmcnt(4)
+    else __builtin_amdgcn_s_waitcnt(0xF70);
+  }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1104,15 +1109,60 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     LT_E_SYNC_OUT();                                                                                                       \
   } while (0)
 
+  // PH == 2: two phases of 16 MFMAs per K-tile (half as many barrier intervals):
+  //   Pa: read B-sub0, B-sub1, A-sub0 | DMA A0, A1 of tile t+1 (other stage: its A halves were last read in Pb of tile t-1) | quadrants (0,0) (0,1)
+  //   Pb: read A-sub1                 | DMA B0, B1 of tile t+2 (this stage: its B halves were last read in Pa)  + vmcnt(4)   | quadrants (1,1) (1,0)
+  // tile t+1 = [B issued in Pb(t-1), A issued in Pa(t)] is complete once only the four DMA instructions of B(t+2) are outstanding; the wait
+  // precedes every wave's first barrier of Pb(t) and the data is first read in Pa(t+1).  Per accumulator the MFMA order over k is unchanged.
+#define LT_E_TILE2(T, ST)                                                                                                  \
+  do {                                                                                                                     \
+    /* Pa */                                                                                                               \
+    lds_frag4<TB, (ST) * HB, 0>(fb0, bb);                                                                                  \
+    lds_frag4<TB, (ST) * HB, 1>(fb1, bb);                                                                                  \
+    lds_frag4<TA, (ST) * HB, 0>(fa[0], ab);                                                                                \
+    lds_frag4<TA, (ST) * HB, 1>(fa[1], ab);                                                                                \
+    if ((T) + 1 < nk) { LT_E_DMA((T) + 1, (ST) ^ 1, 0); LT_E_DMA((T) + 1, (ST) ^ 1, 1); }                                  \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[i][0], 0, 0, 0);                         \
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[i][1], 0, 0, 0);                         \
+    }                                                                                                                      \
+    LT_E_CS_ADD(0);                                                                                                        \
+    LT_E_SYNC_OUT();                                                                                                       \
+    /* Pb */                                                                                                               \
+    lds_frag4<TA, (ST) * HB, 2>(fa[0], ab);                                                                                \
+    lds_frag4<TA, (ST) * HB, 3>(fa[1], ab);                                                                                \
+    if ((T) + 2 < nk) { LT_E_DMA((T) + 2, (ST), 2); LT_E_DMA((T) + 2, (ST), 3); __builtin_amdgcn_s_waitcnt(0xF74); }       \
+    else __builtin_amdgcn_s_waitcnt(0xF70);                                                                                \
+    LT_E_SYNC_IN();                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+      acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[2 + i][1], 0, 0, 0);                 \
+      acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[2 + i][0], 0, 0, 0);                 \
+    }                                                                                                                      \
+    LT_E_CS_ADD(2);                                                                                                        \
+    if (CS) cs_cnt = (cs_cnt + 1 == cs_period) ? 0 : cs_cnt + 1;                                                           \
+    LT_E_SYNC_OUT();                                                                                                       \
+  } while (0)
   // two K-tiles per iteration (one per LDS stage) in ONE straight-line body with one back-edge; an odd last tile is a peeled copy.  (A
   // `break` between the two copies made the register allocator carry the 128 accumulators through copies and scratch.)
   int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    LT_E_TILE(t, 0);
-    LT_E_TILE(t + 1, 1);
+  if (PH == 4) {
+    for (; t + 1 < nk; t += 2) {
+      LT_E_TILE(t, 0);
+      LT_E_TILE(t + 1, 1);
+    }
+    if (t < nk) LT_E_TILE(t, 0);
+  } else {
+    for (; t + 1 < nk; t += 2) {
+      LT_E_TILE2(t, 0);
+      LT_E_TILE2(t + 1, 1);
+    }
+    if (t < nk) LT_E_TILE2(t, 0);
   }
-  if (t < nk) LT_E_TILE(t, 0);
 #undef LT_E_TILE
+#undef LT_E_TILE2
 #undef LT_E_CS_ADD
 #undef LT_E_DMA
 #undef LT_E_SYNC_IN
@@ -1152,17 +1202,25 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   }
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
-int launch_e_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS, int PH>
+int launch_e_ph(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256e_kernel<TA, TB, EPI, SLAB, CS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm256e_kernel<TA, TB, EPI, SLAB, CS>), grid, dim3(NT2), LDS_BYTES, st, g);
+  hipLaunchKernelGGL((gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH>), grid, dim3(NT2), LDS_BYTES, st, g);
   return LT_OK;
+}
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
+int launch_e_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  // phases per K-tile: 2 (default; 16 MFMAs per barrier interval: +1.5 % on the loop-dominated shape, step 81.7 -> 80.9 ms same-process,
+  // profiles/r06b_*) or the q kernel's 4 (LT_GEMM_E_PH=4, read per call: tools/ab_step.py)
+  const char* e = getenv("LT_GEMM_E_PH");
+  if (e && atoi(e) == 4) return launch_e_ph<TA, TB, EPI, SLAB, CS, 4>(g, grid, st);
+  return launch_e_ph<TA, TB, EPI, SLAB, CS, 2>(g, grid, st);
 }
 template <bool TA, bool TB>
 int launch_e(const GemmArgs& g, int epi, bool slab, dim3 grid, hipStream_t st) {

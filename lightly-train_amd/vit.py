@@ -200,11 +200,12 @@ def split_k_plan(M: int, N: int, K: int, trans_a: bool, split: int) -> Dict[str,
     """`split_k` / `force_kernel` arguments of an accumulating GEMM with a split contraction.  The 256-row kernel reduces its K-slices
     through fp32 slabs in a fixed order; the dispatcher sends short contractions (< 4096 rows) to the 128-row kernel, whose slices meet in
     fp32 atomics -- arrival order, last bits differ from run to run.  For reproducible steps (LT_DETERMINISTIC, default on) every split
-    contraction the slab kernel can take is pinned to it (force_kernel 8), and the rest run unsplit."""
+    contraction the slab kernel can take is pinned to it (force_kernel 11: the static-address form of the 256-row kernel, which falls back to
+    the four-phase form 8 where it is not eligible -- same slabs, same bits), and the rest run unsplit."""
     if split <= 1 or not DETERMINISTIC_SPLIT_K:
         return dict(split_k=split)
     if K % 64 == 0 and N % 8 == 0 and N >= 128 and M >= 64 and (not trans_a or M % 8 == 0):
-        return dict(split_k=split, force_kernel=8)
+        return dict(split_k=split, force_kernel=11)
     return dict(split_k=1)
 
 

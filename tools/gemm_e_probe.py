@@ -18,16 +18,26 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--lib", type=int, default=1)
-ap.add_argument("--kernels", default="8,11")
+ap.add_argument("--kernels", default="8,11p4,11")
 ap.add_argument("--quick", type=int, default=0)
 a = ap.parse_args()
-KERNELS = [int(k) for k in a.kernels.split(",")]
+KERNELS = a.kernels.split(",")     # "8", "11" (two phases per K-tile, the default), "11p4" (= force_kernel 11 with LT_GEMM_E_PH=4)
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 
 
 def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
     return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def call(spec, f):
+    """spec "11p4": force_kernel 11 under LT_GEMM_E_PH=4 (the library reads the variable per call)."""
+    fk, _, ph = spec.partition("p")
+    if ph:
+        os.environ["LT_GEMM_E_PH"] = ph
+    else:
+        os.environ.pop("LT_GEMM_E_PH", None)
+    return f(int(fk))
 
 
 def time_rounds(fns):
@@ -58,8 +68,8 @@ def case(name, M, N, K, *, tb=False, epi=ops.EPI_BF16, wgrad=False):
         for fk in KERNELS:
             out = torch.zeros(M, N, device=dev)
             outs[fk] = out
-            fns[fk] = (lambda fk=fk, out=out: ops.gemm(dy, x, out, M=M, N=N, K=K, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=0, lda=M, ldb=N, ldc=N,
-                                                       workspace=slab, force_kernel=fk))
+            fns[fk] = (lambda fk=fk, out=out: call(fk, lambda k: ops.gemm(dy, x, out, M=M, N=N, K=K, trans_a=True, trans_b=True, epilogue=ops.EPI_F32_ACCUM, split_k=0, lda=M, ldb=N,
+                                                                           ldc=N, workspace=slab, force_kernel=k)))
         lib = (lambda: torch.matmul(dy.t(), x)) if a.lib else None
     else:
         A = rnd(M, K)
@@ -73,8 +83,8 @@ def case(name, M, N, K, *, tb=False, epi=ops.EPI_BF16, wgrad=False):
             out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
             out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == ops.EPI_BF16_GELU else None
             outs[fk] = (out, out2)
-            fns[fk] = (lambda fk=fk, out=out, out2=out2: ops.gemm(A, W, out, M=M, N=N, K=K, trans_b=tb, epilogue=epi, bias=bias, gamma=gamma, resid=resid, aux=aux, out2=out2,
-                                                                   force_kernel=fk))
+            fns[fk] = (lambda fk=fk, out=out, out2=out2: call(fk, lambda k: ops.gemm(A, W, out, M=M, N=N, K=K, trans_b=tb, epilogue=epi, bias=bias, gamma=gamma, resid=resid, aux=aux,
+                                                                                      out2=out2, force_kernel=k)))
         Wt = W if tb else W.t()
         lib = (lambda: torch.matmul(A, Wt)) if a.lib else None
     # equality (wgrad: run once from zero)
@@ -95,7 +105,7 @@ def case(name, M, N, K, *, tb=False, epi=ops.EPI_BF16, wgrad=False):
     if lib is not None:
         allf["lib"] = lib
     t = time_rounds(allf)
-    cols = "  ".join(f"k{k}: {t[k]:7.1f} us {fl / t[k] / 1e6:6.0f} TF" for k in KERNELS)
+    cols = "  ".join(f"k{k}: {t[k]:7.1f} us {fl / t[k] / 1e6:5.0f} TF" for k in KERNELS)
     libs = f"  lib: {t['lib']:7.1f} us {fl / t['lib'] / 1e6:6.0f} TF" if lib is not None else ""
     print(f"{name:28s} M {M:6d} N {N:5d} K {K:6d}  {cols}{libs}  bit-equal {same}", flush=True)
 
