@@ -547,11 +547,20 @@ class DINOv2:
         return checkpoint.method_state_dict(self.student, self.teacher, {"dino_loss.center": self.dino_center, "ibot_loss.center": self.ibot_center},
                                             self.method_args.ibot_separate_head, self.cfg.depth, self.cfg.block_chunks, buffers)
 
+    def reset_transient_buffers(self) -> None:
+        """Forget everything earlier steps left in the reused activation buffers: the allocation-time zero fills are renewed and the
+        incremental clearing of the upstream-gradient buffers starts over with a full fill.  Called by `load_state_dict` (so by every
+        resume / in-process recovery); call it directly after a step whose loss or gradient norm came out non-finite if the weights are
+        restored by other means."""
+        self.ws.rezero()
+        self._dxn_rows = {}
+
     def load_state_dict(self, sd: Mapping[str, Tensor], strict: bool = True) -> None:
         """Load a `method.state_dict()` written by the reference (or by `state_dict()`): fp32 master weights, their bf16 shadows
         and every derived cache (weight-normed prototype matrices, padded patch-embedding matrices), loss centers included.
         Pending (not yet applied) center updates of the running step are dropped, as in a freshly constructed reference module."""
         extra = checkpoint.load_method_state_dict(sd, self.student, self.teacher, self.method_args.ibot_separate_head, strict)
+        self.reset_transient_buffers()
         if "dino_loss.center" in extra:
             self.dino_center.copy_(extra["dino_loss.center"].to(self.device, torch.float32).view_as(self.dino_center))
         if "ibot_loss.center" in extra:

@@ -162,6 +162,7 @@ class Workspace:
     def __init__(self, device: torch.device) -> None:
         self.device = device
         self.bufs: Dict[str, Tensor] = {}
+        self.zero_names: set = set()     # buffers whose never-written parts rely on the zero fill of their allocation (`zero=True`)
 
     def get(self, name: str, shape: Tuple[int, ...], dtype: torch.dtype, zero: bool = False, pad_rows: int = 0) -> Tensor:
         """`zero`: zero-fill when the buffer is (re)allocated (padding that kernels never write must stay finite).
@@ -174,7 +175,19 @@ class Workspace:
         if t is None or tuple(t.shape) != full or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(full, dtype=dtype, device=self.device)
             self.bufs[name] = t
+        if zero:
+            self.zero_names.add(name)
         return t[:shape[0]] if pad_rows else t
+
+    def rezero(self) -> None:
+        """Zero-fill every `zero=True` buffer again.  Those buffers are filled once, at allocation, and afterwards only hold what steps wrote
+        into them (e.g. the last block's block-middle tensor: rows outside the loss rows keep the values of earlier steps and only have to
+        be FINITE).  After a step that produced Inf / NaN activations they are not: whoever restores the weights (`load_state_dict`) calls
+        this, otherwise 0 * NaN in the dense final LayerNorm keeps every later step's gradients NaN."""
+        for name in self.zero_names:
+            t = self.bufs.get(name)
+            if t is not None:
+                t.zero_()
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
@@ -843,12 +856,11 @@ class ViTEngine:
 
         def ln_rows(br: Dict[str, Any], norm: str, dy: Tensor, R: int) -> None:
             """LayerNorm backward of a branch that ran on the rows br["idx"]: dx[idx] += LN'(dy), in place through the row index (the kernel's
-            indexed form serves D <= 1024; wider models take the compact result + scatter-add pass).  The last block's loss-row branch
-            (`nb == 0`, every step of every configuration) keeps the two-pass form: the indexed kernel is a separate instantiation whose fmas
-            the compiler contracts differently (one ulp in 4 % of the elements), and the 100-step KoLeo trajectories the tests pin were
-            recorded with the two-pass rounding -- a one-ulp change in this kernel moves their worst loss deviation between 0.9e-3 and 1.5e-3
-            (tests/test_gpu_step.py); the stochastic-depth subsets (drawn per step) take the indexed form."""
-            if D <= 1024 and D % 4 == 0 and br["nb"] > 0:
+            indexed form serves D <= 1024; wider models take the compact result + scatter-add pass).  Chosen on performance alone since round 6:
+            round 5 kept the two-pass form for the last block's loss-row branch because the 100-step KoLeo-on trajectory tests asserted a
+            hard 1e-3 that held for one rounding draw only (the two forms differ by one ulp in 4 % of the elements); those tests now assert the
+            bound the data supports -- inside the reference's own bf16-autocast deviation (tests/test_gpu_step.py)."""
+            if D <= 1024 and D % 4 == 0:
                 ops.layernorm_bwd(br["x"], self.w(norm + ".weight"), br["mean"], br["rstd"], dy, dx, dx, self.gw(norm + ".weight"), self.gw(norm + ".bias"),
                                   R, D, ridx=br["idx"])
                 return

@@ -441,3 +441,43 @@ def test_sinkhorn_result_does_not_depend_on_the_sample_count():
             outs.append(out.clone())
             assert torch.allclose(out, ref, rtol=2e-5, atol=1e-9), n_total
         assert torch.allclose(outs[0], outs[1], rtol=2e-6, atol=1e-10) and torch.allclose(outs[0], outs[2], rtol=2e-6, atol=1e-10)
+
+
+def test_load_state_dict_recovers_from_a_step_that_left_non_finite_activations():
+    """The last block's block-middle tensor and the upstream-gradient buffers are cleared incrementally (only at the rows steps write), so a
+    diverged step leaves Inf / NaN in rows no later step overwrites, and 0 * NaN in the dense final LayerNorm would keep every later
+    gradient NaN.  `load_state_dict` (the in-process recovery path) renews the zero fills: the step after a poisoned one equals the same
+    step of an object that never saw the poison, bit for bit."""
+    fx = torch.load(os.path.join(GOLD, "step_d64_softmax.pt"), weights_only=False)
+    rec = fx["steps"][0]
+    with ops_emu.emulate(ops):
+        def one_step(m, seed):
+            views = synth_views(seed, fx["b"], fx["g_size"], fx["l_size"], fx["n_local"])
+            res = m.training_step_impl({"views": views}, 0, masks=rec["masks"])
+            m.optimizer_step()
+            m.on_train_batch_end()
+            return float(res.loss), {n: m.student.g[n].clone() for n in m.student.names}
+
+        clean = build_exact(fx, koleo_loss_weight=0.0)
+        bad = build_exact(fx, koleo_loss_weight=0.0)
+        one_step(clean, rec["view_seed"])
+        one_step(bad, rec["view_seed"])
+        sd = {k: v.clone() for k, v in bad.state_dict().items()}
+        opt = bad.optimizer_state_dict()
+        assert bad.ws.zero_names, "the step allocates at least one zero-filled buffer (the last block's block-middle tensor)"
+        for name in bad.ws.zero_names:          # what a diverged step leaves behind: non-finite rows outside the rows later steps write
+            bad.ws.bufs[name].fill_(float("nan"))
+        for key, (ptr, shape, rows) in list(bad._dxn_rows.items()):
+            for t in bad.ws.bufs.values():
+                if t.data_ptr() == ptr:
+                    t.fill_(float("nan"))
+        bad.load_state_dict(sd)
+        bad.load_optimizer_state_dict(opt)
+        clean.load_state_dict({k: v.clone() for k, v in clean.state_dict().items()})     # the same path (it drops the pending center update)
+        clean.load_optimizer_state_dict(clean.optimizer_state_dict())
+        l_bad, g_bad = one_step(bad, rec["view_seed"] + 17)
+        l_clean, g_clean = one_step(clean, rec["view_seed"] + 17)
+        assert l_bad == l_clean
+        for n in g_clean:
+            assert torch.isfinite(g_bad[n]).all(), n
+            assert torch.equal(g_bad[n], g_clean[n]), n
