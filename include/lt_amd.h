@@ -318,14 +318,6 @@ int lt_center_tokens(const float* z, void* out_bf16, float* out_f32, int B, int 
 int lt_cka_fwd_bwd(const float* Ks, const float* Kt, const float* coef, float* loss, void* G_bf16, int B, int n, int ld, float eps,
                    void* stream);
 
-/* Row-owning residual GEMM with the next LayerNorm in its epilogue (round 5; csrc/gemm_rows.hip; LT/.../layers/block.py:90-115 + :60,74):
- *   out f32 [M, 768] = resid + gamma * (A bf16 [M, K] . W bf16 [768, K]^T + bias)        resid / gamma / bias may be NULL (0 / 1 / 0)
- *   ln_out bf16 [M, 768] = LayerNorm(out, eps) * ln_w + ln_b,  mean / rstd f32 [M]       (ln_out NULL: the GEMM alone; mean / rstd may be NULL)
- * A workgroup owns 128 whole rows, so the normalised operand of the next GEMM leaves from registers instead of a second pass over the fp32 rows.
- * Embedding width 768 only; K % 32 == 0; row-major operands with leading dimensions K (A, W) and 768 (resid, out, ln_out); 16-byte alignment. */
-int lt_gemm_resid_ln768(const void* a_bf16, const void* w_bf16, const float* bias, const float* gamma, const float* resid, float* out,
-                        const float* ln_w, const float* ln_b, float eps, void* ln_out_bf16, float* mean, float* rstd, int M, int K, void* stream);
-
 /* Order-fixed reductions (bitwise reproducible steps).  Between lt_reduce_begin and lt_reduce_end the kernels that end in a sum over
  * workgroups -- lt_layernorm_bwd(_fused) (dw, db, dbias_next), lt_layerscale_bwd (dgamma, dbias), lt_colsum_bf16, lt_assemble_tokens_bwd
  * (mask-token gradient) -- store per-workgroup partial rows into `scratch` instead of issuing fp32 atomics; their destinations are

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID, EPI_F32, EPI_BF16_GELUGRAD, EPI_F32_ACCUM = range(6)
-ABI_VERSION = 4   # lt_abi_version() of include/lt_amd.h this binding was written against
+ABI_VERSION = 5   # lt_abi_version() of include/lt_amd.h this binding was written against
 
 # name -> argtypes (every function returns int status except lt_last_error)
 SIGNATURES: dict[str, list[Any]] = {
@@ -90,7 +90,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_comm_wait": [vp],
     "lt_comm_size": [],
     "lt_comm_destroy": [],
-    "lt_gemm_resid_ln768": [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp],
     "lt_reduce_begin": [vp, i64],
     "lt_reduce_begin_at": [vp, i64, C.c_int],
     "lt_reduce_flush": [vp],

@@ -16,7 +16,7 @@ void lt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* lt_last_error(void) { return g_err; }
-extern "C" int lt_abi_version(void) { return 4; }
+extern "C" int lt_abi_version(void) { return 5; }
 
 extern "C" int lt_device_info(char* name, int name_len, int* compute_units, int* clock_khz) {
   int dev = 0;

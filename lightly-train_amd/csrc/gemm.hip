@@ -971,6 +971,16 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   const int l = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
   const int wm = wave >> 2, wn = wave & 3;
+  LT_TSTAMP(0);
+#ifdef LT_GEMM_TIMING
+  if (threadIdx.x == 0) {
+    const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (L_ < 16384) {
+      lt_gemm_timing_buf[L_ * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+      lt_gemm_timing_buf[L_ * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+  }
+#endif
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -1049,6 +1059,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  LT_TSTAMP(1);
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of each SIMD by one barrier
 
   bf16x8 fa[2][4], fb0[4], fb1[4];
@@ -1169,6 +1180,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
 #undef LT_E_SYNC_OUT
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
   __syncthreads();
+  LT_TSTAMP(2);
   if (CS) {
     float* dst = g.cs + (size_t)((slice * g.tiles_n + tn) * 4 + wn) * g.M;
 #pragma unroll
@@ -1200,6 +1212,13 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef LT_GEMM_TIMING
+  LT_TSTAMP(3);
+  __builtin_amdgcn_s_waitcnt(0xF70);
+  LT_TSTAMP(6);
+  __syncthreads();
+  LT_TSTAMP(7);
+#endif
 }
 
 template <bool TA, bool TB, int EPI, bool SLAB, bool CS, int PH>

@@ -417,18 +417,6 @@ def fill_f32(dst: Tensor, value: float) -> None:
     check(_lib.load().lt_fill_f32(_p(dst), value, dst.numel(), _stream()), "lt_fill_f32")
 
 
-def gemm_resid_ln768(a: Tensor, w: Tensor, out: Tensor, *, M: int, K: int, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
-                     resid: Optional[Tensor] = None, ln_w: Optional[Tensor] = None, ln_b: Optional[Tensor] = None, eps: float = 1e-6,
-                     ln_out: Optional[Tensor] = None, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None) -> None:
-    """out f32 [M, 768] = resid + gamma * (a bf16 [M, K] @ w bf16 [768, K]^T + bias); with `ln_out`: the LayerNorm of `out` as bf16 plus the
-    row statistics, from the same kernel (lt_gemm_resid_ln768: a workgroup owns whole rows)."""
-    _chk(a, torch.bfloat16, "gemm_resid_ln.a")
-    _chk(w, torch.bfloat16, "gemm_resid_ln.w")
-    _chk(out, torch.float32, "gemm_resid_ln.out")
-    check(_lib.load().lt_gemm_resid_ln768(_p(a), _p(w), _p(bias), _p(gamma), _p(resid), _p(out), _p(ln_w), _p(ln_b), eps, _p(ln_out), _p(mean), _p(rstd),
-                                          M, K, _stream()), "lt_gemm_resid_ln768")
-
-
 # ------------------------------------------------------------------------------------------ attention
 def attention_fwd(qkv: Tensor, out: Tensor, lse: Tensor, B: int, N: int, H: int, dh: int, scale: float) -> None:
     _chk(qkv, torch.bfloat16, "attention.qkv")

@@ -585,34 +585,6 @@ def test_indexed_row_forms_of_the_subset_branch_backward(T, R, D):
     assert torch.equal(got[keep], dx[keep])
 
 
-@pytest.mark.parametrize("M,K,plain", [(300, 64, False), (1000, 768, False), (129, 3072, False), (128, 768, True), (2048 + 17, 768, False), (513, 1024, True)])
-def test_row_owning_residual_gemm_with_the_fused_layernorm(M, K, plain):
-    """lt_gemm_resid_ln768 (csrc/gemm_rows.hip, round 5: a workgroup owns 128 whole 768-wide rows; LayerScale + residual epilogue and the NEXT
-    LayerNorm from the accumulator registers) against the shipped pair lt_gemm_bf16(EPI_RESID) + lt_layernorm_fwd: the fp32 stream bit for bit
-    (same k order of the fp32 accumulation), the normalised bf16 operand to bf16 rounding, mean / rstd to fp32 round-off; ragged row counts,
-    one to 17 tiles, K = 64 ... 3072, with and without bias / LayerScale / residual (`plain`), and the GEMM alone (no LayerNorm outputs)."""
-    o = ops()
-    D = 768
-    g = torch.Generator().manual_seed(M + K)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    W = (torch.randn(D, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
-    bias = None if plain else (torch.randn(D, generator=g) * 0.1).to(DEV)
-    gamma = None if plain else (torch.rand(D, generator=g) + 0.5).to(DEV)
-    resid = None if plain else torch.randn(M, D, generator=g).to(DEV)
-    lw, lb = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
-    out0, out1, out2 = (torch.full((M + 3, D), 7.0, device=DEV) for _ in range(3))
-    y0, y1 = torch.zeros(M + 3, D, device=DEV, dtype=torch.bfloat16), torch.zeros(M + 3, D, device=DEV, dtype=torch.bfloat16)
-    m0, r0, m1, r1 = (torch.zeros(M + 3, device=DEV) for _ in range(4))
-    o.gemm(A, W, out0, M=M, N=D, K=K, epilogue=o.EPI_RESID if not plain else o.EPI_F32, bias=bias, gamma=gamma, resid=resid)
-    o.layernorm_fwd(out0, lw, lb, M, D, y_bf16=y0, mean=m0, rstd=r0, eps=1e-6)
-    o.gemm_resid_ln768(A, W, out1, M=M, K=K, bias=bias, gamma=gamma, resid=resid, ln_w=lw, ln_b=lb, eps=1e-6, ln_out=y1, mean=m1, rstd=r1)
-    o.gemm_resid_ln768(A, W, out2, M=M, K=K, bias=bias, gamma=gamma, resid=resid)
-    assert torch.equal(out1[:M], out0[:M]) and torch.equal(out2[:M], out0[:M])
-    assert float((out1[M:] - 7.0).abs().max()) == 0.0 and float(y1[M:].float().abs().max()) == 0.0      # nothing past the last row is touched
-    assert rel_err(y1[:M].float(), y0[:M].float()) < 8e-3
-    assert (m1[:M] - m0[:M]).abs().max().item() < 1e-6 and ((r1[:M] - r0[:M]).abs() / r0[:M]).max().item() < 1e-6
-
-
 @pytest.mark.parametrize("K,rows_a,rows_b", [(65536, 24, 300), (65536, 256, 700), (20484, 8, 40), (4096, 6, 20), (520, 5, 0)])
 def test_centering_without_the_probability_matrix(K, rows_a, rows_b):
     """lt_softmax_stats_colsum + lt_ce_fwd_bwd_logits (the softmax-centering path of the step: row statistics and column sums in one pass,

@@ -159,7 +159,7 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} declared in lt_amd.h but not exported"
     bound = set(_lib.SIGNATURES) | {"lt_last_error", "lt_attention_bwd_ws_floats", "lt_batchnorm_ws_floats", "lt_reduce_overflows"}
     assert declared == bound, f"header/binding mismatch: {declared ^ bound}"
-    assert lib.lt_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.lt_abi_version() == _lib.ABI_VERSION == 5
     assert ctypes.sizeof(_lib.GemmDesc) >= 120
 
 
