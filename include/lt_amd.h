@@ -240,6 +240,14 @@ int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t* ta, const
 int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const float* t_stats, const float* center_a, const float* center_b,
                          int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot, float scale,
                          float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K, void* stream);
+/* The same two entry points on bf16 logit rows (round 6, the `bf16_logits` option of the DINOv2 step): what the reference's own bf16-mixed
+ * path holds -- the prototype Linear runs under autocast (LT/_methods/dinov2/dinov2_head.py:66-71) and the losses cast back with .float()
+ * (dinov2_loss.py:37-38,88).  Arithmetic in fp32, statistics / column sums / loss terms fp32; the generic path needs K % 8 == 0. */
+int lt_softmax_stats_colsum_bf16(const void* logits_bf16, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
+                                 float* scratch, int64_t scratch_floats, void* stream);
+int lt_ce_fwd_bwd_logits_bf16(const void* s_bf16, const void* t_logits_bf16, const float* t_stats, const float* center_a, const float* center_b,
+                              int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot, float scale,
+                              float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K, void* stream);
 /* Distillation v3 (reference _methods/distillationv3/distillationv3_loss.py:60-115): per row KL(softmax(t/T) || softmax(s/T));
  * loss[0] += coef * KL, dlogits bf16 = coef/T * (softmax(s/T) - softmax(t/T)); rows `ld` (dlogits: `ldd`) elements apart */
 int lt_kl_fwd_bwd(const float* s_logits, const float* t_logits, int ld, float inv_temp, float coef, float* loss,

@@ -74,6 +74,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "lt_center_ema": [vp, vp, f32, f32, i32, vp],
     "lt_softmax_stats_colsum": [vp, vp, vp, vp, i32, i32, f32, vp, i64, vp],
     "lt_ce_fwd_bwd_logits": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, i32, vp],
+    "lt_softmax_stats_colsum_bf16": [vp, vp, vp, vp, i32, i32, f32, vp, i64, vp],
+    "lt_ce_fwd_bwd_logits_bf16": [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, i32, vp],
     "lt_ce_fwd_bwd": [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp],
     "lt_sk_exp": [vp, vp, i64, f32, vp],
     "lt_sk_iter": [vp, vp, i32, i32, f32, f32, vp],

@@ -35,6 +35,17 @@ __device__ __forceinline__ MaxSum block_ms(MaxSum v, float* red) {
   return r;
 }
 
+// Logit rows in fp32 (the default) or bf16 (round 6, `bf16_logits`: what the reference's own bf16-mixed path holds -- the prototype Linear
+// runs under autocast, LT/_methods/dinov2/dinov2_head.py:66-71, and the losses cast back with .float(), dinov2_loss.py:37-38,88): every
+// kernel below that streams logits takes the element type as a template parameter and does its arithmetic in fp32 either way.
+__device__ __forceinline__ float4 load_logits4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load_logits4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float load_logit1(const float* p) { return *p; }
+__device__ __forceinline__ float load_logit1(const bf16_t* p) { return bf2f(*p); }
+
 // probs = softmax((logits - center) * inv_temp)
 __global__ __launch_bounds__(256) void softmax_center_kernel(const float* __restrict__ logits, const float* __restrict__ center,
                                                              float* __restrict__ probs, int K, float inv_temp) {
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(1024) void ce_reg_kernel(const float* __restrict__ 
 // the row statistics take one wave reduction + one barrier per row (combined by wave 0 from a double-buffered LDS slot).
 constexpr int SC_CHUNK = 4;   // float4 loads in flight per thread and chunk
 constexpr int SC_GROUP = 8;   // rows between two barriers
-__global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+template <typename TL>
+__global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const TL* __restrict__ logits, const float* __restrict__ center,
                                                                     float* __restrict__ stats, float* __restrict__ partial, int rows, int K,
                                                                     float inv_temp) {
   // wave partials (max, sum-exp) of SC_GROUP rows, double-buffered: ONE barrier per SC_GROUP rows (a barrier per row drained the
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float*
   for (long it = 0; it < nmine; ++it) {
     const long row = blockIdx.x + it * gridDim.x;
     const int slot = (int)(it % SC_GROUP), par = (int)((it / SC_GROUP) & 1);
-    const float* x = logits + row * K;
+    const TL* x = logits + row * K;
     MaxSum a; a.m = -INFINITY; a.s = 0.f;
 #pragma unroll
     for (int j = 0; j < ROW_NV; j += SC_CHUNK) {
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(1024) void softmax_stats_colsum_kernel(const float*
         const int k = ((j + i) * 1024 + threadIdx.x) * 4;
         u[i] = make_float4(0.f, 0.f, 0.f, 0.f); c[i] = u[i];
         if (k < K) {
-          u[i] = *reinterpret_cast<const float4*>(x + k);
+          u[i] = load_logits4(x + k);
           if (center) c[i] = *reinterpret_cast<const float4*>(center + k);
         }
       }
@@ -295,42 +307,47 @@ __global__ __launch_bounds__(256) void colsum_slabs_f32_kernel(const float* __re
   }
 }
 // generic widths: one 256-thread block per row (statistics only; the column sums come from lt_colsum_f32)
-__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ logits, const float* __restrict__ center,
+template <typename TL>
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const TL* __restrict__ logits, const float* __restrict__ center,
                                                             float* __restrict__ stats, int K, float inv_temp) {
   __shared__ float red[16];
   const long row = blockIdx.x;
-  const float* x = logits + row * K;
+  const TL* x = logits + row * K;
   MaxSum a; a.m = -INFINITY; a.s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) ms_push(a, (x[k] - (center ? center[k] : 0.f)) * inv_temp);
+  for (int k = threadIdx.x; k < K; k += 256) ms_push(a, (load_logit1(x + k) - (center ? center[k] : 0.f)) * inv_temp);
   a = block_ms(a, red);
   if (threadIdx.x == 0) { stats[2 * row] = a.m; stats[2 * row + 1] = 1.f / a.s; }
 }
 
 // teacher probability of column k of teacher row `tr`, rebuilt from its logits: exp((x - center) * inv_temp_t - max) / sum-exp
-struct TRow { const float* x; const float* c; float m, is; };
-__device__ __forceinline__ TRow trow(const float* __restrict__ t_logits, const float* __restrict__ stats, const float* ca, const float* cb,
-                                     int split, int tr, int K) {
-  TRow r;
+template <typename TL> struct TRow { const TL* x; const float* c; float m, is; };
+template <typename TL>
+__device__ __forceinline__ TRow<TL> trow(const TL* __restrict__ t_logits, const float* __restrict__ stats, const float* ca, const float* cb,
+                                         int split, int tr, int K) {
+  TRow<TL> r;
   r.x = t_logits + (long)tr * K;
   r.c = tr < split ? ca : cb;
   r.m = stats[2 * tr];
   r.is = stats[2 * tr + 1];
   return r;
 }
-__device__ __forceinline__ float4 tprob4(const TRow& r, int k, float itt) {
-  const float4 x = *reinterpret_cast<const float4*>(r.x + k);
+template <typename TL>
+__device__ __forceinline__ float4 tprob4(const TRow<TL>& r, int k, float itt) {
+  const float4 x = load_logits4(r.x + k);
   float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r.c) c = *reinterpret_cast<const float4*>(r.c + k);
   return make_float4(__expf((x.x - c.x) * itt - r.m) * r.is, __expf((x.y - c.y) * itt - r.m) * r.is,
                      __expf((x.z - c.z) * itt - r.m) * r.is, __expf((x.w - c.w) * itt - r.m) * r.is);
 }
-__device__ __forceinline__ float tprob1(const TRow& r, int k, float itt) {
-  return __expf((r.x[k] - (r.c ? r.c[k] : 0.f)) * itt - r.m) * r.is;
+template <typename TL>
+__device__ __forceinline__ float tprob1(const TRow<TL>& r, int k, float itt) {
+  return __expf((load_logit1(r.x + k) - (r.c ? r.c[k] : 0.f)) * itt - r.m) * r.is;
 }
 
 // ce_reg_kernel with the teacher probabilities rebuilt from (teacher logits, row statistics, center): same arithmetic per element as
 // softmax_center_reg_kernel followed by ce_reg_kernel, without the probability matrix in between
-__global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __restrict__ s, const float* __restrict__ t_logits,
+template <typename TL>
+__global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const TL* __restrict__ s, const TL* __restrict__ t_logits,
                                                              const float* __restrict__ t_stats, const float* __restrict__ center_a,
                                                              const float* __restrict__ center_b, int split, const int32_t* __restrict__ ta,
                                                              const int32_t* __restrict__ tb, const float* __restrict__ row_weight,
@@ -338,10 +355,10 @@ __global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __rest
                                                              bf16_t* __restrict__ dlogits, int K) {
   __shared__ float red[32];
   const long row = blockIdx.x;
-  const float* z = s + row * K;
-  const TRow r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
+  const TL* z = s + row * K;
+  const TRow<TL> r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
   const bool two = tb && tb[row] >= 0;
-  const TRow r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
+  const TRow<TL> r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
   // The student row stays in registers, so its softmax takes ONE exponential per element: row maximum first (64 v_max per thread + one
   // block reduction), then e = exp(u - max) overwrites u -- its sum gives the log-sum-exp, and e / sum is the probability the gradient
   // needs.  (An online max / sum-exp pushes nearly every element through both of its branches, an exponential each, and the gradient
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __rest
   for (int i = 0; i < ROW_NV; ++i) {
     const int k = (i * 1024 + threadIdx.x) * 4;
     if (k < K) {
-      float4 u = *reinterpret_cast<const float4*>(z + k);
+      float4 u = load_logits4(z + k);
       u.x *= inv_temp; u.y *= inv_temp; u.z *= inv_temp; u.w *= inv_temp;
       v[i] = u;
       float4 t = tprob4(r0, k, inv_temp_t);
@@ -396,7 +413,8 @@ __global__ __launch_bounds__(1024) void ce_logits_reg_kernel(const float* __rest
     }
   }
 }
-__global__ __launch_bounds__(256) void ce_logits_kernel(const float* __restrict__ s, const float* __restrict__ t_logits,
+template <typename TL>
+__global__ __launch_bounds__(256) void ce_logits_kernel(const TL* __restrict__ s, const TL* __restrict__ t_logits,
                                                         const float* __restrict__ t_stats, const float* __restrict__ center_a,
                                                         const float* __restrict__ center_b, int split, const int32_t* __restrict__ ta,
                                                         const int32_t* __restrict__ tb, const float* __restrict__ row_weight, float scale,
@@ -404,14 +422,14 @@ __global__ __launch_bounds__(256) void ce_logits_kernel(const float* __restrict_
                                                         bf16_t* __restrict__ dlogits, int K) {
   __shared__ float red[16];
   const long row = blockIdx.x;
-  const float* z = s + row * K;
-  const TRow r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
+  const TL* z = s + row * K;
+  const TRow<TL> r0 = trow(t_logits, t_stats, center_a, center_b, split, ta[row], K);
   const bool two = tb && tb[row] >= 0;
-  const TRow r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
+  const TRow<TL> r1 = trow(t_logits, t_stats, center_a, center_b, split, two ? tb[row] : ta[row], K);
   MaxSum a; a.m = -INFINITY; a.s = 0.f;
   float dot = 0.f, tsum = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) {
-    const float zk = z[k] * inv_temp;
+    const float zk = load_logit1(z + k) * inv_temp;
     const float tk = tprob1(r0, k, inv_temp_t) + (two ? tprob1(r1, k, inv_temp_t) : 0.f);
     ms_push(a, zk);
     dot += tk * zk;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(256) void ce_logits_kernel(const float* __restrict_
   if (dlogits) {
     const float c2 = coef * inv_temp;
     for (int k = threadIdx.x; k < K; k += 256) {
-      const float zk = z[k] * inv_temp;
+      const float zk = load_logit1(z + k) * inv_temp;
       const float tk = tprob1(r0, k, inv_temp_t) + (two ? tprob1(r1, k, inv_temp_t) : 0.f);
       dlogits[row * K + k] = f2bf(c2 * (__expf(zk - lse) * tsum - tk));
     }
@@ -714,8 +732,11 @@ extern "C" int lt_ce_fwd_bwd(const float* s, const float* teacher, const int32_t
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd");
 }
 extern "C" int lt_colsum_f32(const float* x, float* out, int rows, int N, int accumulate, void* stream);
-extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
-                                       float* scratch, int64_t scratch_floats, void* stream) {
+extern "C" int lt_colsum_bf16(const void* x_bf16, float* out, int rows, int N, void* stream);
+namespace {
+template <typename TL>
+int softmax_stats_colsum_impl(const TL* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp, float* scratch,
+                              int64_t scratch_floats, void* stream) {
   LT_CHECK_ARG(colsum && K > 0 && rows >= 0 && (rows == 0 || (logits && stats)), "lt_softmax_stats_colsum: bad arguments");
   if (rows == 0) {
     if (hipMemsetAsync(colsum, 0, sizeof(float) * K, ST) != hipSuccess) { lt_set_error("lt_softmax_stats_colsum: memset failed"); return LT_ERR_HIP; }
@@ -728,17 +749,22 @@ extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center,
     LT_CHECK_ARG(scratch && scratch_floats >= K && ((uintptr_t)scratch & 15) == 0, "lt_softmax_stats_colsum: needs >= K floats of 16-byte aligned scratch");
     if ((int64_t)grid * K > scratch_floats) grid = (int)(scratch_floats / K);   // fewer, longer row walks when the caller's scratch is small
     float* partial = scratch;
-    hipLaunchKernelGGL(softmax_stats_colsum_kernel, dim3(grid), dim3(1024), 0, ST, logits, center, stats, partial, rows, K, inv_temp);
+    hipLaunchKernelGGL(softmax_stats_colsum_kernel<TL>, dim3(grid), dim3(1024), 0, ST, logits, center, stats, partial, rows, K, inv_temp);
     hipLaunchKernelGGL(colsum_slabs_f32_kernel, dim3(lt_cdiv(K, 256)), dim3(256), 0, ST, partial, colsum, grid, K);
     LT_CHECK_LAUNCH("lt_softmax_stats_colsum");
   }
-  hipLaunchKernelGGL(softmax_stats_kernel, dim3(rows), dim3(256), 0, ST, logits, center, stats, K, inv_temp);
-  return lt_colsum_f32(logits, colsum, rows, K, 0, stream);
+  hipLaunchKernelGGL(softmax_stats_kernel<TL>, dim3(rows), dim3(256), 0, ST, logits, center, stats, K, inv_temp);
+  if constexpr (sizeof(TL) == 4) return lt_colsum_f32((const float*)logits, colsum, rows, K, 0, stream);
+  else {
+    LT_CHECK_ARG(K % 8 == 0, "lt_softmax_stats_colsum_bf16: K must be a multiple of 8 on the generic path");
+    if (hipMemsetAsync(colsum, 0, sizeof(float) * K, ST) != hipSuccess) { lt_set_error("lt_softmax_stats_colsum_bf16: memset failed"); return LT_ERR_HIP; }
+    return lt_colsum_bf16(logits, colsum, rows, K, stream);
+  }
 }
-extern "C" int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const float* t_stats, const float* center_a, const float* center_b,
-                                    int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot,
-                                    float scale, float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K,
-                                    void* stream) {
+template <typename TL>
+int ce_fwd_bwd_logits_impl(const TL* s, const TL* t_logits, const float* t_stats, const float* center_a, const float* center_b, int split_row,
+                           const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot, float scale, float inv_temp,
+                           float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K, void* stream) {
   LT_CHECK_ARG(s && t_logits && t_stats && ta && loss && K > 0, "lt_ce_fwd_bwd_logits: bad arguments");
   if (rows == 0) return LT_OK;
   float* terms = lt_scratch_ring((size_t)rows);
@@ -747,13 +773,36 @@ extern "C" int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const
   auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
   if (reg_rows && K % 4 == 0 && K <= 4096 * ROW_NV && K >= 8192 && al16(s) && al16(t_logits) && al16(center_a) && al16(center_b) &&
       (!dlogits_bf16 || (uintptr_t)dlogits_bf16 % 8 == 0))
-    hipLaunchKernelGGL(ce_logits_reg_kernel, dim3(rows), dim3(1024), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb,
+    hipLaunchKernelGGL(ce_logits_reg_kernel<TL>, dim3(rows), dim3(1024), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb,
                        row_weight, scale, inv_temp, inv_temp_t, terms, (bf16_t*)dlogits_bf16, K);
   else
-    hipLaunchKernelGGL(ce_logits_kernel, dim3(rows), dim3(256), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb, row_weight,
+    hipLaunchKernelGGL(ce_logits_kernel<TL>, dim3(rows), dim3(256), 0, ST, s, t_logits, t_stats, center_a, center_b, split_row, ta, tb, row_weight,
                        scale, inv_temp, inv_temp_t, terms, (bf16_t*)dlogits_bf16, K);
   hipLaunchKernelGGL(rowloss_sum_kernel, dim3(1), dim3(256), 0, ST, terms, slot, rows, loss);
   LT_CHECK_LAUNCH("lt_ce_fwd_bwd_logits");
+}
+}  // namespace
+extern "C" int lt_softmax_stats_colsum(const float* logits, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
+                                       float* scratch, int64_t scratch_floats, void* stream) {
+  return softmax_stats_colsum_impl<float>(logits, center, stats, colsum, rows, K, inv_temp, scratch, scratch_floats, stream);
+}
+extern "C" int lt_softmax_stats_colsum_bf16(const void* logits_bf16, const float* center, float* stats, float* colsum, int rows, int K, float inv_temp,
+                                            float* scratch, int64_t scratch_floats, void* stream) {
+  return softmax_stats_colsum_impl<bf16_t>((const bf16_t*)logits_bf16, center, stats, colsum, rows, K, inv_temp, scratch, scratch_floats, stream);
+}
+extern "C" int lt_ce_fwd_bwd_logits(const float* s, const float* t_logits, const float* t_stats, const float* center_a, const float* center_b,
+                                    int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot,
+                                    float scale, float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K,
+                                    void* stream) {
+  return ce_fwd_bwd_logits_impl<float>(s, t_logits, t_stats, center_a, center_b, split_row, ta, tb, row_weight, slot, scale, inv_temp, inv_temp_t, loss,
+                                       dlogits_bf16, rows, K, stream);
+}
+extern "C" int lt_ce_fwd_bwd_logits_bf16(const void* s_bf16, const void* t_logits_bf16, const float* t_stats, const float* center_a, const float* center_b,
+                                         int split_row, const int32_t* ta, const int32_t* tb, const float* row_weight, const int32_t* slot,
+                                         float scale, float inv_temp, float inv_temp_t, float* loss, void* dlogits_bf16, int rows, int K,
+                                         void* stream) {
+  return ce_fwd_bwd_logits_impl<bf16_t>((const bf16_t*)s_bf16, (const bf16_t*)t_logits_bf16, t_stats, center_a, center_b, split_row, ta, tb, row_weight,
+                                        slot, scale, inv_temp, inv_temp_t, loss, dlogits_bf16, rows, K, stream);
 }
 extern "C" int lt_sk_exp(const float* logits, float* Q, int64_t n, float inv_temp, void* stream) {
   LT_CHECK_ARG(logits && Q, "lt_sk_exp: null pointer");

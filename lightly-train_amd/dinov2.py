@@ -45,6 +45,11 @@ class DINOv2Args:
     ibot_loss_weight: float = 1.0
     koleo_loss_weight: float = 0.1
     center_method: Literal["softmax", "sinkhorn_knopp"] = "softmax"
+    # Not a reference argument: hold the prototype logits of both heads in bf16 -- what the reference's own bf16-mixed run holds (the
+    # prototype Linear runs under autocast, dinov2_head.py:66-71; the losses cast back with .float(), dinov2_loss.py:37-38,88) -- instead of
+    # fp32 (wider than the reference's).  Halves the bytes of the serial logit section of the step; applies to the fused softmax-centering path
+    # (center_method="softmax"), the other paths keep fp32.  LT_BF16_LOGITS=1 / 0 overrides.  Measured: profiles/r06_bf16_logits.md.
+    bf16_logits: bool = False
     center_momentum: float = 0.9
     momentum_start: float = 0.992
     momentum_end: float = 1.0
@@ -163,6 +168,7 @@ class HeadEngine:
         self.P, self.prefix = params, prefix
         self.in_dim, self.hid, self.bn, self.K = in_dim, args.hidden_dim, args.dino_bottleneck_dim, args.output_dim
         self.pad_wgrad_rows = True   # see backward(): weight-gradient GEMMs over a row count padded to whole K-tiles
+        self.logit_dtype = torch.float32   # torch.bfloat16 under DINOv2Args.bf16_logits (set by the method object)
         dev = params.device
         # batch_norm=True (dinov2_head.py:86-92): BatchNorm1d between each hidden Linear and its GELU.  The running estimates are
         # buffers of THIS module: no gradient, not part of the EMA (update_momentum walks parameters() only), saved in the state_dict.
@@ -267,8 +273,8 @@ class HeadEngine:
         zn = ws.get(tag + ".zn", (cap, bn), torch.bfloat16)
         inv = ws.get(tag + ".inv", (cap,), torch.float32)
         ops.l2norm_fwd(z, zn, inv, R, bn, 1e-12)
-        logits = ws.get(tag + ".logits", (cap, K), torch.float32)
-        ops.gemm(zn, self.wn, logits, M=R, N=K, K=bn, epilogue=ops.EPI_F32)
+        logits = ws.get(tag + ".logits", (cap, K), self.logit_dtype)
+        ops.gemm(zn, self.wn, logits, M=R, N=K, K=bn, epilogue=ops.EPI_F32 if self.logit_dtype == torch.float32 else ops.EPI_BF16)
         return dict(x=x, h1=h1, h1p=h1p, h2=h2, h2p=h2p, z=z, zn=zn, inv=inv, logits=logits, R=R, cap=cap, tag=tag, bn=bnc, segs=segs)
 
     def backward(self, ws: Workspace, c: Dict[str, Any], dlogits: Tensor, side: Optional["torch.cuda.Stream"] = None) -> Tensor:
@@ -496,6 +502,11 @@ class DINOv2:
         # softmax centering without the [rows, K] probability matrix (training_step_impl); LT_FUSED_CENTERING=0: softmax, column sums and
         # cross-entropy as three passes
         self.fused_centering = os.environ.get("LT_FUSED_CENTERING", "1") != "0"
+        env_bl = os.environ.get("LT_BF16_LOGITS")
+        self.bf16_logits = (a.bf16_logits if env_bl is None else env_bl != "0") and a.center_method == "softmax" and self.fused_centering
+        if self.bf16_logits:
+            for h_ in (self.s_head, self.t_head, self.s_ihead, self.t_ihead):
+                h_.logit_dtype = torch.bfloat16
         self.sinkhorn_joint = os.environ.get("LT_SINKHORN_JOINT", "1") != "0"   # both heads' Sinkhorn iterations share one all-reduce each
         # gradient accumulation (the reference hands `gradient_accumulation_steps` to Lightning as accumulate_grad_batches,
         # LT/_commands/train_helpers.py:224-236): a caller that accumulates k micro-batches per optimizer step sets, before each
@@ -957,7 +968,7 @@ class DINOv2:
         ops.gather_rows(txn, D, ix["t_cls"], 2 * B, D, out_bf16=t_in[:2 * B])
         ops.gather_rows(txn, D, patch_rows, M, D, out_bf16=t_in[2 * B:2 * B + M])
         sep = a.ibot_separate_head
-        t_logits = ws.get("t.logits_all", (cap_t, K), torch.float32) if sep else None
+        t_logits = ws.get("t.logits_all", (cap_t, K), self.t_head.logit_dtype) if sep else None
         if not sep:
             t_logits = self.t_head.forward(ws, "th", t_in, Rt, cap_t, save=False, segs=[(0, 2 * B), (2 * B, M)],
                                            bn_training=self.teacher_head_training)["logits"]
@@ -1175,8 +1186,8 @@ class DINOv2:
             return L["t_probs"]
         B, M, Rt, K = L["B"], L["M"], L["Rt"], self.method_args.output_dim
         out = torch.empty(Rt, K, dtype=torch.float32, device=self.device)
-        ops.softmax_center(L["t_cls_logits"], self.dino_center.view(-1), out[:2 * B], 2 * B, K, 1.0 / L["teacher_temp"])
-        ops.softmax_center(L["t_patch_logits"], self.ibot_center.view(-1), out[2 * B:], M, K, 1.0 / L["teacher_temp"])
+        ops.softmax_center(L["t_cls_logits"].float(), self.dino_center.view(-1), out[:2 * B], 2 * B, K, 1.0 / L["teacher_temp"])   # (.float(): bf16_logits)
+        ops.softmax_center(L["t_patch_logits"].float(), self.ibot_center.view(-1), out[2 * B:], M, K, 1.0 / L["teacher_temp"])
         return out
 
     def synced_logs(self, res: "TrainingStepResult") -> Dict[str, Tensor]:

@@ -474,8 +474,9 @@ def softmax_stats_colsum(logits: Tensor, center: Optional[Tensor], stats: Tensor
     (256 * K for one workgroup per CU)."""
     _chk(stats, torch.float32, "softmax_stats.stats")
     _chk(scratch, torch.float32, "softmax_stats.scratch")
-    check(_lib.load().lt_softmax_stats_colsum(_p(logits) if rows else None, _p(center), _p(stats) if rows else None, _p(colsum), rows, K, inv_temp,
-                                              _p(scratch), scratch.numel(), _stream()), "lt_softmax_stats_colsum")
+    fn = _lib.load().lt_softmax_stats_colsum_bf16 if logits.dtype == torch.bfloat16 else _lib.load().lt_softmax_stats_colsum   # bf16 logit rows: same arithmetic (fp32)
+    check(fn(_p(logits) if rows else None, _p(center), _p(stats) if rows else None, _p(colsum), rows, K, inv_temp,
+             _p(scratch), scratch.numel(), _stream()), "lt_softmax_stats_colsum")
 
 
 def ce_fwd_bwd_logits(s: Tensor, t_logits: Tensor, t_stats: Tensor, center_a: Optional[Tensor], center_b: Optional[Tensor], split_row: int,
@@ -484,8 +485,10 @@ def ce_fwd_bwd_logits(s: Tensor, t_logits: Tensor, t_stats: Tensor, center_a: Op
     """`ce_fwd_bwd` against teacher probabilities rebuilt from the teacher logits, their row statistics and the centers
     (lt_ce_fwd_bwd_logits): teacher rows < split_row use center_a, the others center_b."""
     _chk(ta, torch.int32, "ce.ta")
-    check(_lib.load().lt_ce_fwd_bwd_logits(_p(s), _p(t_logits), _p(t_stats), _p(center_a), _p(center_b), split_row, _p(ta), _p(tb), _p(row_weight),
-                                           _p(slot), scale, inv_temp, inv_temp_t, _p(loss), _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd_logits")
+    assert s.dtype == t_logits.dtype, "student and teacher logits share one element type"
+    fn = _lib.load().lt_ce_fwd_bwd_logits_bf16 if s.dtype == torch.bfloat16 else _lib.load().lt_ce_fwd_bwd_logits
+    check(fn(_p(s), _p(t_logits), _p(t_stats), _p(center_a), _p(center_b), split_row, _p(ta), _p(tb), _p(row_weight),
+             _p(slot), scale, inv_temp, inv_temp_t, _p(loss), _p(dlogits), rows, K, _stream()), "lt_ce_fwd_bwd_logits")
 
 
 def sk_exp(logits: Tensor, Q: Tensor, inv_temp: float) -> None:

@@ -585,6 +585,48 @@ def test_indexed_row_forms_of_the_subset_branch_backward(T, R, D):
     assert torch.equal(got[keep], dx[keep])
 
 
+@pytest.mark.parametrize("K,rows_a,rows_b", [(65536, 24, 300), (20480, 8, 40), (4096, 6, 20), (520, 5, 3)])
+def test_centering_kernels_on_bf16_logit_rows(K, rows_a, rows_b):
+    """lt_softmax_stats_colsum_bf16 / lt_ce_fwd_bwd_logits_bf16 (the `bf16_logits` option: logit rows held in bf16, arithmetic in fp32): fed
+    bf16 rows, they have to return what the fp32 entry points return on the SAME (bf16-representable) values -- identical loads after the
+    widening, identical arithmetic: statistics, column sums, loss terms and d-logits bit for bit."""
+    o = ops()
+    g = torch.Generator().manual_seed(K + rows_a)
+    Rt = rows_a + rows_b
+    tl16 = (torch.randn(Rt, K, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    tl32 = tl16.float()
+    ca = (torch.randn(K, generator=g) * 0.05).to(DEV)
+    cb = (torch.randn(K, generator=g) * 0.05).to(DEV)
+    itt = 1 / 0.05
+    sws = torch.empty(256 * K, device=DEV)
+    res = {}
+    for name, tl in (("f32", tl32), ("bf16", tl16)):
+        stats = torch.zeros(Rt, 2, device=DEV)
+        cs_a, cs_b = torch.full((K,), 7.0, device=DEV), torch.full((K,), 7.0, device=DEV)
+        o.softmax_stats_colsum(tl[:rows_a], ca, stats[:rows_a], cs_a, rows_a, K, itt, sws)
+        o.softmax_stats_colsum(tl[rows_a:], cb, stats[rows_a:], cs_b, rows_b, K, itt, sws)
+        R = 24
+        gs = torch.Generator().manual_seed(7)
+        s16 = torch.randn(R, K, generator=gs).to(torch.bfloat16).to(DEV)
+        sx = s16 if name == "bf16" else s16.float()
+        ta = torch.randint(0, Rt, (R,), generator=gs, dtype=torch.int32).to(DEV)
+        tb = torch.where(torch.rand(R, generator=gs) < 0.5, torch.randint(0, rows_a, (R,), generator=gs, dtype=torch.int32), torch.full((R,), -1, dtype=torch.int32)).to(DEV)
+        w = torch.rand(R, generator=gs).to(DEV)
+        slot = torch.randint(0, 3, (R,), generator=gs, dtype=torch.int32).to(DEV)
+        loss = torch.zeros(5, device=DEV); dl = torch.empty(R, K, device=DEV, dtype=torch.bfloat16)
+        o.ce_fwd_bwd_logits(sx, tl, stats, ca, cb, rows_a, ta, tb, w, 0.37, 10.0, itt, loss, dl, R, K, slot=slot)
+        res[name] = (stats, cs_a, cs_b, loss, dl)
+    torch.cuda.synchronize()
+    for a_, b_, what in zip(res["f32"], res["bf16"], ("stats", "colsum a", "colsum b", "loss", "dlogits")):
+        if K >= 8192 or what not in ("colsum a", "colsum b"):
+            assert torch.equal(a_, b_), what
+        else:       # generic widths: the bf16 column sums come from lt_colsum_bf16 (another summation order)
+            assert rel_err(b_, a_) < 1e-5, what
+    z = torch.cat([(tl32[:rows_a] - ca) * itt, (tl32[rows_a:] - cb) * itt]).double()
+    assert torch.allclose(res["bf16"][0][:, 0].double(), z.max(-1).values, atol=1e-5)
+    assert rel_err(res["bf16"][1], tl32[:rows_a].double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("K,rows_a,rows_b", [(65536, 24, 300), (65536, 256, 700), (20484, 8, 40), (4096, 6, 20), (520, 5, 0)])
 def test_centering_without_the_probability_matrix(K, rows_a, rows_b):
     """lt_softmax_stats_colsum + lt_ce_fwd_bwd_logits (the softmax-centering path of the step: row statistics and column sums in one pass,
