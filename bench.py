@@ -406,7 +406,7 @@ def main() -> None:
                 traffic_src = tj.get("profile", "profiles/gemm_traffic.json")
             else:
                 traffic_src = "profiles/gemm_traffic.json is stale for this build (kernel sha / launch count differ): not quoted"
-        roofline = {"bound": "mfma", "kernel": "gemm256q_kernel<TA,TB,EPI,SLAB> (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
+        roofline = {"bound": "mfma", "kernel": "gemm256e_kernel<TA,TB,EPI,SLAB,CS,PH> (static-address K-loop; gemm256q_kernel for K % 64 != 0) (lightly-train_amd/csrc/gemm.hip)", "achieved": round(achieved, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per GEMM launch, L2 memory-side (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes)",
                     "traffic_source": traffic_src,

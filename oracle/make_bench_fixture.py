@@ -13,7 +13,8 @@ loss centers after the step's update; from a forward with the reference's defaul
 
     python oracle/make_bench_fixture.py [--batch 32] [--threads 8]
 
-`--reference --local-size 96 [--batch 16]` (round 5): the SAME quantities written by the REFERENCE's own DINOv2 class
+`--reference --local-size 96 [--batch 16] [--arch vit_small]` (round 5; round 6: `--arch vit_small --batch 32` = BASELINE configs[1], ViT-S/16, at a
+quarter of its batch -> tests/golden/bench_vits_ref_b32.pt): the SAME quantities written by the REFERENCE's own DINOv2 class
 (oracle/ref_harness.py imports it from /root/reference; its wrapper refuses 98^2 crops at patch 16, SURVEY 8(d), so the local crops are the
 upstream default 96^2 = 37 tokens) -> tests/golden/bench_vitb_ref_b<batch>.pt.  The seeded weights are loaded into the reference module
 (asserted equal), the masks are the ones its own `create_collated_masks` call sampled, the gradients are autograd's on its parameters.
@@ -50,17 +51,21 @@ def sample(t: torch.Tensor) -> torch.Tensor:
     return m[::16, ::8].clone()
 
 
-def build_inputs(batch: int, seed: int, local: int = 98):
+ARCHS = {"vit_base": (768, 12), "vit_small": (384, 6)}     # embed_dim, heads (12 blocks each): BASELINE configs[2] / configs[1]
+
+
+def build_inputs(batch: int, seed: int, local: int = 98, arch: str = "vit_base"):
     """Weights and views from one generator, in this order (tests/test_gpu_step.py rebuilds them the same way)."""
     g = torch.Generator().manual_seed(seed)
-    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    D, H = ARCHS[arch]
+    vc = ViTConfig(embed_dim=D, depth=12, num_heads=H, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
     bsd = init_vit_state(vc, g)
-    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    shs, ths = init_head_state(D, 2048, 256, 65536, g), init_head_state(D, 2048, 256, 65536, g)
     views = [torch.randn(batch, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(batch, 3, local, local, generator=g) for _ in range(8)]
     return vc, bsd, shs, ths, views
 
 
-def reference_step(b: int, seed: int, mask_seed: int, local: int, koleo, backward: bool, autocast: bool = False):
+def reference_step(b: int, seed: int, mask_seed: int, local: int, koleo, backward: bool, autocast: bool = False, arch: str = "vit_base"):
     """One `training_step_impl` (+ backward) of the reference's own class from the seeded state.  Returns a dict in the layout of the
     restatement's record ("loss", "logs", and with `backward`: grad_norm / tensor_norms / grad_samples / centers / logit_samples / masks)."""
     from oracle import ref_harness as H
@@ -68,11 +73,11 @@ def reference_step(b: int, seed: int, mask_seed: int, local: int, koleo, backwar
     H.install()
     import lightly_train._methods.dinov2.dinov2 as ref_dinov2
 
-    vc, bsd, shs, ths, views = build_inputs(b, seed, local)
+    vc, bsd, shs, ths, views = build_inputs(b, seed, local, arch)
     mk = dict(output_dim=65536)
     if koleo is not None:
         mk["koleo_loss_weight"] = koleo
-    m = H.build_reference_method(arch="vit_base", patch_size=16, img_size=224, method_kwargs=mk, global_batch_size=b, total_steps=100, seed=1)
+    m = H.build_reference_method(arch=arch, patch_size=16, img_size=224, method_kwargs=mk, global_batch_size=b, total_steps=100, seed=1)
     sd, new = m.state_dict(), {}
     for k, v in sd.items():
         for role, head in (("student", shs), ("teacher", ths)):
@@ -150,12 +155,12 @@ def reference_step(b: int, seed: int, mask_seed: int, local: int, koleo, backwar
 
 def main_reference(a) -> None:
     b = a.batch
-    out = {"batch": b, "seed": a.seed, "mask_seed": a.mask_seed, "total_steps": 100, "local_size": a.local_size, "writer": "reference class",
-           "config": f"vit_base/16, K=65536, 2x224^2 + 8x{a.local_size}^2, softmax centering -- LT/_methods/dinov2/dinov2.py:259-397 run from /root/reference"}
-    k0 = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True)
+    out = {"batch": b, "seed": a.seed, "mask_seed": a.mask_seed, "total_steps": 100, "local_size": a.local_size, "writer": "reference class", "arch": a.arch,
+           "config": f"{a.arch}/16, K=65536, 2x224^2 + 8x{a.local_size}^2, softmax centering -- LT/_methods/dinov2/dinov2.py:259-397 run from /root/reference"}
+    k0 = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True, arch=a.arch)
     out["masks"] = k0.pop("masks")
     out["koleo0"] = k0
-    yb = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True, autocast=True)
+    yb = reference_step(b, a.seed, a.mask_seed, a.local_size, 0.0, backward=True, autocast=True, arch=a.arch)
     yard = {"loss": yb["loss"], "logs": yb["logs"], "grad_norm": yb["grad_norm"], "norm_rel_err": {}, "sample_err": {}}
     for n, v in yb["tensor_norms"].items():
         yard["norm_rel_err"][n] = abs(v - k0["tensor_norms"][n]) / max(k0["tensor_norms"][n], 1e-20)
@@ -163,10 +168,10 @@ def main_reference(a) -> None:
         ref = k0["grad_samples"][n]
         yard["sample_err"][n] = float((v.reshape(ref.shape) - ref).abs().max() / (ref.abs().max() + 1e-20))
     out["autocast_yardstick"] = yard
-    d = reference_step(b, a.seed, a.mask_seed, a.local_size, None, backward=False)
+    d = reference_step(b, a.seed, a.mask_seed, a.local_size, None, backward=False, arch=a.arch)
     assert all(torch.equal(d["masks"][k], out["masks"][k]) for k in out["masks"] if torch.is_tensor(out["masks"][k]))
     out["default"] = {"loss": d["loss"], "logs": d["logs"]}
-    path = os.path.join(ROOT, "tests", "golden", f"bench_vitb_ref_b{b}.pt")
+    path = os.path.join(ROOT, "tests", "golden", f"bench_{'vitb' if a.arch == 'vit_base' else 'vits'}_ref_b{b}.pt")
     torch.save(out, path)
     print(path, os.path.getsize(path) // 1024, "KiB", out["koleo0"]["logs"], out["default"]["logs"], "grad-norm", out["koleo0"]["grad_norm"],
           "autocast grad-norm", yard["grad_norm"])
@@ -180,6 +185,7 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--reference", action="store_true", help="write the fixture with the reference's own class (needs /root/reference; --local-size 96)")
     ap.add_argument("--local-size", type=int, default=98)
+    ap.add_argument("--arch", default="vit_base", choices=sorted(ARCHS), help="--reference only: vit_small = BASELINE configs[1] (DINOv2 ViT-S/16) -> bench_vits_ref_b<batch>.pt")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     if a.reference:

@@ -442,7 +442,7 @@ def test_vitb_batch24_step_dispatches_gemm256q_and_matches_oracle():
     assert sq_o ** 0.5 == pytest.approx(sq_r ** 0.5, rel=2e-2)
 
 
-def _bench_method(b, seed, local=98, **args):
+def _bench_method(b, seed, local=98, arch="vit_base", **args):
     """The method object, weights and views of the benchmark configuration exactly as oracle/make_bench_fixture.py builds them (one
     generator: backbone, student head, teacher head, then the ten views)."""
     import lightly_train_amd  # noqa: F401
@@ -450,9 +450,10 @@ def _bench_method(b, seed, local=98, **args):
     from lightly_train_amd.vit import ViTConfig, init_vit_state
 
     g = torch.Generator().manual_seed(seed)
-    vc = ViTConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
+    D_, H_ = {"vit_base": (768, 12), "vit_small": (384, 6)}[arch]
+    vc = ViTConfig(embed_dim=D_, depth=12, num_heads=H_, mlp_ratio=4.0, patch_size=16, img_size=224, init_values=1e-5)
     bsd = init_vit_state(vc, g)
-    shs, ths = init_head_state(768, 2048, 256, 65536, g), init_head_state(768, 2048, 256, 65536, g)
+    shs, ths = init_head_state(D_, 2048, 256, 65536, g), init_head_state(D_, 2048, 256, 65536, g)
     views = [torch.randn(b, 3, 224, 224, generator=g) for _ in range(2)] + [torch.randn(b, 3, local, local, generator=g) for _ in range(8)]
     m = DINOv2(vc, DINOv2Args(**args), global_batch_size=b, total_steps=100, device="cuda", backbone_state=bsd, student_head_state=shs, teacher_head_state=ths)
     return m, views
@@ -465,9 +466,10 @@ def _strided(t):
     return m[::16, ::8]
 
 
-@pytest.mark.parametrize("fixture", ["bench_vitb_b32", "bench_vitb_ref_b16"])
+@pytest.mark.parametrize("fixture", ["bench_vitb_b32", "bench_vitb_ref_b16", "bench_vits_ref_b32"])
 def test_bench_configuration_step_matches_the_committed_fixture(fixture):
-    """`bench_vitb_ref_b16` (round 5): the same model -- ViT-B/16, K = 65 536, softmax centering -- with 96^2 local crops (37 tokens: the
+    """`bench_vits_ref_b32` (round 6): BASELINE configs[1] -- DINOv2 ViT-S/16, K = 65 536, 2 x 224^2 + 8 x 96^2 -- at batch 32, written by the
+    REFERENCE's own class like the next one (`--arch vit_small --batch 32`), with its bf16-autocast column.  `bench_vitb_ref_b16` (round 5): the same model -- ViT-B/16, K = 65 536, softmax centering -- with 96^2 local crops (37 tokens: the
     upstream default, which the reference's wrapper CAN run) at batch 16, written by the REFERENCE's own DINOv2 class
     (`oracle/make_bench_fixture.py --reference --local-size 96 --batch 16`): masks sampled by its `create_collated_masks`, gradients from
     autograd on its parameters.  `bench_vitb_b32`:
@@ -484,7 +486,8 @@ def test_bench_configuration_step_matches_the_committed_fixture(fixture):
     fx = torch.load(os.path.join(GOLD, fixture + ".pt"), weights_only=False)
     b, k0, local = fx["batch"], fx["koleo0"], fx.get("local_size", 98)
     n_loc_tok = (-(-local // 16)) ** 2 + 1
-    m, views = _bench_method(b, fx["seed"], local, koleo_loss_weight=0.0)
+    arch = fx.get("arch", "vit_base")
+    m, views = _bench_method(b, fx["seed"], local, arch, koleo_loss_weight=0.0)
     ovf = ops.reduce_overflows()
     calls, undo = _install_gemm_spy()
     try:
@@ -537,7 +540,7 @@ def test_bench_configuration_step_matches_the_committed_fixture(fixture):
     torch.cuda.synchronize()
     assert rel(m.dino_center.view(-1), k0["dino_center"]) < 2e-2 and rel(m.ibot_center.view(-1), k0["ibot_center"]) < 2e-2
     # the reference's default KoLeo weight (0.1), forward terms
-    m2, _ = _bench_method(b, fx["seed"], local)
+    m2, _ = _bench_method(b, fx["seed"], local, arch)
     res2 = m2.training_step_impl({"views": views}, 0, masks=fx["masks"])
     logs2 = {k.split("/")[-1]: float(v) for k, v in res2.log_dict.items()}
     for k in ("dino_global_loss", "dino_local_loss", "ibot_loss"):
