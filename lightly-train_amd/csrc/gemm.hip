@@ -912,7 +912,38 @@ struct DmaSrcE {
   int wave_off;                 // transposed: byte offset of this wave's first k-row group (w * 8 rows)
   int tile_step;                // bytes per K-tile
   int jstep;                    // transposed: bytes between the two pieces of a wave (4 k-rows)
+  unsigned voff_tail[4];        // KT: per-lane byte offsets [half * 2 + piece] of the partial LAST K-tile (k indices clamped into the operand);
+                                // used with the scalar offset tile * tile_step alone (no wave_off / jstep)
 };
+// KT (K % 64 != 0, forward / dgrad layouts): the last K-tile is loaded with clamped k indices -- duplicates instead of whatever follows the
+// operand in memory -- and the A image's duplicates are overwritten with zeros by the lanes that loaded them (see the kernel), which makes
+// the B image's irrelevant.  `krem` = K % 64 = valid k of the last tile.
+template <bool TR>
+__device__ __forceinline__ void make_dma_tail(DmaSrcE& d, int ld, int rows, int row0, int krem, int w, int l) {
+  if (!TR) {
+    const int ctail = krem >> 3;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = hh * 128 + (w * 2 + j) * 8 + (l >> 3), slot = l & 7;
+        const int c = min(slot ^ ((row >> 1) & 7), ctail - 1);
+        const int gr = min(row0 + row, rows - 1) - row0;
+        d.voff_tail[hh * 2 + j] = (unsigned)gr * (unsigned)ld * 2u + (unsigned)c * 16u;
+      }
+  } else {
+    const int b = l >> 3, slot = l & 7;
+    const int kr = ((slot >> 1) - b) & 3;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      int col = row0 + hh * 128 + b * 16 + (slot & 1) * 8;
+      if (col >= rows) col = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        d.voff_tail[hh * 2 + j] = (unsigned)min(w * 8 + j * 4 + kr, krem - 1) * (unsigned)ld * 2u + (unsigned)col * 2u;
+    }
+  }
+}
 template <bool TR>
 __device__ __forceinline__ DmaSrcE make_dma_src(const bf16_t* P, int ld, int rows, int row0, int kbeg, int w, int l) {
   DmaSrcE d;
@@ -946,8 +977,9 @@ __device__ __forceinline__ DmaSrcE make_dma_src(const bf16_t* P, int ld, int row
   return d;
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false, int PH = 4>
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false, int PH = 4, bool KT = false>
 __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
+  static_assert(!KT || (!TA && !SLAB && !CS), "partial last K-tile: forward / dgrad layouts only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HB = 128 * 128;            // one half-tile buffer; buffer index = half * 2 + stage (halves: A0 A1 B0 B1)
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -967,7 +999,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int kbeg = slice * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg) / BK;
+  const int nk = KT ? (kend - kbeg + BK - 1) / BK : (kend - kbeg) / BK;
   const int l = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
   const int wm = wave >> 2, wn = wave & 3;
@@ -993,6 +1025,16 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   // ---- loop-invariant addresses
   DmaSrcE sa = make_dma_src<TA>(g.A, g.lda, g.M, m0, kbeg, wave, l);
   DmaSrcE sb = make_dma_src<TB>(g.B, g.ldb, g.N, n0, kbeg, wave, l);
+  const int krem = KT ? (g.K & (BK - 1)) : 0;        // valid k of the last tile (0: the last tile is whole)
+  bool ztail[2] = {false, false};                    // KT: this lane's piece j of an A half lies past K in the last tile
+  if (KT && krem) {
+    make_dma_tail<TA>(sa, g.lda, g.M, m0, krem, wave, l);
+    make_dma_tail<TB>(sb, g.ldb, g.N, n0, krem, wave, l);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ztail[j] = (((l & 7) ^ ((j * 4 + (l >> 4)) & 7))) >= (krem >> 3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(sa.voff_tail[k])); asm volatile("" : "+v"(sb.voff_tail[k])); }
+  }
   unsigned ab[4], bb[4];
   {
     const unsigned a_half = (unsigned)(wm * 2) * HB, b_half = (unsigned)((2 + (wn >> 1)) * 2) * HB;
@@ -1026,10 +1068,26 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   do {                                                                                                                    \
     const DmaSrcE& s_ = (H) < 2 ? sa : sb;                                                                                \
     constexpr bool TR_ = (H) < 2 ? TA : TB;                                                                               \
-    const int so_ = (TILE) * s_.tile_step + s_.wave_off;                                                                  \
     char* d_ = smem + ((H) * 2 + (ST)) * HB + lds_w;                                                                      \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)d_, 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2], so_, 0, 0);                   \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)(d_ + 1024), 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2 + 1], so_ + s_.jstep, 0, 0); \
+    if (KT && krem && (TILE) == nk - 1) {   /* the partial last tile: clamped sources (scalar branch) */                    \
+      const int so_ = (TILE) * s_.tile_step;                                                                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)d_, 16, s_.voff_tail[((H) & 1) * 2], so_, 0, 0);           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)(d_ + 1024), 16, s_.voff_tail[((H) & 1) * 2 + 1], so_, 0, 0); \
+    } else {                                                                                                              \
+      const int so_ = (TILE) * s_.tile_step + s_.wave_off;                                                                \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)d_, 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2], so_, 0, 0);                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s_.srd, (lptr_t*)(d_ + 1024), 16, TR_ ? s_.voff[(H) & 1] : s_.voff[((H) & 1) * 2 + 1], so_ + s_.jstep, 0, 0); \
+    }                                                                                                                     \
+  } while (0)
+  // after this wave's DMAs of the partial last tile have landed (its own vmcnt wait) and before the barrier that publishes the tile: every
+  // lane zeroes the 16-byte pieces of the two A halves it loaded itself whose source chunk lies past K
+#define LT_E_ZERO_TAIL(TILE, ST)                                                                                          \
+  do {                                                                                                                    \
+    if (KT && krem && (TILE) == nk - 1) {                                                                                 \
+      _Pragma("unroll") for (int hh_ = 0; hh_ < 2; ++hh_)                                                                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                    \
+        if (ztail[j_]) *reinterpret_cast<uint4*>(smem + (hh_ * 2 + (ST)) * HB + lds_w + j_ * 1024 + l * 16) = make_uint4(0, 0, 0, 0); \
+    }                                                                                                                     \
   } while (0)
 #define LT_E_SYNC_IN()                          \
   do {                                          \
@@ -1055,6 +1113,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     if (nk > 1) { LT_E_DMA(1, 1, 2); LT_E_DMA(1, 1, 3); __builtin_amdgcn_s_waitcnt(0xF74); }                     // vmcnt(4)
     else __builtin_amdgcn_s_waitcnt(0xF70);
   }
+  LT_E_ZERO_TAIL(0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1112,6 +1171,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     /* P4 */                                                                                                               \
     if ((T) + 2 < nk) { LT_E_DMA((T) + 2, (ST), 3); LT_E_DMA((T) + 2, (ST), 0); __builtin_amdgcn_s_waitcnt(0xF76); }       \
     else __builtin_amdgcn_s_waitcnt(0xF70);                                                                                \
+    LT_E_ZERO_TAIL((T) + 1, (ST) ^ 1);                                                                                     \
     LT_E_SYNC_IN();                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[2 + i][0], 0, 0, 0); \
@@ -1146,6 +1206,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     lds_frag4<TA, (ST) * HB, 3>(fa[1], ab);                                                                                \
     if ((T) + 2 < nk) { LT_E_DMA((T) + 2, (ST), 2); LT_E_DMA((T) + 2, (ST), 3); __builtin_amdgcn_s_waitcnt(0xF74); }       \
     else __builtin_amdgcn_s_waitcnt(0xF70);                                                                                \
+    LT_E_ZERO_TAIL((T) + 1, (ST) ^ 1);                                                                                     \
     LT_E_SYNC_IN();                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
@@ -1176,6 +1237,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
 #undef LT_E_TILE2
 #undef LT_E_CS_ADD
 #undef LT_E_DMA
+#undef LT_E_ZERO_TAIL
 #undef LT_E_SYNC_IN
 #undef LT_E_SYNC_OUT
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
@@ -1221,17 +1283,29 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
 #endif
 }
 
-template <bool TA, bool TB, int EPI, bool SLAB, bool CS, int PH>
+template <bool TA, bool TB, int EPI, bool SLAB, bool CS, int PH, bool KT = false>
 int launch_e_ph(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH, KT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH>), grid, dim3(NT2), LDS_BYTES, st, g);
+  hipLaunchKernelGGL((gemm256e_kernel<TA, TB, EPI, SLAB, CS, PH, KT>), grid, dim3(NT2), LDS_BYTES, st, g);
   return LT_OK;
+}
+// partial last K-tile (forward / dgrad layouts; two phases per K-tile only)
+template <bool TB>
+int launch_e_ktail(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_e_ph<false, TB, EPI_BF16, false, false, 2, true>(g, grid, st);
+    case EPI_BF16_GELU: return launch_e_ph<false, TB, EPI_BF16_GELU, false, false, 2, true>(g, grid, st);
+    case EPI_RESID: return launch_e_ph<false, TB, EPI_RESID, false, false, 2, true>(g, grid, st);
+    case EPI_F32: return launch_e_ph<false, TB, EPI_F32, false, false, 2, true>(g, grid, st);
+    case EPI_BF16_GELUGRAD: return launch_e_ph<false, TB, EPI_BF16_GELUGRAD, false, false, 2, true>(g, grid, st);
+    default: lt_set_error("lt_gemm_bf16: no partial-K-tile kernel for epilogue %d", epi); return LT_ERR_INVALID;
+  }
 }
 template <bool TA, bool TB, int EPI, bool SLAB, bool CS = false>
 int launch_e_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
@@ -1471,7 +1545,7 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   bool big = eligible && d->force_kernel != 1 && batch == 1 && d->N >= (ktail ? 256 : 128) &&
              ((!d->trans_a && d->M >= 2048) || (d->trans_a && d->K >= wgrad_min_k && d->M >= wgrad_min_m));
   if (d->force_kernel == 2 || d->force_kernel == 8 || d->force_kernel == 11) {
-    LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
+    LT_CHECK_ARG(eligible && (!ktail || d->force_kernel == 8 || d->force_kernel == 11), "lt_gemm_bf16: shape/layout not eligible for the 256-row LDS-DMA kernel");
     big = true;
   }
   if (big && ktail) {
@@ -1479,6 +1553,12 @@ extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
     g.tiles_m = lt_cdiv(d->M, 256); g.tiles_n = lt_cdiv(d->N, 256);
     g.k_per_split = lt_cdiv(d->K, BK) * BK;
     dim3 gridk(g.tiles_m * g.tiles_n, 1);
+    const char* env_ek = getenv("LT_GEMM_E");   // the static-address kernel's partial-K-tile variant (round 6); LT_GEMM_E=0 / force_kernel = 8: the q kernel's
+    const bool ek_fits = ((size_t)256 * d->lda + d->K) * 2 < 0x7fffffffull &&
+                         (d->trans_b ? (size_t)g.k_per_split * d->ldb : (size_t)256 * d->ldb + d->K) * 2 < 0x7fffffffull;
+    if (ek_fits && d->N >= 256 && d->force_kernel != 8 && (!env_ek || atoi(env_ek) != 0))
+      rc = d->trans_b ? g256::launch_e_ktail<true>(g, d->epilogue, gridk, st) : g256::launch_e_ktail<false>(g, d->epilogue, gridk, st);
+    else
     rc = d->trans_b ? g256::launch_q_ktail<true>(g, d->epilogue, gridk, st) : g256::launch_q_ktail<false>(g, d->epilogue, gridk, st);
     if (rc != LT_OK) return rc;
     LT_CHECK_LAUNCH("lt_gemm_bf16");

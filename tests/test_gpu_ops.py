@@ -58,7 +58,8 @@ def test_gemm_layouts(M, N, K, ta, tb):
                          # automatic dispatch on ViT-S widths (N = 256 m + r: the last column tile is partly padding)
                          [(2309, 384, 384, 0), (4096, 1152, 384, 0), (2048, 328, 1536, 0), (2100, 640, 128, 0)] +
                          # K not a multiple of 64 (SwiGLU widths 2736 / 5472 and small cases): the partial last K-tile of the four-phase kernel
-                         [(2100, 1024, 2736, 0), (2048, 512, 5472, 0), (2300, 256, 72, 0), (2048, 304, 200, 8), (2500, 768, 136, 8)])
+                         [(2100, 1024, 2736, 0), (2048, 512, 5472, 0), (2300, 256, 72, 0), (2048, 304, 200, 8), (2500, 768, 136, 8), (2048, 304, 200, 11), (2500, 768, 136, 11),
+                          (2300, 256, 72, 11), (4099, 512, 2736, 11)])
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_256_kernel(M, N, K, tb, fk):
     """the 256x256 LDS-DMA kernel (forced, or dispatched) against the fp32 reference, incl. M/N tails and every
