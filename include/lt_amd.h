@@ -79,6 +79,12 @@ typedef struct lt_gemm_desc {
                                      gradient of the same Linear (the column sums of dY), formed from the A fragments the kernel holds anyway
                                      instead of a second pass over dY.  Fused into the four-phase slab kernel when the reduction ledger
                                      (lt_reduce_begin) is open; otherwise a separate column-sum launch precedes the GEMM.  NULL = none */
+  /* LT_EPI_RESID only (round 6): the NEXT LayerNorm of the residual stream handed to the GEMM call -- x + ls(attn(norm1(x))) followed by norm2,
+   * x + ls(mlp(norm2(x))) followed by the next block's norm1 (LT/.../layers/block.py:90-115, :60,74):
+   *   ln_out bf16 [M][N] (row stride N) = LayerNorm(C[m][0..N), ln_eps) * ln_weight + ln_bias,  ln_mean / ln_rstd f32 [M] (may be NULL).
+   * The library issues lt_layernorm_fwd on the stream behind the GEMM (one call across this ABI instead of two; a row-owning kernel that
+   * normalised inside the GEMM was measured slower and removed, profiles/r06_rowln_probe.md).  ln_out NULL = none. */
+  const float* ln_weight; const float* ln_bias; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps;
 } lt_gemm_desc;
 
 int lt_gemm_bf16(const lt_gemm_desc* d, void* stream);

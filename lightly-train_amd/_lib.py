@@ -21,6 +21,7 @@ class GemmDesc(C.Structure):
         ("bias", vp), ("gamma", vp), ("resid", vp), ("ldr", i32), ("aux", vp), ("ldaux", i32),
         ("alpha", f32), ("split_k", i32), ("force_kernel", i32), ("rowscale", vp), ("branch_scale", f32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
         ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("colsum", vp),
+        ("ln_weight", vp), ("ln_bias", vp), ("ln_out", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32),
     ]
 
 

@@ -1014,6 +1014,8 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   }
 #endif
 
+  // ---- loop-invariant addresses
+  DmaSrcE sa = make_dma_src<TA>(g.A, g.lda, g.M, m0, kbeg, wave, l);
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1021,9 +1023,6 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // ---- loop-invariant addresses
-  DmaSrcE sa = make_dma_src<TA>(g.A, g.lda, g.M, m0, kbeg, wave, l);
   DmaSrcE sb = make_dma_src<TB>(g.B, g.ldb, g.N, n0, kbeg, wave, l);
   const int krem = KT ? (g.K & (BK - 1)) : 0;        // valid k of the last tile (0: the last tile is whole)
   bool ztail[2] = {false, false};                    // KT: this lane's piece j of an A half lies past K in the last tile
@@ -1478,8 +1477,19 @@ int launch_epi(const GemmArgs& g, int epi, bool vec, dim3 grid, hipStream_t st) 
 
 }  // namespace
 
+extern "C" int lt_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean, float* rstd, int rows, int D,
+                                float eps, void* stream);
+static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream);
 extern "C" int lt_gemm_bf16(const lt_gemm_desc* d, void* stream) {
   LT_CHECK_ARG(d != nullptr, "lt_gemm_bf16: null descriptor");
+  const bool want_ln = d->ln_out != nullptr;
+  LT_CHECK_ARG(!want_ln || (d->epilogue == LT_EPI_RESID && d->ln_weight && d->ln_bias && d->batch <= 1 && d->ldc == d->N),
+               "lt_gemm_bf16: the fused LayerNorm needs the residual epilogue, its weight and bias, and densely stored output rows");
+  const int rc = gemm_bf16_impl(d, stream);
+  if (rc != LT_OK || !want_ln || d->M == 0) return rc;
+  return lt_layernorm_fwd((const float*)d->C, d->ln_weight, d->ln_bias, d->ln_out, nullptr, d->ln_mean, d->ln_rstd, d->M, d->N, d->ln_eps, stream);
+}
+static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
   LT_CHECK_ARG(d->M >= 0 && d->N > 0 && d->K > 0, "lt_gemm_bf16: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   if (d->M == 0) return LT_OK;
   LT_CHECK_ARG(d->A && d->B && d->C, "lt_gemm_bf16: null operand");

@@ -3,7 +3,7 @@ allocations and the HIP stream; every arithmetic op below runs in liblt_amd.so."
 from __future__ import annotations
 
 import ctypes as C
-from typing import Any, Optional
+from typing import Dict, Any, Any, Optional
 
 import torch
 from torch import Tensor
@@ -115,7 +115,7 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
          alpha: float = 1.0, split_k: int = 1, lda: Optional[int] = None, ldb: Optional[int] = None,
          ldc: Optional[int] = None, force_kernel: int = 0, workspace: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, branch_scale: float = 1.0, batch: int = 1, stride_a: int = 0, stride_b: int = 0,
-         stride_c: int = 0, colsum: Optional[Tensor] = None) -> Tensor:
+         stride_c: int = 0, colsum: Optional[Tensor] = None, ln: Optional[Dict[str, Any]] = None) -> Tensor:
     """out[M,N] = op(a) @ op(b)^T-like contraction, see lt_gemm_bf16 in include/lt_amd.h.  batch > 1: that many independent
     problems, operands `stride_*` elements apart (plain epilogues of the 128x128 kernel).  colsum (weight gradients, trans_a): f32 [M]
     += the column sums of the stored A = dY, i.e. the bias gradient of the same Linear, taken from the fragments the kernel holds."""
@@ -147,6 +147,9 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, M: int, N: int, K: int, trans_a: 
     if colsum is not None:
         _chk(colsum, torch.float32, "gemm.colsum")
     d.colsum = _p(colsum)
+    if ln is not None:   # EPI_RESID: the next LayerNorm behind the GEMM -- dict(weight, bias, out bf16 [M, N], mean, rstd, eps); see lt_gemm_desc
+        _chk(ln["out"], torch.bfloat16, "gemm.ln.out")
+        d.ln_weight, d.ln_bias, d.ln_out, d.ln_mean, d.ln_rstd, d.ln_eps = _p(ln["weight"]), _p(ln["bias"]), _p(ln["out"]), _p(ln.get("mean")), _p(ln.get("rstd")), ln["eps"]
     check(_lib.load().lt_gemm_bf16(C.byref(d), _stream()), "lt_gemm_bf16")
     return out
 

@@ -334,6 +334,9 @@ class ViTEngine:
         self._resize_taps: Dict[Tuple[int, int, int, int], Any] = {}
         self._fwd_graphs: Dict[Any, Dict[str, Any]] = {}
         self.graph_forward = os.environ.get("LT_GRAPH_FWD", "0") != "0"   # HIP-graph replay of the static forward blocks (`_graphed_blocks`)
+        # the LayerNorm behind a residual GEMM handed to the GEMM call (lt_gemm_desc.ln_*; round 6: the library issues the LayerNorm launch, one
+        # call across the C ABI instead of two).  LT_FUSE_LN=0: separate calls from here -- same launches, same bits
+        self.fuse_ln = os.environ.get("LT_FUSE_LN", "1") != "0" and not self.graph_forward
         D = cfg.embed_dim
         kreal = cfg.in_chans * cfg.patch_size ** 2
         self.kreal = kreal
@@ -568,9 +571,17 @@ class ViTEngine:
             br.update(mode="subset", rows=Ts, nb=sb, x=xs, idx=idx, scale=B / sb)
             return br
 
-        def run_block(i: int, x: Tensor, prefix: str, save: bool, keep_out: bool):
+        def ln1_buffers(prefix: str) -> Dict[str, Any]:
+            """Where a block keeps its first LayerNorm (operand of the qkv GEMM and of its weight gradient, row statistics for backward)."""
+            return dict(out=ws.get(prefix + "ln1", (T, D), torch.bfloat16, pad_rows=64), mean=ws.get(prefix + "mean1", (T,), torch.float32),
+                        rstd=ws.get(prefix + "rstd1", (T,), torch.float32))
+
+        def run_block(i: int, x: Tensor, prefix: str, save: bool, keep_out: bool, ln1_done: bool = False, next_ln: Optional[Dict[str, Any]] = None):
             """One transformer block.  `prefix`: workspace names of its saved activations; `keep_out`: give the block output its
-            own per-block buffer (it is the next block's input: the only activation kept under activation checkpointing)."""
+            own per-block buffer (it is the next block's input: the only activation kept under activation checkpointing).
+            Round 6 -- the LayerNorm that follows a residual GEMM is handed to the GEMM call (lt_gemm_desc.ln_*: the library issues it; a kernel
+            that normalised inside the GEMM was measured slower, profiles/r06_rowln_probe.md): norm2 behind the attention projection, and the
+            NEXT block's norm1 behind fc2 (`next_ln`: that block's buffers and parameters; it is then called with `ln1_done`)."""
             s = prefix
             pre = f"blocks.{i}."
             g1 = self.w(pre + "ls1.gamma") if self.has(pre + "ls1.gamma") else None
@@ -582,9 +593,13 @@ class ViTEngine:
             # ---------------- attention branch
             a = branch_setup(e1, s, "a", x, 2 * i)
             R, nb = a["rows"], a["nb"]
-            ln1 = ws.get(s + "ln1", (T, D), torch.bfloat16, pad_rows=64)
-            a["mean"], a["rstd"] = ws.get(s + "mean1", (T,), torch.float32), ws.get(s + "rstd1", (T,), torch.float32)
-            ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"], eps=cfg.ln_eps)
+            lb1 = ln1_buffers(s)
+            ln1 = lb1["out"]
+            a["mean"], a["rstd"] = lb1["mean"], lb1["rstd"]
+            if not ln1_done:
+                ops.layernorm_fwd(a["x"], self.w(pre + "norm1.weight"), self.w(pre + "norm1.bias"), R, D, y_bf16=ln1, mean=a["mean"], rstd=a["rstd"], eps=cfg.ln_eps)
+            else:
+                assert a["mode"] == "plain"
             qkv = ws.get(s + "qkv", (T, 3 * D), torch.bfloat16)
             ops.gemm(ln1, self.wb(pre + "attn.qkv.weight"), qkv, M=R, N=3 * D, K=D, epilogue=ops.EPI_BF16, bias=self.w(pre + "attn.qkv.bias"))
             att = ws.get(s + "att", (T, D), torch.bfloat16, pad_rows=64)
@@ -593,6 +608,7 @@ class ViTEngine:
                 ops.rope_apply(qkv, rope[i][0], rope[i][1], nb, N, Hh, dh, 1 + n_reg)
             ops.attention_fwd(qkv, att, lse, nb, N, Hh, dh, scale)
             y1 = None   # the LayerScale gradient comes from the weight gradient (ops.layerscale_dgamma): no saved branch output
+            ln2_fused: Optional[Dict[str, Any]] = None
             if a["mode"] == "subset":
                 delta = ws.get(tag + ".delta", (T, D), torch.float32)
                 ops.gemm(att, self.wb(pre + "attn.proj.weight"), delta, M=R, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
@@ -619,14 +635,19 @@ class ViTEngine:
                 a["proj_rows"] = dict(idx=ridx, R=Rr, att_r=att_r)
             else:
                 xm = ws.get(s + "xm" if save else (tag + ".xb"), (T, D), torch.float32)
+                if e2 is None and self.fuse_ln:   # the MLP branch runs on every row: its LayerNorm rides behind the projection GEMM
+                    ln2_fused = dict(weight=self.w(pre + "norm2.weight"), bias=self.w(pre + "norm2.bias"), eps=cfg.ln_eps,
+                                     out=ws.get(s + "ln2", (T, D), torch.bfloat16, pad_rows=64), mean=ws.get(s + "mean2", (T,), torch.float32),
+                                     rstd=ws.get(s + "rstd2", (T,), torch.float32))
                 ops.gemm(att, self.wb(pre + "attn.proj.weight"), xm, M=T, N=D, K=D, epilogue=ops.EPI_RESID, bias=self.w(pre + "attn.proj.bias"),
-                         gamma=g1, resid=x, out2=y1, rowscale=a["rowscale"])
+                         gamma=g1, resid=x, out2=y1, rowscale=a["rowscale"], ln=ln2_fused)
             # ---------------- MLP branch
             m = branch_setup(e2, s, "m", xm, 2 * i + 1)
             R2 = m["rows"]
             ln2 = ws.get(s + "ln2", (T, D), torch.bfloat16, pad_rows=64)
             m["mean"], m["rstd"] = ws.get(s + "mean2", (T,), torch.float32), ws.get(s + "rstd2", (T,), torch.float32)
-            ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"], eps=cfg.ln_eps)
+            if ln2_fused is None:
+                ops.layernorm_fwd(m["x"], self.w(pre + "norm2.weight"), self.w(pre + "norm2.bias"), R2, D, y_bf16=ln2, mean=m["mean"], rstd=m["rstd"], eps=cfg.ln_eps)
             act = ws.get(s + "act", (T, hid), torch.bfloat16, pad_rows=64)
             if cfg.swiglu:   # w12 -> silu(x1) * x2 -> w3
                 hpre = ws.get(s + "hpre", (T, 2 * hid), torch.bfloat16)
@@ -645,7 +666,9 @@ class ViTEngine:
             else:
                 xo = ws.get(f"{tag}.b{i}.xo" if keep_out else (tag + ".xa"), (T, D), torch.float32)
                 ops.gemm(act, self.wb(pre + fc2 + ".weight"), xo, M=T, N=D, K=hid, epilogue=ops.EPI_RESID, bias=self.w(pre + fc2 + ".bias"),
-                         gamma=g2, resid=xm, out2=y2, rowscale=m["rowscale"])
+                         gamma=g2, resid=xm, out2=y2, rowscale=m["rowscale"], ln=next_ln)
+                next_ln = None     # consumed: the next block's norm1 is in its buffers
+            assert next_ln is None, "the caller asked for the next block's LayerNorm behind an fc2 GEMM that does not run on every row"
             a.update(ln=ln1, qkv=qkv, att=att, lse=lse, y=y1)
             m.update(ln=ln2, act=act, hpre=hpre, y=y2)
             return xo, a, m
@@ -676,7 +699,16 @@ class ViTEngine:
             x, gblocks = self._graphed_blocks(tag, x, save, n_graph, run_block)
             if save:
                 blocks.extend(gblocks)
+        ln1_done = False
         for i in range(n_graph, cfg.depth):
+            # the NEXT block's norm1 behind this block's fc2 GEMM: both on every row (no stochastic-depth draw on either branch, not the last
+            # block's loss-row MLP), buffers of the next block's prefix
+            nxt = None
+            if (self.fuse_ln and not (save and checkpoint) and n_graph == 0 and i + 1 < cfg.depth and not cap_set
+                    and (drop_plan is None or (drop_plan[2 * i + 1] is None and drop_plan[2 * (i + 1)] is None))
+                    and not (i == cfg.depth - 1 and last_mlp_rows is not None)):
+                nb_ = ln1_buffers(f"{tag}.b{i + 1}." if save else f"{tag}.tmp.")
+                nxt = dict(weight=self.w(f"blocks.{i + 1}.norm1.weight"), bias=self.w(f"blocks.{i + 1}.norm1.bias"), eps=cfg.ln_eps, **nb_)
             if save and checkpoint:
                 # activation checkpointing (reference _activation_checkpointing.py): keep only the block input, recompute the
                 # block in backward.  Subset stochastic depth updates x in place, so the input is copied aside first.
@@ -689,7 +721,8 @@ class ViTEngine:
                     block_in.append(x)
                 x, _, _ = run_block(i, x, f"{tag}.ck.", False, True)
             else:
-                x, a_, m_ = run_block(i, x, f"{tag}.b{i}." if save else f"{tag}.tmp.", save, save)
+                x, a_, m_ = run_block(i, x, f"{tag}.b{i}." if save else f"{tag}.tmp.", save, save, ln1_done=ln1_done, next_ln=nxt)
+                ln1_done = nxt is not None
                 if save:
                     blocks.append({"attn": a_, "mlp": m_})
             if i in cap_set:

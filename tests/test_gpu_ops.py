@@ -1096,3 +1096,40 @@ def test_comm_handle_single_rank_allreduce_is_ordered_with_the_streams():
     finally:
         comm.destroy()
     assert comm.lib.lt_comm_size() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (2500, 768, 3072), (2048, 384, 384), (4099, 1024, 1024), (300, 768, 768), (2304, 768, 200)])
+def test_residual_gemm_with_the_next_layernorm_behind_it(M, N, K):
+    """lt_gemm_desc.ln_* (round 6): LT_EPI_RESID with the next LayerNorm handed to the GEMM call -- the library issues lt_layernorm_fwd behind
+    the GEMM, whichever kernel took it (256-row static-address kernel, 128-row kernel at M = 300, partial K-tile at K = 200).  Must equal
+    lt_gemm_bf16 followed by lt_layernorm_fwd BIT FOR BIT: the fp32 residual stream, the bf16 operand, mean and rstd; ragged row counts,
+    N = 384, 768, 1024.  (LT_GEMM_ROWLN is no longer read: the row-owning kernel mode it switched was removed, profiles/r06_rowln_probe.md.)"""
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    lw, lb = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
+    ref_x = torch.empty(M, N, device=DEV)
+    o.gemm(A, W, ref_x, M=M, N=N, K=K, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid)
+    ref_y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); ref_m = torch.empty(M, device=DEV); ref_r = torch.empty(M, device=DEV)
+    o.layernorm_fwd(ref_x, lw, lb, M, N, y_bf16=ref_y, mean=ref_m, rstd=ref_r, eps=1e-6)
+    for env in (None, "0"):
+        if env is None:
+            os.environ.pop("LT_GEMM_ROWLN", None)
+        else:
+            os.environ["LT_GEMM_ROWLN"] = env
+        try:
+            x = torch.full((M, N), float("nan"), device=DEV)
+            y = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16); mu = torch.zeros(M, device=DEV); rs = torch.zeros(M, device=DEV)
+            o.gemm(A, W, x, M=M, N=N, K=K, epilogue=o.EPI_RESID, bias=bias, gamma=gamma, resid=resid, ln=dict(weight=lw, bias=lb, out=y, mean=mu, rstd=rs, eps=1e-6))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("LT_GEMM_ROWLN", None)
+        assert torch.equal(x, ref_x), env
+        assert torch.equal(y, ref_y) and torch.equal(mu, ref_m) and torch.equal(rs, ref_r), env
+    ref = resid + gamma * (A.float() @ W.float().t() + bias)
+    assert rel_err(ref_x, ref) < 1e-5
+    assert rel_err(ref_y, F.layer_norm(ref, (N,), lw, lb, 1e-6)) < 8e-3

@@ -66,6 +66,9 @@ def emulate(ops):
             bs = kw.get("branch_scale", 1.0) or 1.0
             base = kw["resid"].reshape(-1, N)[:M].float() if kw.get("resid") is not None else 0.0
             o2[:M, :N] = (base + bs * br).to(out.dtype)
+            if kw.get("ln") is not None:               # the next LayerNorm behind the residual GEMM (lt_gemm_desc.ln_*): GEMM + lt_layernorm_fwd
+                ln = kw["ln"]
+                layernorm_fwd(o2[:M, :N], ln["weight"], ln["bias"], M, N, y_bf16=ln["out"], mean=ln.get("mean"), rstd=ln.get("rstd"), eps=ln["eps"])
         else:
             assert epilogue in (ops.EPI_BF16, ops.EPI_F32), epilogue
             o2[:M, :N] = r.to(out.dtype)
