@@ -1003,6 +1003,13 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   const int l = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
   const int wm = wave >> 2, wn = wave & 3;
+  if (g.stagger > 0) {
+    const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (L_ < 256 && (L_ & 8)) {
+      const unsigned long long t0_ = wall_clock64();
+      while (wall_clock64() - t0_ < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   LT_TSTAMP(0);
 #ifdef LT_GEMM_TIMING
   if (threadIdx.x == 0) {
@@ -1282,6 +1289,161 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
 #endif
 }
 
+// ---- 128-row tiles for the LAST, partly filled round of a 256-row launch (round 6) --------------------------------------------------------
+// The N = 768 GEMMs of a ViT-B pass (attention projection, fc2, three data gradients) are 591 tiles of 256 x 256 on 256 CUs: 2.31 rounds, the
+// third 31 % full.  The dispatcher gives the first two rounds to gemm256e_kernel and the remaining tile rows to this kernel as 128 x 256
+// tiles (158 workgroups of half the work: one short round instead of a long, mostly empty one).  Same LDS images, fragment reads, static
+// addressing and epilogues as the e kernel; per accumulator the same MFMA order over k (bit-identical results).  What differs:
+//   * 8 waves as 2 (M) x 4 (N), wave tile 64 x 64 (64 accumulator registers), ONE A half-tile (128 rows) + two B half-tiles per K-tile;
+//   * THREE LDS stages of 48 KiB and one phase of 16 MFMAs per K-tile: the loads of tile t + 2 are issued in the load segment of tile t (its
+//     stage held tile t - 1, whose reads were retired before the previous phase's barrier) and waited for one whole tile later (vmcnt(6) in
+//     the load segment of tile t + 1's predecessor), i.e. the same one-K-tile slack as the 256-row kernel's;
+//   * the second wave of a SIMD is staggered by one barrier as there, so one wave's MFMA segment runs beside its partner's load segment.
+// Forward / dgrad layouts (A K-contiguous), K % 64 == 0, no split-K.
+template <bool TB, int EPI>
+__global__ __launch_bounds__(NT2) void gemm128e_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HB = 128 * 128;            // one half-tile buffer; buffer index = half * 3 + stage (halves: A0 B0 B1)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int id;
+  {
+    const int L = (int)blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = L & 7, j = L >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / g.tiles_n, tn = id % g.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int nk = g.K / BK;
+  const int l = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  DmaSrcE sa = make_dma_src<false>(g.A, g.lda, g.M, m0, 0, wave, l);
+  DmaSrcE sb = make_dma_src<TB>(g.B, g.ldb, g.N, n0, 0, wave, l);
+  unsigned ab[4], bb[4];
+  {
+    const unsigned b_half = (unsigned)((1 + (wn >> 1)) * 3) * HB;
+    const int bcol = (wn & 1) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ab[ks] = (unsigned)(wm * 2) * 4096 + (l & 31) * 128 + ((((ks * 2 + (l >> 5)) ^ (((l & 31) >> 1) & 7))) << 4);
+    if (!TB) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bb[ks] = b_half + bcol * 4096 + (l & 31) * 128 + ((((ks * 2 + (l >> 5)) ^ (((l & 31) >> 1) & 7))) << 4);
+    } else {
+      const int i = l & 15, cb = (l >> 4) & 1, kh = l >> 5;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) bb[p] = b_half + bcol * 256 + kh * 2048 + cb * 128 + ((((i >> 2) + cb + 2 * p) & 3) << 5) + ((i & 3) << 3);
+      bb[2] = bb[3] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(ab[k])); asm volatile("" : "+v"(bb[k])); asm volatile("" : "+v"(sa.voff[k])); asm volatile("" : "+v"(sb.voff[k])); }
+  }
+  const int lds_w = wave * 2048;
+
+  // K-tile TILE into stage ST: the A half-tile and both B half-tiles (6 DMA instructions per wave)
+#define LT_S_DMA(TILE, ST)                                                                                                 \
+  do {                                                                                                                     \
+    const int sa_ = (TILE) * sa.tile_step, sb_ = (TILE) * sb.tile_step + sb.wave_off;                                      \
+    char* da_ = smem + (ST) * HB + lds_w;                                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.srd, (lptr_t*)da_, 16, sa.voff[0], sa_, 0, 0);                             \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sa.srd, (lptr_t*)(da_ + 1024), 16, sa.voff[1], sa_, 0, 0);                    \
+    _Pragma("unroll") for (int hh_ = 0; hh_ < 2; ++hh_) {                                                                  \
+      char* db_ = smem + ((1 + hh_) * 3 + (ST)) * HB + lds_w;                                                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.srd, (lptr_t*)db_, 16, TB ? sb.voff[hh_] : sb.voff[hh_ * 2], sb_, 0, 0);  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sb.srd, (lptr_t*)(db_ + 1024), 16, TB ? sb.voff[hh_] : sb.voff[hh_ * 2 + 1], sb_ + sb.jstep, 0, 0); \
+    }                                                                                                                      \
+  } while (0)
+
+  if (nk > 0) LT_S_DMA(0, 0);
+  if (nk > 1) { LT_S_DMA(1, 1); __builtin_amdgcn_s_waitcnt(0xF76); }   // vmcnt(6): tile 0 landed
+  else __builtin_amdgcn_s_waitcnt(0xF70);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of each SIMD by one barrier
+
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+  // one K-tile in stage ST (a literal), NXT = the stage tile T + 2 goes to
+#define LT_S_TILE(T, ST, NXT)                                                                                              \
+  do {                                                                                                                     \
+    lds_frag4<TB, (ST) * HB, 0>(fb0, bb);                                                                                  \
+    lds_frag4<TB, (ST) * HB, 1>(fb1, bb);                                                                                  \
+    lds_frag4<false, (ST) * HB, 0>(fa[0], ab);                                                                             \
+    lds_frag4<false, (ST) * HB, 1>(fa[1], ab);                                                                             \
+    if ((T) + 2 < nk) { LT_S_DMA((T) + 2, (NXT)); __builtin_amdgcn_s_waitcnt(0xF76); }   /* tile T + 1 landed */             \
+    else __builtin_amdgcn_s_waitcnt(0xF70);                                                                                \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                    \
+    asm volatile("" ::: "memory");                                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                          \
+    asm volatile("" ::: "memory");                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb0[ks], acc[i][0], 0, 0, 0);                         \
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb1[ks], acc[i][1], 0, 0, 0);                         \
+    }                                                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                         \
+    asm volatile("" ::: "memory");                                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                          \
+    asm volatile("" ::: "memory");                                                                                         \
+  } while (0)
+  int t = 0;
+  for (; t + 2 < nk; t += 3) {
+    LT_S_TILE(t, 0, 2);
+    LT_S_TILE(t + 1, 1, 0);
+    LT_S_TILE(t + 2, 2, 1);
+  }
+  if (t < nk) LT_S_TILE(t, 0, 2);
+  if (t + 1 < nk) LT_S_TILE(t + 1, 1, 0);
+#undef LT_S_TILE
+#undef LT_S_DMA
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        wl[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 64 + j * 32 + (l & 31)] = acc[ii][j][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  emit_subtile<EPI>(g, wl, m0 + wm * 64, n0 + wn * 64, l, false);
+}
+constexpr int LDS_BYTES_S = 9 * 128 * 128;   // three stages x (A0 + B0 + B1) x 16 KiB
+template <bool TB, int EPI>
+int launch_s_one(const GemmArgs& g, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128e_kernel<TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_S);
+    if (e != hipSuccess) { lt_set_error("lt_gemm_bf16: cannot enable 144 KiB LDS: %s", hipGetErrorString(e)); return LT_ERR_HIP; }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm128e_kernel<TB, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(NT2), LDS_BYTES_S, st, g);
+  return LT_OK;
+}
+template <bool TB>
+int launch_s(const GemmArgs& g, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_s_one<TB, EPI_BF16>(g, st);
+    case EPI_BF16_GELU: return launch_s_one<TB, EPI_BF16_GELU>(g, st);
+    case EPI_RESID: return launch_s_one<TB, EPI_RESID>(g, st);
+    case EPI_F32: return launch_s_one<TB, EPI_F32>(g, st);
+    case EPI_BF16_GELUGRAD: return launch_s_one<TB, EPI_BF16_GELUGRAD>(g, st);
+    default: lt_set_error("lt_gemm_bf16: no 128-row tail kernel for epilogue %d", epi); return LT_ERR_INVALID;
+  }
+}
+
 template <bool TA, bool TB, int EPI, bool SLAB, bool CS, int PH, bool KT = false>
 int launch_e_ph(const GemmArgs& g, dim3 grid, hipStream_t st) {
   static bool configured = false;
@@ -1509,6 +1671,7 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
   g.alpha = d->alpha;
   g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
   g.band = 0;
+  g.stagger = 0;
   g.cs = nullptr;
   // column sums of the transposed A operand (bias gradient beside a weight gradient): fused into the four-phase slab kernel below when
   // it is the kernel that runs and the reduction ledger is open; every other path starts with the stand-alone column-sum launch
@@ -1615,6 +1778,7 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
       g.band = (!d->trans_a && g.tiles_n >= 8 && nb > 0 && (env_b || g.tiles_n % nb == 0)) ? nb : 0;
     }
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
+    { const char* env_sg = getenv("LT_GEMM_STAGGER_NS"); g.stagger = env_sg ? atoi(env_sg) / 10 : 0; }
     static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
     const bool q_kernel = bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || d->force_kernel == 11 || use_q);
     if (cs_pending && q_kernel && slab && d->trans_a && d->trans_b) {
@@ -1637,6 +1801,41 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
     const bool e_fits = (d->trans_a ? (size_t)g.k_per_split * d->lda : (size_t)256 * d->lda + d->K) * 2 < 0x7fffffffull &&
                         (d->trans_b ? (size_t)g.k_per_split * d->ldb : (size_t)256 * d->ldb + d->K) * 2 < 0x7fffffffull;
     const bool e_kernel = q_kernel && d->K % BK == 0 && e_fits && d->force_kernel != 8 && (d->force_kernel == 11 || !env_e || atoi(env_e) != 0);
+    // the partly filled last round as 128-row tiles (gemm128e_kernel; LT_GEMM_TAIL128=0, read per call: one 256-row launch as before): when the
+    // 256 x 256 tiles are not a multiple of the CU count and the tile rows left after the full rounds fit ONE round of 128 x 256 tiles, the
+    // full rounds go to the e kernel and the remaining rows to the tail kernel -- N = 768 at 50 432 rows: 510 + 162 workgroups instead of
+    // 591 (2.31 rounds -> 2 + a short one)
+    bool tail128 = false;
+    int big_rows = g.tiles_m;
+    if (e_kernel && !d->trans_a && sp == 1 && !slab && d->epilogue != LT_EPI_F32_ACCUM) {
+      const char* env_t = getenv("LT_GEMM_TAIL128");
+      const long tiles = (long)g.tiles_m * g.tiles_n, full = tiles / cus;
+      if ((!env_t || atoi(env_t) != 0) && full >= 1 && tiles % cus != 0) {
+        const int br = (int)(full * cus / g.tiles_n);
+        const int rem = d->M - br * 256;
+        if (br >= 1 && rem > 0 && (long)lt_cdiv(rem, 128) * g.tiles_n <= cus) { tail128 = true; big_rows = br; }
+      }
+    }
+    if (tail128) {
+      GemmArgs gb = g;
+      gb.tiles_m = big_rows;
+      if (!(gb.band > 0 && gb.tiles_n >= 8)) gb.band = 0;
+      dim3 gridb(gb.tiles_m * gb.tiles_n, 1);
+      rc = d->trans_b ? g256::launch_e<false, true>(gb, d->epilogue, false, gridb, st) : g256::launch_e<false, false>(gb, d->epilogue, false, gridb, st);
+      if (rc != LT_OK) return rc;
+      GemmArgs gs = g;
+      const size_t r0 = (size_t)big_rows * 256;
+      gs.A = g.A + r0 * g.lda;
+      gs.C = f32out ? (void*)((float*)g.C + r0 * g.ldc) : (void*)((bf16_t*)g.C + r0 * g.ldc);
+      if (g.C2) gs.C2 = (bf16_t*)g.C2 + r0 * g.ldc2;
+      if (g.resid) gs.resid = g.resid + r0 * g.ldr;
+      if (g.aux) gs.aux = g.aux + r0 * g.ldaux;
+      if (g.rowscale) gs.rowscale = g.rowscale + r0;
+      gs.M = d->M - (int)r0;
+      gs.tiles_m = lt_cdiv(gs.M, 128);
+      gs.band = 0;
+      rc = d->trans_b ? g256::launch_s<true>(gs, d->epilogue, st) : g256::launch_s<false>(gs, d->epilogue, st);
+    } else
     if (e_kernel) {
       if (!d->trans_a && !d->trans_b) rc = g256::launch_e<false, false>(g, d->epilogue, slab, grid2, st);
       else if (!d->trans_a) rc = g256::launch_e<false, true>(g, d->epilogue, slab, grid2, st);

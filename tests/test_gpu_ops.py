@@ -1133,3 +1133,52 @@ def test_residual_gemm_with_the_next_layernorm_behind_it(M, N, K):
     ref = resid + gamma * (A.float() @ W.float().t() + bias)
     assert rel_err(ref_x, ref) < 1e-5
     assert rel_err(ref_y, F.layer_norm(ref, (N,), lw, lb, 1e-6)) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,tb,epi", [(50432, 768, 768, False, "resid"), (50432, 768, 3072, True, "bf16"), (25216, 768, 768, False, "bf16"), (50000, 768, 768, True, "f32"),
+                                          (50432, 3072, 768, False, "gelu"), (50432, 3072, 768, True, "gelugrad"), (51200, 768, 2304, True, "bf16"), (66000, 768, 192, False, "resid")])
+def test_last_round_as_128_row_tiles_is_bit_identical(M, N, K, tb, epi):
+    """gemm128e_kernel (round 6): when the 256 x 256 tiles of a forward / dgrad GEMM leave a partly filled last round that fits one round of
+    128 x 256 tiles, the dispatcher gives the full rounds to the 256-row kernel and the remaining rows to the 128-row tail kernel.  Same
+    per-accumulator MFMA order: every output must equal the single 256-row launch (LT_GEMM_TAIL128=0) BIT FOR BIT -- all five epilogues,
+    both B layouts, ragged row counts (50 000: the last tile row partial; 66 000: 258 tile rows)."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b_in = W.t().contiguous() if tb else W
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    kw = {}
+    f32 = epi in ("resid", "f32")
+    if epi == "resid":
+        kw = dict(epilogue=o.EPI_RESID, bias=bias, gamma=(torch.rand(N, generator=g) + 0.5).to(DEV), resid=torch.randn(M, N, generator=g).to(DEV),
+                  rowscale=torch.rand(M, generator=g).to(DEV))
+    elif epi == "f32":
+        kw = dict(epilogue=o.EPI_F32, bias=bias)
+    elif epi == "bf16":
+        kw = dict(epilogue=o.EPI_BF16, bias=bias)
+    elif epi == "gelu":
+        kw = dict(epilogue=o.EPI_BF16_GELU, bias=bias)
+    else:
+        kw = dict(epilogue=o.EPI_BF16_GELUGRAD, aux=bf(torch.randn(M, N, generator=g)).to(DEV))
+    outs = []
+    for env in ("0", None):
+        if env is None:
+            os.environ.pop("LT_GEMM_TAIL128", None)
+        else:
+            os.environ["LT_GEMM_TAIL128"] = env
+        try:
+            out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+            out2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16) if epi in ("gelu", "resid") else None
+            o.gemm(A, b_in, out, M=M, N=N, K=K, trans_b=tb, out2=out2, **kw)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("LT_GEMM_TAIL128", None)
+        outs.append((out, out2))
+    assert not torch.isnan(outs[1][0].float()).any()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = A[:512].float() @ W.float().t()
+    if epi == "f32":
+        assert rel_err(outs[1][0][:512], ref + bias) < 1e-5

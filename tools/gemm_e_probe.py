@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--lib", type=int, default=1)
-ap.add_argument("--kernels", default="8,11p4,11")
+ap.add_argument("--kernels", default="8,11t0,11")
 ap.add_argument("--quick", type=int, default=0)
 a = ap.parse_args()
 KERNELS = a.kernels.split(",")     # "8", "11" (two phases per K-tile, the default), "11p4" (= force_kernel 11 with LT_GEMM_E_PH=4)
@@ -31,12 +31,16 @@ def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
 
 
 def call(spec, f):
-    """spec "11p4": force_kernel 11 under LT_GEMM_E_PH=4 (the library reads the variable per call)."""
-    fk, _, ph = spec.partition("p")
-    if ph:
-        os.environ["LT_GEMM_E_PH"] = ph
-    else:
-        os.environ.pop("LT_GEMM_E_PH", None)
+    """spec "11p4": force_kernel 11 under LT_GEMM_E_PH=4; "11t0": without the 128-row tail kernel (LT_GEMM_TAIL128=0); "11s8000": every second
+    first-round workgroup starts 8000 ns late (LT_GEMM_STAGGER_NS).  The library reads the variables per call."""
+    import re
+    m = re.match(r"^(\d+)(?:p(\d))?(t0)?(?:s(\d+))?$", spec)
+    fk, ph, t0, sg = m.group(1), m.group(2), m.group(3), m.group(4)
+    for var, val in (("LT_GEMM_E_PH", ph), ("LT_GEMM_TAIL128", "0" if t0 else None), ("LT_GEMM_STAGGER_NS", sg)):
+        if val:
+            os.environ[var] = val
+        else:
+            os.environ.pop(var, None)
     return f(int(fk))
 
 
