@@ -1003,13 +1003,6 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
   const int l = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: everything derived from it stays scalar
   const int wm = wave >> 2, wn = wave & 3;
-  if (g.stagger > 0) {
-    const int L_ = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-    if (L_ < 256 && (L_ & 8)) {
-      const unsigned long long t0_ = wall_clock64();
-      while (wall_clock64() - t0_ < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
-    }
-  }
   LT_TSTAMP(0);
 #ifdef LT_GEMM_TIMING
   if (threadIdx.x == 0) {
@@ -1671,7 +1664,6 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
   g.alpha = d->alpha;
   g.sa = d->stride_a; g.sb = d->stride_b; g.sc = d->stride_c;
   g.band = 0;
-  g.stagger = 0;
   g.cs = nullptr;
   // column sums of the transposed A operand (bias gradient beside a weight gradient): fused into the four-phase slab kernel below when
   // it is the kernel that runs and the reduction ledger is open; every other path starts with the stand-alone column-sum launch
@@ -1778,7 +1770,6 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
       g.band = (!d->trans_a && g.tiles_n >= 8 && nb > 0 && (env_b || g.tiles_n % nb == 0)) ? nb : 0;
     }
     dim3 grid2(g.tiles_m * g.tiles_n, sp);
-    { const char* env_sg = getenv("LT_GEMM_STAGGER_NS"); g.stagger = env_sg ? atoi(env_sg) / 10 : 0; }
     static const int use_q = [] { const char* e = getenv("LT_GEMM_Q"); return e ? atoi(e) : 1; }();  // LT_GEMM_Q=0: fall back to the 2-stage K-loop
     const bool q_kernel = bn == 256 && d->force_kernel != 2 && (d->force_kernel == 8 || d->force_kernel == 11 || use_q);
     if (cs_pending && q_kernel && slab && d->trans_a && d->trans_b) {

@@ -26,7 +26,6 @@ struct GemmArgs {
   int tiles_m, tiles_n, k_per_split;
   int band;         // four-phase kernel: column tiles per band of the tile order (0 / >= tiles_n: plain row-major order)
   long sa, sb, sc;  // batched launch (gridDim.z > 1) of the 128x128 kernel: element strides of A, B, C between batch entries
-  int stagger;      // e kernel: every second first-round workgroup of an XCD starts this many 10-ns ticks late (0: off)
   float* cs;        // four-phase slab kernel with CS: per-(slice, column tile, wave column) partial sums over k of the transposed A operand,
                     // [gridDim.y * tiles_n * 4][M] floats (the bias gradient of the Linear whose weight gradient this GEMM forms)
 };

@@ -45,6 +45,39 @@ if len(sys.argv) > 1 and sys.argv[1] == "ab":   # python tools/attn_bench.py ab 
     for v in vals:
         print(f"{name}={v}: median {statistics.median(t[v]):7.1f} us  min {min(t[v]):7.1f}")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "abf":   # python tools/attn_bench.py abf B N SPEC SPEC ...: FORWARD at one shape; a SPEC is a comma-separated list
+    # of per-call switches (e.g. LT_ATTN_FWD_HPB=12,LT_ATTN_FWD_W=4; "-" = defaults) alternating launch by launch in one process; outputs compared
+    # with the first SPEC's bit for bit
+    import statistics
+    B, N, specs = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4:]
+    H, dh = 12, 64
+    qkv = torch.randn(B, N, 3 * H * dh, device="cuda").to(torch.bfloat16)
+    names = sorted({kv.split("=")[0] for sp in specs for kv in sp.split(",") if "=" in kv})
+    def apply(sp):
+        for n in names: os.environ.pop(n, None)
+        for kv in sp.split(","):
+            if "=" in kv: os.environ[kv.split("=")[0]] = kv.split("=")[1]
+    outs = {}
+    for sp in specs:
+        apply(sp)
+        out = torch.full((B, N, H * dh), float("nan"), device="cuda", dtype=torch.bfloat16); lse = torch.full((B, H, N), float("nan"), device="cuda")
+        ops.attention_fwd(qkv, out, lse, B, N, H, dh, dh ** -0.5); torch.cuda.synchronize()
+        outs[sp] = (out, lse)
+    t = {sp: [] for sp in specs}
+    out, lse = outs[specs[0]][0].clone(), outs[specs[0]][1].clone()
+    for i in range(25 * len(specs)):
+        sp = specs[i % len(specs)]
+        apply(sp)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention_fwd(qkv, out, lse, B, N, H, dh, dh ** -0.5)
+        e1.record(); torch.cuda.synchronize()
+        if i >= 5 * len(specs):
+            t[sp].append(e0.elapsed_time(e1) * 1e3)
+    for sp in specs:
+        same = bool(torch.equal(outs[sp][0], outs[specs[0]][0]) and torch.equal(outs[sp][1], outs[specs[0]][1]))
+        print(f"B={B} N={N} {sp:44s}: median {statistics.median(t[sp]):7.1f} us  min {min(t[sp]):7.1f}  bit-equal to the first: {same}")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "global":   # profiling runs: the global-crop shape only
     bench("global 224/16", 256, 197, iters=3)
     sys.exit(0)
