@@ -124,6 +124,7 @@ SIGNATURES: dict[str, list[Any]] = {
 }
 
 _lib: C.CDLL | None = None
+_recording: Any = None   # ops.record_plan(): a proxy of the library that also logs every launch it forwards (LaunchPlan)
 
 
 class LtAmdError(RuntimeError):
@@ -133,6 +134,8 @@ class LtAmdError(RuntimeError):
 def load() -> C.CDLL:
     """Load liblt_amd.so; raise loudly when it has not been built (python __graft_entry__.py build)."""
     global _lib
+    if _recording is not None:
+        return _recording
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):

@@ -490,6 +490,10 @@ class DINOv2:
         self.fwd_teacher_stream = int(os.environ.get("LT_FWD_TEACHER_STREAM", "1") != "0")
         # HIP-graph replay of the static blocks of the backward pass (`_backward_backbone`); the forward's switch lives on the ViT engines
         self.graph_backward = int(os.environ.get("LT_GRAPH_BWD", "0") != "0")
+        # launch-plan replay of the same static blocks (round 6, ops.LaunchPlan; the default): the calls across the C ABI and the event edges of
+        # blocks depth-2 .. 0 of both chains and the weight-gradient stream, logged on the third step of a geometry and replayed by a bare
+        # loop afterwards -- the launches, their order and their streams are the eager step's
+        self.plan_backward = int(os.environ.get("LT_PLAN_BWD", "1") != "0") and not self.graph_backward
         self._bwd_graph: Dict[str, Any] = {}
         self._graph_chain_stream: Optional["torch.cuda.Stream"] = None
         # one weight-gradient GEMM per layer for the global- and the local-crop pass (vit.JointWgrad): half the split-K slab traffic
@@ -746,9 +750,11 @@ class DINOv2:
             # in those blocks depends on the step (no stochastic-depth draws, no rotary draws, no early all-reduces, no recomputation).
             plain = lambda c: all(b[k]["mode"] == "plain" and b[k]["rowscale"] is None for b in c["blocks"][:-1] for k in ("attn", "mlp"))   # noqa: E731
             gkey = None
-            if (self.graph_backward and sync is None and depth > 1 and self.device.type == "cuda" and not self.activation_checkpointing
+            use_plan = bool(self.plan_backward) and not self.graph_backward and ops.plan_replay_enabled
+            if ((self.graph_backward or use_plan) and sync is None and depth > 1 and self.device.type == "cuda" and not self.activation_checkpointing
                     and sl.get("rope") is None and sl.get("block_in") is None and sg.get("block_in") is None and plain(sl) and plain(sg)):
-                gkey = (sg["T"], sl["T"], jw is not None, det, dxn_g.data_ptr(), dxn_l.data_ptr())
+                gkey = (sg["T"], sl["T"], jw is not None, det, dxn_g.data_ptr(), dxn_l.data_ptr(), ws.generation, use_plan,
+                        main.cuda_stream, lstream2.cuda_stream, side.cuda_stream)
             G = self._bwd_graph
             if gkey is None or G.get("key") != gkey:
                 G.clear()
@@ -801,12 +807,24 @@ class DINOv2:
                 boundary()
                 if replaying:
                     G["graph"].replay()
+                    G["replays"] = G.get("replays", 0) + 1
                 elif G["calls"] < 2 or dbg == "eager":   # first step of this geometry: the same structure, launched eagerly (allocates)
                     for _ in range(depth - 1):
                         one_iteration()
                     main.wait_stream(lstream2)
                     main.wait_stream(side)
                     after_static(main)
+                elif use_plan:                        # second step: the same launches on the same streams, logged as they are made
+                    with ops.record_plan() as lp:
+                        for _ in range(depth - 1):
+                            one_iteration()
+                        for c in (sl, sg):
+                            c["_bwd_consumed"].clear()
+                        main.wait_stream(lstream2)
+                        main.wait_stream(side)
+                        after_static(main)
+                    if ws.generation == gkey[6]:
+                        G["graph"] = lp
                 else:                                 # second step: capture, then run it
                     g = torch.cuda.CUDAGraph()
                     # The capture's ORIGIN is the weight-gradient stream; both dgrad chains are streams forked off it (the global-crop

@@ -35,6 +35,124 @@ def _chk(t: Tensor, dtype: torch.dtype, name: str) -> None:
         raise ValueError(f"{name}: expected contiguous device tensor of {dtype}, got {t.dtype} contiguous={t.is_contiguous()} cuda={t.is_cuda}")
 
 
+# ------------------------------------------------------------------------------------------ launch plans
+# The static part of a step (transformer blocks without stochastic-depth draws: the same kernels on the same buffers every step) is ~600 of
+# the step's ~930 calls across the C ABI, each preceded by Python that re-derives what it derived the step before (workspace look-ups,
+# descriptor fields, shape checks): 11 ms of launch-thread time per 80-ms step.  A LaunchPlan is the list of those calls as they were made
+# once -- the bound library function with its marshalled arguments, and the cross-stream event edges between them -- replayed by a loop
+# that does nothing else.  Unlike a HIP graph (measured: the ROCm 7.0 executor serialises the backward's three branches, +7 ms,
+# profiles/r05_graph_replay_ab.log) a replay issues the very same launches on the very same streams as the eager step: the device sees
+# no difference, results are bitwise equal by construction, and the library's host-side state (reduction ledger) runs as it does eagerly.
+_QUERY_CALLS = frozenset(("lt_last_error", "lt_abi_version", "lt_device_info", "lt_attention_bwd_ws_floats", "lt_batchnorm_ws_floats",
+                          "lt_reduce_overflows"))
+_EV_RECORD, _EV_WAIT = torch.cuda.Event.record, torch.cuda.Event.wait
+
+
+class LaunchPlan:
+    """ops: (0, library function, argument tuple) | (1, event, stream): record | (2, event, stream): wait | (3, callable, None)."""
+    __slots__ = ("ops",)
+
+    def __init__(self) -> None:
+        self.ops: list = []
+
+    def counts(self) -> Dict[str, int]:
+        c = {"launches": 0, "event_records": 0, "event_waits": 0, "callables": 0}
+        for k, _, _ in self.ops:
+            c[("launches", "event_records", "event_waits", "callables")[k]] += 1
+        return c
+
+    def replay(self) -> None:
+        for k, a, b in self.ops:
+            if k == 0:
+                rc = a(*b)
+                if rc:
+                    check(rc, a.__name__)
+            elif k == 1:
+                _EV_RECORD(a, b)
+            elif k == 2:
+                _EV_WAIT(a, b)
+            else:
+                a()
+
+
+class _RecordingLib:
+    """What `_lib.load()` returns while a plan is recorded: forwards every call to the library and logs it."""
+
+    def __init__(self, lib: Any, plan: LaunchPlan) -> None:
+        self._lib, self._plan, self._wrapped = lib, plan, {}
+
+    def __getattr__(self, name: str) -> Any:
+        fn = getattr(self._lib, name)
+        if name in _QUERY_CALLS:
+            return fn
+        w = self._wrapped.get(name)
+        if w is None:
+            plan = self._plan
+
+            def w(*args: Any, _fn: Any = fn) -> int:
+                rc = _fn(*args)
+                plan.ops.append((0, _fn, args))    # (ctypes.byref arguments keep their structure alive; ops.gemm builds a fresh one per call)
+                return rc
+            self._wrapped[name] = w
+        return w
+
+
+_active_plan: Optional[LaunchPlan] = None
+plan_replay_enabled = True    # process-wide switch (instrumented runs that wrap ops.* functions must see every call: bench.py's roofline leg)
+
+
+class record_plan:
+    """with ops.record_plan() as plan: the launches made inside run as usual AND are logged: calls across the C ABI through `_lib.load()`,
+    event records / waits through torch.cuda.Event (Stream.record_event / wait_event / wait_stream end there), other device work through
+    `ops.recordable`.  The caller guarantees that nothing inside depends on the step (same buffers, same sizes, same streams)."""
+    _saved: Any = (None, None)    # the two torch.cuda.Event methods as they were when the recording began
+
+    def __enter__(self) -> LaunchPlan:
+        global _active_plan
+        if _active_plan is not None:      # a recording that an exception cut short: drop it
+            record_plan.__exit__(self)
+        plan = LaunchPlan()
+
+        def rec(ev: Any, stream: Any = None) -> None:
+            stream = torch.cuda.current_stream() if stream is None else stream
+            _EV_RECORD(ev, stream)
+            plan.ops.append((1, ev, stream))
+
+        def wait(ev: Any, stream: Any = None) -> None:
+            stream = torch.cuda.current_stream() if stream is None else stream
+            _EV_WAIT(ev, stream)
+            plan.ops.append((2, ev, stream))
+
+        real = _lib.load()
+        record_plan._saved = (torch.cuda.Event.record, torch.cuda.Event.wait)
+        torch.cuda.Event.record, torch.cuda.Event.wait = rec, wait
+        _lib._recording = _RecordingLib(real, plan)
+        _active_plan = plan
+        return plan
+
+    def __exit__(self, *exc: Any) -> None:
+        global _active_plan
+        torch.cuda.Event.record, torch.cuda.Event.wait = record_plan._saved
+        _lib._recording = None
+        _active_plan = None
+
+
+def recordable(fn: Any) -> None:
+    """Device work that does not cross the C ABI (a torch fill of pad rows): run it, and log it when a plan is being recorded.  `fn` must
+    capture the stream it runs on itself if that is not the current stream at replay."""
+    fn()
+    if _active_plan is not None:
+        st = torch.cuda.current_stream() if torch.cuda.is_available() else None
+
+        def on_stream(fn_: Any = fn, st_: Any = st) -> None:
+            if st_ is None:
+                fn_()
+                return
+            with torch.cuda.stream(st_):
+                fn_()
+        _active_plan.ops.append((3, on_stream, None))
+
+
 def require_device(dev: torch.device, who: str) -> None:
     """The methods run on an MI355X only: there is no CPU path behind these wrappers."""
     if torch.device(dev).type != "cuda":

@@ -1272,13 +1272,16 @@ def test_activation_checkpointing_gives_the_same_gradients(rate):
     assert d <= 2e-5 * outs[0][1].abs().max().item(), d
 
 
-def test_hip_graph_replay_of_the_static_blocks_is_bitwise_equal_to_eager_launches():
-    """`graph_forward` (vit.ViTEngine) / `graph_backward` (DINOv2): blocks 0 .. depth-2 of the three forward passes and blocks depth-2 .. 0 of
-    both backward chains with the weight-gradient stream are captured into HIP graphs on the second step and replayed afterwards (one launch
-    per forward pass, one for the backward).  The captured kernels are the eagerly launched ones with the same arguments, and every
-    cross-workgroup sum goes through the order-fixed ledger (a region of its own for the replayed part), so five steps with replay must
-    equal five eagerly launched steps BIT FOR BIT: loss terms of every step, parameters, EMA teacher, last gradients, centers.  Shapes on
-    the 64-row grid at ViT-S width (joint weight gradients active) and off it (197-token crops at batch 6: pad-row fills inside the graph)."""
+@pytest.mark.parametrize("mode", ["plan", "graph"])
+def test_replay_of_the_static_blocks_is_bitwise_equal_to_eager_launches(mode):
+    """Blocks 0 .. depth-2 of the three forward passes and blocks depth-2 .. 0 of both backward chains with the weight-gradient stream are the
+    same launches every step.  "plan" (round 6, the default: `ViTEngine.plan_forward`, `DINOv2.plan_backward`, ops.LaunchPlan): the calls
+    across the C ABI and the event edges between the streams are logged on the third step and replayed by a bare loop afterwards -- same
+    launches, same order, same streams.  "graph" (round 5, opt-in: `graph_forward` / `graph_backward`): captured into HIP graphs on the second
+    step (one launch per forward pass, one for the backward; the ledger gets a region of its own for the replayed part).  Either way six
+    steps must equal six eagerly launched steps BIT FOR BIT: loss terms of every step, parameters, EMA teacher, last gradients, centers.
+    Shapes on the 64-row grid at ViT-S width (joint weight gradients active) and off it (197-token crops at batch 6: pad-row fills inside
+    the replayed part)."""
     import random
 
     from lightly_train_amd import ops
@@ -1292,19 +1295,30 @@ def test_hip_graph_replay_of_the_static_blocks_is_bitwise_equal_to_eager_launche
         views = [torch.randn(B, 3, gsz, gsz, generator=g) for _ in range(2)] + [torch.randn(B, 3, lsz, lsz, generator=g) for _ in range(4)]
         before = ops.reduce_overflows()
         finals = []
-        for graphs in (0, 1):
+        for replay in (None, mode):
             m = DINOv2(cfg, args, global_batch_size=B, total_steps=100, device="cuda", seed=3)
-            m.graph_backward = graphs
-            m.s_vit.graph_forward = m.t_vit.graph_forward = bool(graphs)
+            m.graph_backward = int(replay == "graph")
+            m.s_vit.graph_forward = m.t_vit.graph_forward = replay == "graph"
+            m.plan_backward = int(replay == "plan")
+            m.s_vit.plan_forward = m.t_vit.plan_forward = replay == "plan"
             losses = []
-            for step in range(5):
+            for step in range(6):
                 random.seed(100 + step)
                 m.train_step(views)
                 losses.append(m._loss_slots.clone())
             torch.cuda.synchronize()
-            if graphs:
+            if replay == "graph":
                 assert m._bwd_graph.get("graph") is not None, "the backward graph was never captured"
                 assert any(e["graph"] is not None for e in m.s_vit._fwd_graphs.values()) and any(e["graph"] is not None for e in m.t_vit._fwd_graphs.values())
+            elif replay == "plan":
+                assert isinstance(m._bwd_graph.get("graph"), ops.LaunchPlan) and m._bwd_graph.get("replays", 0) >= 2, "the backward plan was never replayed"
+                for eng, n_pass in ((m.s_vit, 2), (m.t_vit, 1)):
+                    live = [e for e in eng._fwd_plans.values() if e["plan"] is not None and e["replays"] >= 2]
+                    assert len(live) == n_pass, (len(live), n_pass, [(e["calls"], e["replays"]) for e in eng._fwd_plans.values()])
+                c = m._bwd_graph["graph"].counts()
+                assert c["launches"] > 50 and c["event_records"] > 10 and c["event_waits"] > 10, c
+            else:
+                assert m._bwd_graph.get("graph") is None and not m.s_vit._fwd_plans and not m.s_vit._fwd_graphs
             finals.append((torch.stack(losses), m.student.data.clone(), m.student.grad.clone(), m.teacher.data.clone(), m.dino_center.clone()))
         for what, a, b in zip(("loss terms", "student parameters", "last gradients", "teacher parameters", "center"), *finals):
             if what == "last gradients" and not torch.equal(a, b):

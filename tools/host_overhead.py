@@ -13,7 +13,7 @@ g = torch.Generator().manual_seed(0)
 B = 128
 views = [torch.randn(B, 3, 224, 224, generator=g).cuda() for _ in range(2)] + [torch.randn(B, 3, 96, 96, generator=g).cuda() for _ in range(8)]
 random.seed(0)
-for _ in range(2):
+for _ in range(5):     # (launch plans are logged on the third step of a geometry and replayed from the fourth)
     m.train_step(views)
 torch.cuda.synchronize()
 import cProfile, pstats
