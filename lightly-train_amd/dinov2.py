@@ -784,6 +784,10 @@ class DINOv2:
                 partial rows live at addresses the graph holds, which no eagerly launched kernel of any later step may be handed."""
                 main.wait_stream(lstream2)
                 main.wait_stream(side)
+                # ... and the local-crop chain joins them too: its map of "the weight-gradient stream still reads this buffer" events is
+                # dropped below, so the join has to stand in for them (without it, block depth-2's attention backward on that chain could
+                # overwrite the qkv gradient the joint weight-gradient GEMM of block depth-1 was still reading: seen once in a full-suite run)
+                lstream2.wait_event(main.record_event())
                 for c in (sl, sg):
                     c["_bwd_consumed"].clear()     # every event in there is behind the join
                 if det:

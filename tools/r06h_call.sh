@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06h; mkdir -p $O
-python tools/host_overhead.py vit_base > $O/host_plan_full.log 2>&1
-python tools/host_overhead.py vit_base 0.2 > $O/host_dp02_full.log 2>&1
-grep -E "host-only" $O/host_plan_full.log $O/host_dp02_full.log
+cd $GRAFT_REPO_ROOT
+for t in 1 0 1 0; do
+  echo "== LT_GEMM_TAIL128=$t"
+  LT_GEMM_TAIL128=$t timeout 600 python -m pytest tests/test_gpu_step.py -q -x -k "bench_configuration_step_matches" 2>&1 | grep -E "passed|failed|checks off" | cut -c1-300
+done
