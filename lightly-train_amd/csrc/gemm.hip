@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(NT2) void gemm256e_kernel(const GemmArgs g) {
 
 // ---- 128-row tiles for the LAST, partly filled round of a 256-row launch (round 6) --------------------------------------------------------
 // The N = 768 GEMMs of a ViT-B pass (attention projection, fc2, three data gradients) are 591 tiles of 256 x 256 on 256 CUs: 2.31 rounds, the
-// third 31 % full.  The dispatcher gives the first two rounds to gemm256e_kernel and the remaining tile rows to this kernel as 128 x 256
+// third 31 % full.  With LT_GEMM_TAIL128=1 the dispatcher gives the first two rounds to gemm256e_kernel and the remaining tile rows to this kernel as 128 x 256
 // tiles (158 workgroups of half the work: one short round instead of a long, mostly empty one).  Same LDS images, fragment reads, static
 // addressing and epilogues as the e kernel; per accumulator the same MFMA order over k (bit-identical results).  What differs:
 //   * 8 waves as 2 (M) x 4 (N), wave tile 64 x 64 (64 accumulator registers), ONE A half-tile (128 rows) + two B half-tiles per K-tile;
@@ -1792,16 +1792,18 @@ static int gemm_bf16_impl(const lt_gemm_desc* d, void* stream) {
     const bool e_fits = (d->trans_a ? (size_t)g.k_per_split * d->lda : (size_t)256 * d->lda + d->K) * 2 < 0x7fffffffull &&
                         (d->trans_b ? (size_t)g.k_per_split * d->ldb : (size_t)256 * d->ldb + d->K) * 2 < 0x7fffffffull;
     const bool e_kernel = q_kernel && d->K % BK == 0 && e_fits && d->force_kernel != 8 && (d->force_kernel == 11 || !env_e || atoi(env_e) != 0);
-    // the partly filled last round as 128-row tiles (gemm128e_kernel; LT_GEMM_TAIL128=0, read per call: one 256-row launch as before): when the
-    // 256 x 256 tiles are not a multiple of the CU count and the tile rows left after the full rounds fit ONE round of 128 x 256 tiles, the
-    // full rounds go to the e kernel and the remaining rows to the tail kernel -- N = 768 at 50 432 rows: 510 + 162 workgroups instead of
-    // 591 (2.31 rounds -> 2 + a short one)
+    // the partly filled last round as 128-row tiles (gemm128e_kernel; OPT-IN: LT_GEMM_TAIL128=1, read per call): when the 256 x 256 tiles are
+    // not a multiple of the CU count and the tile rows left after the full rounds fit ONE round of 128 x 256 tiles, the full rounds go to
+    // the e kernel and the remaining rows to the tail kernel -- N = 768 at 50 432 rows: 510 + 162 workgroups instead of 591 (2.31 rounds
+    // -> 2 + a short one).  Alone on the chip every N = 768 shape gains 5-15 % (profiles/r06g_stagger_probe.md, last column); inside the
+    // five-stream step, where other streams' kernels fill the last round anyway, the second launch and the narrower tiles COST 1.0 ms
+    // (81.54 vs 82.55 ms, 30 alternating steps each, profiles/r06i_ab_tail128.log): off by default
     bool tail128 = false;
     int big_rows = g.tiles_m;
     if (e_kernel && !d->trans_a && sp == 1 && !slab && d->epilogue != LT_EPI_F32_ACCUM) {
       const char* env_t = getenv("LT_GEMM_TAIL128");
       const long tiles = (long)g.tiles_m * g.tiles_n, full = tiles / cus;
-      if ((!env_t || atoi(env_t) != 0) && full >= 1 && tiles % cus != 0) {
+      if (env_t && atoi(env_t) != 0 && full >= 1 && tiles % cus != 0) {
         const int br = (int)(full * cus / g.tiles_n);
         const int rem = d->M - br * 256;
         if (br >= 1 && rem > 0 && (long)lt_cdiv(rem, 128) * g.tiles_n <= cus) { tail128 = true; big_rows = br; }

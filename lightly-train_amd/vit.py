@@ -124,11 +124,17 @@ def init_vit_state(cfg: ViTConfig, generator: Optional[torch.Generator] = None) 
     return sd
 
 
+_DROP_RATES: Dict[Tuple[float, int], List[float]] = {}
+
+
 def block_drop_rates(cfg: ViTConfig) -> List[float]:
     """Per-block stochastic-depth rate (vision_transformer.py:150-157): uniform or linspace(0, rate, depth)."""
     if cfg.drop_path_uniform:
         return [float(cfg.drop_path_rate)] * cfg.depth
-    return [x.item() for x in torch.linspace(0, cfg.drop_path_rate, cfg.depth)]
+    key = (float(cfg.drop_path_rate), int(cfg.depth))     # (asked for twice per step: the torch linspace + 12 .item() calls are cached)
+    if key not in _DROP_RATES:
+        _DROP_RATES[key] = [x.item() for x in torch.linspace(0, cfg.drop_path_rate, cfg.depth)]
+    return list(_DROP_RATES[key])
 
 
 def make_drop_plan(cfg: ViTConfig, batch: int, generator: Optional[torch.Generator] = None) -> Optional[List[Any]]:
