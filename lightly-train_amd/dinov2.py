@@ -784,6 +784,9 @@ class DINOv2:
                 partial rows live at addresses the graph holds, which no eagerly launched kernel of any later step may be handed."""
                 main.wait_stream(lstream2)
                 main.wait_stream(side)
+                # (An event-only boundary -- the chains' buffer-reuse events replaced by one per-step event of the weight-gradient stream, the
+                # first region summed on an idle stream, no stream waiting for another -- was built and measured: 82.8-85.2 ms against
+                # 79.1-79.4 with this join and 78.9-79.3 eager, profiles/r06j_plan_boundary_ab.log; removed.)
                 # ... and the local-crop chain joins them too: its map of "the weight-gradient stream still reads this buffer" events is
                 # dropped below, so the join has to stand in for them (without it, block depth-2's attention backward on that chain could
                 # overwrite the qkv gradient the joint weight-gradient GEMM of block depth-1 was still reading: seen once in a full-suite run)
