@@ -306,6 +306,11 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(res.loss)
+    # launch-plan replays so far (warm-up + timed steps; DINOv2 method): how often the static blocks ran from their logged launch list
+    plan_replays = None
+    if hasattr(method, "_bwd_graph") and hasattr(method, "s_vit"):
+        plan_replays = {"forward_passes": sum(e.get("replays", 0) for eng in (method.s_vit, method.t_vit) for e in eng._fwd_plans.values()),
+                        "backward": int(method._bwd_graph.get("replays", 0) or 0)}
     comm = None
     if world > 1 and getattr(method, "comm_events", None):
         ev = method.comm_events
@@ -466,6 +471,8 @@ def main() -> None:
             # MLP branch that no loss reads.  roofline.achieved counts the FLOPs of the GEMMs that ran;
             # step_algorithmic_gflop_per_image / step_frac_of_mfma_peak keep the reference's dense count.
             out["config"]["last_block_mlp"] = "evaluated on the token rows the losses read (cls + masked patches) only"
+        if plan_replays is not None:
+            out["config"]["launch_plan_replays"] = plan_replays
         if comm is not None:
             out["comm"] = comm
         print(json.dumps(out), flush=True)

@@ -43,6 +43,11 @@ LT_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-nod
 timeout 1500 python -m pytest tests/ -q -m gpu > $O/gpu_tests_full.log 2>&1; grep -E "passed|failed" $O/gpu_tests_full.log | tail -1 > $O/gpu_tests_tail.log
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_b.log 2>&1
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_c.log 2>&1
+python tools/copybuffer_census.py $(find $O/ks_single -name "*.db" | head -1) > $O/copybuffer_census.log 2>&1
+python tools/host_overhead.py vit_base > $O/host_overhead_plans.log 2>&1
+LT_PLAN_FWD=0 LT_PLAN_BWD=0 python tools/host_overhead.py vit_base > $O/host_overhead_eager.log 2>&1
+python tools/gemm_e_probe.py --kernels 8,11t0,11 --lib 1 > $O/gemm_e_probe.log 2>&1
+python tools/attn_bench.py > $O/attn_bench.log 2>&1
 rm -rf $O/ks_* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA
 set +x
 ls $O; cat $O/gpu_tests_tail.log
