@@ -23,7 +23,12 @@ bool on = false;
 std::vector<Ent> pending;
 long overflows = 0;
 int flush_idx = 0;
-struct Slot { std::vector<char> host; void* dev = nullptr; size_t dev_cap = 0; void* pinned = nullptr; size_t pinned_cap = 0; };
+constexpr int PIN_RING = 8;
+struct Slot {
+  std::vector<char> host; void* dev = nullptr; size_t dev_cap = 0; void* pinned = nullptr; size_t pinned_cap = 0;
+  // eager uploads: a ring of pinned staging buffers, each guarded by the event recorded behind its last copy (round 6)
+  void* pin[PIN_RING] = {nullptr}; size_t pin_cap[PIN_RING] = {0}; hipEvent_t pin_ev[PIN_RING] = {nullptr}; unsigned next = 0;
+};
 std::vector<Slot> slots;   // one cached device table per flush of a step: identical steps upload nothing
 
 // One workgroup per (destination, 256-column group): 64 column lanes x 4 columns, 4 part lanes.  Part lane q adds the partial rows
@@ -123,13 +128,31 @@ int flush_locked(hipStream_t st) {
         s.dev = s.pinned = nullptr; s.dev_cap = s.pinned_cap = 0; lt_set_error("lt_reduce_flush: table allocation failed"); return LT_ERR_HIP;
       }
     }
-    // Eagerly the table is uploaded from pageable memory: the runtime stages it before returning, so `host` may change afterwards and the
-    // launch thread never waits for the device.  Under stream capture the copy becomes a graph node that re-reads its source at every
-    // replay: it goes through the slot's own pinned buffer, written here and left alone afterwards (a slot range that is captured
-    // belongs to the graph's region: lt_reduce_begin_at).
-    const void* src = host.data();
-    if (capturing) { memcpy(s.pinned, host.data(), host.size()); src = s.pinned; }
-    if (hipMemcpyAsync(s.dev, src, host.size(), hipMemcpyHostToDevice, st) != hipSuccess) { lt_set_error("lt_reduce_flush: table upload failed"); return LT_ERR_HIP; }
+    // Under stream capture the copy becomes a graph node that re-reads its source at every replay: it goes through the slot's own pinned
+    // buffer, written here and left alone afterwards (a slot range that is captured belongs to the graph's region: lt_reduce_begin_at).
+    // Eagerly the table goes through a ring of pinned staging buffers (round 6).  It used to be uploaded from pageable memory, which the
+    // runtime stages before returning -- by waiting for the stream to reach the copy: a table that changes every step (the first ledger
+    // region's does: its partial counts follow the number of masked tokens) cost the launch thread its whole lead over the device at
+    // every flush, and with one flush per region that was a bubble per region boundary.  A pinned source is a queued DMA; a ring entry is
+    // taken again only after the event recorded behind its last copy (8 deep: further than the launch thread ever leads).
+    if (capturing) {
+      memcpy(s.pinned, host.data(), host.size());
+      if (hipMemcpyAsync(s.dev, s.pinned, host.size(), hipMemcpyHostToDevice, st) != hipSuccess) { lt_set_error("lt_reduce_flush: table upload failed"); return LT_ERR_HIP; }
+    } else {
+      const unsigned r = s.next++ % PIN_RING;
+      if (s.pin_ev[r]) (void)hipEventSynchronize(s.pin_ev[r]);
+      if (s.pin_cap[r] < host.size()) {
+        if (s.pin[r]) hipHostFree(s.pin[r]);
+        s.pin_cap[r] = host.size() * 2;
+        if (hipHostMalloc(&s.pin[r], s.pin_cap[r], hipHostMallocDefault) != hipSuccess) {
+          s.pin[r] = nullptr; s.pin_cap[r] = 0; lt_set_error("lt_reduce_flush: pinned staging allocation failed"); return LT_ERR_HIP;
+        }
+      }
+      if (!s.pin_ev[r] && hipEventCreateWithFlags(&s.pin_ev[r], hipEventDisableTiming) != hipSuccess) { lt_set_error("lt_reduce_flush: event creation failed"); return LT_ERR_HIP; }
+      memcpy(s.pin[r], host.data(), host.size());
+      if (hipMemcpyAsync(s.dev, s.pin[r], host.size(), hipMemcpyHostToDevice, st) != hipSuccess) { lt_set_error("lt_reduce_flush: table upload failed"); return LT_ERR_HIP; }
+      (void)hipEventRecord(s.pin_ev[r], st);
+    }
     s.host = host;
   }
   const DevGrp* dg = reinterpret_cast<const DevGrp*>(s.dev);

@@ -3,6 +3,7 @@ allocations and the HIP stream; every arithmetic op below runs in liblt_amd.so."
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Any, Any, Optional
 
 import torch
@@ -62,6 +63,8 @@ class LaunchPlan:
         return c
 
     def replay(self) -> None:
+        # (events: the logged objects are recorded again -- a fresh event per record, as the eager step makes them, measured no better:
+        # profiles/r06l_plan_ab.log)
         for k, a, b in self.ops:
             if k == 0:
                 rc = a(*b)

@@ -1,2 +1,3 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06j; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_step.py -q -x -k "replay_of_the_static or bitwise_reproducible or binding_mixin or bench_configuration" 2>&1 | tail -3 | tee $O/tests.log
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06l; mkdir -p $O
+python tools/plan_ab_probe.py vit_small 10 6 2>&1 | grep -v amdgpu | tee $O/plan_ab_vits.log
+python tools/plan_ab_probe.py vit_base 8 5 2>&1 | grep -v amdgpu | tee $O/plan_ab_vitb.log
