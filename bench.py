@@ -290,17 +290,36 @@ def main() -> None:
         else:
             for _ in range(n):
                 out = method.train_step(views)
+                if step_marks is not None:     # one HIP event per step on the stream the step ends on (no sync: read after the timed region)
+                    e_ = torch.cuda.Event(enable_timing=True)
+                    e_.record()
+                    step_marks.append((e_, time.perf_counter()))
         return out
+
+    step_marks = None
 
     host_priority = raise_host_priority()
     run(args.warmup)
     if world > 1 and hasattr(method, "comm_events"):
         method.comm_events = []          # exposed (not hidden under backward) gradient all-reduce time, HIP events on the main stream
     barrier()
+    step_marks = []
+    e_start = torch.cuda.Event(enable_timing=True)
+    e_start.record()
     t0 = time.perf_counter()
     res = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    # how the timed region was spent step by step: device time between the per-step events, and when the launch thread had enqueued each step
+    step_stats = None
+    if step_marks:
+        evs = [e_start] + [e for e, _ in step_marks]
+        per = sorted(a.elapsed_time(b) for a, b in zip(evs, evs[1:]))
+        enq = [t - t0 for _, t in step_marks]
+        step_stats = {"device_ms_per_step": {"min": round(per[0], 2), "median": round(per[len(per) // 2], 2), "max": round(per[-1], 2)},
+                      "launch_thread_done_enqueuing_at_ms": round(enq[-1] * 1e3, 1),
+                      "launch_thread_ms_per_step_max": round(max(b - a for a, b in zip([0.0] + enq, enq)) * 1e3, 1)}
+    step_marks = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -473,6 +492,8 @@ def main() -> None:
             out["config"]["last_block_mlp"] = "evaluated on the token rows the losses read (cls + masked patches) only"
         if plan_replays is not None:
             out["config"]["launch_plan_replays"] = plan_replays
+        if step_stats is not None:
+            out["config"]["timed_region"] = step_stats
         if comm is not None:
             out["comm"] = comm
         print(json.dumps(out), flush=True)

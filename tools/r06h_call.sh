@@ -1,3 +1,6 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r06l; mkdir -p $O
-python tools/plan_ab_probe.py vit_small 10 6 2>&1 | grep -v amdgpu | tee $O/plan_ab_vits.log
-python tools/plan_ab_probe.py vit_base 8 5 2>&1 | grep -v amdgpu | tee $O/plan_ab_vitb.log
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r06m; mkdir -p $O
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["config"].get("timed_region"))'
+for i in 1 2 3 4 5 6; do
+python bench.py --no-cpu-baseline --no-roofline --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "$P"
+done | tee $O/bench_repeat.log
+rocm-smi --showclocks --showpower --showtemp 2>/dev/null | head -30 | tee $O/smi.log
