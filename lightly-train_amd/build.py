@@ -75,13 +75,8 @@ def build_timing() -> str:
     src = [s_ for s_ in sources() if s_.endswith("gemm.hip")][0]
     subprocess.run([hipcc, *FLAGS, "-DLT_GEMM_TIMING", "-x", "hip", "-c", src, "-o", obj], check=True)
     others = [os.path.join(OBJDIR, os.path.basename(s_) + ".o") for s_ in sources() if not s_.endswith("gemm.hip")]
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *others, obj, "-o", out], check=True)
+    subprocess.run([hipcc, FLAGS[0], "-shared", "-fPIC", *others, obj, "-o", out], check=True)
     return out
-
-
-if __name__ == "__main__":
-    import sys
-    print(build_timing() if "--timing" in sys.argv else build(verbose=True))
 
 
 def build_variant(defines: list, name: str) -> str:
@@ -94,5 +89,10 @@ def build_variant(defines: list, name: str) -> str:
     src = [s_ for s_ in sources() if s_.endswith("gemm.hip")][0]
     subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-x", "hip", "-c", src, "-o", obj], check=True)
     others = [os.path.join(OBJDIR, os.path.basename(s_) + ".o") for s_ in sources() if not s_.endswith("gemm.hip")]
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *others, obj, "-o", out], check=True)
+    subprocess.run([hipcc, FLAGS[0], "-shared", "-fPIC", *others, obj, "-o", out], check=True)
     return out
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_timing() if "--timing" in sys.argv else build(verbose=True))

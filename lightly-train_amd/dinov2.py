@@ -762,12 +762,8 @@ class DINOv2:
             G["calls"] += 1
             replaying = gkey is not None and G["graph"] is not None
             stop = 1 if replaying else None
-            dbg = os.environ.get("LT_BWD_GRAPH_DEBUG", "")
-            gside = None if (gkey is not None and dbg == "noside") else side
-            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=gside, joint=jw, stop_after=stop)),
-                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=gside, joint=jw, stop_after=stop))]
-            if gkey is not None and dbg == "onechain":
-                chains[0] = (main, chains[0][1])
+            chains = [(lstream2, self.s_vit.backward_iter(ws, sl, dxn_l, side=side, joint=jw, stop_after=stop)),
+                      (main, self.s_vit.backward_iter(ws, sg, dxn_g, side=side, joint=jw, stop_after=stop))]
             live = [True, True]
 
             def one_iteration() -> None:
@@ -815,7 +811,7 @@ class DINOv2:
                 if replaying:
                     G["graph"].replay()
                     G["replays"] = G.get("replays", 0) + 1
-                elif G["calls"] < 2 or dbg == "eager":   # first step of this geometry: the same structure, launched eagerly (allocates)
+                elif G["calls"] < 2:                  # first step of this geometry: the same structure, launched eagerly (allocates)
                     for _ in range(depth - 1):
                         one_iteration()
                     main.wait_stream(lstream2)
@@ -846,27 +842,17 @@ class DINOv2:
                         chains[1] = (gstream, chains[1][1])
                         for st in (lstream2, gstream):
                             st.wait_stream(side)      # fork
-                        n_cap = int(os.environ.get("LT_BWD_GRAPH_ITERS", depth - 1))     # (diagnostic: capture fewer iterations)
-                        for _ in range(n_cap):
+                        for _ in range(depth - 1):
                             one_iteration()
                         for c in (sl, sg):
                             c["_bwd_consumed"].clear()
                         for st in (lstream2, gstream):
                             side.wait_stream(st)      # join
-                        if n_cap == depth - 1:
-                            after_static(side)
+                        after_static(side)
                     chains[1] = (main, chains[1][1])
                     torch.cuda.set_stream(main)
                     g.replay()
-                    if n_cap == depth - 1:
-                        G["graph"] = g
-                    else:
-                        for _ in range(depth - 1 - n_cap):
-                            one_iteration()
-                        main.wait_stream(lstream2)
-                        main.wait_stream(side)
-                        after_static(main)
-                        G["calls"] = 1
+                    G["graph"] = g
                 if det:                               # third region: the tails (and whatever follows until reduce_end)
                     ops.reduce_begin(self._reduce_scratch("reduce.scratch"), 128)
                 if replaying:

@@ -743,6 +743,7 @@ def _wrap_get_trainer() -> None:
     def get_trainer(*args: Any, **kwargs: Any) -> Any:
         import inspect
 
+        _LAST_TRAINER.clear()    # a train() that aborted between get_trainer and get_method_cls must not leave its Trainer to the next run
         bound = inspect.signature(orig).bind(*args, **kwargs)
         k = int(bound.arguments.get("gradient_accumulation_steps", 1) or 1)
         bound.arguments["gradient_accumulation_steps"] = 1

@@ -215,7 +215,7 @@ def h2d(t: Tensor, dev: torch.device) -> Tensor:
         v, i = ring.stage(t.contiguous())
         out = v.to(dev, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(dev))    # the stream of the device the copy was queued on (not the current device's)
         ring.evs[i] = ev
         return out
     return t.to(dev, non_blocking=True)
