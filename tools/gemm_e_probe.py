@@ -31,12 +31,12 @@ def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
 
 
 def call(spec, f):
-    """spec "11p4": force_kernel 11 under LT_GEMM_E_PH=4; "11t0": without the opt-in 128-row tail kernel (LT_GEMM_TAIL128=0; every other spec runs WITH it); "11s8000": every second
-    first-round workgroup starts 8000 ns late (LT_GEMM_STAGGER_NS).  The library reads the variables per call."""
+    """spec "11p4": force_kernel 11 under LT_GEMM_E_PH=4; "11t0": without the opt-in 128-row tail kernel (LT_GEMM_TAIL128=0; every other spec runs
+    WITH it).  The library reads the variables per call."""
     import re
-    m = re.match(r"^(\d+)(?:p(\d))?(t0)?(?:s(\d+))?$", spec)
-    fk, ph, t0, sg = m.group(1), m.group(2), m.group(3), m.group(4)
-    for var, val in (("LT_GEMM_E_PH", ph), ("LT_GEMM_TAIL128", "0" if t0 else "1"), ("LT_GEMM_STAGGER_NS", sg)):
+    m = re.match(r"^(\d+)(?:p(\d))?(t0)?$", spec)
+    fk, ph, t0 = m.group(1), m.group(2), m.group(3)
+    for var, val in (("LT_GEMM_E_PH", ph), ("LT_GEMM_TAIL128", "0" if t0 else "1")):
         if val:
             os.environ[var] = val
         else:
